@@ -1,0 +1,129 @@
+"""Generate tests/golden/*.npz from the REAL reference (build container only).
+
+    python oracle/gen_golden.py            # writes tests/golden/*.npz
+
+Imports the unmodified reference from /root/reference through `oracle/ref_shim.py`, feeds it
+deterministic inputs (instances from `restate.atsp_synthetic`, weights from `restate.make_weights`
+loaded with `load_state_dict(strict=True)`, neighbour-sample indices captured from the reference's
+own `torch.multinomial` call), records the reference outputs, and checks that `oracle/restate.py`
+reproduces them EXACTLY on this machine before writing each fixture.  The fixtures hold inputs and
+expected outputs only — no reference source.  The reference never travels to the GPU box.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref_shim, restate  # noqa: E402
+
+ref_shim.install()
+from tensordict import TensorDict  # noqa: E402  (the shim's stand-in)
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+POLICY_KW = dict(embed_dim=128, num_heads=8, num_encoder_layers=6, normalization="instance",
+                 use_graph_context=False, nab_type="gating")
+
+
+class _Gen:  # minimal generator attributes the reference envs read
+    def __init__(self, num_loc):
+        self.num_loc, self.min_dist, self.max_dist = num_loc, 0.0, 1.0
+        self.min_loc, self.max_loc, self.vehicle_capacity = 0.0, 1.0, 1.0
+
+
+class _CaptureMultinomial:
+    def __enter__(self):
+        self.calls, self._orig = [], torch.multinomial
+
+        def wrapped(*a, **k):
+            out = self._orig(*a, **k)
+            self.calls.append(out.clone())
+            return out
+        torch.multinomial = wrapped
+        return self
+
+    def __exit__(self, *exc):
+        torch.multinomial = self._orig
+
+
+def _np(d):
+    return {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in d.items()}
+
+
+def gen_atsp(tag, B, N, S, sample_size, seed, layers=6, aug=False, keep_trace=True):
+    from rrnco.envs.atsp.env import ATSPEnv
+    from rrnco.models.policy import RRNetPolicy
+
+    torch.manual_seed(seed)
+    inst = restate.atsp_synthetic(B, N, seed)
+    env = ATSPEnv(generator=_Gen(N), check_solution=True)
+    kw = dict(POLICY_KW, num_encoder_layers=layers)
+    pol = RRNetPolicy(env_name="atsp", init_embedding_kwargs=dict(
+        use_coords=True, use_polar_feats=True, use_dist=True, use_matnet_init=False,
+        sample_type="prob", sample_size=sample_size), **kw).eval()
+    tmpl = {k: tuple(v.shape) for k, v in pol.state_dict().items()}
+    assert tmpl == restate.atsp_weight_template(128, layers, 512, sample_size), "state_dict template drift"
+    w = restate.make_weights(tmpl, seed)
+    pol.load_state_dict(w, strict=True)
+
+    td_in = TensorDict({k: v.clone() for k, v in inst.items()}, batch_size=[B])
+    if aug:
+        from rrnco.models.utils.transforms import StateAugmentation
+        td_in = StateAugmentation(augment_fn="dihedral8", no_aug_coords=False)(td_in)
+    td = env.reset(td_in)
+    decode = "multistart_greedy" if S > 1 else "greedy"
+    enc_out = []
+    hook = pol.encoder.register_forward_hook(lambda m, a, o: enc_out.append(o))
+    with torch.inference_mode(), _CaptureMultinomial() as cap:
+        out = pol(td.clone(), env, phase="val", decode_type=decode, num_starts=S if S > 1 else None,
+                  return_actions=True)
+    hook.remove()
+    out["hidden"] = enc_out[0]
+    assert len(cap.calls) == 1
+    Bp = td["distance_matrix"].shape[0]
+    sidx = cap.calls[0].reshape(Bp, N, sample_size)
+
+    # ---- restatement must agree exactly with the reference on this machine
+    st = dict(inst)
+    if aug:
+        st = restate.augment_state(st)
+    st0 = restate.atsp_reset(st)
+    for k in ("distance_matrix", "min_distance", "max_distance"):
+        assert torch.equal(st0[k], td[k]), k
+    trace = {}
+    with torch.inference_mode():
+        mine = restate.atsp_policy(w, st0, sidx, S, "greedy", trace=trace)
+    assert torch.equal(mine["actions"], out["actions"]), "restatement tours differ from reference"
+    for k in ("reward", "normalized_reward", "log_likelihood"):
+        assert torch.equal(mine[k], out[k]), k
+    assert torch.equal(trace["row_emb"], out["hidden"][0]) and torch.equal(trace["col_emb"], out["hidden"][1])
+
+    fx = dict(
+        kind="atsp", B=B, N=N, S=S, sample_size=sample_size, seed=seed, layers=layers, aug=int(aug),
+        locs=inst["locs"], distance_matrix=inst["distance_matrix"], sample_idx=sidx,
+        norm_distance=td["distance_matrix"], min_distance=td["min_distance"], max_distance=td["max_distance"],
+        row_emb=out["hidden"][0], col_emb=out["hidden"][1],
+        actions=out["actions"], reward=out["reward"], normalized_reward=out["normalized_reward"],
+        log_likelihood=out["log_likelihood"], logprobs=mine["logprobs"],
+    )
+    if keep_trace:
+        fx["trace_logits"] = torch.stack(trace["logits"], 0)
+        fx["trace_mask"] = torch.stack(trace["mask"], 0)
+        fx["trace_logp"] = torch.stack(trace["logp"], 0)
+    path = os.path.join(GOLD, f"{tag}.npz")
+    np.savez_compressed(path, **_np(fx))
+    print(f"wrote {path}  ({os.path.getsize(path)/1e3:.0f} kB)  reward[:3]={out['reward'][:3].tolist()}")
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    which = sys.argv[1:] or ["atsp"]
+    if "atsp" in which:
+        gen_atsp("atsp_n20_b4_greedy", B=4, N=20, S=0, sample_size=15, seed=11)
+        gen_atsp("atsp_n20_b4_pomo", B=4, N=20, S=20, sample_size=15, seed=12)
+        gen_atsp("atsp_n20_b2_pomo_aug8", B=2, N=20, S=20, sample_size=15, seed=13, aug=True, keep_trace=False)
+        gen_atsp("atsp_n100_b2_pomo", B=2, N=100, S=100, sample_size=25, seed=14, keep_trace=False)

@@ -1,0 +1,480 @@
+"""ORACLE — CPU restatement of the RRNCO construction-rollout hot path (TEST INFRASTRUCTURE).
+
+Plain torch-CPU fp32, op-for-op with the reference so that, on the same machine and the same
+inputs, it reproduces the reference bit-for-bit (checked by `oracle/gen_golden.py`, which runs the
+real reference through `oracle/ref_shim.py` in the build container and refuses to write a fixture
+unless this file agrees exactly).  Pinned against: the committed `tests/golden/*.npz` fixtures
+(reference outputs).  The reference's own test-suite holds no numeric vectors for this path
+(SURVEY.md §4), so those fixtures are the pin.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this
+module.  The product (`rrnco_amd`) never does: it fails loudly if the HIP library is missing.
+
+Weights are a flat ``dict[str, Tensor]`` using the reference's ``state_dict`` names
+(`RRNetPolicy.state_dict()`), state is a plain ``dict[str, Tensor]``.
+
+Reference citations are relative to /root/reference.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+W = Dict[str, Tensor]
+
+
+# ----------------------------------------------------------------------------------------------
+# rl4co ops (rl4co 0.6.0 `rl4co/utils/ops.py`, absent from /root/reference; call sites:
+# rrnco/models/decoding.py:189,203  rrnco/models/decoder.py:173,187  rrnco/models/rl.py:112)
+# ----------------------------------------------------------------------------------------------
+def batchify(x: Tensor, n: int) -> Tensor:
+    """repeat-major: out[r*B + b] = x[b]."""
+    if n <= 0:
+        return x
+    s = x.shape
+    return x.expand(n, *s).contiguous().view(s[0] * n, *s[1:])
+
+
+def unbatchify(x: Tensor, n: int) -> Tensor:
+    """'(r b) ... -> b r ...'."""
+    if n <= 0:
+        return x
+    s = x.shape
+    return x.view(n, s[0] // n, *s[1:]).permute(1, 0, *range(2, len(s) + 1))
+
+
+def batchify_state(td: dict, n: int) -> dict:
+    return {k: batchify(v, n) for k, v in td.items()}
+
+
+def gather_by_index(src: Tensor, idx: Tensor, dim: int = 1, squeeze: bool = True) -> Tensor:
+    expanded_shape = list(src.shape)
+    expanded_shape[dim] = -1
+    idx = idx.view(idx.shape + (1,) * (src.dim() - idx.dim())).expand(expanded_shape)
+    squeeze = idx.size(dim) == 1 and squeeze
+    return src.gather(dim, idx).squeeze(dim) if squeeze else src.gather(dim, idx)
+
+
+def lin(w: W, name: str, x: Tensor) -> Tensor:
+    return F.linear(x, w[name + ".weight"], w.get(name + ".bias"))
+
+
+# ----------------------------------------------------------------------------------------------
+# Synthetic instances (rrnco/envs/atsp/generator_lazy.py:208-237)
+# ----------------------------------------------------------------------------------------------
+def atsp_synthetic(batch: int, n: int, seed: int) -> dict:
+    g = torch.Generator().manual_seed(seed)
+    locs = torch.rand(batch, n, 2, generator=g)
+    dms = torch.rand(batch, n, n, generator=g)
+    dms[..., torch.arange(n), torch.arange(n)] = 0
+    for i in range(n):  # TMAT class: triangle closure
+        dms = torch.minimum(dms, dms[..., :, [i]] + dms[..., [i], :])
+    return {"locs": locs, "distance_matrix": dms}
+
+
+def dihedral8(xy: Tensor) -> Tensor:
+    """rrnco/models/utils/transforms.py:15-37 — 8 blocks stacked on dim 0 (aug-major)."""
+    x, y = xy.split(1, dim=2)
+    zs = [(x, y), (1 - x, y), (x, 1 - y), (1 - x, 1 - y), (y, x), (1 - y, x), (y, 1 - x), (1 - y, 1 - x)]
+    return torch.cat([torch.cat(z, dim=2) for z in zs], dim=0)
+
+
+def augment_state(td: dict, num_augment: int = 8) -> dict:
+    """StateAugmentation(augment_fn='dihedral8', no_aug_coords=False) as test.py:28 builds it
+    (transforms.py:142-154): batchify everything x8, replace `locs` by the 8 reflections of the
+    first 1/8 (transforms.py:40-47)."""
+    assert num_augment == 8
+    out = batchify_state(td, 8)
+    b = td["locs"].shape[0]
+    out["locs"] = dihedral8(out["locs"][:b])
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# ATSP env (rrnco/envs/atsp/env.py)
+# ----------------------------------------------------------------------------------------------
+def atsp_reset(td: dict, normalize: bool = True) -> dict:
+    """env.py:107-155 (+ RL4COEnvBase.reset adds done=False)."""
+    distance = td["distance_matrix"]
+    B = distance.shape[0]
+    out = {}
+    if normalize:
+        mn = distance.amin(dim=(-2, -1), keepdim=True)
+        mx = distance.amax(dim=(-2, -1), keepdim=True)
+        distance = ((distance - mn) / (mx - mn + 1e-6)).to(torch.float32)
+        out["min_distance"] = mn.squeeze(-1).squeeze(-1)
+        out["max_distance"] = mx.squeeze(-1).squeeze(-1)
+    n = distance.shape[-1]
+    out.update(
+        distance_matrix=distance,
+        first_node=torch.zeros(B, 1, dtype=torch.int64),
+        current_node=torch.zeros(B, 1, dtype=torch.int64),
+        i=torch.zeros(B, 1, dtype=torch.int64),
+        action_mask=torch.ones(B, n, dtype=torch.bool),
+        done=torch.zeros(B, 1, dtype=torch.bool),
+    )
+    if "locs" in td:
+        out["locs"] = td["locs"]
+    return out
+
+
+def atsp_step(td: dict) -> dict:
+    """env.py:80-105."""
+    cur = td["action"]
+    first = cur if td["i"].flatten()[0].item() == 0 else td["first_node"]
+    avail = td["action_mask"].scatter(-1, cur.unsqueeze(-1).expand_as(td["action_mask"]), 0)
+    done = torch.count_nonzero(avail, dim=-1) <= 0
+    td.update(first_node=first, current_node=cur, i=td["i"] + 1, action_mask=avail,
+              reward=torch.zeros_like(done), done=done)
+    return td
+
+
+def atsp_reward(td: dict, actions: Tensor, normalize: bool = True):
+    """env.py:192-211 — returns (real, normalized) when normalize."""
+    D = td["distance_matrix"]
+    src, tgt = actions, torch.roll(actions, -1, dims=1)
+    bidx = torch.arange(D.shape[0]).unsqueeze(1)
+    if normalize:
+        nd = -D[bidx, src, tgt].sum(-1)
+        real = nd * (td["max_distance"] - td["min_distance"] + 1e-6) + td["min_distance"]
+        return real, nd
+    return -D[bidx, src, tgt].sum(-1)
+
+
+def atsp_check(actions: Tensor) -> bool:
+    """env.py:213-220."""
+    n = actions.size(1)
+    return bool((torch.arange(n).view(1, -1).expand_as(actions) == actions.sort(1)[0]).all())
+
+
+# ----------------------------------------------------------------------------------------------
+# Init embedding (rrnco/models/env_embeddings/atsp.py)
+# ----------------------------------------------------------------------------------------------
+def sample_neighbor_indices(distance: Tensor, sample_size: int, generator=None) -> Tensor:
+    """atsp.py:55-67 ('prob' sampling).  The index tensor is an explicit input to both the
+    oracle and the HIP path: this helper only produces one."""
+    B, N, _ = distance.shape
+    idx = torch.arange(N)
+    pd = distance.clone()
+    pd[:, idx, idx] = 1e6
+    inv = 1 / (pd + 1e-6)
+    prob = (inv / inv.sum(dim=-1, keepdim=True)).reshape(B * N, -1)
+    return torch.multinomial(prob, sample_size, replacement=False, generator=generator).reshape(B, N, sample_size)
+
+
+def contextual_gating(w: W, p: str, coord: Tensor, dist: Tensor) -> Tensor:
+    """atsp.py:108-121 — scalar gate per node."""
+    comb = torch.cat([coord, dist], dim=-1)
+    g = torch.sigmoid(lin(w, p + ".gating_fc.2", F.relu(lin(w, p + ".gating_fc.0", comb))))
+    return g * coord + (1 - g) * dist
+
+
+def atsp_init_embedding(w: W, locs: Tensor, distance: Tensor, sidx: Tensor):
+    """atsp.py:69-91 (use_coords and use_dist)."""
+    p = "encoder.init_embedding"
+    node = lin(w, p + ".init_embed", locs.float())
+    rowd = distance.gather(2, sidx)
+    cold = distance.transpose(1, 2).gather(2, sidx)
+    row = lin(w, p + ".row_embed", rowd.sort(dim=-1).values)
+    col = lin(w, p + ".col_embed", cold.sort(dim=-1).values)
+    return (contextual_gating(w, p + ".gating_network_row", node, row),
+            contextual_gating(w, p + ".gating_network_col", node, col))
+
+
+# ----------------------------------------------------------------------------------------------
+# Encoder net (rrnco/models/nn/attn_freenet.py)
+# ----------------------------------------------------------------------------------------------
+def instance_norm(w: W, p: str, x: Tensor) -> Tensor:
+    """Normalization('instance') attn_freenet.py:104-105: InstanceNorm1d(E, affine) over nodes."""
+    return F.instance_norm(x.permute(0, 2, 1), weight=w[p + ".normalizer.weight"],
+                           bias=w[p + ".normalizer.bias"], eps=1e-5).permute(0, 2, 1)
+
+
+def pairwise_angles(coords: Tensor) -> Tensor:
+    """attn_freenet.py:254-262."""
+    d = coords.unsqueeze(2) - coords.unsqueeze(1)
+    return torch.atan2(d[..., 1], d[..., 0])
+
+
+def nab_gating(w: W, p: str, coords: Tensor, cost: Tensor, dur: Optional[Tensor]) -> Tensor:
+    """DistAngleFusion.forward attn_freenet.py:242-289."""
+    def mlp(q, x):
+        return lin(w, q + ".2", F.relu(lin(w, q + ".0", x.unsqueeze(-1))))
+    angles = pairwise_angles(coords)
+    de = mlp(p + ".dist_emb", cost)
+    ae = mlp(p + ".angle_emb", angles)
+    if dur is not None:
+        du = mlp(p + ".dur_emb", dur)
+        gi = torch.cat([de, ae, du], dim=-1)
+        logits = lin(w, p + ".gate.2", F.silu(lin(w, p + ".gate.0", gi)))
+        g = F.softmax(logits / w[p + ".gate_temperature"].exp(), dim=-1)
+        fused = g[..., [0]] * de + g[..., [1]] * ae + g[..., [2]] * du
+    else:
+        g = torch.sigmoid(lin(w, p + ".gate.0", torch.cat([de, ae], dim=-1)))
+        fused = g * de + (1 - g) * ae
+    return lin(w, p + ".out_lin", fused).squeeze(-1)
+
+
+def aft_full(w: W, p: str, x: Tensor, y: Tensor, bias: Tensor) -> Tensor:
+    """AFTFull.forward attn_freenet.py:309-327 (note exp(softmax(.)) twice)."""
+    Q = lin(w, p + ".to_q", x)
+    K = lin(w, p + ".to_k", y)
+    V = lin(w, p + ".to_v", y)
+    a = torch.softmax(bias, dim=-1)
+    K = torch.softmax(K, dim=1)
+    temp = torch.exp(a) @ torch.mul(torch.exp(K), V)
+    weighted = temp / (torch.exp(a) @ torch.exp(K))
+    return lin(w, p + ".project", torch.mul(torch.sigmoid(Q), weighted))
+
+
+def block(w: W, p: str, row: Tensor, col: Tensor, cost: Tensor, coords: Tensor, dur, nab_name: str) -> Tensor:
+    """AttnFree_Block.forward attn_freenet.py:417-441."""
+    row = instance_norm(w, p + ".norm1", row)
+    col = instance_norm(w, p + ".norm2", col)
+    bias = nab_gating(w, p + "." + nab_name, coords, cost, dur) * w[p + ".alpha"]
+    out = aft_full(w, p + ".attn_free", row, col, bias)
+    out = instance_norm(w, p + ".norm3", lin(w, p + ".multi_head_combine", out))
+    f = p + ".feed_forward.ops"
+    x = instance_norm(w, f + ".norm1", row + out)
+    return instance_norm(w, f + ".norm2", x + lin(w, f + ".ffn.W2", F.relu(lin(w, f + ".ffn.W1", x))))
+
+
+def encoder_net(w: W, row: Tensor, col: Tensor, cost: Tensor, coords: Tensor, dur=None, num_layers: int = 6):
+    """AttnFreeNet / Attn_Free_Layer attn_freenet.py:472-488, 517-521."""
+    nab = "neural_adaptive_bias" if dur is not None else "angle_distance_fusion"
+    for l in range(num_layers):
+        p = f"encoder.net.layers.{l}"
+        r = block(w, p + ".row_encoding_block", row, col, cost, coords, dur, nab)
+        c = block(w, p + ".col_encoding_block", col, row, cost.transpose(1, 2), coords,
+                  None if dur is None else dur.transpose(1, 2), nab)
+        row, col = r, c
+    return row, col
+
+
+def num_layers_of(w: W) -> int:
+    return 1 + max(int(k.split(".")[3]) for k in w if k.startswith("encoder.net.layers."))
+
+
+def atsp_encoder(w: W, td: dict, sidx: Tensor):
+    """RRNetEncoder.forward encoder.py:80-112 for env_name='atsp'."""
+    row, col = atsp_init_embedding(w, td["locs"], td["distance_matrix"], sidx)
+    return encoder_net(w, row, col, td["distance_matrix"], td["locs"].float(), None, num_layers_of(w))
+
+
+# ----------------------------------------------------------------------------------------------
+# Decoder (rrnco/models/decoder.py) + decoding (rrnco/models/decoding.py)
+# ----------------------------------------------------------------------------------------------
+def precompute_cache(w: W, row_emb: Tensor, col_emb: Tensor) -> dict:
+    """decoder.py:214-232."""
+    gk, gv, lk = F.linear(col_emb, w["decoder.project_node_embeddings.weight"]).chunk(3, dim=-1)
+    return dict(node_embeddings=row_emb, glimpse_key=gk, glimpse_val=gv, logit_key=lk)
+
+
+def atsp_context(w: W, emb: Tensor, td: dict) -> Tensor:
+    """rl4co TSPContext (absent from the tree).  td is [B,S]-shaped here."""
+    B = emb.size(0)
+    if td["i"].flatten()[0].item() < 1:
+        ph = w["decoder.context_embedding.W_placeholder"]
+        if td["_two_d"]:
+            ctx = ph[None, None, :].expand(B, td["current_node"].shape[1], ph.size(-1))
+        else:
+            ctx = ph[None, :].expand(B, ph.size(-1))
+    else:
+        node_dim = (-1,) if td["first_node"].dim() == 1 else (td["first_node"].size(-1), -1)
+        ctx = gather_by_index(emb, torch.stack([td["first_node"], td["current_node"]], -1).view(B, -1)).view(B, *node_dim)
+    return F.linear(ctx, w["decoder.context_embedding.project_context.weight"])
+
+
+def pointer(w: W, q: Tensor, k: Tensor, v: Tensor, lk: Tensor, mask: Tensor, num_heads: int = 8) -> Tensor:
+    """RRNet_PointerAttention.forward decoder.py:281-323."""
+    def heads(t):  # '... g (h s) -> ... h g s'
+        return t.unflatten(-1, (num_heads, -1)).transpose(-2, -3)
+    am = mask.unsqueeze(1) if mask.ndim == 3 else mask.unsqueeze(1).unsqueeze(2)
+    h = F.scaled_dot_product_attention(heads(q), heads(k), heads(v), attn_mask=am)
+    h = h.transpose(-2, -3).flatten(-2)
+    g = h + q
+    g = F.linear(F.relu(F.linear(g, w["decoder.pointer.ffn.lins.0.weight"], w["decoder.pointer.ffn.lins.0.bias"])),
+                 w["decoder.pointer.ffn.lins.1.weight"], w["decoder.pointer.ffn.lins.1.bias"]) + g
+    logits = torch.bmm(g, lk.squeeze(-2).transpose(-2, -1)).squeeze(-2) / math.sqrt(g.size(-1))
+    return logits
+
+
+def atsp_decoder_step(w: W, td_flat: dict, cache: dict, S: int):
+    """RRNetDecoder.forward decoder.py:151-206 for atsp (multistart: unbatchify to [B,S,..])."""
+    if S > 1:
+        td = {k: unbatchify(v, S) for k, v in td_flat.items() if k in ("first_node", "current_node", "i", "action_mask")}
+        td["_two_d"] = True
+        D = cache["_D"]  # [B,N,N] un-batchified (== unbatchify(td["distance_matrix"])[:,0])
+    else:
+        td = {k: td_flat[k] for k in ("first_node", "current_node", "i", "action_mask")}
+        td["_two_d"] = False
+        D = td_flat["distance_matrix"]
+    q = atsp_context(w, cache["node_embeddings"], td)
+    q = q.unsqueeze(1) if q.ndim == 2 else q
+    mask = td["action_mask"]
+    logits = pointer(w, q, cache["glimpse_key"], cache["glimpse_val"], cache["logit_key"], mask)
+    if S > 1:
+        # reference gathers from the S-times batchified matrix; identical values
+        bias = w["decoder.alpha"] * gather_by_index(D.unsqueeze(1).expand(-1, S, -1, -1), td["current_node"], dim=-2)
+    else:
+        bias = w["decoder.alpha"] * gather_by_index(D, td["current_node"], dim=-2)
+    logits = torch.log(torch.exp(logits.to(torch.float32) - bias.to(torch.float32)) + 1e-6)
+    if S > 1:
+        logits = logits.permute(1, 0, 2).reshape(-1, logits.shape[-1])  # 'b s l -> (s b) l'
+        mask = mask.permute(1, 0, 2).reshape(-1, mask.shape[-1])
+    return logits, mask
+
+
+def process_logits(logits: Tensor, mask: Tensor, temperature: float = 1.0, tanh_clipping: float = 10.0) -> Tensor:
+    """decoding.py:311-361 (top-k/top-p off)."""
+    if tanh_clipping > 0:
+        logits = torch.tanh(logits) * tanh_clipping
+    logits = logits.clone()
+    logits[~mask] = float("-inf")
+    logits = logits / temperature
+    return F.log_softmax(logits, dim=-1)
+
+
+def atsp_policy(w: W, td0: dict, sidx: Tensor, num_starts: int, decode: str = "greedy",
+                actions: Optional[Tensor] = None, trace: Optional[dict] = None, normalize: bool = True) -> dict:
+    """RRNetPolicy.forward (policy.py:138-255) + pre/post decoder hooks (decoding.py:157-217)
+    for ATSP.  `td0` is a *reset* state.  decode in {'greedy','evaluate'}; multistart iff
+    num_starts > 1 (get_decoding_strategy: 'multistart_greedy').  With `trace` given, per-step
+    logits / mask / logprobs are appended (golden traces)."""
+    row, col = atsp_encoder(w, td0, sidx)
+    if trace is not None:
+        trace["row_emb"], trace["col_emb"] = row, col
+    B, N = td0["action_mask"].shape
+    S = num_starts if num_starts > 1 else 0
+    acts, lps = [], []
+    step = 0
+    if S >= 1:
+        a0 = torch.arange(S).repeat_interleave(B) % N  # select_start_nodes for atsp
+        if actions is not None:
+            a0 = actions[:, 0]
+        td = batchify_state({k: v for k, v in td0.items() if k not in ("locs",)}, S)
+        td["action"] = a0
+        td = atsp_step(td)
+        lps.append(torch.zeros_like(a0, dtype=torch.float32))
+        acts.append(a0)
+        step = 1 if actions is not None else 0
+    else:
+        td = dict(td0)
+    cache = precompute_cache(w, row, col)
+    cache["_D"] = td0["distance_matrix"]
+    k = 0
+    while not td["done"].all():
+        logits, mask = atsp_decoder_step(w, td, cache, S)
+        logp = process_logits(logits, mask)
+        if decode == "greedy":
+            sel = logp.argmax(dim=-1)
+        elif decode == "evaluate":
+            sel = actions[:, k + (1 if S >= 1 else 0)]
+        else:
+            raise ValueError(decode)
+        if trace is not None:
+            trace.setdefault("logits", []).append(logits)
+            trace.setdefault("mask", []).append(mask)
+            trace.setdefault("logp", []).append(logp)
+        lps.append(gather_by_index(logp, sel, dim=1))
+        acts.append(sel)
+        td["action"] = sel
+        td = atsp_step(td)
+        k += 1
+    logprobs = torch.stack(lps, 1)
+    actions_out = torch.stack(acts, 1)
+    tdr = dict(td)
+    out = {}
+    if normalize:
+        real, nd = atsp_reward(tdr, actions_out, True)
+        out["reward"], out["normalized_reward"] = real, nd
+    else:
+        out["reward"] = atsp_reward(tdr, actions_out, False)
+    assert (logprobs > -1000).all()
+    out["log_likelihood"] = logprobs.sum(1)
+    out["actions"] = actions_out
+    out["logprobs"] = logprobs
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# Deterministic weights (inputs shared by oracle, reference and the HIP path)
+# ----------------------------------------------------------------------------------------------
+def make_weights(template: Dict[str, tuple], seed: int) -> W:
+    """Reproducible stand-in for `nn.Linear` default init (U(-1/sqrt(fan_in), 1/sqrt(fan_in))),
+    norm weights 1 + small noise, scalars (alpha/beta/temperature) perturbed around their
+    defaults — drawn from numpy PCG64 keyed by (seed, parameter name) so the vectors do not
+    depend on module construction order or torch's RNG stream."""
+    import zlib
+
+    import numpy as np
+    out = {}
+    for name, shape in template.items():
+        rng = np.random.default_rng([seed, zlib.crc32(name.encode())])
+        if name.endswith("normalizer.weight"):
+            a = 1.0 + 0.1 * rng.standard_normal(shape)
+        elif name.endswith("normalizer.bias"):
+            a = 0.1 * rng.standard_normal(shape)
+        elif name.endswith(".alpha") or name.endswith(".beta"):
+            a = 1.0 + 0.1 * rng.standard_normal(shape)
+        elif name.endswith("gate_temperature"):
+            a = np.full(shape, 5.0) + 0.1 * rng.standard_normal(shape)
+        elif name.endswith("W_placeholder"):
+            a = rng.uniform(-1, 1, shape)
+        else:
+            fan_in = shape[-1] if len(shape) > 1 else None
+            if fan_in is None:  # bias: fan_in of the sibling weight
+                wname = name[: -len("bias")] + "weight"
+                fan_in = template[wname][-1] if wname in template else shape[0]
+            bound = 1.0 / math.sqrt(fan_in)
+            a = rng.uniform(-bound, bound, shape)
+        out[name] = torch.from_numpy(np.asarray(a, dtype=np.float32).reshape(shape)).clone()
+    return out
+
+
+def atsp_weight_template(embed_dim: int = 128, num_layers: int = 6, ff: int = 512, sample_size: int = 25) -> Dict[str, tuple]:
+    """state_dict names/shapes of RRNetPolicy(env_name='atsp', ...) (probed from the reference;
+    `oracle/gen_golden.py` asserts equality with the real module's state_dict)."""
+    E = embed_dim
+    t: Dict[str, tuple] = {}
+    p = "encoder.init_embedding"
+    t[p + ".init_embed.weight"] = (E, 2); t[p + ".init_embed.bias"] = (E,)
+    for rc in ("row", "col"):
+        t[f"{p}.{rc}_embed.weight"] = (E, sample_size); t[f"{p}.{rc}_embed.bias"] = (E,)
+    for rc in ("row", "col"):
+        q = f"{p}.gating_network_{rc}.gating_fc"
+        t[q + ".0.weight"] = (2 * E, 2 * E); t[q + ".0.bias"] = (2 * E,)
+        t[q + ".2.weight"] = (1, 2 * E); t[q + ".2.bias"] = (1,)
+    for l in range(num_layers):
+        for rc in ("row", "col"):
+            b = f"encoder.net.layers.{l}.{rc}_encoding_block"
+            t[b + ".alpha"] = (1,)
+            for nm in ("to_q", "to_k", "to_v", "project"):
+                t[f"{b}.attn_free.{nm}.weight"] = (E, E); t[f"{b}.attn_free.{nm}.bias"] = (E,)
+            t[b + ".multi_head_combine.weight"] = (E, E); t[b + ".multi_head_combine.bias"] = (E,)
+            f = b + ".angle_distance_fusion"
+            for nm in ("dist_emb", "angle_emb"):
+                t[f"{f}.{nm}.0.weight"] = (E, 1); t[f"{f}.{nm}.0.bias"] = (E,)
+                t[f"{f}.{nm}.2.weight"] = (E, E); t[f"{f}.{nm}.2.bias"] = (E,)
+            t[f + ".gate.0.weight"] = (1, 2 * E); t[f + ".gate.0.bias"] = (1,)
+            t[f + ".out_lin.weight"] = (1, E); t[f + ".out_lin.bias"] = (1,)
+            o = b + ".feed_forward.ops"
+            t[o + ".norm1.normalizer.weight"] = (E,); t[o + ".norm1.normalizer.bias"] = (E,)
+            t[o + ".ffn.W1.weight"] = (ff, E); t[o + ".ffn.W1.bias"] = (ff,)
+            t[o + ".ffn.W2.weight"] = (E, ff); t[o + ".ffn.W2.bias"] = (E,)
+            t[o + ".norm2.normalizer.weight"] = (E,); t[o + ".norm2.normalizer.bias"] = (E,)
+            for nm in ("norm1", "norm2", "norm3"):
+                t[f"{b}.{nm}.normalizer.weight"] = (E,); t[f"{b}.{nm}.normalizer.bias"] = (E,)
+    t["decoder.alpha"] = (1,)
+    t["decoder.context_embedding.W_placeholder"] = (2 * E,)
+    t["decoder.context_embedding.project_context.weight"] = (E, 2 * E)
+    t["decoder.pointer.project_out.weight"] = (E, E)
+    t["decoder.pointer.ffn.lins.0.weight"] = (4 * E, E); t["decoder.pointer.ffn.lins.0.bias"] = (4 * E,)
+    t["decoder.pointer.ffn.lins.1.weight"] = (E, 4 * E); t["decoder.pointer.ffn.lins.1.bias"] = (E,)
+    t["decoder.project_node_embeddings.weight"] = (3 * E, E)
+    t["decoder.project_fixed_context.weight"] = (E, E)
+    return t
