@@ -1,0 +1,179 @@
+// Shared device helpers for the RRNCO construction-rollout kernels (gfx950 / CDNA4 only).
+//
+// Numeric layout convention used by every MFMA kernel in this directory ("transposed tiles"):
+//   we always compute  Y^T = W * X^T  with v_mfma_f32_16x16x4_f32, i.e.
+//     A operand  = a 16(features) x 4(k) slice of a weight-like matrix      lane l: A[i = l&15][k = l>>4]
+//     B operand  = a 4(k) x 16(nodes|rollouts) slice of an activation^T      lane l: B[k = l>>4][j = l&15]
+//     C/D        = 16(features) x 16(nodes) tile                              lane l: D[row = 4*(l>>4)+reg][col = l&15]
+//   so "which node / rollout" always lives on the low 4 lane bits (j) and the feature index lives on
+//   (g = lane>>4, reg).  A lane therefore owns 4 CONSECUTIVE features of one node, which is exactly one
+//   float4 of a row-major [node][feature] activation tile: C tiles are written back to LDS with one
+//   ds_write_b128, and re-read as the next GEMM's B operand with one ds_read_b128 per 4 MFMAs.
+//   The K index is consumed in the permuted order  k = 16*kk + 4*g + m  (m = 0..3 = the 4 MFMAs fed by one
+//   float4); A and B use the same permutation so the sum is over every k exactly once.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define RR_WAVE 64
+#define RR_E 128          // embed dim (fixed by the architecture: configs/experiment/rrnet.yaml:22)
+#define RR_FF 512         // feed-forward hidden (encoder FFN and decoder pointer MLP)
+#define RR_HEADS 8
+#define RR_HD 16          // head dim
+#define RR_MAXN 103       // max nodes for the LDS-resident per-instance kernels
+#define RR_NT 7           // node / rollout tiles of 16 per workgroup (covers up to 112)
+
+#define RR_OK 0
+#define RR_EINVAL -1
+#define RR_ELAUNCH -2
+
+__device__ __forceinline__ f32x4 rr_mfma(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x4 rr_zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+
+__device__ __forceinline__ float4 rr_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void rr_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// acc[nt] (features 16t.., nodes 16nt..) += Wp(tile t, k-groups [kk0,kk0+nkk)) * X^T
+//   Wp   : packed A operand, float4 index [(t*KK + kk)*64 + lane]  (see rrnco_amd/packing.py)
+//   X    : LDS (or global) row-major activation [node][ldx]; rows clamped to n_valid-1
+//   xk0  : column offset in X of k-group kk0 (X may be a chunk of the full K range)
+template <int NT>
+__device__ __forceinline__ void rr_gemm_wx(f32x4 (&acc)[NT], const float4* __restrict__ wp, int kk0, int nkk,
+                                           const float* X, int ldx, int xk0, int n_valid, int lane) {
+  const int j = lane & 15, g = lane >> 4;
+  int rowoff[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    int node = nt * 16 + j;
+    node = node < n_valid ? node : n_valid - 1;
+    rowoff[nt] = node * ldx + 4 * g + xk0;
+  }
+  float4 a = wp[(size_t)kk0 * 64 + lane];
+#pragma unroll 1
+  for (int kk = 0; kk < nkk; ++kk) {
+    float4 an = a;
+    if (kk + 1 < nkk) an = wp[(size_t)(kk0 + kk + 1) * 64 + lane];
+    float4 b[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = rr_ld4(X + rowoff[nt] + kk * 16);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = rr_mfma(a.x, b[nt].x, acc[nt]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = rr_mfma(a.y, b[nt].y, acc[nt]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = rr_mfma(a.z, b[nt].z, acc[nt]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = rr_mfma(a.w, b[nt].w, acc[nt]);
+    a = an;
+  }
+}
+
+// add a per-feature bias (feature = fbase + 4g + reg) to every node tile
+template <int NT>
+__device__ __forceinline__ void rr_add_bias(f32x4 (&acc)[NT], const float* __restrict__ bias, int fbase, int lane) {
+  const int g = lane >> 4;
+  float4 b = rr_ld4(bias + fbase + 4 * g);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    acc[nt][0] += b.x; acc[nt][1] += b.y; acc[nt][2] += b.z; acc[nt][3] += b.w;
+  }
+}
+
+// write C tiles to a row-major [node][ld] buffer at columns fbase+4g..+3 (rows >= n_valid skipped)
+template <int NT>
+__device__ __forceinline__ void rr_store_tiles(const f32x4 (&acc)[NT], float* X, int ld, int fbase, int n_valid, int lane) {
+  const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    int node = nt * 16 + j;
+    if (node < n_valid) rr_st4(X + node * ld + fbase + 4 * g, make_float4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]));
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void rr_load_tiles(f32x4 (&acc)[NT], const float* X, int ld, int fbase, int n_valid, int lane) {
+  const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    int node = nt * 16 + j;
+    node = node < n_valid ? node : n_valid - 1;
+    float4 v = rr_ld4(X + node * ld + fbase + 4 * g);
+    acc[nt][0] = v.x; acc[nt][1] = v.y; acc[nt][2] = v.z; acc[nt][3] = v.w;
+  }
+}
+
+// reductions over the 16 lanes that share g (= over the nodes of one tile column set)
+__device__ __forceinline__ float rr_sum16(float v) {
+  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+  return v;
+}
+__device__ __forceinline__ float rr_max16(float v) {
+  v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2));
+  v = fmaxf(v, __shfl_xor(v, 4)); v = fmaxf(v, __shfl_xor(v, 8));
+  return v;
+}
+// reductions over g (the 4 lane groups that share j = one node / rollout)
+__device__ __forceinline__ float rr_sum_g(float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; }
+__device__ __forceinline__ float rr_max_g(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16)); v = fmaxf(v, __shfl_xor(v, 32)); return v;
+}
+__device__ __forceinline__ float rr_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float rr_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float rr_wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// InstanceNorm1d(E, affine) over the node axis on C-layout tiles (attn_freenet.py:84,104-105):
+// per feature: mean over nodes, biased variance, eps 1e-5.  Lanes with node >= n_valid are ignored.
+template <int NT>
+__device__ __forceinline__ void rr_instnorm_tiles(f32x4 (&x)[NT], const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, int fbase, int n_valid, int lane) {
+  const int j = lane & 15, g = lane >> 4;
+  const float inv_n = 1.0f / (float)n_valid;
+  float4 gm = rr_ld4(gamma + fbase + 4 * g), bt = rr_ld4(beta + fbase + 4 * g);
+  float gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float s = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) s += (nt * 16 + j < n_valid) ? x[nt][r] : 0.f;
+    float mean = rr_sum16(s) * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { float d = x[nt][r] - mean; q += (nt * 16 + j < n_valid) ? d * d : 0.f; }
+    float var = rr_sum16(q) * inv_n;
+    float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) x[nt][r] = (x[nt][r] - mean) * rstd * gmv[r] + btv[r];
+  }
+}
+
+// counter-based uniform / Gumbel noise for the sampling decode (keyed by seed, rollout, step, key)
+__device__ __forceinline__ uint32_t rr_hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x;
+}
+__device__ __forceinline__ float rr_uniform(uint64_t seed, uint32_t r, uint32_t step, uint32_t key) {
+  uint32_t h = rr_hash32((uint32_t)seed ^ rr_hash32(r + 0x9e3779b9U * (uint32_t)(seed >> 32)));
+  h = rr_hash32(h ^ rr_hash32(step * 131u + key + 0x85ebca6bU));
+  return ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0,1)
+}
+__device__ __forceinline__ float rr_gumbel(uint64_t seed, uint32_t r, uint32_t step, uint32_t key) {
+  return -logf(-logf(rr_uniform(seed, r, step, key)));
+}
+
+static inline int rr_check(hipError_t e) { return e == hipSuccess ? RR_OK : RR_ELAUNCH; }

@@ -1,0 +1,447 @@
+// RRNet encoder for gfx950: init embedding, the AFT encoder block (instance norms + folded Neural
+// Adaptive Bias + AFT-full mixing + FFN) and the decoder's per-instance cache projections.
+// One workgroup (512 threads = 8 waves) owns one instance for a whole block; all [N,E] activations of
+// the block live in three LDS buffers, GEMMs run on v_mfma_f32_16x16x4_f32 in the transposed-tile
+// convention of rr_common.h.  Reference: rrnco/models/nn/attn_freenet.py (cited per stage below).
+#include "rr_common.h"
+
+#define ENC_THREADS 512
+#define ENC_WAVES 8
+#define LD 128      // row stride of the [node][feature] LDS buffers
+#define LDA 112     // row stride of the exp(softmax(bias)) matrix (k padded to 7 groups of 16)
+#define BUF_FLOATS (RR_MAXN * LD)
+
+struct EncBlockW {
+  const float *n1g, *n1b, *n2g, *n2b, *n3g, *n3b, *f1g, *f1b, *f2g, *f2b;  // instance-norm affine [E]
+  const float4 *wq, *wk, *wv, *wp, *wc, *w1, *w2;                             // packed A operands
+  const float *bq, *bk, *bv, *bp, *bc, *b1, *b2;
+  const float* nab;  // folded NAB: rows a_d,b_d,co_d,cg_d,a_a,b_a,co_a,cg_a [8][E] + 8 scalars
+};
+
+// ------------------------------------------------------------------------------------------------
+// Folded gating NAB (DistAngleFusion, attn_freenet.py:242-289) for one edge.
+//   u = W2d relu(a_d d + b_d) + b2d ; v = same on the angle ; g = sigmoid(wg.[u;v] + bg)
+//   bias = wo.(g u + (1-g) v) + bo = g (wo.u) + (1-g) (wo.v) + bo
+// wo.u and wg_u.u are linear in the hidden vector h = relu(a d + b): co = W2^T wo, cg = W2^T wg_u are
+// folded on the host (rrnco_amd/packing.py), so the E x E contraction never happens per edge.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float nab_edge(const float* __restrict__ nab, float d, float th) {
+  float pod = 0.f, pgd = 0.f, poa = 0.f, pga = 0.f;
+#pragma unroll 8
+  for (int k = 0; k < RR_E; ++k) {
+    float hd = fmaxf(fmaf(nab[0 * RR_E + k], d, nab[1 * RR_E + k]), 0.f);
+    pod = fmaf(nab[2 * RR_E + k], hd, pod);
+    pgd = fmaf(nab[3 * RR_E + k], hd, pgd);
+    float ha = fmaxf(fmaf(nab[4 * RR_E + k], th, nab[5 * RR_E + k]), 0.f);
+    poa = fmaf(nab[6 * RR_E + k], ha, poa);
+    pga = fmaf(nab[7 * RR_E + k], ha, pga);
+  }
+  const float* s = nab + 8 * RR_E;  // ko_d, kg_d, ko_a, kg_a, bg, bo, alpha
+  float z = (pgd + s[1]) + (pga + s[3]) + s[4];
+  float gt = 1.0f / (1.0f + expf(-z));
+  float bo = gt * (pod + s[0]) + (1.0f - gt) * (poa + s[2]) + s[5];
+  return bo * s[6];
+}
+
+// den/num GEMM: acc[nt] (features 16w.., query nodes 16nt..) += sum_k Z[k][16w+i] * ea[node][k]
+//   Z  : LDS [node][LD]   (A operand, read per element: lane (i,g) needs rows 16kk+4g+m)
+//   ea : LDS [node][LDA]  (B operand, float4 per lane)
+template <int NT>
+__device__ __forceinline__ void aft_mix(f32x4 (&acc)[NT], const float* Z, const float* ea, int fbase, int N, int lane) {
+  const int j = lane & 15, g = lane >> 4;
+  int rowoff[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    int node = nt * 16 + j; node = node < N ? node : N - 1;
+    rowoff[nt] = node * LDA + 4 * g;
+  }
+  const int nkk = (N + 15) >> 4;
+#pragma unroll 1
+  for (int kk = 0; kk < nkk; ++kk) {
+    float a[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      int k = kk * 16 + 4 * g + m; k = k < N ? k : N - 1;   // ea is zero for k >= N
+      a[m] = Z[k * LD + fbase + j];
+    }
+    float4 b[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = rr_ld4(ea + rowoff[nt] + kk * 16);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = rr_mfma(a[0], b[nt].x, acc[nt]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = rr_mfma(a[1], b[nt].y, acc[nt]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = rr_mfma(a[2], b[nt].z, acc[nt]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = rr_mfma(a[3], b[nt].w, acc[nt]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// One AttnFree_Block (attn_freenet.py:417-441).  blockIdx.x = instance, blockIdx.y = 0 row block /
+// 1 col block of the same layer (Attn_Free_Layer.forward :472-488: the col block sees (col,row,D^T)).
+// dbg (optional): stage dumps [stage][N][E] per instance for the parity tests.
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(ENC_THREADS, 2) void k_enc_block(EncBlockW wr, EncBlockW wcol,
+                                                              const float* __restrict__ row_in, const float* __restrict__ col_in,
+                                                              float* __restrict__ row_out, float* __restrict__ col_out,
+                                                              const float* __restrict__ D, const float* __restrict__ locs,
+                                                              int N, float* __restrict__ dbg) {
+  __shared__ __attribute__((aligned(16))) float smem[3 * BUF_FLOATS];
+  float* A = smem;                   // r = IN1(x)
+  float* B = smem + BUF_FLOATS;      // c = IN2(y) -> eK -> Z -> Y -> x1
+  float* C = smem + 2 * BUF_FLOATS;  // ea -> P -> H chunks
+
+  const int b = blockIdx.x, is_col = blockIdx.y;
+  const EncBlockW& w = is_col ? wcol : wr;
+  const float* x_in = (is_col ? col_in : row_in) + (size_t)b * N * RR_E;
+  const float* y_in = (is_col ? row_in : col_in) + (size_t)b * N * RR_E;
+  float* out = (is_col ? col_out : row_out) + (size_t)b * N * RR_E;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int fb = 16 * wave;  // this wave's feature tile in every 128-wide GEMM
+  float* dbgb = dbg ? dbg + (size_t)(b * 2 + is_col) * 8 * N * RR_E : nullptr;
+
+  // ---- S0: stage x, y
+  for (int i = tid; i < N * (RR_E / 4); i += ENC_THREADS) {
+    rr_st4(A + i * 4, rr_ld4(x_in + i * 4));
+    rr_st4(B + i * 4, rr_ld4(y_in + i * 4));
+  }
+  __syncthreads();
+
+  // ---- S1: r = norm1(x), c = norm2(y)  (:421-422) — each wave owns 16 features of all nodes
+  {
+    f32x4 t[NT];
+    rr_load_tiles<NT>(t, A, LD, fb, N, lane);
+    rr_instnorm_tiles<NT>(t, w.n1g, w.n1b, fb, N, lane);
+    rr_store_tiles<NT>(t, A, LD, fb, N, lane);
+    rr_load_tiles<NT>(t, B, LD, fb, N, lane);
+    rr_instnorm_tiles<NT>(t, w.n2g, w.n2b, fb, N, lane);
+    rr_store_tiles<NT>(t, B, LD, fb, N, lane);
+  }
+
+  // ---- S2: ea = exp(softmax_j(NAB(D, theta) * alpha))  (:427-429, 318, 320) -> C [N][LDA]
+  {
+    const float* Db = D + (size_t)b * N * N;
+    const float* lc = locs + (size_t)b * N * 2;
+    float xj[2], yj[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      int jj = lane + 64 * q; jj = jj < N ? jj : N - 1;
+      xj[q] = lc[jj * 2]; yj[q] = lc[jj * 2 + 1];
+    }
+    for (int i = wave; i < N; i += ENC_WAVES) {
+      const float xi = lc[i * 2], yi = lc[i * 2 + 1];
+      float bs[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        int jj = lane + 64 * q;
+        bs[q] = -INFINITY;
+        if (jj < N) {
+          float d = is_col ? Db[jj * N + i] : Db[i * N + jj];
+          float th = atan2f(yi - yj[q], xi - xj[q]);
+          bs[q] = nab_edge(w.nab, d, th);
+        }
+      }
+      float m = rr_wave_max(fmaxf(bs[0], bs[1]));
+      float e0 = expf(bs[0] - m), e1 = expf(bs[1] - m);   // exp(-inf) = 0 for padding lanes
+      float s = rr_wave_sum(e0 + e1);
+      if (lane < LDA) C[i * LDA + lane] = lane < N ? expf(e0 / s) : 0.f;
+      if (lane + 64 < LDA) C[i * LDA + lane + 64] = (lane + 64 < N) ? expf(e1 / s) : 0.f;
+    }
+  }
+  __syncthreads();
+  if (dbgb) {
+    for (int i = tid; i < N * RR_E; i += ENC_THREADS) { dbgb[0 * N * RR_E + i] = A[i]; dbgb[1 * N * RR_E + i] = B[i]; }
+    for (int i = tid; i < N * N; i += ENC_THREADS) dbgb[2 * N * RR_E + i] = C[(i / N) * LDA + (i % N)];
+  }
+
+  // ---- S3: K, V = lin(c)  (:314-315); eK = exp(softmax_nodes(K)) (:319,321); Z = eK * V
+  f32x4 num[NT], den[NT];
+  {
+    f32x4 ka[NT], va[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { ka[nt] = rr_zero4(); va[nt] = rr_zero4(); num[nt] = rr_zero4(); den[nt] = rr_zero4(); }
+    rr_gemm_wx<NT>(ka, w.wk + (size_t)wave * 8 * 64, 0, 8, B, LD, 0, N, lane);
+    rr_gemm_wx<NT>(va, w.wv + (size_t)wave * 8 * 64, 0, 8, B, LD, 0, N, lane);
+    rr_add_bias<NT>(ka, w.bk, fb, lane);
+    rr_add_bias<NT>(va, w.bv, fb, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float m = -INFINITY;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) m = fmaxf(m, (nt * 16 + j < N) ? ka[nt][r] : -INFINITY);
+      m = rr_max16(m);
+      float s = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        float e = (nt * 16 + j < N) ? expf(ka[nt][r] - m) : 0.f;
+        ka[nt][r] = e; s += e;
+      }
+      s = rr_sum16(s);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        float ek = expf(ka[nt][r] / s);
+        ka[nt][r] = ek;          // eK
+        va[nt][r] = ek * va[nt][r];  // Z
+      }
+    }
+    __syncthreads();  // every wave has finished reading c
+    rr_store_tiles<NT>(ka, B, LD, fb, N, lane);
+    __syncthreads();
+    aft_mix<NT>(den, B, C, fb, N, lane);   // den = ea @ eK   (:322)
+    __syncthreads();
+    rr_store_tiles<NT>(va, B, LD, fb, N, lane);
+    __syncthreads();
+    aft_mix<NT>(num, B, C, fb, N, lane);   // num = ea @ (eK*V)  (:321)
+  }
+
+  // ---- S4: Y = sigmoid(Q) * num / den  (:313,316,322-324)
+  {
+    f32x4 qa[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) qa[nt] = rr_zero4();
+    rr_gemm_wx<NT>(qa, w.wq + (size_t)wave * 8 * 64, 0, 8, A, LD, 0, N, lane);
+    rr_add_bias<NT>(qa, w.bq, fb, lane);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float sg = 1.0f / (1.0f + expf(-qa[nt][r]));
+        qa[nt][r] = sg * (num[nt][r] / den[nt][r]);
+      }
+    __syncthreads();  // all waves done with Z (B) and ea (C)
+    rr_store_tiles<NT>(qa, B, LD, fb, N, lane);
+  }
+  __syncthreads();
+  if (dbgb) for (int i = tid; i < N * RR_E; i += ENC_THREADS) dbgb[3 * N * RR_E + i] = B[i];
+
+  // ---- S5: P = project(Y) (:325) -> C
+  {
+    f32x4 pa[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) pa[nt] = rr_zero4();
+    rr_gemm_wx<NT>(pa, w.wp + (size_t)wave * 8 * 64, 0, 8, B, LD, 0, N, lane);
+    rr_add_bias<NT>(pa, w.bp, fb, lane);
+    rr_store_tiles<NT>(pa, C, LD, fb, N, lane);
+  }
+  __syncthreads();
+
+  // ---- S6: out = norm3(combine(P)) (:435-436); x1 = ffn.norm1(r + out) (:355)
+  f32x4 x1[NT];
+  {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) x1[nt] = rr_zero4();
+    rr_gemm_wx<NT>(x1, w.wc + (size_t)wave * 8 * 64, 0, 8, C, LD, 0, N, lane);
+    rr_add_bias<NT>(x1, w.bc, fb, lane);
+    rr_instnorm_tiles<NT>(x1, w.n3g, w.n3b, fb, N, lane);
+    f32x4 rt[NT];
+    rr_load_tiles<NT>(rt, A, LD, fb, N, lane);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) x1[nt] = rt[nt] + x1[nt];
+    rr_instnorm_tiles<NT>(x1, w.f1g, w.f1b, fb, N, lane);
+    rr_store_tiles<NT>(x1, B, LD, fb, N, lane);   // B (Y) is dead: every wave passed the S5 barrier
+  }
+  __syncthreads();
+  if (dbgb) for (int i = tid; i < N * RR_E; i += ENC_THREADS) dbgb[4 * N * RR_E + i] = B[i];
+
+  // ---- S7: x2 = ffn.norm2(x1 + W2 relu(W1 x1 + b1) + b2) (:356, 536), hidden in 4 chunks of 128
+  {
+    f32x4 fa[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) fa[nt] = rr_zero4();
+    for (int c = 0; c < RR_FF / 128; ++c) {
+      f32x4 ha[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) ha[nt] = rr_zero4();
+      rr_gemm_wx<NT>(ha, w.w1 + (size_t)(c * 8 + wave) * 8 * 64, 0, 8, B, LD, 0, N, lane);
+      rr_add_bias<NT>(ha, w.b1, c * 128 + fb, lane);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ha[nt][r] = fmaxf(ha[nt][r], 0.f);
+      __syncthreads();  // previous chunk's W2 pass (and S6's reads of C) are complete
+      rr_store_tiles<NT>(ha, C, LD, fb, N, lane);
+      __syncthreads();
+      rr_gemm_wx<NT>(fa, w.w2 + (size_t)wave * 32 * 64, c * 8, 8, C, LD, 0, N, lane);
+    }
+    rr_add_bias<NT>(fa, w.b2, fb, lane);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) fa[nt] = x1[nt] + fa[nt];
+    rr_instnorm_tiles<NT>(fa, w.f2g, w.f2b, fb, N, lane);
+    rr_store_tiles<NT>(fa, out, RR_E, fb, N, lane);
+  }
+}
+
+extern "C" int rr_enc_layer(const EncBlockW* wrow, const EncBlockW* wcol, const float* row_in, const float* col_in,
+                            float* row_out, float* col_out, const float* D, const float* locs, int Bp, int N,
+                            float* dbg, hipStream_t st) {
+  if (Bp <= 0 || N < 2 || N > RR_MAXN || wrow == nullptr || wcol == nullptr) return RR_EINVAL;
+  dim3 grid(Bp, 2), blk(ENC_THREADS);
+  if (N <= 32) hipLaunchKernelGGL(k_enc_block<2>, grid, blk, 0, st, *wrow, *wcol, row_in, col_in, row_out, col_out, D, locs, N, dbg);
+  else if (N <= 64) hipLaunchKernelGGL(k_enc_block<4>, grid, blk, 0, st, *wrow, *wcol, row_in, col_in, row_out, col_out, D, locs, N, dbg);
+  else hipLaunchKernelGGL(k_enc_block<7>, grid, blk, 0, st, *wrow, *wcol, row_in, col_in, row_out, col_out, D, locs, N, dbg);
+  return rr_check(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// ATSP init embedding (rrnco/models/env_embeddings/atsp.py:69-91, 108-121).
+//   node = Lin(2,E)(locs); rowd/cold = sorted sampled D[i,idx] / D[idx,i]; row/col = Lin(S,E)(sorted);
+//   out = g*node + (1-g)*dist  with  g = sigmoid(Lin(2E,1)(relu(Lin(2E,2E)([node;dist]))))  (scalar gate)
+// The sampled index tensor [Bp,N,SS] is an input.
+// ------------------------------------------------------------------------------------------------
+struct InitW {
+  const float *wi, *bi;            // init_embed [E,2],[E]
+  const float *wr, *br, *wcl, *bcl;  // row_embed / col_embed [E,SS],[E]
+  const float4 *g0r, *g0c;         // gating_fc.0 packed [16 tiles][16 kk][64]
+  const float *g0rb, *g0cb;        // [2E]
+  const float *g2r, *g2c;          // gating_fc.2 weight [2E]
+  float g2rb, g2cb;                // gating_fc.2 bias
+};
+
+#define MAXSS 32
+
+template <int NT>
+__global__ __launch_bounds__(ENC_THREADS, 2) void k_atsp_init(InitW w, const float* __restrict__ D, const float* __restrict__ locs,
+                                                              const int64_t* __restrict__ sidx, float* __restrict__ row_out,
+                                                              float* __restrict__ col_out, int N, int SS) {
+  __shared__ __attribute__((aligned(16))) float smem[3 * BUF_FLOATS];
+  float* comb = smem;                      // [N][256] = [node | dist-embedding]
+  float* scr = smem + 2 * BUF_FLOATS;      // sorted samples [N][MAXSS], then gate partials [16][112]
+  float* gpart = scr + RR_MAXN * MAXSS;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const float* Db = D + (size_t)b * N * N;
+  const float* lc = locs + (size_t)b * N * 2;
+  const int64_t* sx = sidx + (size_t)b * N * SS;
+
+  for (int pass = 0; pass < 2; ++pass) {   // 0: row embedding, 1: col embedding
+    // gather + rank sort (ascending) of the SS sampled distances of every node
+    for (int e = tid; e < N * SS; e += ENC_THREADS) {
+      int i = e / SS, s = e % SS;
+      int k = (int)sx[i * SS + s];
+      float v = pass == 0 ? Db[i * N + k] : Db[k * N + i];
+      int rank = 0;
+      for (int s2 = 0; s2 < SS; ++s2) {
+        int k2 = (int)sx[i * SS + s2];
+        float v2 = pass == 0 ? Db[i * N + k2] : Db[k2 * N + i];
+        rank += (v2 < v) || (v2 == v && s2 < s);
+      }
+      scr[i * MAXSS + rank] = v;
+    }
+    __syncthreads();
+    // comb[:, 0:E] = node embedding, comb[:, E:2E] = Lin(SS,E)(sorted)
+    const float* wd = pass == 0 ? w.wr : w.wcl;
+    const float* bd = pass == 0 ? w.br : w.bcl;
+    for (int e = tid; e < N * RR_E; e += ENC_THREADS) {
+      int i = e >> 7, f = e & 127;
+      comb[i * 256 + f] = fmaf(w.wi[f * 2 + 1], lc[i * 2 + 1], w.wi[f * 2] * lc[i * 2]) + w.bi[f];
+      float acc = 0.f;
+      for (int s = 0; s < SS; ++s) acc = fmaf(wd[f * SS + s], scr[i * MAXSS + s], acc);
+      comb[i * 256 + 128 + f] = acc + bd[f];
+    }
+    __syncthreads();
+    // hidden = relu(W0 comb + b0) [2E]; gate logit = w2 . hidden + b2 ; two feature tiles per wave
+    const float4* g0 = pass == 0 ? w.g0r : w.g0c;
+    const float* g0b = pass == 0 ? w.g0rb : w.g0cb;
+    const float* g2 = pass == 0 ? w.g2r : w.g2c;
+    for (int tt = 0; tt < 2; ++tt) {
+      int t = wave + 8 * tt;
+      f32x4 h[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) h[nt] = rr_zero4();
+      rr_gemm_wx<NT>(h, g0 + (size_t)t * 16 * 64, 0, 16, comb, 256, 0, N, lane);
+      rr_add_bias<NT>(h, g0b, 16 * t, lane);
+      float4 w2v = rr_ld4(g2 + 16 * t + 4 * g);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        float p = fmaxf(h[nt][0], 0.f) * w2v.x + fmaxf(h[nt][1], 0.f) * w2v.y + fmaxf(h[nt][2], 0.f) * w2v.z +
+                  fmaxf(h[nt][3], 0.f) * w2v.w;
+        p = rr_sum_g(p);
+        if (g == 0) gpart[t * 112 + nt * 16 + j] = p;
+      }
+    }
+    __syncthreads();
+    float* outp = (pass == 0 ? row_out : col_out) + (size_t)b * N * RR_E;
+    const float g2b = pass == 0 ? w.g2rb : w.g2cb;
+    for (int e = tid; e < N * RR_E; e += ENC_THREADS) {
+      int i = e >> 7, f = e & 127;
+      float z = g2b;
+      for (int t = 0; t < 16; ++t) z += gpart[t * 112 + i];
+      float gt = 1.0f / (1.0f + expf(-z));
+      outp[e] = gt * comb[i * 256 + f] + (1.0f - gt) * comb[i * 256 + 128 + f];
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int rr_atsp_init_embed(const InitW* w, const float* D, const float* locs, const int64_t* sidx,
+                                  float* row_out, float* col_out, int Bp, int N, int SS, hipStream_t st) {
+  if (Bp <= 0 || N < 2 || N > RR_MAXN || SS < 1 || SS > MAXSS || w == nullptr) return RR_EINVAL;
+  dim3 grid(Bp), blk(ENC_THREADS);
+  if (N <= 32) hipLaunchKernelGGL(k_atsp_init<2>, grid, blk, 0, st, *w, D, locs, sidx, row_out, col_out, N, SS);
+  else if (N <= 64) hipLaunchKernelGGL(k_atsp_init<4>, grid, blk, 0, st, *w, D, locs, sidx, row_out, col_out, N, SS);
+  else hipLaunchKernelGGL(k_atsp_init<7>, grid, blk, 0, st, *w, D, locs, sidx, row_out, col_out, N, SS);
+  return rr_check(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decoder cache (rrnco/models/decoder.py:214-232) + per-node step-context tables.
+//   K, V, L = chunk3(project_node_embeddings(col_emb));  Vt = V^T zero-padded to 112 keys
+//   ctxA = Wctx[:, 0:E] row_emb   (ATSP: first-node half of TSPContext's Linear(2E,E))
+//   ctxB = Wctx[:, E:2E] row_emb  (current-node half; for the VRP contexts ctxB = Wctx[:, 0:E] row_emb
+//                                   and ctxA is unused)
+// ------------------------------------------------------------------------------------------------
+struct CacheW { const float4 *wk, *wv, *wl, *wca, *wcb; };
+
+template <int NT>
+__global__ __launch_bounds__(ENC_THREADS, 2) void k_dec_cache(CacheW w, const float* __restrict__ row_emb, const float* __restrict__ col_emb,
+                                                              float* __restrict__ K, float* __restrict__ Vt, float* __restrict__ L,
+                                                              float* __restrict__ ctxA, float* __restrict__ ctxB, int N) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * BUF_FLOATS];
+  float* R = smem; float* Cc = smem + BUF_FLOATS;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, g = lane >> 4, fb = 16 * wave;
+  const size_t off = (size_t)b * N * RR_E;
+  for (int i = tid; i < N * (RR_E / 4); i += ENC_THREADS) {
+    rr_st4(R + i * 4, rr_ld4(row_emb + off + i * 4));
+    rr_st4(Cc + i * 4, rr_ld4(col_emb + off + i * 4));
+  }
+  __syncthreads();
+  f32x4 a[NT];
+  auto run = [&](const float4* wp, const float* X) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) a[nt] = rr_zero4();
+    rr_gemm_wx<NT>(a, wp + (size_t)wave * 8 * 64, 0, 8, X, LD, 0, N, lane);
+  };
+  run(w.wk, Cc); rr_store_tiles<NT>(a, K + off, RR_E, fb, N, lane);
+  run(w.wl, Cc); rr_store_tiles<NT>(a, L + off, RR_E, fb, N, lane);
+  run(w.wv, Cc);
+  {  // Vt[b][feature][key], keys padded to 112 with zeros
+    float* vt = Vt + (size_t)b * RR_E * 112;
+#pragma unroll
+    for (int nt = 0; nt < RR_NT; ++nt) {
+      int node = nt * 16 + j;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = 0.f;
+        if (nt < NT && node < N) v = a[nt < NT ? nt : 0][r];
+        vt[(fb + 4 * g + r) * 112 + node] = v;
+      }
+    }
+  }
+  if (w.wca) { run(w.wca, R); rr_store_tiles<NT>(a, ctxA + off, RR_E, fb, N, lane); }
+  run(w.wcb, R); rr_store_tiles<NT>(a, ctxB + off, RR_E, fb, N, lane);
+}
+
+extern "C" int rr_dec_cache(const CacheW* w, const float* row_emb, const float* col_emb, float* K, float* Vt, float* L,
+                            float* ctxA, float* ctxB, int Bp, int N, hipStream_t st) {
+  if (Bp <= 0 || N < 2 || N > RR_MAXN || w == nullptr) return RR_EINVAL;
+  dim3 grid(Bp), blk(ENC_THREADS);
+  if (N <= 32) hipLaunchKernelGGL(k_dec_cache<2>, grid, blk, 0, st, *w, row_emb, col_emb, K, Vt, L, ctxA, ctxB, N);
+  else if (N <= 64) hipLaunchKernelGGL(k_dec_cache<4>, grid, blk, 0, st, *w, row_emb, col_emb, K, Vt, L, ctxA, ctxB, N);
+  else hipLaunchKernelGGL(k_dec_cache<7>, grid, blk, 0, st, *w, row_emb, col_emb, K, Vt, L, ctxA, ctxB, N);
+  return rr_check(hipGetLastError());
+}

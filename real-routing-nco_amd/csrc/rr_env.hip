@@ -1,0 +1,240 @@
+// Environment-side kernels of the RRNCO rollout: reset normalisation, masked env.step for
+// ATSP / RCVRP / RCVRPTW, tour cost (reward) and the logits -> action selection step.
+// All integer / boolean outputs are bit-exact restatements of the reference; see include/rrnco_hip.h
+// for the reference file:line each entry point replaces.
+#include "rr_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// min-max normalisation of a [B, M] batch of matrices (rrnco/envs/atsp/env.py:113-120)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_minmax_normalize(const float* __restrict__ in, float* __restrict__ out,
+                                                          float* __restrict__ mn_out, float* __restrict__ mx_out, int M) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* src = in + (size_t)b * M;
+  float* dst = out + (size_t)b * M;
+  float mn = INFINITY, mx = -INFINITY;
+  for (int i = tid; i < M; i += 256) { float v = src[i]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+  mn = rr_wave_min(mn); mx = rr_wave_max(mx);
+  __shared__ float smn[4], smx[4];
+  if ((tid & 63) == 0) { smn[tid >> 6] = mn; smx[tid >> 6] = mx; }
+  __syncthreads();
+  mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+  mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+  const float den = (mx - mn) + 1e-6f;
+  for (int i = tid; i < M; i += 256) dst[i] = (src[i] - mn) / den;
+  if (tid == 0) { mn_out[b] = mn; mx_out[b] = mx; }
+}
+
+extern "C" int rr_minmax_normalize(const float* in, float* out, float* mn, float* mx, int B, int M, hipStream_t st) {
+  if (B <= 0 || M <= 0) return RR_EINVAL;
+  hipLaunchKernelGGL(k_minmax_normalize, dim3(B), dim3(256), 0, st, in, out, mn, mx, M);
+  return rr_check(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// ATSP step (rrnco/envs/atsp/env.py:80-105): available[r, action[r]] = 0; done = no node left
+// one wave per rollout row; mask is uint8 (torch.bool storage)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_atsp_step(const int64_t* __restrict__ action, const uint8_t* __restrict__ mask_in,
+                                                   uint8_t* __restrict__ mask_out, uint8_t* __restrict__ done, int R, int N) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const int a = (int)action[r];
+  int cnt = 0;
+  for (int j = lane; j < N; j += 64) {
+    uint8_t m = mask_in[(size_t)r * N + j];
+    if (j == a) m = 0;
+    mask_out[(size_t)r * N + j] = m;
+    cnt += (m != 0);
+  }
+  cnt = (int)rr_wave_sum((float)cnt);
+  if (lane == 0) done[r] = (cnt <= 0);
+}
+
+extern "C" int rr_atsp_step(const int64_t* action, const uint8_t* mask_in, uint8_t* mask_out, uint8_t* done,
+                            int R, int N, hipStream_t st) {
+  if (R <= 0 || N <= 0) return RR_EINVAL;
+  hipLaunchKernelGGL(k_atsp_step, dim3((R + 3) / 4), dim3(256), 0, st, action, mask_in, mask_out, done, R, N);
+  return rr_check(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// RCVRP step + action mask (rrnco/envs/rcvrp/env.py:90-122, 183-195).  One wave per rollout.
+//   demand [Bp, N] (customers, shared by the S starts: rollout r uses instance r % Bp)
+//   used_capacity / vehicle_capacity [R] f32, visited [R, N+1] u8, action_mask [R, N+1] u8
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rcvrp_step(const int64_t* __restrict__ action, const float* __restrict__ demand,
+                                                    const float* __restrict__ vcap, float* __restrict__ used,
+                                                    uint8_t* __restrict__ visited, uint8_t* __restrict__ mask,
+                                                    int64_t* __restrict__ cur_out, uint8_t* __restrict__ done,
+                                                    int R, int Bp, int N /*customers*/) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const int b = r % Bp;
+  const int a = (int)action[r];
+  const float* dem = demand + (size_t)b * N;
+  int ci = a - 1; ci = ci < 0 ? 0 : (ci > N - 1 ? N - 1 : ci);
+  const float sel = dem[ci];
+  const float u = (used[r] + sel) * (a != 0 ? 1.0f : 0.0f);
+  const float cap = vcap[r];
+  uint8_t* vis = visited + (size_t)r * (N + 1);
+  uint8_t* mk = mask + (size_t)r * (N + 1);
+  int nvis = 0, nfree = 0;
+  for (int j = lane; j <= N; j += 64) {
+    uint8_t v = vis[j];
+    if (j == a) v = 1;
+    vis[j] = v;
+    nvis += (v != 0);
+    if (j >= 1) {
+      bool exceeds = dem[j - 1] + u > cap;
+      bool mloc = (v != 0) || exceeds;
+      mk[j] = !mloc;
+      nfree += !mloc;
+    }
+  }
+  nvis = (int)rr_wave_sum((float)nvis);
+  nfree = (int)rr_wave_sum((float)nfree);
+  if (lane == 0) {
+    bool mask_depot = (a == 0) && (nfree > 0);
+    mk[0] = !mask_depot;
+    used[r] = u;
+    cur_out[r] = a;
+    done[r] = (nvis == N + 1);
+  }
+}
+
+extern "C" int rr_rcvrp_step(const int64_t* action, const float* demand, const float* vcap, float* used,
+                             uint8_t* visited, uint8_t* mask, int64_t* cur_out, uint8_t* done,
+                             int R, int Bp, int N, hipStream_t st) {
+  if (R <= 0 || N <= 0 || Bp <= 0) return RR_EINVAL;
+  hipLaunchKernelGGL(k_rcvrp_step, dim3((R + 3) / 4), dim3(256), 0, st, action, demand, vcap, used, visited, mask,
+                     cur_out, done, R, Bp, N);
+  return rr_check(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tour cost (reward): mode 0 closed tour (atsp/env.py:192-211), mode 1 depot-prefixed open list that
+// returns to the depot (rcvrp/env.py:197-219, rmtvrp/env.py:430-455).  One wave per rollout.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tour_cost(const float* __restrict__ D, const int64_t* __restrict__ actions,
+                                                   const float* __restrict__ mn, const float* __restrict__ mx,
+                                                   float* __restrict__ norm_out, float* __restrict__ real_out,
+                                                   int R, int Bp, int N, int T, int mode) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const int b = r % Bp;
+  const float* Db = D + (size_t)b * N * N;
+  const int64_t* act = actions + (size_t)r * T;
+  float s = 0.f;
+  if (mode == 0) {
+    for (int t = lane; t < T; t += 64) {
+      int u = (int)act[t], v = (int)act[t + 1 < T ? t + 1 : 0];
+      s += Db[u * N + v];
+    }
+  } else {
+    // edges: (0 -> a_0), (a_t -> a_{t+1}), (a_{T-1} -> 0)
+    for (int t = lane; t <= T; t += 64) {
+      int u = t == 0 ? 0 : (int)act[t - 1];
+      int v = t == T ? 0 : (int)act[t];
+      s += Db[u * N + v];
+    }
+  }
+  s = rr_wave_sum(s);
+  if (lane == 0) {
+    float nd = -s;
+    norm_out[r] = nd;
+    if (mn != nullptr) real_out[r] = nd * ((mx[b] - mn[b]) + 1e-6f) + mn[b];
+    else real_out[r] = nd;
+  }
+}
+
+extern "C" int rr_tour_cost(const float* D, const int64_t* actions, const float* mn, const float* mx,
+                            float* norm_out, float* real_out, int R, int Bp, int N, int T, int mode, hipStream_t st) {
+  if (R <= 0 || N <= 0 || T <= 0 || Bp <= 0) return RR_EINVAL;
+  hipLaunchKernelGGL(k_tour_cost, dim3((R + 3) / 4), dim3(256), 0, st, D, actions, mn, mx, norm_out, real_out, R, Bp, N, T, mode);
+  return rr_check(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// logits -> (action, logp): process_logits + greedy / sampling / evaluate
+// (rrnco/models/decoding.py:311-361, 272-298, 266).  One wave per row, N <= 128.
+// mode: 0 greedy (first index on ties), 1 sampling (inverse-CDF on a counter-based uniform),
+//       2 evaluate (action given).  logp_all (optional) receives the full log-softmax row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits, const uint8_t* __restrict__ mask,
+                                                const int64_t* __restrict__ action_in, int64_t* __restrict__ action_out,
+                                                float* __restrict__ logp_out, float* __restrict__ logp_all,
+                                                int R, int N, float tanh_clip, float temperature, int mode,
+                                                uint64_t seed, uint32_t step) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  float x[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    int j = lane + 64 * q;
+    float v = -INFINITY;
+    if (j < N) {
+      v = logits[(size_t)r * N + j];
+      if (tanh_clip > 0.f) v = tanhf(v) * tanh_clip;
+      if (mask != nullptr && mask[(size_t)r * N + j] == 0) v = -INFINITY;
+      v = v / temperature;
+    }
+    x[q] = v;
+  }
+  float m = rr_wave_max(fmaxf(x[0], x[1]));
+  float e0 = (lane < N) ? expf(x[0] - m) : 0.f;
+  float e1 = (lane + 64 < N) ? expf(x[1] - m) : 0.f;
+  float ssum = rr_wave_sum(e0 + e1);
+  float lse = logf(ssum);
+  float lp0 = x[0] - m - lse, lp1 = x[1] - m - lse;
+  if (logp_all != nullptr) {
+    if (lane < N) logp_all[(size_t)r * N + lane] = lp0;
+    if (lane + 64 < N) logp_all[(size_t)r * N + lane + 64] = lp1;
+  }
+  int sel;
+  if (mode == 2) {
+    sel = (int)action_in[r];
+  } else if (mode == 0) {
+    // argmax, lowest index on ties (torch.argmax on CPU returns the first maximal index)
+    float bv = lp0; int bi = lane;
+    if (lane + 64 < N && lp1 > bv) { bv = lp1; bi = lane + 64; }
+    if (lane >= N) { bv = -INFINITY; bi = 0x7fffffff; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      float ov = __shfl_xor(bv, o); int oi = __shfl_xor(bi, o);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    sel = bi;
+  } else {
+    // Gumbel-max: argmax(logp + G) is an exact draw from softmax(logits); same noise keying as the
+    // fused rollout kernel so both paths draw identical actions for a given (seed, rollout, step)
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    if (lane < N && lp0 > -INFINITY) { bv = lp0 + rr_gumbel(seed, (uint32_t)r, step, (uint32_t)lane); bi = lane; }
+    if (lane + 64 < N && lp1 > -INFINITY) {
+      float v1 = lp1 + rr_gumbel(seed, (uint32_t)r, step, (uint32_t)(lane + 64));
+      if (v1 > bv) { bv = v1; bi = lane + 64; }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      float ov = __shfl_xor(bv, o); int oi = __shfl_xor(bi, o);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    sel = bi;
+  }
+  float lpsel = (sel & 64) ? __shfl(lp1, sel & 63) : __shfl(lp0, sel & 63);
+  if (lane == 0) { action_out[r] = sel; logp_out[r] = lpsel; }
+}
+
+extern "C" int rr_select(const float* logits, const uint8_t* mask, const int64_t* action_in, int64_t* action_out,
+                         float* logp_out, float* logp_all, int R, int N, float tanh_clip, float temperature,
+                         int mode, uint64_t seed, uint32_t step, hipStream_t st) {
+  if (R <= 0 || N <= 0 || N > 128 || temperature <= 0.f) return RR_EINVAL;
+  if (mode == 2 && action_in == nullptr) return RR_EINVAL;
+  hipLaunchKernelGGL(k_select, dim3((R + 3) / 4), dim3(256), 0, st, logits, mask, action_in, action_out, logp_out,
+                     logp_all, R, N, tanh_clip, temperature, mode, seed, step);
+  return rr_check(hipGetLastError());
+}

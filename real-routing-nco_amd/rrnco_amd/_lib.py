@@ -1,0 +1,101 @@
+"""ctypes binding of the C-ABI hot-path library (csrc/librrnco_hip.so, declared in include/rrnco_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or a launch fails, we raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "librrnco_hip.so")
+
+vp, i32, f32, u64, u32 = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint32
+
+
+class EncBlockW(C.Structure):
+    _fields_ = [(n, vp) for n in (
+        "n1g", "n1b", "n2g", "n2b", "n3g", "n3b", "f1g", "f1b", "f2g", "f2b",
+        "wq", "wk", "wv", "wp", "wc", "w1", "w2",
+        "bq", "bk", "bv", "bp", "bc", "b1", "b2", "nab")]
+
+
+class InitW(C.Structure):
+    _fields_ = [(n, vp) for n in ("wi", "bi", "wr", "br", "wcl", "bcl", "g0r", "g0c", "g0rb", "g0cb", "g2r", "g2c")] + \
+               [("g2rb", f32), ("g2cb", f32)]
+
+
+class CacheW(C.Structure):
+    _fields_ = [(n, vp) for n in ("wk", "wv", "wl", "wca", "wcb")]
+
+
+class DecW(C.Structure):
+    _fields_ = [(n, vp) for n in ("w1", "w2", "b1", "b2", "q0", "wstate")] + [("alpha", f32), ("beta", f32)]
+
+
+class RolloutIO(C.Structure):
+    _fields_ = [(n, vp) for n in (
+        "K", "Vt", "L", "ctxA", "ctxB", "D", "Dur", "demand", "cur", "first", "mask", "visited", "used", "vcap",
+        "done", "actions", "logp", "logits_out", "actions_in", "steps_out")] + \
+        [(n, i32) for n in ("Bp", "N", "S", "T", "t0", "nsteps", "mode", "use_placeholder", "set_first",
+                            "write_state", "logits_only")] + \
+        [("tanh_clip", f32), ("temperature", f32), ("seed", u64)]
+
+
+_SIGS = {
+    "rr_minmax_normalize": [vp, vp, vp, vp, i32, i32, vp],
+    "rr_atsp_step": [vp, vp, vp, vp, i32, i32, vp],
+    "rr_rcvrp_step": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "rr_tour_cost": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "rr_select": [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, u64, u32, vp],
+    "rr_enc_layer": [C.POINTER(EncBlockW), C.POINTER(EncBlockW), vp, vp, vp, vp, vp, vp, i32, i32, vp, vp],
+    "rr_atsp_init_embed": [C.POINTER(InitW), vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "rr_dec_cache": [C.POINTER(CacheW), vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "rr_rollout": [C.POINTER(DecW), C.POINTER(RolloutIO), i32, vp],
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"rrnco_amd: HIP library not built: {LIB_PATH} (run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C real-routing-nco_amd/csrc`). There is no CPU fallback.")
+        _lib = C.CDLL(LIB_PATH)
+        for name, args in _SIGS.items():
+            fn = getattr(_lib, name)
+            fn.argtypes = args
+            fn.restype = i32
+    return _lib
+
+
+def exported_symbols():
+    return list(_SIGS)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "rrnco_amd kernels need contiguous tensors"
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"rrnco_amd: {what} failed with status {rc} (-1 invalid argument, -2 HIP launch error)")
+
+
+def require_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError("rrnco_amd: the MI355X hot path needs tensors on a ROCm device (no CPU fallback)")

@@ -1,0 +1,156 @@
+"""RRNetEncoder — drop-in for rrnco.models.encoder.RRNetEncoder (rrnco/models/encoder.py:80-112).
+
+The module tree exists to own the parameters under the reference's state_dict names (so the published
+checkpoints load with `load_state_dict`); `forward` runs the HIP kernels of csrc/rr_encoder.hip.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+
+
+class _Norm(nn.Module):          # Normalization('instance') attn_freenet.py:78-116 -> `.normalizer.{weight,bias}`
+    def __init__(self, E):
+        super().__init__()
+        self.normalizer = nn.InstanceNorm1d(E, affine=True)
+
+
+class _MLP1(nn.Sequential):      # nn.Sequential(Linear(1,E), ReLU, Linear(E,E))  attn_freenet.py:216-225
+    def __init__(self, E):
+        super().__init__(nn.Linear(1, E), nn.ReLU(), nn.Linear(E, E))
+
+
+class _DistAngleFusion(nn.Module):   # attn_freenet.py:201-240 (no duration)
+    def __init__(self, E):
+        super().__init__()
+        self.dist_emb, self.angle_emb = _MLP1(E), _MLP1(E)
+        self.gate = nn.Sequential(nn.Linear(2 * E, 1), nn.Sigmoid())
+        self.out_lin = nn.Linear(E, 1)
+
+
+class _AFT(nn.Module):           # AFTFull attn_freenet.py:292-307
+    def __init__(self, E):
+        super().__init__()
+        self.to_q, self.to_k, self.to_v, self.project = (nn.Linear(E, E) for _ in range(4))
+
+
+class _FFN(nn.Module):           # FeedForward attn_freenet.py:524-536
+    def __init__(self, E, ff):
+        super().__init__()
+        self.W1, self.W2 = nn.Linear(E, ff), nn.Linear(ff, E)
+
+
+class _TransformerFFN(nn.Module):  # attn_freenet.py:330-357
+    def __init__(self, E, ff):
+        super().__init__()
+        self.ops = nn.ModuleDict({"norm1": _Norm(E), "ffn": _FFN(E, ff), "norm2": _Norm(E)})
+
+
+class _Block(nn.Module):         # AttnFree_Block attn_freenet.py:360-415
+    def __init__(self, E, ff):
+        super().__init__()
+        self.alpha = nn.Parameter(torch.ones(1))
+        self.attn_free = _AFT(E)
+        self.multi_head_combine = nn.Linear(E, E)
+        self.angle_distance_fusion = _DistAngleFusion(E)
+        self.feed_forward = _TransformerFFN(E, ff)
+        self.norm1, self.norm2, self.norm3 = _Norm(E), _Norm(E), _Norm(E)
+
+
+class _Layer(nn.Module):         # Attn_Free_Layer attn_freenet.py:444-470
+    def __init__(self, E, ff):
+        super().__init__()
+        self.row_encoding_block, self.col_encoding_block = _Block(E, ff), _Block(E, ff)
+
+
+class AttnFreeNet(nn.Module):    # attn_freenet.py:491-515
+    def __init__(self, embed_dim=128, feedforward_hidden=512, num_layers=3, **unused):
+        super().__init__()
+        self.layers = nn.ModuleList([_Layer(embed_dim, feedforward_hidden) for _ in range(num_layers)])
+
+
+class _Gating(nn.Module):        # ContextualGating env_embeddings/atsp.py:108-121
+    def __init__(self, E):
+        super().__init__()
+        self.gating_fc = nn.Sequential(nn.Linear(2 * E, 2 * E), nn.ReLU(), nn.Linear(2 * E, 1))
+
+
+class ATSPInitEmbedding(nn.Module):   # env_embeddings/atsp.py:5-35
+    def __init__(self, embed_dim, linear_bias=True, use_coords=True, use_polar_feats=False, use_dist=True,
+                 use_matnet_init=True, sample_type="prob", sample_size=25):
+        super().__init__()
+        if not (use_coords and use_dist and sample_type == "prob"):
+            raise NotImplementedError("rrnco_amd implements the RRNet configuration: use_coords, use_dist, sample_type='prob'")
+        self.sample_size = sample_size
+        self.init_embed = nn.Linear(2, embed_dim, linear_bias)
+        self.row_embed = nn.Linear(sample_size, embed_dim, linear_bias)
+        self.col_embed = nn.Linear(sample_size, embed_dim, linear_bias)
+        self.gating_network_row, self.gating_network_col = _Gating(embed_dim), _Gating(embed_dim)
+
+    @staticmethod
+    def sample_indices(distance, sample_size):
+        """env_embeddings/atsp.py:55-67: multinomial without replacement on 1/(d+1e-6), diagonal 1e6."""
+        B, N, _ = distance.shape
+        ar = torch.arange(N, device=distance.device)
+        pd = distance.clone()
+        pd[:, ar, ar] = 1e6
+        inv = 1 / (pd + 1e-6)
+        prob = (inv / inv.sum(dim=-1, keepdim=True)).reshape(B * N, -1)
+        return torch.multinomial(prob, sample_size, replacement=False).reshape(B, N, sample_size)
+
+
+class RRNetEncoder(nn.Module):
+    def __init__(self, embed_dim=128, init_embedding=None, init_embedding_kwargs=None, env_name="rcvrp",
+                 num_heads=8, num_layers=3, normalization="batch", feedforward_hidden=512, net=None,
+                 sdpa_fn=None, moe_kwargs=None, use_coords=False, use_polar_feats=False, nab_type="gating"):
+        super().__init__()
+        if embed_dim != 128 or feedforward_hidden != 512:
+            raise NotImplementedError("rrnco_amd kernels are specialised for embed_dim=128, feedforward_hidden=512")
+        if normalization != "instance" or nab_type != "gating":
+            raise NotImplementedError("rrnco_amd implements normalization='instance', nab_type='gating' (configs/experiment/rrnet.yaml)")
+        self.env_name = getattr(env_name, "name", env_name)
+        kw = dict(init_embedding_kwargs or {})
+        if init_embedding is not None:
+            self.init_embedding = init_embedding
+        elif self.env_name == "atsp":
+            self.init_embedding = ATSPInitEmbedding(embed_dim, **kw)
+        else:
+            from .vrp_embeddings import make_vrp_init_embedding
+            self.init_embedding = make_vrp_init_embedding(self.env_name, embed_dim, **kw)
+        self.net = AttnFreeNet(embed_dim, feedforward_hidden, num_layers) if net is None else net
+
+    def forward(self, td, phase: str = "val", mask=None, packed=None):
+        """-> (row_emb, col_emb) [B,N,E].  `packed` = packing.pack_policy(...) (the policy caches it)."""
+        assert packed is not None, "RRNetEncoder.forward needs packed weights (call through RRNetPolicy or pass packed=)"
+        D = td["distance_matrix"].contiguous()
+        L.require_gpu(D)
+        locs = td["locs"].float().contiguous()
+        Bp, N = D.shape[0], D.shape[-1]
+        dev = D.device
+        lib = L.lib()
+        row = torch.empty(Bp, N, 128, device=dev, dtype=torch.float32)
+        col = torch.empty_like(row)
+        if self.env_name == "atsp":
+            sidx = td.get("sample_idx", None)
+            if sidx is None:
+                sidx = ATSPInitEmbedding.sample_indices(D, self.init_embedding.sample_size)
+            sidx = sidx.contiguous()
+            L.check(lib.rr_atsp_init_embed(packed["init"], L.ptr(D), L.ptr(locs), L.ptr(sidx), L.ptr(row), L.ptr(col),
+                                           Bp, N, sidx.shape[-1], L.stream()), "rr_atsp_init_embed")
+        else:
+            from .vrp_embeddings import run_vrp_init_embedding
+            run_vrp_init_embedding(self, td, packed, row, col)
+        self._last_init = (row, col)
+        row2, col2 = torch.empty_like(row), torch.empty_like(col)
+        dbg = getattr(self, "_debug_buffer", None)
+        for l, (wr, wc) in enumerate(packed["blocks"]):
+            L.check(lib.rr_enc_layer(wr, wc, L.ptr(row), L.ptr(col), L.ptr(row2), L.ptr(col2), L.ptr(D), L.ptr(locs),
+                                     Bp, N, L.ptr(dbg) if (dbg is not None and l == 0) else None, L.stream()),
+                    "rr_enc_layer")
+            if l == 0 and dbg is not None:
+                row, col, row2, col2 = row2, col2, torch.empty_like(row), torch.empty_like(col)
+            else:
+                row, col, row2, col2 = row2, col2, row, col
+        return row, col

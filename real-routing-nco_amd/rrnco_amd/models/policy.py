@@ -1,0 +1,129 @@
+"""RRNetPolicy — drop-in for rrnco.models.policy.RRNetPolicy (rrnco/models/policy.py:138-255)."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import packing
+from ..ops import get_log_likelihood
+from .decoder import RRNetDecoder
+from .decoding import get_decoding_strategy
+from .encoder import RRNetEncoder
+from .rollout import PROB_ID, launch_rollout
+
+
+class RRNetPolicy(nn.Module):
+    def __init__(self, encoder=None, decoder=None, embed_dim=128, num_encoder_layers=3, num_heads=8,
+                 normalization="batch", feedforward_hidden=512, env_name="rcvrp", encoder_network=None,
+                 init_embedding=None, init_embedding_kwargs={}, context_embedding=None, dynamic_embedding=None,
+                 use_graph_context=True, linear_bias_decoder=False, sdpa_fn=None, sdpa_fn_encoder=None,
+                 sdpa_fn_decoder=None, mask_inner=True, out_bias_pointer_attn=False, check_nan=True,
+                 temperature=1.0, tanh_clipping=10.0, mask_logits=True, train_decode_type="sampling",
+                 val_decode_type="greedy", test_decode_type="greedy", moe_kwargs={"encoder": None, "decoder": None},
+                 nab_type="gating", **unused_kwargs):
+        super().__init__()
+        self.encoder = encoder if encoder is not None else RRNetEncoder(
+            embed_dim=embed_dim, num_heads=num_heads, num_layers=num_encoder_layers, env_name=env_name,
+            normalization=normalization, feedforward_hidden=feedforward_hidden, net=encoder_network,
+            init_embedding=init_embedding, init_embedding_kwargs=init_embedding_kwargs, nab_type=nab_type)
+        self.decoder = decoder if decoder is not None else RRNetDecoder(
+            embed_dim=embed_dim, num_heads=num_heads, env_name=env_name, mask_inner=mask_inner,
+            out_bias_pointer_attn=out_bias_pointer_attn, linear_bias=linear_bias_decoder,
+            use_graph_context=use_graph_context, check_nan=check_nan)
+        self.env_name = getattr(env_name, "name", env_name)
+        self.temperature, self.tanh_clipping, self.mask_logits = temperature, tanh_clipping, mask_logits
+        self.train_decode_type, self.val_decode_type, self.test_decode_type = \
+            train_decode_type, val_decode_type, test_decode_type
+        self._pack_cache = None
+
+    # ---- packed (MFMA-ordered / folded) weights, rebuilt when any parameter changes
+    def packed(self, device):
+        key = (str(device), tuple(p._version for p in self.parameters()), tuple(p.data_ptr() for p in self.parameters()))
+        if self._pack_cache is None or self._pack_cache[0] != key:
+            self._pack_cache = (key, packing.pack_policy(self.state_dict(), self.env_name, device))
+        return self._pack_cache[1]
+
+    @torch.no_grad()
+    def forward(self, td, env=None, phase="train", calc_reward=True, return_actions=True, return_entropy=False,
+                return_hidden=False, return_init_embeds=False, return_sum_log_likelihood=True, actions=None,
+                max_steps=1_000_000, fused=True, **decoding_kwargs) -> dict:
+        if env is None or isinstance(env, str):
+            raise ValueError("pass an instantiated rrnco_amd env")
+        if return_entropy:
+            raise NotImplementedError("return_entropy (store_all_logp) is available through fused=False only")
+        packed = self.packed(td.device)
+        row_emb, col_emb = self.encoder(td, phase=phase, packed=packed)
+
+        decode_type = decoding_kwargs.pop("decode_type", None)
+        if actions is not None:
+            decode_type = "evaluate"
+        elif decode_type is None:
+            decode_type = getattr(self, f"{phase}_decode_type")
+        strategy = get_decoding_strategy(
+            decode_type, temperature=decoding_kwargs.pop("temperature", self.temperature),
+            tanh_clipping=decoding_kwargs.pop("tanh_clipping", self.tanh_clipping),
+            mask_logits=decoding_kwargs.pop("mask_logits", self.mask_logits),
+            store_all_logp=decoding_kwargs.pop("store_all_logp", return_entropy), **decoding_kwargs)
+
+        td, env, num_starts = strategy.pre_decoder_hook(td, env)
+        td, env, cache = self.decoder.pre_decoder_hook(td, env, (row_emb, col_emb), num_starts, packed=packed)
+
+        if fused and self.env_name in PROB_ID and strategy.mask_logits:
+            logprobs, actions_out, td = self._fused_rollout(td, env, cache, packed, strategy, actions)
+        else:
+            step = 0
+            while not td["done"].all():
+                logits, mask = self.decoder(td, cache, num_starts, packed=packed)
+                td = strategy.step(logits, mask, td, action=actions[..., step] if actions is not None else None)
+                td = env.step(td)["next"]
+                step += 1
+                if step > max_steps:
+                    break
+            logprobs, actions_out, td, env = strategy.post_decoder_hook(td, env)
+
+        if calc_reward:
+            if env.normalize:
+                real, normd = env.get_reward(td, actions_out)
+                td.set("reward", real)
+            else:
+                td.set("reward", env.get_reward(td, actions_out))
+        out = {"reward": td["reward"],
+               "log_likelihood": get_log_likelihood(logprobs, actions_out, td.get("mask", None), return_sum_log_likelihood)}
+        if calc_reward and env.normalize:
+            out["normalized_reward"] = normd
+        if return_actions:
+            out["actions"] = actions_out
+        if return_hidden:
+            out["hidden"] = cache
+        return out
+
+    def _fused_rollout(self, td, env, cache, packed, strategy, actions_in):
+        """The whole `while not done` loop of policy.py:210-228 as ONE kernel launch."""
+        R, N = td["action_mask"].shape
+        dev = td.device
+        t0 = len(strategy.actions)                      # 1 after a multistart hook, else 0
+        if self.env_name == "atsp":
+            T, nsteps = N, N - t0
+        else:
+            T, nsteps = 2 * N + 2, 0                    # data-dependent; trimmed to the longest rollout below
+        acts = torch.zeros(R, T, dtype=torch.int64, device=dev)
+        logp = torch.zeros(R, T, dtype=torch.float32, device=dev)
+        if t0:
+            acts[:, 0] = strategy.actions[0]
+        steps_out = torch.zeros(1, dtype=torch.int32, device=dev)
+        ain = None
+        if actions_in is not None:                      # evaluate: actions[..., step] feeds decode step `step`
+            ain = torch.zeros(R, T, dtype=torch.int64, device=dev)
+            ain[:, t0:t0 + actions_in.shape[1]] = actions_in
+        st = launch_rollout(self.env_name, packed, cache, td, strategy.num_starts, actions=acts, logp=logp, t0=t0,
+                            nsteps=nsteps, mode=strategy.mode, actions_in=ain, write_state=True,
+                            tanh_clip=strategy.tanh_clipping, temperature=strategy.temperature, seed=strategy.seed,
+                            steps_out=steps_out)
+        if self.env_name != "atsp":
+            T_used = t0 + int(steps_out.item())
+            acts, logp = acts[:, :T_used].contiguous(), logp[:, :T_used].contiguous()
+        td.update({"current_node": st["cur"], "action_mask": st["mask"].bool(), "action": acts[:, -1]})
+        if st["first"] is not None:
+            td.set("first_node", st["first"])
+        td.set("done", torch.ones(R, dtype=torch.bool, device=dev))
+        return logp, acts, td

@@ -1,0 +1,59 @@
+"""Host launcher of the persistent rollout kernel (csrc/rr_decode.hip)."""
+from __future__ import annotations
+
+import torch
+
+from .. import _lib as L
+
+PROB_ID = {"atsp": 0, "rcvrp": 1}
+MODE_ID = {"greedy": 0, "sampling": 1, "evaluate": 2}
+
+
+def launch_rollout(env_name, packed, cache, td, num_starts, *, actions=None, logp=None, t0=0, nsteps=1,
+                   mode="greedy", actions_in=None, logits_out=None, logits_only=False, write_state=False,
+                   tanh_clip=10.0, temperature=1.0, seed=0, steps_out=None, state=None):
+    """Runs `nsteps` decode steps (nsteps <= 0: until every rollout is done) for all rollouts of `td`.
+    `td` is the batchified rollout state (R = S*Bp rows, per-instance keys left at Bp rows)."""
+    if env_name not in PROB_ID:
+        raise NotImplementedError(f"fused rollout for env '{env_name}'")
+    D = td["distance_matrix"]
+    Bp, N = D.shape[0], D.shape[-1]
+    mask = td["action_mask"]
+    R = mask.shape[0]
+    S = max(R // Bp, 1)
+    assert S * Bp == R
+    io = L.RolloutIO()
+    st = state if state is not None else {}
+    cur = st.get("cur")
+    if cur is None:
+        cur = td["current_node"].reshape(-1).contiguous()
+    first = st.get("first")
+    if first is None and "first_node" in td:
+        first = td["first_node"].reshape(-1).contiguous()
+    io.K, io.Vt, io.L = L.ptr(cache.glimpse_key), L.ptr(cache.glimpse_val_t), L.ptr(cache.logit_key)
+    io.ctxA, io.ctxB = L.ptr(cache.ctx_a), L.ptr(cache.ctx_b)
+    io.D, io.Dur = L.ptr(D.contiguous()), None
+    io.cur, io.first = L.ptr(cur), L.ptr(first)
+    mask = mask.contiguous()
+    io.mask = L.ptr(mask)
+    keep = [cur, first, mask]
+    if env_name == "rcvrp":
+        dem, vis = td["demand"].contiguous(), td["visited"].contiguous()
+        used, vcap = td["used_capacity"].reshape(-1).contiguous(), td["vehicle_capacity"].reshape(-1).contiguous()
+        io.demand, io.visited, io.used, io.vcap = L.ptr(dem), L.ptr(vis), L.ptr(used), L.ptr(vcap)
+        keep += [dem, vis, used, vcap]
+    done = td["done"].reshape(-1).contiguous() if "done" in td and td["done"].numel() == R else None
+    io.done = L.ptr(done)
+    io.actions, io.logp = L.ptr(actions), L.ptr(logp)
+    io.logits_out, io.actions_in = L.ptr(logits_out), L.ptr(actions_in)
+    io.steps_out = L.ptr(steps_out)
+    io.Bp, io.N, io.S = Bp, N, S
+    io.T = actions.shape[1] if actions is not None else 1
+    io.t0, io.nsteps = t0, nsteps
+    io.mode = MODE_ID[mode]
+    io.use_placeholder = int(env_name == "atsp" and td.meta.get("i", 1) == 0)
+    io.set_first = int(env_name == "atsp" and td.meta.get("i", 1) == 0)
+    io.write_state, io.logits_only = int(write_state), int(logits_only)
+    io.tanh_clip, io.temperature, io.seed = float(tanh_clip), float(temperature), int(seed)
+    L.check(L.lib().rr_rollout(packed["dec"], io, PROB_ID[env_name], L.stream()), "rr_rollout")
+    return {"cur": cur, "first": first, "mask": mask, "done": done, "keep": keep}

@@ -1,0 +1,115 @@
+"""Weight preparation for the HIP kernels: MFMA A-operand packing and algebraic folding of the NAB.
+
+Nothing here touches per-instance data; it runs once per set of weights (cached on the policy).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _lib as L
+
+E = 128
+
+
+def pack_a(Wm: torch.Tensor) -> torch.Tensor:
+    """[M,K] -> [M/16, K/16, 64, 4] float32: lane (i = l&15, g = l>>4) of tile t, k-group kk holds
+    W[16t+i][16kk+4g+m], m = 0..3 (csrc/rr_common.h).  M, K zero-padded to multiples of 16."""
+    M, K = Wm.shape
+    Mp, Kp = (M + 15) // 16 * 16, (K + 15) // 16 * 16
+    Wp = torch.zeros(Mp, Kp, dtype=torch.float32, device=Wm.device)
+    Wp[:M, :K] = Wm
+    x = Wp.view(Mp // 16, 16, Kp // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous()
+    return x.view(Mp // 16, Kp // 16, 64, 4)
+
+
+def fold_nab(sd, p: str, alpha: torch.Tensor) -> torch.Tensor:
+    """DistAngleFusion without duration (attn_freenet.py:242-289) -> [8*E + 8] coefficients.
+    wo.(W2 h + b2) = (W2^T wo).h + wo.b2, same for the two gate halves; folded in float64."""
+    d = lambda k: sd[p + k].detach().double().cpu()  # noqa: E731
+    wo, bo = d(".out_lin.weight")[0], d(".out_lin.bias")[0]
+    wg, bg = d(".gate.0.weight")[0], d(".gate.0.bias")[0]
+    rows, ks = [], []
+    for nm, wgh in (("dist_emb", wg[:E]), ("angle_emb", wg[E:])):
+        W2, b2 = d(f".{nm}.2.weight"), d(f".{nm}.2.bias")
+        rows += [d(f".{nm}.0.weight")[:, 0], d(f".{nm}.0.bias"), W2.t() @ wo, W2.t() @ wgh]
+        ks += [wo @ b2, wgh @ b2]
+    tail = torch.stack(ks + [bg, bo, alpha.detach().double().cpu().reshape(()), torch.zeros((), dtype=torch.float64)])
+    return torch.cat([torch.cat(rows), tail]).float()
+
+
+class _Arena:
+    """Keeps every packed tensor alive and hands out raw device pointers."""
+
+    def __init__(self, device):
+        self.device = device
+        self.keep = []
+
+    def put(self, t: torch.Tensor):
+        t = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        self.keep.append(t)
+        return t.data_ptr()
+
+
+def pack_policy(sd: dict, env_name: str, device) -> dict:
+    """state_dict (reference names) -> ctypes structs for the kernels."""
+    ar = _Arena(device)
+    nl = 1 + max(int(k.split(".")[3]) for k in sd if k.startswith("encoder.net.layers."))
+    blocks = []
+    nabname = "angle_distance_fusion" if env_name in ("atsp", "rcvrp") else "neural_adaptive_bias"
+    for l in range(nl):
+        pair = []
+        for rc in ("row", "col"):
+            b = f"encoder.net.layers.{l}.{rc}_encoding_block"
+            w = L.EncBlockW()
+            for f, k in (("n1", "norm1"), ("n2", "norm2"), ("n3", "norm3"),
+                         ("f1", "feed_forward.ops.norm1"), ("f2", "feed_forward.ops.norm2")):
+                setattr(w, f + "g", ar.put(sd[f"{b}.{k}.normalizer.weight"]))
+                setattr(w, f + "b", ar.put(sd[f"{b}.{k}.normalizer.bias"]))
+            for f, k in (("q", "attn_free.to_q"), ("k", "attn_free.to_k"), ("v", "attn_free.to_v"),
+                         ("p", "attn_free.project"), ("c", "multi_head_combine"),
+                         ("1", "feed_forward.ops.ffn.W1"), ("2", "feed_forward.ops.ffn.W2")):
+                setattr(w, "w" + f, ar.put(pack_a(sd[f"{b}.{k}.weight"].detach().float())))
+                setattr(w, "b" + f, ar.put(sd[f"{b}.{k}.bias"]))
+            w.nab = ar.put(fold_nab(sd, f"{b}.{nabname}", sd[f"{b}.alpha"]))
+            pair.append(w)
+        blocks.append(tuple(pair))
+
+    out = {"arena": ar, "blocks": blocks, "num_layers": nl}
+    p = "encoder.init_embedding"
+    if env_name == "atsp":
+        iw = L.InitW()
+        iw.wi, iw.bi = ar.put(sd[p + ".init_embed.weight"]), ar.put(sd[p + ".init_embed.bias"])
+        iw.wr, iw.br = ar.put(sd[p + ".row_embed.weight"]), ar.put(sd[p + ".row_embed.bias"])
+        iw.wcl, iw.bcl = ar.put(sd[p + ".col_embed.weight"]), ar.put(sd[p + ".col_embed.bias"])
+        for rc, s in (("row", "r"), ("col", "c")):
+            q = f"{p}.gating_network_{rc}.gating_fc"
+            setattr(iw, "g0" + s, ar.put(pack_a(sd[q + ".0.weight"].detach().float())))
+            setattr(iw, "g0" + s + "b", ar.put(sd[q + ".0.bias"]))
+            setattr(iw, "g2" + s, ar.put(sd[q + ".2.weight"].reshape(-1)))
+            setattr(iw, "g2" + s + "b", float(sd[q + ".2.bias"].reshape(-1)[0]))
+        out["init"] = iw
+        out["sample_size"] = sd[p + ".row_embed.weight"].shape[1]
+
+    wn = sd["decoder.project_node_embeddings.weight"].detach().float()   # [3E,E] -> K,V,L chunks
+    wctx = sd["decoder.context_embedding.project_context.weight"].detach().float()
+    cw = L.CacheW()
+    cw.wk, cw.wv, cw.wl = ar.put(pack_a(wn[:E])), ar.put(pack_a(wn[E:2 * E])), ar.put(pack_a(wn[2 * E:]))
+    dw = L.DecW()
+    if env_name == "atsp":
+        cw.wca, cw.wcb = ar.put(pack_a(wctx[:, :E])), ar.put(pack_a(wctx[:, E:2 * E]))
+        ph = sd["decoder.context_embedding.W_placeholder"].detach().float()
+        dw.q0 = ar.put(wctx @ ph.to(wctx.device))
+        dw.wstate = None
+    else:
+        cw.wca, cw.wcb = None, ar.put(pack_a(wctx[:, :E]))
+        dw.q0 = None
+        dw.wstate = ar.put(wctx[:, E:].t().contiguous())   # [nstate][E]
+    dw.w1 = ar.put(pack_a(sd["decoder.pointer.ffn.lins.0.weight"].detach().float()))
+    dw.w2 = ar.put(pack_a(sd["decoder.pointer.ffn.lins.1.weight"].detach().float()))
+    dw.b1, dw.b2 = ar.put(sd["decoder.pointer.ffn.lins.0.bias"]), ar.put(sd["decoder.pointer.ffn.lins.1.bias"])
+    dw.alpha = float(sd["decoder.alpha"].reshape(-1)[0])
+    dw.beta = float(sd["decoder.beta"].reshape(-1)[0]) if "decoder.beta" in sd else 0.0
+    out["cache"], out["dec"] = cw, dw
+    return out

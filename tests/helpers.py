@@ -1,0 +1,55 @@
+"""Shared helpers for the parity tests: fixtures, deterministic weights, oracle <-> product glue."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from oracle import restate
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_fixture(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    out = {}
+    for k in z.files:
+        a = z[k]
+        out[k] = torch.from_numpy(a) if a.ndim > 0 else a.item()
+    return out
+
+
+def atsp_weights(fx_or_ss, layers=6, seed=None):
+    if isinstance(fx_or_ss, dict):
+        ss, layers, seed = fx_or_ss["sample_size"], fx_or_ss["layers"], fx_or_ss["seed"]
+    else:
+        ss = fx_or_ss
+    return restate.make_weights(restate.atsp_weight_template(128, layers, 512, ss), seed)
+
+
+def make_policy(w, env_name="atsp", device="cuda"):
+    from rrnco_amd.models import RRNetPolicy
+    layers = restate.num_layers_of(w)
+    ss = w["encoder.init_embedding.row_embed.weight"].shape[1]
+    pol = RRNetPolicy(env_name=env_name, embed_dim=128, num_heads=8, num_encoder_layers=layers,
+                      normalization="instance", use_graph_context=False, nab_type="gating",
+                      init_embedding_kwargs=dict(use_coords=True, use_polar_feats=True, use_dist=True,
+                                                 use_matnet_init=False, sample_type="prob", sample_size=ss))
+    pol.load_state_dict(w, strict=True)
+    return pol.to(device).eval()
+
+
+def fixture_state(fx):
+    """Raw instance dict (oracle side) of a fixture, incl. augmentation."""
+    st = {"locs": fx["locs"], "distance_matrix": fx["distance_matrix"]}
+    if fx["aug"]:
+        st = restate.augment_state(st)
+    return st
+
+
+def tour_agreement(act_hip, act_ref, gaps=None):
+    """fraction of rollouts whose whole tour matches + index of first divergence per rollout (-1 = none)."""
+    neq = act_hip != act_ref
+    first = torch.where(neq.any(1), neq.float().argmax(1), torch.full((act_ref.shape[0],), -1))
+    return float((first < 0).float().mean()), first
