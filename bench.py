@@ -1,0 +1,155 @@
+"""Benchmark of the hot path: solved instances/sec, ATSP n=100, B=512 per GPU, POMO (S=100 starts x 8 dihedral
+augmentations) greedy — BASELINE.json configs[1].
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = reset -> x8 augmentation -> policy (encoder + persistent rollout) -> get_reward -> best-of-(aug,start)
+over one batch already resident in HBM.  Instances shard over ranks with no data-path collective (weak scaling).
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "real-routing-nco_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+N_NODES, BATCH, STARTS, AUG = 100, 512, 100, 8
+FLOP_PER_ROLLOUT_STEP = 404_480          # pointer step K6-K7, per rollout per decode step
+PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: fp32 matrix peak
+
+
+def make_policy(device):
+    from oracle import restate                      # only for the deterministic random-init weight vectors
+    from rrnco_amd.models import RRNetPolicy
+    w = restate.make_weights(restate.atsp_weight_template(128, 6, 512, 25), 1234)
+    pol = RRNetPolicy(env_name="atsp", embed_dim=128, num_heads=8, num_encoder_layers=6, normalization="instance",
+                      use_graph_context=False, nab_type="gating",
+                      init_embedding_kwargs=dict(use_coords=True, use_polar_feats=True, use_dist=True,
+                                                 use_matnet_init=False, sample_type="prob", sample_size=25))
+    pol.load_state_dict(w, strict=True)
+    return pol.to(device).eval(), w
+
+
+def hot_path_step(pol, env, inst, sample_idx):
+    """test.py:188-213 shaped: augment -> reset -> policy -> reward -> max over starts, then over augs."""
+    from rrnco_amd import TensorDict
+    from rrnco_amd.models.transforms import StateAugmentation
+    from rrnco_amd.ops import unbatchify
+    td = TensorDict(dict(inst), batch_size=[inst["locs"].shape[0]])
+    td = StateAugmentation(augment_fn="dihedral8", no_aug_coords=False)(td)
+    td["sample_idx"] = sample_idx
+    td = env.reset(td)
+    out = pol(td, env, phase="val", decode_type="multistart_greedy", num_starts=STARTS, return_actions=True)
+    rew = unbatchify(out["reward"], (AUG, STARTS))          # [B, A, S]
+    best = rew.max(dim=-1).values.max(dim=-1).values
+    return best, out
+
+
+def cpu_baseline(w, seed=4321, n_inst=2):
+    """The oracle (op-for-op CPU restatement of the reference, fp32, all host cores) on a bounded sample of
+    the same workload: n_inst instances x 8 augmentations x 100 starts."""
+    from oracle import restate
+    torch.set_num_threads(os.cpu_count() or 1)
+    inst = restate.atsp_synthetic(n_inst, N_NODES, seed)
+    t0 = time.perf_counter()
+    with torch.inference_mode():
+        st = restate.atsp_reset(restate.augment_state(inst))
+        sidx = restate.sample_neighbor_indices(st["distance_matrix"], 25)
+        restate.atsp_policy(w, st, sidx, STARTS, "greedy")
+    dt = time.perf_counter() - t0
+    return {"value": n_inst / dt, "unit": "instances/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_inst} ATSP n=100 instances x8 aug x100 starts greedy, torch-CPU fp32 oracle, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    dist = world > 1
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if dist:
+        import torch.distributed as td_
+        td_.init_process_group("nccl", device_id=dev)
+
+    from rrnco_amd.envs import ATSPEnv, ATSPGenerator
+    from rrnco_amd.models import rollout as R
+    pol, w = make_policy(dev)
+    env = ATSPEnv(generator_params=dict(num_loc=N_NODES, device=dev), check_solution=False, device=dev)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    inst_td = ATSPGenerator(num_loc=N_NODES, device=dev)(args.batch, generator=gen)
+    inst = {"locs": inst_td["locs"], "distance_matrix": inst_td["distance_matrix"]}
+    # neighbour-sample indices are an input of the hot path; drawn once, on device
+    from rrnco_amd.models.encoder import ATSPInitEmbedding
+    nd = env.reset(inst_td)["distance_matrix"]
+    sample_idx = ATSPInitEmbedding.sample_indices(nd, 25).repeat(AUG, 1, 1).contiguous()
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist:
+            td_.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        hot_path_step(pol, env, inst, sample_idx)
+    R.TIMING = []
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        best, out = hot_path_step(pol, env, inst, sample_idx)
+    sync_all()
+    dt = time.perf_counter() - t0
+    kern_ms = [a.elapsed_time(b) for a, b in R.TIMING]
+    R.TIMING = None
+    if dist:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        td_.all_reduce(t, op=td_.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total_inst = args.batch * world * args.steps
+        rollout_steps = args.batch * AUG * STARTS * (N_NODES - 1)
+        k_ms = sum(kern_ms) / max(len(kern_ms), 1)
+        achieved = rollout_steps * FLOP_PER_ROLLOUT_STEP / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        line = {
+            "metric": "solved instances/sec (ATSP n=100, B=512, POMO greedy)", "value": total_inst / dt,
+            "unit": "instances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"ATSP n={N_NODES}, batch={args.batch}/GPU, POMO S={STARTS} starts x {AUG} dihedral aug, greedy "
+                                   "(BASELINE.json configs[1]); random-init RRNet E=128 L=6",
+                       "rollouts_per_gpu": args.batch * AUG * STARTS, "sharding": f"instances over {world} rank(s), no collective"},
+            "roofline": {"bound": "mfma", "kernel": "k_rollout<7,0> (persistent POMO decode)", "achieved": achieved,
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                         "traffic": None, "kernel_ms": k_ms,
+                         "algorithmic_flop_per_launch": rollout_steps * FLOP_PER_ROLLOUT_STEP},
+            "mean_best_cost": float(-best.mean().item()),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(w)
+        print(json.dumps(line))
+    if dist:
+        td_.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -7,6 +7,7 @@ from .. import _lib as L
 
 PROB_ID = {"atsp": 0, "rcvrp": 1}
 MODE_ID = {"greedy": 0, "sampling": 1, "evaluate": 2}
+TIMING = None   # bench.py sets this to a list to collect (start, end) HIP events around each full rollout launch
 
 
 def launch_rollout(env_name, packed, cache, td, num_starts, *, actions=None, logp=None, t0=0, nsteps=1,
@@ -55,5 +56,12 @@ def launch_rollout(env_name, packed, cache, td, num_starts, *, actions=None, log
     io.set_first = int(env_name == "atsp" and td.meta.get("i", 1) == 0)
     io.write_state, io.logits_only = int(write_state), int(logits_only)
     io.tanh_clip, io.temperature, io.seed = float(tanh_clip), float(temperature), int(seed)
+    timed = TIMING is not None and not logits_only
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     L.check(L.lib().rr_rollout(packed["dec"], io, PROB_ID[env_name], L.stream()), "rr_rollout")
+    if timed:
+        e1.record()
+        TIMING.append((e0, e1))
     return {"cur": cur, "first": first, "mask": mask, "done": done, "keep": keep}
