@@ -125,13 +125,10 @@ def main():
     dt = time.perf_counter() - t0
     kern_ms = [a.elapsed_time(b) for a, b in R.TIMING]
     R.TIMING = None
-    if dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        td_.all_reduce(t, op=td_.ReduceOp.MAX)
-        dt = float(t.item())
+    from rrnco_amd.parallel import aggregate_throughput
+    total_inst, dt = aggregate_throughput(args.batch * args.steps, dt, dist, dev)
 
     if rank == 0:
-        total_inst = args.batch * world * args.steps
         rollout_steps = args.batch * AUG * STARTS * (N_NODES - 1)
         k_ms = sum(kern_ms) / max(len(kern_ms), 1)
         achieved = rollout_steps * FLOP_PER_ROLLOUT_STEP / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0

@@ -1,0 +1,94 @@
+/* C ABI of the MI355X (gfx950) construction-rollout hot path — librrnco_hip.so.
+ *
+ * Plain pointers and sizes only; every pointer is a DEVICE pointer unless marked host.  Launchers never
+ * allocate, never synchronise, enqueue on `stream` and return 0 (RR_OK), -1 (invalid argument) or -2 (HIP launch
+ * error).  Each entry point cites the reference code (relative to the reference repo root) it replaces.
+ *
+ * Layout conventions: all tensors row-major contiguous, float32 / int64 / uint8(bool) exactly as the reference's
+ * torch tensors.  Rollout index r = s*Bp + b (start-major over the Bp encoder instances; rl4co `batchify`).
+ * Per-instance data (distance matrices, demands) is never replicated per start: rollout r reads instance r % Bp.
+ */
+#ifndef RRNCO_HIP_H
+#define RRNCO_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* hipStream_t;
+
+/* ---- packed-weight descriptors (built by rrnco_amd/packing.py; host structs holding device pointers) ---- */
+typedef struct {                /* one AttnFree_Block: rrnco/models/nn/attn_freenet.py:360-441 */
+  const float *n1g, *n1b, *n2g, *n2b, *n3g, *n3b, *f1g, *f1b, *f2g, *f2b;   /* InstanceNorm1d affine [128] */
+  const void *wq, *wk, *wv, *wp, *wc, *w1, *w2;   /* MFMA A-operand packs: [M/16][K/16][64 lanes][4] floats  */
+  const float *bq, *bk, *bv, *bp, *bc, *b1, *b2;
+  const float *nab;             /* folded DistAngleFusion (:201-289): 8 rows x 128 + 8 scalars              */
+} EncBlockW;
+
+typedef struct {                /* ATSPInitEmbedding: rrnco/models/env_embeddings/atsp.py:5-121 */
+  const float *wi, *bi, *wr, *br, *wcl, *bcl;
+  const void *g0r, *g0c;        /* gating_fc.0 packs [16][16][64][4] */
+  const float *g0rb, *g0cb, *g2r, *g2c;
+  float g2rb, g2cb;
+} InitW;
+
+typedef struct { const void *wk, *wv, *wl, *wca, *wcb; } CacheW;   /* rrnco/models/decoder.py:214-232 + context */
+
+typedef struct {                /* pointer MLP + inductive-bias scalars: rrnco/models/decoder.py:186-198, 272-277 */
+  const void *w1, *w2; const float *b1, *b2, *q0, *wstate; float alpha, beta;
+} DecW;
+
+typedef struct {                /* arguments of the persistent rollout: see csrc/rr_decode.hip */
+  const float *K, *Vt, *L, *ctxA, *ctxB, *D, *Dur, *demand;
+  int64_t *cur, *first; uint8_t *mask, *visited; float *used, *vcap; uint8_t *done;
+  int64_t *actions; float *logp, *logits_out; const int64_t *actions_in; int *steps_out;
+  int Bp, N, S, T, t0, nsteps, mode, use_placeholder, set_first, write_state, logits_only;
+  float tanh_clip, temperature; unsigned long long seed;
+} RolloutIO;
+
+/* ATSPEnv._reset / RCVRPEnv._reset / RMTVRPEnv._reset min-max normalisation
+ * (rrnco/envs/atsp/env.py:113-120, rcvrp/env.py:137-146, rmtvrp/env.py:289-300): out = (in-min)/(max-min+1e-6)
+ * per matrix of M elements; mn/mx [B]. */
+int rr_minmax_normalize(const float* in, float* out, float* mn, float* mx, int B, int M, hipStream_t stream);
+
+/* ATSPEnv._step (rrnco/envs/atsp/env.py:80-105): mask_out[r, action[r]] = 0, done[r] = no node left. */
+int rr_atsp_step(const int64_t* action, const uint8_t* mask_in, uint8_t* mask_out, uint8_t* done,
+                 int R, int N, hipStream_t stream);
+
+/* RCVRPEnv._step + get_action_mask (rrnco/envs/rcvrp/env.py:90-122, 183-195); N = customers. */
+int rr_rcvrp_step(const int64_t* action, const float* demand, const float* vcap, float* used, uint8_t* visited,
+                  uint8_t* mask, int64_t* cur_out, uint8_t* done, int R, int Bp, int N, hipStream_t stream);
+
+/* _get_reward: mode 0 closed tour (rrnco/envs/atsp/env.py:192-211), mode 1 depot-prefixed route list
+ * (rrnco/envs/rcvrp/env.py:197-219, rmtvrp/env.py:430-455).  norm_out = -sum, real_out de-normalised. */
+int rr_tour_cost(const float* D, const int64_t* actions, const float* mn, const float* mx, float* norm_out,
+                 float* real_out, int R, int Bp, int N, int T, int mode, hipStream_t stream);
+
+/* process_logits + Greedy/Sampling/Evaluate._step + logp gather (rrnco/models/decoding.py:311-361, 272-298, 266).
+ * mode 0 greedy, 1 sampling (Gumbel-max on a counter-based generator), 2 evaluate (action_in). */
+int rr_select(const float* logits, const uint8_t* mask, const int64_t* action_in, int64_t* action_out,
+              float* logp_out, float* logp_all, int R, int N, float tanh_clip, float temperature, int mode,
+              uint64_t seed, uint32_t step, hipStream_t stream);
+
+/* One Attn_Free_Layer = row block + col block (rrnco/models/nn/attn_freenet.py:472-488). */
+int rr_enc_layer(const EncBlockW* wrow, const EncBlockW* wcol, const float* row_in, const float* col_in,
+                 float* row_out, float* col_out, const float* D, const float* locs, int Bp, int N,
+                 float* dbg, hipStream_t stream);
+
+/* ATSPInitEmbedding.forward (rrnco/models/env_embeddings/atsp.py:69-91); sidx [Bp,N,SS] int64 is an input. */
+int rr_atsp_init_embed(const InitW* w, const float* D, const float* locs, const int64_t* sidx, float* row_out,
+                       float* col_out, int Bp, int N, int SS, hipStream_t stream);
+
+/* RRNetDecoder._precompute_cache (rrnco/models/decoder.py:214-232) + per-node step-context tables. */
+int rr_dec_cache(const CacheW* w, const float* row_emb, const float* col_emb, float* K, float* Vt, float* L,
+                 float* ctxA, float* ctxB, int Bp, int N, hipStream_t stream);
+
+/* The decode loop of RRNetPolicy.forward (rrnco/models/policy.py:210-228) = RRNetDecoder.forward
+ * (decoder.py:151-206) + DecodingStrategy.step (decoding.py:219-270) + env.step, `nsteps` steps in one launch;
+ * logits_only = a single pure RRNetDecoder.forward.  prob 0 = ATSP, 1 = RCVRP. */
+int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

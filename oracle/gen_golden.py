@@ -102,6 +102,17 @@ def gen_atsp(tag, B, N, S, sample_size, seed, layers=6, aug=False, keep_trace=Tr
         assert torch.equal(mine[k], out[k]), k
     assert torch.equal(trace["row_emb"], out["hidden"][0]) and torch.equal(trace["col_emb"], out["hidden"][1])
 
+    # evaluate mode: feeding the decode-loop actions back must reproduce the log-likelihood (reference + restatement)
+    if N <= 20:
+        a_in = out["actions"][:, 1:] if S > 1 else out["actions"]
+        with torch.inference_mode(), _CaptureMultinomial():
+            torch.multinomial = lambda *a, **k: sidx.reshape(-1, sample_size)   # replay the same neighbour samples
+            ev = pol(td.clone(), env, phase="val", actions=a_in, num_starts=S if S > 1 else None, return_actions=True)
+            mine_ev = restate.atsp_policy(w, st0, sidx, S, "evaluate", actions=a_in)
+        assert torch.equal(ev["actions"], out["actions"]) and torch.equal(mine_ev["actions"], out["actions"])
+        assert torch.equal(ev["log_likelihood"], mine_ev["log_likelihood"])
+        assert torch.allclose(ev["log_likelihood"], out["log_likelihood"], atol=1e-5)
+
     fx = dict(
         kind="atsp", B=B, N=N, S=S, sample_size=sample_size, seed=seed, layers=layers, aug=int(aug),
         locs=inst["locs"], distance_matrix=inst["distance_matrix"], sample_idx=sidx,

@@ -351,17 +351,13 @@ def atsp_policy(w: W, td0: dict, sidx: Tensor, num_starts: int, decode: str = "g
     B, N = td0["action_mask"].shape
     S = num_starts if num_starts > 1 else 0
     acts, lps = [], []
-    step = 0
     if S >= 1:
         a0 = torch.arange(S).repeat_interleave(B) % N  # select_start_nodes for atsp
-        if actions is not None:
-            a0 = actions[:, 0]
         td = batchify_state({k: v for k, v in td0.items() if k not in ("locs",)}, S)
         td["action"] = a0
         td = atsp_step(td)
         lps.append(torch.zeros_like(a0, dtype=torch.float32))
         acts.append(a0)
-        step = 1 if actions is not None else 0
     else:
         td = dict(td0)
     cache = precompute_cache(w, row, col)
@@ -373,7 +369,7 @@ def atsp_policy(w: W, td0: dict, sidx: Tensor, num_starts: int, decode: str = "g
         if decode == "greedy":
             sel = logp.argmax(dim=-1)
         elif decode == "evaluate":
-            sel = actions[:, k + (1 if S >= 1 else 0)]
+            sel = actions[:, k]   # policy.py:218: actions[..., step], step counts decode-loop iterations
         else:
             raise ValueError(decode)
         if trace is not None:

@@ -1,0 +1,25 @@
+"""Data-parallel sharding of instances over ranks (one process per GPU).  Instances are independent, so the
+inference path has NO data-path collective: each rank owns all A x S rollouts of its instances.
+Only the timing/throughput aggregation uses torch.distributed (RCCL on GPUs, gloo in the CPU tests)."""
+from __future__ import annotations
+
+import torch
+
+
+def shard_range(n_instances: int, rank: int, world: int):
+    """Contiguous [lo, hi) block of instances for `rank` (before augmentation / multistart expansion)."""
+    base, rem = divmod(n_instances, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def aggregate_throughput(local_units: int, local_seconds: float, distributed: bool, device):
+    """-> (units processed by all ranks, max over ranks of the elapsed time)."""
+    if not distributed:
+        return local_units, local_seconds
+    import torch.distributed as dist
+    u = torch.tensor([float(local_units)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(local_seconds)], dtype=torch.float64, device=device)
+    dist.all_reduce(u, op=dist.ReduceOp.SUM)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(round(u.item())), float(t.item())
