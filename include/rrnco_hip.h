@@ -25,11 +25,16 @@ typedef struct {                /* one AttnFree_Block: rrnco/models/nn/attn_free
   const float *nab;             /* folded DistAngleFusion (:201-289): 8 rows x 128 + 8 scalars              */
 } EncBlockW;
 
-typedef struct {                /* ATSPInitEmbedding: rrnco/models/env_embeddings/atsp.py:5-121 */
+typedef struct {                /* ATSPInitEmbedding (rrnco/models/env_embeddings/atsp.py:5-121) and
+                                 * RVRPInitEmbedding / RVRPTWInitEmbedding (rcvrp.py:5-200, rcvrptw.py) */
   const float *wi, *bi, *wr, *br, *wcl, *bcl;
   const void *g0r, *g0c;        /* gating_fc.0 packs [16][16][64][4] */
   const float *g0rb, *g0cb, *g2r, *g2c;
+  const float *wdep, *bdep, *wdm, *bdm;   /* VRP: depot Linear(2,E), demand_init Linear(F,E) */
+  const void *cmr, *cmc;        /* VRP: combine_{row,col}_embed packs [8][16][64][4] */
+  const float *cmrb, *cmcb;
   float g2rb, g2cb;
+  int nfeat;
 } InitW;
 
 typedef struct { const void *wk, *wv, *wl, *wca, *wcb; } CacheW;   /* rrnco/models/decoder.py:214-232 + context */
@@ -75,9 +80,11 @@ int rr_enc_layer(const EncBlockW* wrow, const EncBlockW* wcol, const float* row_
                  float* row_out, float* col_out, const float* D, const float* locs, int Bp, int N,
                  float* dbg, hipStream_t stream);
 
-/* ATSPInitEmbedding.forward (rrnco/models/env_embeddings/atsp.py:69-91); sidx [Bp,N,SS] int64 is an input. */
-int rr_atsp_init_embed(const InitW* w, const float* D, const float* locs, const int64_t* sidx, float* row_out,
-                       float* col_out, int Bp, int N, int SS, hipStream_t stream);
+/* kind 0: ATSPInitEmbedding.forward (rrnco/models/env_embeddings/atsp.py:69-91);
+ * kind 1: RVRPInitEmbedding._embed_with_distance (rcvrp.py:88-102; rcvrptw.py with F=4), node 0 = depot,
+ * vfeat [Bp,N,F] = (demand with 0 at the depot[, tw0, tw1, service]).  sidx [Bp,N,SS] int64 is an input. */
+int rr_init_embed(const InitW* w, int kind, const float* D, const float* locs, const int64_t* sidx,
+                  const float* vfeat, float* row_out, float* col_out, int Bp, int N, int SS, hipStream_t stream);
 
 /* RRNetDecoder._precompute_cache (rrnco/models/decoder.py:214-232) + per-node step-context tables. */
 int rr_dec_cache(const CacheW* w, const float* row_emb, const float* col_emb, float* K, float* Vt, float* L,

@@ -33,6 +33,7 @@ class _Gen:  # minimal generator attributes the reference envs read
     def __init__(self, num_loc):
         self.num_loc, self.min_dist, self.max_dist = num_loc, 0.0, 1.0
         self.min_loc, self.max_loc, self.vehicle_capacity = 0.0, 1.0, 1.0
+        self.capacity, self.min_demand, self.max_demand = 1.0, 1, 10
 
 
 class _CaptureMultinomial:
@@ -130,6 +131,73 @@ def gen_atsp(tag, B, N, S, sample_size, seed, layers=6, aug=False, keep_trace=Tr
     print(f"wrote {path}  ({os.path.getsize(path)/1e3:.0f} kB)  reward[:3]={out['reward'][:3].tolist()}")
 
 
+def gen_rcvrp(tag, B, N, S, sample_size, seed, capacity, layers=6, keep_trace=True):
+    from rrnco.envs.rcvrp.env import RCVRPEnv
+    from rrnco.models.policy import RRNetPolicy
+
+    torch.manual_seed(seed)
+    inst = restate.rcvrp_synthetic(B, N, seed, capacity)
+    env = RCVRPEnv(generator=_Gen(N), check_solution=True)
+    pol = RRNetPolicy(env_name="rcvrp", init_embedding_kwargs=dict(
+        use_coords=True, use_polar_feats=True, use_dist=True, use_matnet_init=False,
+        sample_type="prob", sample_size=sample_size), **dict(POLICY_KW, num_encoder_layers=layers)).eval()
+    tmpl = {k: tuple(v.shape) for k, v in pol.state_dict().items()}
+    assert tmpl == restate.rcvrp_weight_template(128, layers, 512, sample_size), \
+        (set(tmpl) ^ set(restate.rcvrp_weight_template(128, layers, 512, sample_size)))
+    w = restate.make_weights(tmpl, seed)
+    pol.load_state_dict(w, strict=True)
+    td = env.reset(TensorDict({k: v.clone() for k, v in inst.items()}, batch_size=[B]))
+    enc_out = []
+    hook = pol.encoder.register_forward_hook(lambda m, a, o: enc_out.append(o))
+    with torch.inference_mode(), _CaptureMultinomial() as cap:
+        out = pol(td.clone(), env, phase="val", decode_type="multistart_greedy" if S > 1 else "greedy",
+                  num_starts=S if S > 1 else None, return_actions=True)
+    hook.remove()
+    sidx = cap.calls[0].reshape(B, N + 1, sample_size)
+    st0 = restate.rcvrp_reset(inst)
+    for k in ("distance_matrix", "min_distance", "max_distance", "action_mask", "locs"):
+        assert torch.equal(st0[k], td[k]), k
+    trace = {}
+    w_same = dict(pol.state_dict())      # same storage as the reference module: identical CPU kernel paths
+    with torch.inference_mode():
+        mine = restate.rcvrp_policy(w_same, st0, sidx, S, "greedy", trace=trace)
+    T = min(mine["actions"].shape[1], out["actions"].shape[1])
+    neq = mine["actions"][:, :T] != out["actions"][:, :T]
+    same = ~neq.any(1)
+    if not bool(same.all()):
+        # ulp-level CPU noise (alignment-dependent vectorised paths) can flip a near-tie: every divergence must be one
+        lp = torch.stack(trace["logp"], 1)
+        top2 = torch.nan_to_num(lp, neginf=-1e9).topk(2, -1).values
+        gap = top2[..., 0] - top2[..., 1]
+        off = 1 if S > 1 else 0
+        for r in torch.nonzero(~same).flatten().tolist():
+            t = int(neq[r].float().argmax())
+            assert gap[r, t - off] < 1e-4, f"rollout {r} diverges at step {t} with gap {gap[r, t - off]}"
+    assert float(same.float().mean()) >= 0.99
+    exact = bool(same.all()) and mine["actions"].shape == out["actions"].shape and \
+        all(torch.equal(mine[k], out[k]) for k in ("reward", "normalized_reward", "log_likelihood")) and \
+        torch.equal(trace["row_emb"], enc_out[0][0]) and torch.equal(trace["col_emb"], enc_out[0][1])
+    assert torch.allclose(mine["reward"][same], out["reward"][same], atol=1e-5)
+    assert torch.allclose(mine["log_likelihood"][same], out["log_likelihood"][same], atol=5e-4)
+    assert torch.allclose(trace["row_emb"], enc_out[0][0], atol=1e-4) and torch.allclose(trace["col_emb"], enc_out[0][1], atol=1e-4)
+    print(f"  tours identical on {float(same.float().mean())*100:.2f}% of rollouts")
+    print(f"  restatement vs reference: tours identical, floats {'bit-exact' if exact else 'within 1e-4 (not bit-exact)'}")
+    R = out["actions"].shape[0]
+    chk = {"demand": inst["demand"][torch.arange(R) % B], "vehicle_capacity": torch.ones(R, 1)}
+    assert restate.rcvrp_check(chk, out["actions"])
+    fx = dict(kind="rcvrp", B=B, N=N, S=S, sample_size=sample_size, seed=seed, layers=layers, capacity=capacity,
+              locs=inst["locs"], depot=inst["depot"], distance_matrix=inst["distance_matrix"], demand=inst["demand"],
+              sample_idx=sidx, norm_distance=td["distance_matrix"], min_distance=td["min_distance"],
+              max_distance=td["max_distance"], row_emb=enc_out[0][0], col_emb=enc_out[0][1], actions=out["actions"],
+              reward=out["reward"], normalized_reward=out["normalized_reward"], log_likelihood=out["log_likelihood"])
+    if keep_trace:
+        fx["trace_logits"] = torch.stack(trace["logits"], 0)
+        fx["trace_mask"] = torch.stack(trace["mask"], 0)
+    path = os.path.join(GOLD, f"{tag}.npz")
+    np.savez_compressed(path, **_np(fx))
+    print(f"wrote {path}  ({os.path.getsize(path)/1e3:.0f} kB) T={out['actions'].shape[1]} reward[:3]={out['reward'][:3].tolist()}")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     which = sys.argv[1:] or ["atsp"]
@@ -138,3 +206,7 @@ if __name__ == "__main__":
         gen_atsp("atsp_n20_b4_pomo", B=4, N=20, S=20, sample_size=15, seed=12)
         gen_atsp("atsp_n20_b2_pomo_aug8", B=2, N=20, S=20, sample_size=15, seed=13, aug=True, keep_trace=False)
         gen_atsp("atsp_n100_b2_pomo", B=2, N=100, S=100, sample_size=25, seed=14, keep_trace=False)
+    if "rcvrp" in which:
+        gen_rcvrp("rcvrp_n20_b4_pomo", B=4, N=20, S=21, sample_size=15, seed=21, capacity=30.0)
+        gen_rcvrp("rcvrp_n20_b4_greedy", B=4, N=20, S=0, sample_size=15, seed=22, capacity=30.0)
+        gen_rcvrp("rcvrp_n100_b2_pomo", B=2, N=100, S=101, sample_size=25, seed=23, capacity=50.0, keep_trace=False)

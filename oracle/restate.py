@@ -474,3 +474,198 @@ def atsp_weight_template(embed_dim: int = 128, num_layers: int = 6, ff: int = 51
     t["decoder.project_node_embeddings.weight"] = (3 * E, E)
     t["decoder.project_fixed_context.weight"] = (E, E)
     return t
+
+
+# ==============================================================================================
+# RCVRP  (rrnco/envs/rcvrp/env.py, rrnco/models/env_embeddings/rcvrp.py, rl4co VRPContext)
+# ==============================================================================================
+def rcvrp_synthetic(batch: int, n: int, seed: int, capacity: float = 50.0) -> dict:
+    """Synthetic RCVRP instance: uniform depot/customers (rcvrp/generator_lazy.py:244-257),
+    an asymmetric matrix D = cdist * (1 + 0.2 U) with zero diagonal supplied explicitly (the env's Euclidean
+    fallback has the wrong shape), integer demands 1..9 / capacity
+    (scripts/generate_data.py:206-207)."""
+    g = torch.Generator().manual_seed(seed)
+    depot = torch.rand(batch, 2, generator=g)
+    locs = torch.rand(batch, n, 2, generator=g)
+    pts = torch.cat([depot[:, None], locs], 1)
+    D = torch.cdist(pts, pts) * (1 + 0.2 * torch.rand(batch, n + 1, n + 1, generator=g))
+    D[:, torch.arange(n + 1), torch.arange(n + 1)] = 0
+    demand = torch.randint(1, 10, (batch, n), generator=g).float() / capacity
+    return {"locs": locs, "depot": depot, "distance_matrix": D, "demand": demand}
+
+
+def rcvrp_action_mask(td: dict) -> Tensor:
+    """env.py:183-195."""
+    exceeds = td["demand"] + td["used_capacity"] > td["vehicle_capacity"]
+    mask_loc = td["visited"][..., 1:].to(exceeds.dtype) | exceeds
+    mask_depot = (td["current_node"] == 0) & ((mask_loc == 0).int().sum(-1) > 0)[:, None]
+    return ~torch.cat((mask_depot, mask_loc), -1)
+
+
+def rcvrp_reset(td: dict, vehicle_capacity: float = 1.0, normalize: bool = True) -> dict:
+    """env.py:124-181."""
+    distance = td["distance_matrix"]
+    B = distance.shape[0]
+    out = {}
+    if normalize:
+        mn = distance.amin(dim=(-2, -1), keepdim=True)
+        mx = distance.amax(dim=(-2, -1), keepdim=True)
+        distance = ((distance - mn) / (mx - mn + 1e-6)).to(torch.float32)
+        out["min_distance"], out["max_distance"] = mn.squeeze(-1).squeeze(-1), mx.squeeze(-1).squeeze(-1)
+    depot = td["depot"].unsqueeze(1) if td["depot"].ndim == 2 else td["depot"]
+    out.update(
+        locs=torch.cat((depot, td["locs"]), dim=-2), distance_matrix=distance, demand=td["demand"],
+        current_node=torch.zeros(B, 1, dtype=torch.long), used_capacity=torch.zeros(B, 1),
+        vehicle_capacity=torch.full((B, 1), vehicle_capacity),
+        visited=torch.zeros(B, td["locs"].shape[-2] + 1, dtype=torch.uint8),
+        done=torch.zeros(B, 1, dtype=torch.bool))
+    out["action_mask"] = rcvrp_action_mask(out)
+    return out
+
+
+def rcvrp_step(td: dict) -> dict:
+    """env.py:90-122."""
+    cur = td["action"][:, None]
+    n_loc = td["demand"].size(-1)
+    sel = gather_by_index(td["demand"], torch.clamp(cur - 1, 0, n_loc - 1), squeeze=False)
+    used = (td["used_capacity"] + sel) * (cur != 0).float()
+    visited = td["visited"].scatter(-1, cur, 1)
+    done = visited.sum(-1) == visited.size(-1)
+    td.update(current_node=cur, used_capacity=used, visited=visited, reward=torch.zeros_like(done), done=done)
+    td["action_mask"] = rcvrp_action_mask(td)
+    return td
+
+
+def vrp_reward(td: dict, actions: Tensor, normalize: bool = True):
+    """rcvrp/env.py:197-219 (depot-prefixed, rolled)."""
+    D = td["distance_matrix"]
+    go_from = torch.cat((torch.zeros_like(actions[:, :1]), actions), dim=1)
+    go_to = torch.roll(go_from, -1, dims=1)
+    dist = gather_by_index(gather_by_index(D, go_from, dim=1, squeeze=False), go_to, dim=2, squeeze=False).squeeze(-1)
+    if normalize:
+        nd = -dist.sum(-1)
+        return nd * (td["max_distance"] - td["min_distance"] + 1e-6) + td["min_distance"], nd
+    return -dist.sum(-1)
+
+
+def rcvrp_check(td: dict, actions: Tensor) -> bool:
+    """env.py:221-249."""
+    B, n = td["demand"].size()
+    sp = actions.sort(1)[0]
+    ok = bool((torch.arange(1, n + 1).view(1, -1).expand(B, n) == sp[:, -n:]).all() and (sp[:, :-n] == 0).all())
+    d = torch.cat((-td["vehicle_capacity"], td["demand"]), 1).gather(1, actions)
+    used = torch.zeros_like(td["demand"][:, 0])
+    for i in range(actions.size(1)):
+        used = used + d[:, i]
+        used[used < 0] = 0
+        ok = ok and bool((used <= td["vehicle_capacity"][:, 0] + 1e-5).all())
+    return ok
+
+
+def rcvrp_init_embedding(w: W, locs: Tensor, demand: Tensor, distance: Tensor, sidx: Tensor, extra_feats: Optional[Tensor] = None):
+    """RVRPInitEmbedding._embed_with_distance rcvrp.py:88-102 (+ CoordinateExpert :105-124, DistanceExpert :127-150);
+    rcvrptw.py differs only in demand_init taking (demand, tw0, tw1, service) (`extra_feats`)."""
+    p = "encoder.init_embedding"
+    locs = locs.float()
+    depot, cities = locs[:, :1, :], locs[:, 1:, :]
+    c = cities - depot
+    ang = torch.atan2(c[..., 1:], c[..., :1])
+    node = torch.cat([lin(w, p + ".coord_expert.init_embed_depot", depot),
+                      lin(w, p + ".coord_expert.init_embed", torch.cat([cities, ang], dim=-1))], dim=-2)
+    rowd = distance.gather(2, sidx)
+    cold = distance.transpose(1, 2).gather(2, sidx)
+    row = lin(w, p + ".distance_expert.row_embed", rowd.sort(dim=-1).values)
+    col = lin(w, p + ".distance_expert.col_embed", cold.sort(dim=-1).values)
+    crow = contextual_gating(w, p + ".gating_network_row", node, row)
+    ccol = contextual_gating(w, p + ".gating_network_col", node, col)
+    dem = torch.cat([torch.zeros_like(demand[:, :1]), demand], dim=1)[..., None]
+    feats = dem if extra_feats is None else torch.cat([dem, extra_feats], -1)
+    de = lin(w, p + ".demand_init", feats)
+    return (lin(w, p + ".combine_row_embed", torch.cat([crow, de], -1)),
+            lin(w, p + ".combine_col_embed", torch.cat([ccol, de], -1)))
+
+
+def rcvrp_decoder_step(w: W, td_flat: dict, cache: dict, S: int):
+    """RRNetDecoder.forward for rcvrp (decoder.py:151-206) with rl4co VRPContext (E+1 -> E)."""
+    keys = ("current_node", "used_capacity", "vehicle_capacity", "action_mask")
+    td = {k: (unbatchify(td_flat[k], S) if S > 1 else td_flat[k]) for k in keys}
+    emb = cache["node_embeddings"]
+    cur = gather_by_index(emb, td["current_node"])
+    q = F.linear(torch.cat([cur, td["vehicle_capacity"] - td["used_capacity"]], -1),
+                 w["decoder.context_embedding.project_context.weight"])
+    q = q.unsqueeze(1) if q.ndim == 2 else q
+    mask = td["action_mask"]
+    logits = pointer(w, q, cache["glimpse_key"], cache["glimpse_val"], cache["logit_key"], mask)
+    D = cache["_D"]
+    if S > 1:
+        bias = w["decoder.alpha"] * gather_by_index(D.unsqueeze(1).expand(-1, S, -1, -1), td["current_node"], dim=-2)
+    else:
+        bias = w["decoder.alpha"] * gather_by_index(D, td["current_node"], dim=-2)
+    logits = torch.log(torch.exp(logits.to(torch.float32) - bias.to(torch.float32)) + 1e-6)
+    if S > 1:
+        logits = logits.permute(1, 0, 2).reshape(-1, logits.shape[-1])
+        mask = mask.permute(1, 0, 2).reshape(-1, mask.shape[-1])
+    return logits, mask
+
+
+def rcvrp_policy(w: W, td0: dict, sidx: Tensor, num_starts: int, decode: str = "greedy",
+                 actions: Optional[Tensor] = None, trace: Optional[dict] = None) -> dict:
+    """RRNetPolicy.forward for RCVRP; td0 = rcvrp_reset(...).  S = N+1 starts as test.py:132 uses."""
+    row, col = rcvrp_init_embedding(w, td0["locs"], td0["demand"], td0["distance_matrix"], sidx)
+    row, col = encoder_net(w, row, col, td0["distance_matrix"], td0["locs"].float(), None, num_layers_of(w))
+    if trace is not None:
+        trace["row_emb"], trace["col_emb"] = row, col
+    B, N1 = td0["action_mask"].shape
+    n_loc = N1 - 1
+    S = num_starts if num_starts > 1 else 0
+    acts, lps = [], []
+    static = ("locs", "distance_matrix", "min_distance", "max_distance")
+    if S >= 1:
+        a0 = torch.arange(S).repeat_interleave(B) % n_loc + 1
+        td = batchify_state({k: v for k, v in td0.items() if k not in static}, S)
+        td["action"] = a0
+        td = rcvrp_step(td)
+        lps.append(torch.zeros_like(a0, dtype=torch.float32)); acts.append(a0)
+    else:
+        td = {k: v for k, v in td0.items() if k not in static}
+    cache = precompute_cache(w, row, col)
+    cache["_D"] = td0["distance_matrix"]
+    k = 0
+    while not td["done"].all():
+        logits, mask = rcvrp_decoder_step(w, td, cache, S)
+        logp = process_logits(logits, mask)
+        sel = logp.argmax(dim=-1) if decode == "greedy" else actions[:, k]
+        if trace is not None:
+            trace.setdefault("logits", []).append(logits); trace.setdefault("mask", []).append(mask)
+            trace.setdefault("logp", []).append(logp)
+        lps.append(gather_by_index(logp, sel, dim=1)); acts.append(sel)
+        td["action"] = sel
+        td = rcvrp_step(td)
+        k += 1
+    logprobs, actions_out = torch.stack(lps, 1), torch.stack(acts, 1)
+    R = actions_out.shape[0]
+    rtd = {"distance_matrix": td0["distance_matrix"][torch.arange(R) % B],
+           "min_distance": td0["min_distance"][torch.arange(R) % B], "max_distance": td0["max_distance"][torch.arange(R) % B]}
+    real, nd = vrp_reward(rtd, actions_out, True)
+    return {"reward": real, "normalized_reward": nd, "log_likelihood": logprobs.sum(1), "actions": actions_out,
+            "logprobs": logprobs}
+
+
+def rcvrp_weight_template(embed_dim: int = 128, num_layers: int = 6, ff: int = 512, sample_size: int = 25,
+                          demand_feats: int = 1, ctx_state: int = 1) -> Dict[str, tuple]:
+    E = embed_dim
+    t = {k: v for k, v in atsp_weight_template(E, num_layers, ff, sample_size).items()
+         if not k.startswith("encoder.init_embedding") and "context_embedding" not in k}
+    p = "encoder.init_embedding"
+    t[p + ".coord_expert.init_embed_depot.weight"] = (E, 2); t[p + ".coord_expert.init_embed_depot.bias"] = (E,)
+    t[p + ".coord_expert.init_embed.weight"] = (E, 3); t[p + ".coord_expert.init_embed.bias"] = (E,)
+    for rc in ("row", "col"):
+        q = f"{p}.gating_network_{rc}.gating_fc"
+        t[q + ".0.weight"] = (2 * E, 2 * E); t[q + ".0.bias"] = (2 * E,)
+        t[q + ".2.weight"] = (1, 2 * E); t[q + ".2.bias"] = (1,)
+        t[f"{p}.combine_{rc}_embed.weight"] = (E, 2 * E); t[f"{p}.combine_{rc}_embed.bias"] = (E,)
+        t[f"{p}.distance_expert.{rc}_embed.weight"] = (E, sample_size); t[f"{p}.distance_expert.{rc}_embed.bias"] = (E,)
+        t[f"{p}.distance_expert.{rc}_combine_embed.weight"] = (E, 2 * E); t[f"{p}.distance_expert.{rc}_combine_embed.bias"] = (E,)
+    t[p + ".demand_init.weight"] = (E, demand_feats); t[p + ".demand_init.bias"] = (E,)
+    t["decoder.context_embedding.project_context.weight"] = (E, E + ctx_state)
+    return t

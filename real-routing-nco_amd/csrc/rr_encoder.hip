@@ -298,15 +298,21 @@ struct InitW {
   const float4 *g0r, *g0c;         // gating_fc.0 packed [16 tiles][16 kk][64]
   const float *g0rb, *g0cb;        // [2E]
   const float *g2r, *g2c;          // gating_fc.2 weight [2E]
+  // VRP only (RVRPInitEmbedding, env_embeddings/rcvrp.py:88-124): depot Linear(2,E), demand_init Linear(F,E),
+  // combine_{row,col}_embed Linear(2E,E) packed [8][16][64]
+  const float *wdep, *bdep, *wdm, *bdm;
+  const float4 *cmr, *cmc;
+  const float *cmrb, *cmcb;
   float g2rb, g2cb;                // gating_fc.2 bias
+  int nfeat;                       // F: 1 (demand) or 4 (demand, tw0, tw1, service)
 };
 
 #define MAXSS 32
 
-template <int NT>
-__global__ __launch_bounds__(ENC_THREADS, 2) void k_atsp_init(InitW w, const float* __restrict__ D, const float* __restrict__ locs,
-                                                              const int64_t* __restrict__ sidx, float* __restrict__ row_out,
-                                                              float* __restrict__ col_out, int N, int SS) {
+template <int NT, int KIND>   // KIND 0 = ATSP, 1 = VRP (depot at node 0, extra node features `vfeat` [Bp][N][F])
+__global__ __launch_bounds__(ENC_THREADS, 2) void k_init_embed(InitW w, const float* __restrict__ D, const float* __restrict__ locs,
+                                                               const int64_t* __restrict__ sidx, const float* __restrict__ vfeat,
+                                                               float* __restrict__ row_out, float* __restrict__ col_out, int N, int SS) {
   __shared__ __attribute__((aligned(16))) float smem[3 * BUF_FLOATS];
   float* comb = smem;                      // [N][256] = [node | dist-embedding]
   float* scr = smem + 2 * BUF_FLOATS;      // sorted samples [N][MAXSS], then gate partials [16][112]
@@ -337,7 +343,15 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_atsp_init(InitW w, const flo
     const float* bd = pass == 0 ? w.br : w.bcl;
     for (int e = tid; e < N * RR_E; e += ENC_THREADS) {
       int i = e >> 7, f = e & 127;
-      comb[i * 256 + f] = fmaf(w.wi[f * 2 + 1], lc[i * 2 + 1], w.wi[f * 2] * lc[i * 2]) + w.bi[f];
+      if (KIND == 0) {
+        comb[i * 256 + f] = fmaf(w.wi[f * 2 + 1], lc[i * 2 + 1], w.wi[f * 2] * lc[i * 2]) + w.bi[f];
+      } else if (i == 0) {   // CoordinateExpert: depot Linear(2,E)
+        comb[f] = fmaf(w.wdep[f * 2 + 1], lc[1], w.wdep[f * 2] * lc[0]) + w.bdep[f];
+      } else {               // customers Linear(3,E) on (x, y, atan2(y - y_depot, x - x_depot))
+        float x = lc[i * 2], y = lc[i * 2 + 1];
+        float ang = atan2f(y - lc[1], x - lc[0]);
+        comb[i * 256 + f] = fmaf(w.wi[f * 3 + 2], ang, fmaf(w.wi[f * 3 + 1], y, w.wi[f * 3] * x)) + w.bi[f];
+      }
       float acc = 0.f;
       for (int s = 0; s < SS; ++s) acc = fmaf(wd[f * SS + s], scr[i * MAXSS + s], acc);
       comb[i * 256 + 128 + f] = acc + bd[f];
@@ -371,19 +385,43 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_atsp_init(InitW w, const flo
       float z = g2b;
       for (int t = 0; t < 16; ++t) z += gpart[t * 112 + i];
       float gt = 1.0f / (1.0f + expf(-z));
-      outp[e] = gt * comb[i * 256 + f] + (1.0f - gt) * comb[i * 256 + 128 + f];
+      float gated = gt * comb[i * 256 + f] + (1.0f - gt) * comb[i * 256 + 128 + f];
+      if (KIND == 0) outp[e] = gated;
+      else {
+        const float* vf = vfeat + ((size_t)b * N + i) * w.nfeat;
+        float de = w.bdm[f];
+        for (int q = 0; q < w.nfeat; ++q) de = fmaf(w.wdm[f * w.nfeat + q], vf[q], de);
+        comb[i * 256 + f] = gated;            // [gated | demand_emb] feeds combine_{row,col}_embed
+        comb[i * 256 + 128 + f] = de;
+      }
     }
     __syncthreads();
+    if (KIND == 1) {
+      f32x4 o[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) o[nt] = rr_zero4();
+      rr_gemm_wx<NT>(o, (pass == 0 ? w.cmr : w.cmc) + (size_t)wave * 16 * 64, 0, 16, comb, 256, 0, N, lane);
+      rr_add_bias<NT>(o, pass == 0 ? w.cmrb : w.cmcb, 16 * wave, lane);
+      rr_store_tiles<NT>(o, outp, RR_E, 16 * wave, N, lane);
+      __syncthreads();
+    }
   }
 }
 
-extern "C" int rr_atsp_init_embed(const InitW* w, const float* D, const float* locs, const int64_t* sidx,
-                                  float* row_out, float* col_out, int Bp, int N, int SS, hipStream_t st) {
-  if (Bp <= 0 || N < 2 || N > RR_MAXN || SS < 1 || SS > MAXSS || w == nullptr) return RR_EINVAL;
+extern "C" int rr_init_embed(const InitW* w, int kind, const float* D, const float* locs, const int64_t* sidx,
+                             const float* vfeat, float* row_out, float* col_out, int Bp, int N, int SS, hipStream_t st) {
+  if (Bp <= 0 || N < 2 || N > RR_MAXN || SS < 1 || SS > MAXSS || w == nullptr || kind < 0 || kind > 1) return RR_EINVAL;
+  if (kind == 1 && (vfeat == nullptr || w->nfeat < 1 || w->nfeat > 8)) return RR_EINVAL;
   dim3 grid(Bp), blk(ENC_THREADS);
-  if (N <= 32) hipLaunchKernelGGL(k_atsp_init<2>, grid, blk, 0, st, *w, D, locs, sidx, row_out, col_out, N, SS);
-  else if (N <= 64) hipLaunchKernelGGL(k_atsp_init<4>, grid, blk, 0, st, *w, D, locs, sidx, row_out, col_out, N, SS);
-  else hipLaunchKernelGGL(k_atsp_init<7>, grid, blk, 0, st, *w, D, locs, sidx, row_out, col_out, N, SS);
+#define RR_INIT(NTV)                                                                                               \
+  do {                                                                                                             \
+    if (kind == 0) hipLaunchKernelGGL((k_init_embed<NTV, 0>), grid, blk, 0, st, *w, D, locs, sidx, vfeat, row_out, col_out, N, SS); \
+    else hipLaunchKernelGGL((k_init_embed<NTV, 1>), grid, blk, 0, st, *w, D, locs, sidx, vfeat, row_out, col_out, N, SS);          \
+  } while (0)
+  if (N <= 32) RR_INIT(2);
+  else if (N <= 64) RR_INIT(4);
+  else RR_INIT(7);
+#undef RR_INIT
   return rr_check(hipGetLastError());
 }
 

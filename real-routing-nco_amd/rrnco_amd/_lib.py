@@ -23,8 +23,9 @@ class EncBlockW(C.Structure):
 
 
 class InitW(C.Structure):
-    _fields_ = [(n, vp) for n in ("wi", "bi", "wr", "br", "wcl", "bcl", "g0r", "g0c", "g0rb", "g0cb", "g2r", "g2c")] + \
-               [("g2rb", f32), ("g2cb", f32)]
+    _fields_ = [(n, vp) for n in ("wi", "bi", "wr", "br", "wcl", "bcl", "g0r", "g0c", "g0rb", "g0cb", "g2r", "g2c",
+                                  "wdep", "bdep", "wdm", "bdm", "cmr", "cmc", "cmrb", "cmcb")] + \
+               [("g2rb", f32), ("g2cb", f32), ("nfeat", i32)]
 
 
 class CacheW(C.Structure):
@@ -51,7 +52,7 @@ _SIGS = {
     "rr_tour_cost": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "rr_select": [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, u64, u32, vp],
     "rr_enc_layer": [C.POINTER(EncBlockW), C.POINTER(EncBlockW), vp, vp, vp, vp, vp, vp, i32, i32, vp, vp],
-    "rr_atsp_init_embed": [C.POINTER(InitW), vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "rr_init_embed": [C.POINTER(InitW), i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "rr_dec_cache": [C.POINTER(CacheW), vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "rr_rollout": [C.POINTER(DecW), C.POINTER(RolloutIO), i32, vp],
 }

@@ -137,11 +137,16 @@ class RRNetEncoder(nn.Module):
             if sidx is None:
                 sidx = ATSPInitEmbedding.sample_indices(D, self.init_embedding.sample_size)
             sidx = sidx.contiguous()
-            L.check(lib.rr_atsp_init_embed(packed["init"], L.ptr(D), L.ptr(locs), L.ptr(sidx), L.ptr(row), L.ptr(col),
-                                           Bp, N, sidx.shape[-1], L.stream()), "rr_atsp_init_embed")
+            L.check(lib.rr_init_embed(packed["init"], 0, L.ptr(D), L.ptr(locs), L.ptr(sidx), None, L.ptr(row), L.ptr(col),
+                                      Bp, N, sidx.shape[-1], L.stream()), "rr_init_embed")
         else:
-            from .vrp_embeddings import run_vrp_init_embedding
-            run_vrp_init_embedding(self, td, packed, row, col)
+            sidx = td.get("sample_idx", None)
+            if sidx is None:
+                sidx = ATSPInitEmbedding.sample_indices(D, self.init_embedding.sample_size)
+            sidx = sidx.contiguous()
+            vfeat = self.init_embedding.node_features(td).contiguous()
+            L.check(lib.rr_init_embed(packed["init"], 1, L.ptr(D), L.ptr(locs), L.ptr(sidx), L.ptr(vfeat), L.ptr(row),
+                                      L.ptr(col), Bp, N, sidx.shape[-1], L.stream()), "rr_init_embed")
         self._last_init = (row, col)
         row2, col2 = torch.empty_like(row), torch.empty_like(col)
         dbg = getattr(self, "_debug_buffer", None)

@@ -89,8 +89,27 @@ def pack_policy(sd: dict, env_name: str, device) -> dict:
             setattr(iw, "g0" + s + "b", ar.put(sd[q + ".0.bias"]))
             setattr(iw, "g2" + s, ar.put(sd[q + ".2.weight"].reshape(-1)))
             setattr(iw, "g2" + s + "b", float(sd[q + ".2.bias"].reshape(-1)[0]))
+        iw.nfeat = 0
         out["init"] = iw
         out["sample_size"] = sd[p + ".row_embed.weight"].shape[1]
+    else:   # RVRPInitEmbedding / RVRPTWInitEmbedding (rcvrp.py:29-46); distance_expert.*_combine_embed are unused (:127-150)
+        iw = L.InitW()
+        iw.wdep, iw.bdep = ar.put(sd[p + ".coord_expert.init_embed_depot.weight"]), ar.put(sd[p + ".coord_expert.init_embed_depot.bias"])
+        iw.wi, iw.bi = ar.put(sd[p + ".coord_expert.init_embed.weight"]), ar.put(sd[p + ".coord_expert.init_embed.bias"])
+        iw.wr, iw.br = ar.put(sd[p + ".distance_expert.row_embed.weight"]), ar.put(sd[p + ".distance_expert.row_embed.bias"])
+        iw.wcl, iw.bcl = ar.put(sd[p + ".distance_expert.col_embed.weight"]), ar.put(sd[p + ".distance_expert.col_embed.bias"])
+        iw.wdm, iw.bdm = ar.put(sd[p + ".demand_init.weight"]), ar.put(sd[p + ".demand_init.bias"])
+        iw.nfeat = sd[p + ".demand_init.weight"].shape[1]
+        for rc, s in (("row", "r"), ("col", "c")):
+            q = f"{p}.gating_network_{rc}.gating_fc"
+            setattr(iw, "g0" + s, ar.put(pack_a(sd[q + ".0.weight"].detach().float())))
+            setattr(iw, "g0" + s + "b", ar.put(sd[q + ".0.bias"]))
+            setattr(iw, "g2" + s, ar.put(sd[q + ".2.weight"].reshape(-1)))
+            setattr(iw, "g2" + s + "b", float(sd[q + ".2.bias"].reshape(-1)[0]))
+            setattr(iw, "cm" + s, ar.put(pack_a(sd[f"{p}.combine_{rc}_embed.weight"].detach().float())))
+            setattr(iw, "cm" + s + "b", ar.put(sd[f"{p}.combine_{rc}_embed.bias"]))
+        out["init"] = iw
+        out["sample_size"] = sd[p + ".distance_expert.row_embed.weight"].shape[1]
 
     wn = sd["decoder.project_node_embeddings.weight"].detach().float()   # [3E,E] -> K,V,L chunks
     wctx = sd["decoder.context_embedding.project_context.weight"].detach().float()

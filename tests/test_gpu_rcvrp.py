@@ -1,0 +1,86 @@
+"""`-m gpu` parity tests for RCVRP (BASELINE configs[2] shape at N=100) against the golden vectors of the real reference."""
+import pytest
+import torch
+
+from oracle import restate
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+ENC_ATOL, LL_RTOL, LL_ATOL, COST_ATOL, GAP_TOL = 5e-4, 2e-5, 2e-3, 5e-5, 1e-3
+FIXTURES = ["rcvrp_n20_b4_pomo", "rcvrp_n20_b4_greedy", "rcvrp_n100_b2_pomo"]
+
+
+def _setup(name):
+    from rrnco_amd import TensorDict
+    from rrnco_amd.envs import RCVRPEnv
+    fx = H.load_fixture(name)
+    w = H.rcvrp_weights(fx)
+    pol = H.make_policy(w, env_name="rcvrp")
+    inst = H.rcvrp_instance(fx)
+    env = RCVRPEnv(generator_params=dict(num_loc=fx["N"]), check_solution=True)
+    td_in = TensorDict({k: v.cuda() for k, v in inst.items()}, batch_size=[fx["B"]])
+    td_in["sample_idx"] = fx["sample_idx"].cuda()
+    return fx, w, pol, inst, env, td_in
+
+
+def test_rcvrp_env_step_mask_reward_bit_exact_vs_oracle():
+    from rrnco_amd.ops import batchify
+    fx, w, pol, inst, env, td_in = _setup("rcvrp_n20_b4_pomo")
+    S, B = fx["S"], fx["B"]
+    td0 = env.reset(td_in)
+    o0 = restate.rcvrp_reset(inst)
+    assert torch.equal(td0["distance_matrix"].cpu(), fx["norm_distance"]) and torch.equal(td0["action_mask"].cpu(), o0["action_mask"])
+    assert env.get_num_starts(td0) == fx["N"] + 1                                   # S = N+1
+    assert torch.equal(env.select_start_nodes(td0, S).cpu(), fx["actions"][:, 0])   # start 101 duplicates start 1
+    td = batchify(td0, S)
+    static = ("locs", "distance_matrix", "min_distance", "max_distance")
+    otd = restate.batchify_state({k: v for k, v in o0.items() if k not in static}, S)
+    for t in range(fx["actions"].shape[1]):
+        a = fx["actions"][:, t]
+        td.set("action", a.cuda()); td = env.step(td)["next"]
+        otd["action"] = a; otd = restate.rcvrp_step(otd)
+        assert torch.equal(td["action_mask"].cpu(), otd["action_mask"]), t
+        assert torch.equal(td["visited"].cpu(), otd["visited"]) and torch.equal(td["done"].cpu(), otd["done"])
+        assert torch.equal(td["used_capacity"].cpu(), otd["used_capacity"])          # fp32 adds in the same order: exact
+    assert td["done"].all()
+    real, nd = env.get_reward(td, fx["actions"].cuda())
+    assert torch.allclose(real.cpu(), fx["reward"], atol=COST_ATOL) and torch.allclose(nd.cpu(), fx["normalized_reward"], atol=COST_ATOL)
+    bad = fx["actions"].clone(); bad[:, 3] = bad[:, 2]
+    with pytest.raises(AssertionError):
+        env.get_reward(td, bad.cuda())
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_rcvrp_encoder_matches_reference_embeddings(name):
+    fx, w, pol, inst, env, td_in = _setup(name)
+    row, col = pol.encoder(env.reset(td_in), packed=pol.packed(torch.device("cuda")))
+    assert torch.allclose(row.cpu(), fx["row_emb"], atol=ENC_ATOL) and torch.allclose(col.cpu(), fx["col_emb"], atol=ENC_ATOL)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("name", FIXTURES)
+def test_rcvrp_policy_greedy_routes_match_reference(name, fused):
+    fx, w, pol, inst, env, td_in = _setup(name)
+    S = fx["S"]
+    out = pol(env.reset(td_in), env, phase="val", decode_type="multistart_greedy" if S > 1 else "greedy",
+              num_starts=S if S > 1 else None, return_actions=True, fused=fused)
+    acts = out["actions"].cpu()
+    R = acts.shape[0]
+    chk = {"demand": inst["demand"][torch.arange(R) % fx["B"]], "vehicle_capacity": torch.ones(R, 1)}
+    assert restate.rcvrp_check(chk, acts)                       # every customer once, capacity respected
+    T = min(acts.shape[1], fx["actions"].shape[1])
+    frac, first = H.tour_agreement(acts[:, :T], fx["actions"][:, :T])
+    if frac < 1.0:
+        tr = {}
+        with torch.inference_mode():
+            restate.rcvrp_policy(w, restate.rcvrp_reset(inst), fx["sample_idx"], S, "greedy", trace=tr)
+        lp = torch.nan_to_num(torch.stack(tr["logp"], 1), neginf=-1e9).topk(2, -1).values
+        gap = lp[..., 0] - lp[..., 1]
+        for r in torch.nonzero(first >= 0).flatten().tolist():
+            assert gap[r, int(first[r]) - (1 if S > 1 else 0)] < GAP_TOL
+    assert frac >= 0.98
+    same = first < 0
+    assert torch.allclose(out["reward"].cpu()[same], fx["reward"][same], atol=COST_ATOL)
+    assert torch.allclose(out["log_likelihood"].cpu()[same], fx["log_likelihood"][same], rtol=LL_RTOL, atol=LL_ATOL)
+    if frac == 1.0:
+        assert acts.shape == fx["actions"].shape               # data-dependent route length trimmed like torch.stack
