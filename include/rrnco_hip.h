@@ -47,7 +47,7 @@ typedef struct {                /* arguments of the persistent rollout: see csrc
   const float *K, *Vt, *L, *ctxA, *ctxB, *D, *Dur, *demand;
   int64_t *cur, *first; uint8_t *mask, *visited; float *used, *vcap; uint8_t *done;
   int64_t *actions; float *logp, *logits_out; const int64_t *actions_in; int *steps_out;
-  int Bp, N, S, T, t0, nsteps, mode, use_placeholder, set_first, write_state, logits_only;
+  int Bp, N, S, T, t0, nsteps, mode, use_placeholder, set_first, write_state, logits_only, stagger;
   float tanh_clip, temperature; unsigned long long seed;
 } RolloutIO;
 

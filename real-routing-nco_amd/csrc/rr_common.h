@@ -117,10 +117,26 @@ __device__ __forceinline__ float rr_max16(float v) {
   v = fmaxf(v, __shfl_xor(v, 4)); v = fmaxf(v, __shfl_xor(v, 8));
   return v;
 }
+// lane l <-> l^16 and l <-> l^32 exchanges on the gfx950 VALU (v_permlane16_swap / v_permlane32_swap) instead of
+// ds_bpermute through the LDS crossbar: with both operands equal to v, the two results hold (own, partner) in every lane
+__device__ __forceinline__ void rr_pair16(float v, float& a, float& b) {
+  auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  a = __uint_as_float(p[0]); b = __uint_as_float(p[1]);
+}
+__device__ __forceinline__ void rr_pair32(float v, float& a, float& b) {
+  auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  a = __uint_as_float(p[0]); b = __uint_as_float(p[1]);
+}
 // reductions over g (the 4 lane groups that share j = one node / rollout)
-__device__ __forceinline__ float rr_sum_g(float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; }
+__device__ __forceinline__ float rr_sum_g(float v) {
+  float a, b;
+  rr_pair16(v, a, b); v = a + b;
+  rr_pair32(v, a, b); return a + b;
+}
 __device__ __forceinline__ float rr_max_g(float v) {
-  v = fmaxf(v, __shfl_xor(v, 16)); v = fmaxf(v, __shfl_xor(v, 32)); return v;
+  float a, b;
+  rr_pair16(v, a, b); v = fmaxf(a, b);
+  rr_pair32(v, a, b); return fmaxf(a, b);
 }
 __device__ __forceinline__ float rr_wave_sum(float v) {
 #pragma unroll
@@ -163,6 +179,29 @@ __device__ __forceinline__ void rr_instnorm_tiles(f32x4 (&x)[NT], const float* _
   }
 }
 
+// ---- transcendental helpers on the hardware v_exp_f32 / v_log_f32 / v_rcp_f32 (1 ulp each).
+// exp keeps full fp32 accuracy by carrying the rounding error of x*log2(e) into a first-order correction, without
+// the range / denormal handling of the libm version (our arguments are <= 0 after max-subtraction, or |x| < 30).
+__device__ __forceinline__ float rr_exp(float x) {
+  const float L2E = 1.44269504088896341f, L2E_LO = 1.92596299112661746e-08f, LN2 = 0.693147180559945309f;
+  float xc = fmaxf(x, -104.0f);          // exp(-inf) must be 0, not NaN: clamp, then v_exp_f32 underflows to 0
+  float v = xc * L2E;
+  float lo = fmaf(xc, L2E, -v);
+  lo = fmaf(xc, L2E_LO, lo);
+  float e = __builtin_amdgcn_exp2f(v);   // 2^-150 -> 0 (v_exp_f32 flushes)
+  return fmaf(e, lo * LN2, e);
+}
+__device__ __forceinline__ float rr_log(float x) {
+  const float LN2_HI = 0.693147180559945309f, LN2_LO = -1.90465429995776804e-09f;
+  float l2 = __builtin_amdgcn_logf(x);
+  return fmaf(l2, LN2_LO, l2 * LN2_HI);
+}
+__device__ __forceinline__ float rr_tanh(float x) {          // 1 - 2/(e^{2x}+1); abs error ~1e-7
+  float t = rr_exp(2.0f * x);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
+}
+__device__ __forceinline__ float rr_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + rr_exp(-x)); }
+
 // counter-based uniform / Gumbel noise for the sampling decode (keyed by seed, rollout, step, key)
 __device__ __forceinline__ uint32_t rr_hash32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x;
@@ -173,7 +212,7 @@ __device__ __forceinline__ float rr_uniform(uint64_t seed, uint32_t r, uint32_t 
   return ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0,1)
 }
 __device__ __forceinline__ float rr_gumbel(uint64_t seed, uint32_t r, uint32_t step, uint32_t key) {
-  return -logf(-logf(rr_uniform(seed, r, step, key)));
+  return -rr_log(-rr_log(rr_uniform(seed, r, step, key)));
 }
 
 static inline int rr_check(hipError_t e) { return e == hipSuccess ? RR_OK : RR_ELAUNCH; }

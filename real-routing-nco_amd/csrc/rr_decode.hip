@@ -13,6 +13,7 @@
 //            logits = log(exp(l - alpha*D[cur,:] - beta*Dur[cur,:]) + 1e-6); 10*tanh; mask; log-softmax;
 //            greedy argmax (lowest index on ties) | Gumbel-max sample | given action; env.step
 #include "rr_common.h"
+#include <stdlib.h>
 
 #define DEC_THREADS 512
 #define ROWS 112               // rollouts per workgroup (7 tiles of 16)
@@ -49,6 +50,7 @@ struct RolloutIO {
   int set_first;                         // ATSP: first_node := action of step t0==0
   int write_state;                       // write cur/first/mask/... back (0 for a pure decoder.forward)
   int logits_only;                       // stop after writing logits_out (no selection)
+  int stagger;                           // k_rollout_w: initial delay of waves 4-7, in units of ~8k cycles
   float tanh_clip, temperature;
   unsigned long long seed;
 };
@@ -173,9 +175,9 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_rollout(DecW w, RolloutIO io
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { float e = expf(sc[kt][r] - mx); sc[kt][r] = e; sum += e; }
+          for (int r = 0; r < 4; ++r) { float e = rr_exp(sc[kt][r] - mx); sc[kt][r] = e; sum += e; }
         sum = rr_sum_g(sum);
-        const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+        const float inv = sum > 0.f ? __builtin_amdgcn_rcpf(sum) : 0.f;
         f32x4 o0 = rr_zero4(), o1 = rr_zero4();
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
@@ -253,14 +255,14 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_rollout(DecW w, RolloutIO io
           int key = kt * 16 + 4 * g + rg;
           float v = -INFINITY;
           if (key < N) {
-            float l = la[kt][rg] / sqe;                               // decoder.py:300-302
+            float l = la[kt][rg] * (1.0f / sqe);                      // decoder.py:300-302
             float bias = w.alpha * Ds[cur * N + key];                  // decoder.py:191-193
-            l = logf(expf(l - bias) + 1e-6f);                          // decoder.py:198
+            l = rr_log(rr_exp(l - bias) + 1e-6f);                      // decoder.py:198
             if (io.logits_out && step == 0 && rvalid) io.logits_out[r * N + key] = l;
             uint32_t wsel = (key >> 5) == 0 ? av0 : (key >> 5) == 1 ? av1 : (key >> 5) == 2 ? av2 : av3;
             if ((wsel >> (key & 31)) & 1u) {
-              v = io.tanh_clip > 0.f ? tanhf(l) * io.tanh_clip : l;   // decoding.py:342-343
-              v = v / io.temperature;                                  // decoding.py:350
+              v = io.tanh_clip > 0.f ? rr_tanh(l) * io.tanh_clip : l;   // decoding.py:342-343
+              v = v * (1.0f / io.temperature);                         // decoding.py:350
             }
           }
           la[kt][rg] = v;
@@ -273,9 +275,9 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_rollout(DecW w, RolloutIO io
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-          for (int rg = 0; rg < 4; ++rg) sum += expf(la[kt][rg] - mx);
+          for (int rg = 0; rg < 4; ++rg) sum += rr_exp(la[kt][rg] - mx);
         sum = rr_sum_g(sum);
-        const float lse = logf(sum);
+        const float lse = rr_log(sum);
         // log-probs; pick
         float bv = -INFINITY, blp = 0.f; int bi = 0x7fffffff;
         const int want = (io.mode == 2 && rvalid) ? (int)io.actions_in[r * io.T + t] : -1;
@@ -367,21 +369,55 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_rollout(DecW w, RolloutIO io
   if (io.steps_out && tid == 0) atomicMax(io.steps_out, step);
 }
 
+#include "rr_rollout_w.inc"
+
 extern "C" int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStream_t st) {
   if (w == nullptr || io == nullptr) return RR_EINVAL;
   const int N = io->N, S = io->S;
   if (io->Bp <= 0 || N < 2 || N > RR_MAXN || S < 1 || io->T < 1 || prob < 0 || prob > 1) return RR_EINVAL;
   if (io->mode == 2 && io->actions_in == nullptr) return RR_EINVAL;
-  dim3 grid(io->Bp, (S + ROWS - 1) / ROWS), blk(DEC_THREADS);
-  const int need = N > (S < ROWS ? S : ROWS) ? N : (S < ROWS ? S : ROWS);
+  static const int variant = getenv("RR_ROLLOUT_VARIANT") ? atoi(getenv("RR_ROLLOUT_VARIANT")) : 1;
+  if (variant == 0) {   // workgroup-per-instance variant (kept for A/B measurements)
+    dim3 grid(io->Bp, (S + ROWS - 1) / ROWS), blk(DEC_THREADS);
+    const int need = N > (S < ROWS ? S : ROWS) ? N : (S < ROWS ? S : ROWS);
 #define RR_LAUNCH(NTV)                                                                       \
   do {                                                                                       \
     if (prob == 0) hipLaunchKernelGGL((k_rollout<NTV, 0>), grid, blk, 0, st, *w, *io);       \
     else hipLaunchKernelGGL((k_rollout<NTV, 1>), grid, blk, 0, st, *w, *io);                 \
   } while (0)
-  if (need <= 32) RR_LAUNCH(2);
-  else if (need <= 64) RR_LAUNCH(4);
-  else RR_LAUNCH(7);
+    if (need <= 32) RR_LAUNCH(2);
+    else if (need <= 64) RR_LAUNCH(4);
+    else RR_LAUNCH(7);
 #undef RR_LAUNCH
+    return rr_check(hipGetLastError());
+  }
+  const int ntask = io->Bp * ((S + 15) / 16);
+  dim3 grid((ntask + WWAVES - 1) / WWAVES), blk(WTHREADS);
+  const int mode = io->logits_only ? 3 : io->mode;
+#define RR_LAUNCHW2(NTV, P)                                                                                  \
+  do {                                                                                                       \
+    if (mode == 0) hipLaunchKernelGGL((k_rollout_w<NTV, P, 0>), grid, blk, 0, st, *w, *io);                  \
+    else if (mode == 1) hipLaunchKernelGGL((k_rollout_w<NTV, P, 1>), grid, blk, 0, st, *w, *io);             \
+    else if (mode == 2) hipLaunchKernelGGL((k_rollout_w<NTV, P, 2>), grid, blk, 0, st, *w, *io);             \
+    else hipLaunchKernelGGL((k_rollout_w<NTV, P, 3>), grid, blk, 0, st, *w, *io);                            \
+  } while (0)
+#define RR_LAUNCHW(NTV)                                                                      \
+  do {                                                                                       \
+    if (prob == 0) RR_LAUNCHW2(NTV, 0);                                                      \
+    else RR_LAUNCHW2(NTV, 1);                                                                \
+  } while (0)
+  if (N <= 32) RR_LAUNCHW(2);
+  else if (N <= 64) RR_LAUNCHW(4);
+  else RR_LAUNCHW(7);
+#undef RR_LAUNCHW2
+#undef RR_LAUNCHW
   return rr_check(hipGetLastError());
 }
+
+#ifdef RR_STAMP
+extern "C" int rr_debug_stamps(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rr_stamps), sizeof(unsigned long long) * 8) != hipSuccess) return RR_ELAUNCH;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rr_stamps), z, sizeof(z)) != hipSuccess) return RR_ELAUNCH; }
+  return RR_OK;
+}
+#endif

@@ -179,17 +179,17 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
     float v = -INFINITY;
     if (j < N) {
       v = logits[(size_t)r * N + j];
-      if (tanh_clip > 0.f) v = tanhf(v) * tanh_clip;
+      if (tanh_clip > 0.f) v = rr_tanh(v) * tanh_clip;
       if (mask != nullptr && mask[(size_t)r * N + j] == 0) v = -INFINITY;
-      v = v / temperature;
+      v = v * (1.0f / temperature);
     }
     x[q] = v;
   }
   float m = rr_wave_max(fmaxf(x[0], x[1]));
-  float e0 = (lane < N) ? expf(x[0] - m) : 0.f;
-  float e1 = (lane + 64 < N) ? expf(x[1] - m) : 0.f;
+  float e0 = (lane < N) ? rr_exp(x[0] - m) : 0.f;
+  float e1 = (lane + 64 < N) ? rr_exp(x[1] - m) : 0.f;
   float ssum = rr_wave_sum(e0 + e1);
-  float lse = logf(ssum);
+  float lse = rr_log(ssum);
   float lp0 = x[0] - m - lse, lp1 = x[1] - m - lse;
   if (logp_all != nullptr) {
     if (lane < N) logp_all[(size_t)r * N + lane] = lp0;

@@ -41,7 +41,7 @@ class RolloutIO(C.Structure):
         "K", "Vt", "L", "ctxA", "ctxB", "D", "Dur", "demand", "cur", "first", "mask", "visited", "used", "vcap",
         "done", "actions", "logp", "logits_out", "actions_in", "steps_out")] + \
         [(n, i32) for n in ("Bp", "N", "S", "T", "t0", "nsteps", "mode", "use_placeholder", "set_first",
-                            "write_state", "logits_only")] + \
+                            "write_state", "logits_only", "stagger")] + \
         [("tanh_clip", f32), ("temperature", f32), ("seed", u64)]
 
 

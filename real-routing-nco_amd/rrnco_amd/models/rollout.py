@@ -7,6 +7,8 @@ from .. import _lib as L
 
 PROB_ID = {"atsp": 0, "rcvrp": 1}
 MODE_ID = {"greedy": 0, "sampling": 1, "evaluate": 2}
+import os
+STAGGER = int(os.environ.get("RR_STAGGER", "0"))   # initial delay of the second wave of every SIMD (units of ~8k cycles)
 TIMING = None   # bench.py sets this to a list to collect (start, end) HIP events around each full rollout launch
 
 
@@ -55,6 +57,7 @@ def launch_rollout(env_name, packed, cache, td, num_starts, *, actions=None, log
     io.use_placeholder = int(env_name == "atsp" and td.meta.get("i", 1) == 0)
     io.set_first = int(env_name == "atsp" and td.meta.get("i", 1) == 0)
     io.write_state, io.logits_only = int(write_state), int(logits_only)
+    io.stagger = STAGGER
     io.tanh_clip, io.temperature, io.seed = float(tanh_clip), float(temperature), int(seed)
     timed = TIMING is not None and not logits_only
     if timed:

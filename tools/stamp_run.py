@@ -1,0 +1,28 @@
+"""Diagnostic: per-phase cycle shares of k_rollout_w (stamped build). Not part of the product."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "real-routing-nco_amd"))
+from rrnco_amd import _lib
+_lib.LIB_PATH = _lib.LIB_PATH.replace("librrnco_hip.so", "librrnco_hip_stamp.so")
+import torch
+import bench
+from rrnco_amd.envs import ATSPEnv, ATSPGenerator
+from rrnco_amd.models.encoder import ATSPInitEmbedding
+dev = torch.device("cuda")
+pol, w = bench.make_policy(dev)
+env = ATSPEnv(generator_params=dict(num_loc=100, device=dev), check_solution=False, device=dev)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+inst_td = ATSPGenerator(num_loc=100, device=dev)(B, generator=torch.Generator(device=dev).manual_seed(1))
+inst = {"locs": inst_td["locs"], "distance_matrix": inst_td["distance_matrix"]}
+sidx = ATSPInitEmbedding.sample_indices(env.reset(inst_td)["distance_matrix"], 25).repeat(8, 1, 1).contiguous()
+bench.hot_path_step(pol, env, inst, sidx); torch.cuda.synchronize()
+lib = _lib.lib(); lib.rr_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+out = (ctypes.c_ulonglong * 8)()
+lib.rr_debug_stamps(out, 1)
+bench.hot_path_step(pol, env, inst, sidx); torch.cuda.synchronize()
+lib.rr_debug_stamps(out, 0)
+names = ["loop-top", "ctx gather", "attention", "MLP", "logits MFMA", "select+step"]
+waves = out[7]; tot = sum(out[i] for i in range(6))
+print(f"waves={waves} total cycles/wave={tot/waves:.3e} per step={tot/waves/99:.0f}")
+for i, n in enumerate(names):
+    print(f"  {n:12s} {out[i]/waves/99:10.0f} cycles/step  {100*out[i]/tot:5.1f}%")
