@@ -198,6 +198,64 @@ def gen_rcvrp(tag, B, N, S, sample_size, seed, capacity, layers=6, keep_trace=Tr
     print(f"wrote {path}  ({os.path.getsize(path)/1e3:.0f} kB) T={out['actions'].shape[1]} reward[:3]={out['reward'][:3].tolist()}")
 
 
+def gen_rcvrptw(tag, B, N, S, sample_size, seed, layers=6, keep_trace=True):
+    from rrnco.envs.rmtvrp.env import RMTVRPEnv
+    from rrnco.models.policy import RRNetPolicy
+
+    torch.manual_seed(seed)
+    inst = restate.rcvrptw_synthetic(B, N, seed)
+    env = RMTVRPEnv(generator=_Gen(N), check_solution=False)
+    pol = RRNetPolicy(env_name="rcvrptw", init_embedding_kwargs=dict(
+        use_coords=True, use_polar_feats=True, use_dist=True, use_matnet_init=False,
+        sample_type="prob", sample_size=sample_size), **dict(POLICY_KW, num_encoder_layers=layers)).eval()
+    tmpl = {k: tuple(v.shape) for k, v in pol.state_dict().items()}
+    mine_t = restate.rcvrptw_weight_template(128, layers, 512, sample_size)
+    assert tmpl == mine_t, (set(tmpl) ^ set(mine_t), [k for k in tmpl if k in mine_t and tmpl[k] != mine_t[k]])
+    w = restate.make_weights(tmpl, seed)
+    pol.load_state_dict(w, strict=True)
+    td = env.reset(TensorDict({k: v.clone() for k, v in inst.items()}, batch_size=[B]))
+    enc_out = []
+    hook = pol.encoder.register_forward_hook(lambda m, a, o: enc_out.append(o))
+    with torch.inference_mode(), _CaptureMultinomial() as cap:
+        out = pol(td.clone(), env, phase="val", decode_type="multistart_greedy" if S > 1 else "greedy",
+                  num_starts=S if S > 1 else None, return_actions=True)
+    hook.remove()
+    sidx = cap.calls[0].reshape(B, N + 1, sample_size)
+    st0 = restate.rmtvrp_reset(inst)
+    for k in ("distance_matrix", "duration_matrix", "min_distance", "max_distance", "action_mask", "demand_linehaul"):
+        assert torch.equal(st0[k], td[k]), k
+    trace = {}
+    with torch.inference_mode():
+        mine = restate.rcvrptw_policy(dict(pol.state_dict()), st0, sidx, S, "greedy", trace=trace)
+    T = min(mine["actions"].shape[1], out["actions"].shape[1])
+    neq = mine["actions"][:, :T] != out["actions"][:, :T]
+    same = ~neq.any(1)
+    if not bool(same.all()):
+        lp = torch.stack(trace["logp"], 1)
+        top2 = torch.nan_to_num(lp, neginf=-1e9).topk(2, -1).values
+        gap = top2[..., 0] - top2[..., 1]
+        off = 1 if S > 1 else 0
+        for r in torch.nonzero(~same).flatten().tolist():
+            t = int(neq[r].float().argmax())
+            assert gap[r, t - off] < 1e-3, f"rollout {r} diverges at step {t} with gap {gap[r, t - off]}"
+    assert float(same.float().mean()) >= 0.98
+    assert torch.allclose(mine["reward"][same], out["reward"][same], atol=1e-5)
+    assert torch.allclose(mine["log_likelihood"][same], out["log_likelihood"][same], atol=5e-4)
+    assert torch.allclose(trace["row_emb"], enc_out[0][0], atol=1e-4) and torch.allclose(trace["col_emb"], enc_out[0][1], atol=1e-4)
+    print(f"  tours identical on {float(same.float().mean())*100:.2f}% of rollouts")
+    fx = dict(kind="rcvrptw", B=B, N=N, S=S, sample_size=sample_size, seed=seed, layers=layers,
+              **{k: inst[k] for k in inst}, sample_idx=sidx, norm_distance=td["distance_matrix"],
+              min_distance=td["min_distance"], max_distance=td["max_distance"], row_emb=enc_out[0][0], col_emb=enc_out[0][1],
+              actions=out["actions"], reward=out["reward"], normalized_reward=out["normalized_reward"],
+              log_likelihood=out["log_likelihood"])
+    if keep_trace:
+        fx["trace_logits"] = torch.stack(trace["logits"], 0)
+        fx["trace_mask"] = torch.stack(trace["mask"], 0)
+    path = os.path.join(GOLD, f"{tag}.npz")
+    np.savez_compressed(path, **_np(fx))
+    print(f"wrote {path}  ({os.path.getsize(path)/1e3:.0f} kB) T={out['actions'].shape[1]} reward[:3]={out['reward'][:3].tolist()}")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     which = sys.argv[1:] or ["atsp"]
@@ -210,3 +268,7 @@ if __name__ == "__main__":
         gen_rcvrp("rcvrp_n20_b4_pomo", B=4, N=20, S=21, sample_size=15, seed=21, capacity=30.0)
         gen_rcvrp("rcvrp_n20_b4_greedy", B=4, N=20, S=0, sample_size=15, seed=22, capacity=30.0)
         gen_rcvrp("rcvrp_n100_b2_pomo", B=2, N=100, S=101, sample_size=25, seed=23, capacity=50.0, keep_trace=False)
+    if "rcvrptw" in which:
+        gen_rcvrptw("rcvrptw_n20_b4_pomo", B=4, N=20, S=20, sample_size=15, seed=31)
+        gen_rcvrptw("rcvrptw_n20_b4_greedy", B=4, N=20, S=0, sample_size=15, seed=32)
+        gen_rcvrptw("rcvrptw_n100_b2_pomo", B=2, N=100, S=100, sample_size=25, seed=33, keep_trace=False)

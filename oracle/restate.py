@@ -669,3 +669,223 @@ def rcvrp_weight_template(embed_dim: int = 128, num_layers: int = 6, ff: int = 5
     t[p + ".demand_init.weight"] = (E, demand_feats); t[p + ".demand_init.bias"] = (E,)
     t["decoder.context_embedding.project_context.weight"] = (E, E + ctx_state)
     return t
+
+
+# ==============================================================================================
+# RCVRPTW = RMTVRPEnv with the vrptw preset (rrnco/envs/rmtvrp/env.py, configs/env/rcvrptw.yaml)
+# ==============================================================================================
+def vrptw_capacity(n: int) -> float:
+    """rmtvrp/generator.py:20-33."""
+    return 30.0 + (n // 5 if n > 20 else 0)
+
+
+def rcvrptw_synthetic(batch: int, n: int, seed: int, max_time: float = 4.6) -> dict:
+    """Synthetic VRPTW instance: LazyRMTVRPGenerator(variant_preset='vrptw') synthetic branch
+    (rmtvrp/generator_lazy.py:302-348): uniform locs incl. depot, integer linehaul demands 1..9 / capacity
+    (generator.py:445-469 with backhaul_ratio 0, scale_demand), time windows / service times of
+    generator.py:495-513 (speed 1), plus explicit asymmetric distance and min-max normalised duration
+    matrices (generator.py:246-262 normalises durations) so that D != Dur != D^T."""
+    g = torch.Generator().manual_seed(seed)
+    locs = torch.rand(batch, n + 1, 2, generator=g)
+    cd = torch.cdist(locs, locs)
+    D = cd * (1 + 0.2 * torch.rand(batch, n + 1, n + 1, generator=g))
+    T = cd * (1 + 0.3 * torch.rand(batch, n + 1, n + 1, generator=g))
+    ar = torch.arange(n + 1)
+    D[:, ar, ar] = 0; T[:, ar, ar] = 0
+    tmn, tmx = T.amin(dim=(1, 2), keepdim=True), T.amax(dim=(1, 2), keepdim=True)
+    T = (T - tmn) / (tmx - tmn)
+    demand = (torch.rand(batch, n, generator=g) * 9).int().add(1).float() / vrptw_capacity(n)
+    a, b, c = 0.15, 0.18, 0.2
+    service = a + (b - a) * torch.rand(batch, n, generator=g)
+    tw_len = b + (c - b) * torch.rand(batch, n, generator=g)
+    d0 = (locs[:, 0:1] - locs[:, 1:]).norm(p=2, dim=-1)
+    h_max = (max_time - service - tw_len) / d0 - 1
+    tw_start = (1 + (h_max - 1) * torch.rand(batch, n, generator=g)) * d0
+    tw_end = tw_start + tw_len
+    tw = torch.stack((torch.cat((torch.zeros(batch, 1), tw_start), -1),
+                      torch.cat((torch.full((batch, 1), max_time), tw_end), -1)), dim=-1)
+    service = torch.cat((torch.zeros(batch, 1), service), dim=-1)
+    return {"locs": locs, "distance_matrix": D, "duration_matrix": T, "demand_linehaul": demand,
+            "time_windows": tw, "service_time": service}
+
+
+def rmtvrp_action_mask(td: dict) -> Tensor:
+    """rmtvrp/env.py:343-428 (all 16-variant terms computed; O/L/B/MB are inert under the vrptw preset)."""
+    cur = td["current_node"]
+    B = cur.shape[0]
+    bi = torch.arange(B)
+    D, T = td["distance_matrix"], td["duration_matrix"]
+    dist_ij, dist_j0 = D[bi, cur, :], D[:, :, 0]
+    dur_ij, dur_j0 = T[bi, cur, :], T[:, :, 0]
+    early, late = td["time_windows"][..., 0], td["time_windows"][..., 1]
+    arrival = td["current_time"] + dur_ij
+    can_reach_customer = arrival < late
+    can_reach_depot = (torch.max(arrival, early) + td["service_time"] + dur_j0) * ~td["open_route"] < late[..., 0:1]
+    exceeds_dist = td["current_route_length"] + dist_ij + (dist_j0 * ~td["open_route"]) > td["distance_limit"]
+    ex_l = td["demand_linehaul"] + td["used_capacity_linehaul"] > td["vehicle_capacity"]
+    ex_b = td["demand_backhaul"] + td["used_capacity_backhaul"] > td["vehicle_capacity"]
+    line_missing = ((td["demand_linehaul"] * ~td["visited"]).sum(-1) > 0)[..., None]
+    carrying_b = gather_by_index(td["demand_backhaul"], cur, dim=1, squeeze=False) > 0
+    ok1 = (line_missing & ~ex_l & ~carrying_b & (td["demand_linehaul"] > 0)) | (~ex_b & (td["demand_backhaul"] > 0))
+    cannot_l = td["demand_linehaul"] > td["vehicle_capacity"] - td["used_capacity_backhaul"]
+    ok2 = ~ex_l & ~ex_b & ~cannot_l
+    ok = ((td["backhaul_class"] == 1) & ok1) | ((td["backhaul_class"] == 2) & ok2)
+    can = can_reach_customer & can_reach_depot & ok & ~exceeds_dist & ~td["visited"]
+    can[:, 0] = ~((cur == 0) & (can[:, 1:].sum(-1) > 0))
+    return can
+
+
+def rmtvrp_reset(td: dict, normalize: bool = True) -> dict:
+    """rmtvrp/env.py:217-341."""
+    B = td["locs"].shape[0]
+    dl = torch.cat([torch.zeros_like(td["demand_linehaul"][..., :1]), td["demand_linehaul"]], dim=1)
+    db = torch.cat([torch.zeros_like(td["demand_linehaul"][..., :1]),
+                    td.get("demand_backhaul", torch.zeros_like(td["demand_linehaul"]))], dim=1)
+    D = td["distance_matrix"]
+    out = {}
+    if normalize:
+        mn, mx = D.amin(dim=(-2, -1), keepdim=True), D.amax(dim=(-2, -1), keepdim=True)
+        D = ((D - mn) / (mx - mn + 1e-6)).to(torch.float32)
+        out["min_distance"], out["max_distance"] = mn.squeeze(-1).squeeze(-1), mx.squeeze(-1).squeeze(-1)
+    speed = torch.ones_like(dl[..., :1])
+    out.update(
+        locs=td["locs"], distance_matrix=D, duration_matrix=td.get("duration_matrix", D / speed[:, None]),
+        demand_backhaul=db, demand_linehaul=dl, backhaul_class=torch.full((B, 1), 1, dtype=torch.int32),
+        distance_limit=torch.full_like(dl[..., :1], float("inf")), service_time=td["service_time"],
+        open_route=torch.zeros_like(dl[..., :1], dtype=torch.bool), time_windows=td["time_windows"], speed=speed,
+        vehicle_capacity=torch.ones_like(dl[..., :1]), capacity_original=torch.ones_like(dl[..., :1]),
+        current_node=torch.zeros(B, dtype=torch.long), current_route_length=torch.zeros(B, 1),
+        current_time=torch.zeros(B, 1), used_capacity_backhaul=torch.zeros(B, 1), used_capacity_linehaul=torch.zeros(B, 1),
+        visited=torch.zeros(B, td["locs"].shape[-2], dtype=torch.bool), done=torch.zeros(B, 1, dtype=torch.bool))
+    out["action_mask"] = rmtvrp_action_mask(out)
+    return out
+
+
+def rmtvrp_step(td: dict) -> dict:
+    """rmtvrp/env.py:155-215."""
+    prev, cur = td["current_node"], td["action"]
+    bi = torch.arange(cur.shape[0])
+    dist = td["distance_matrix"][bi, prev, cur]
+    dur = td["duration_matrix"][bi, prev, cur]
+    service = gather_by_index(td["service_time"], cur, dim=1, squeeze=False)
+    start = gather_by_index(td["time_windows"], cur, dim=1, squeeze=False)[..., 0]
+    nz = cur[:, None] != 0
+    ctime = nz * (torch.max(td["current_time"] + dur[:, None], start) + service)
+    clen = nz * (td["current_route_length"] + dist[:, None])
+    ul = nz * (td["used_capacity_linehaul"] + gather_by_index(td["demand_linehaul"], cur, dim=1, squeeze=False))
+    ub = nz * (td["used_capacity_backhaul"] + gather_by_index(td["demand_backhaul"], cur, dim=1, squeeze=False))
+    visited = td["visited"].scatter(-1, cur[..., None], True)
+    done = visited.sum(-1) == visited.size(-1)
+    td.update(current_node=cur, current_route_length=clen, current_time=ctime, done=done,
+              reward=torch.zeros_like(done).float(), used_capacity_linehaul=ul, used_capacity_backhaul=ub, visited=visited)
+    td["action_mask"] = rmtvrp_action_mask(td)
+    return td
+
+
+def mtvrp_context(w: W, emb: Tensor, td: dict) -> Tensor:
+    """MTVRPContextEmbedding env_embeddings/context.py:34-70 (Linear(E+4, E, bias=False))."""
+    cur = gather_by_index(emb, td["current_node"])
+    used = torch.where(td["used_capacity_backhaul"] == 0, td["used_capacity_linehaul"], td["used_capacity_backhaul"])
+    rem = torch.nan_to_num(td["distance_limit"] - td["current_route_length"], posinf=10)
+    feats = torch.cat((td["vehicle_capacity"] - used, td["current_time"], td["open_route"].float(), rem), -1)
+    return F.linear(torch.cat([cur, feats], -1), w["decoder.context_embedding.project_context.weight"])
+
+
+RMTVRP_DYN = ("current_node", "used_capacity_backhaul", "used_capacity_linehaul", "vehicle_capacity", "current_time",
+              "open_route", "distance_limit", "current_route_length", "action_mask")
+
+
+def rcvrptw_decoder_step(w: W, td_flat: dict, cache: dict, S: int):
+    """RRNetDecoder.forward for rcvrptw (decoder.py:151-206): bias = alpha*D[cur,:] + beta*Dur[cur,:]."""
+    td = {k: (unbatchify(td_flat[k], S) if S > 1 else td_flat[k]) for k in RMTVRP_DYN}
+    q = mtvrp_context(w, cache["node_embeddings"], td)
+    q = q.unsqueeze(1) if q.ndim == 2 else q
+    mask = td["action_mask"]
+    logits = pointer(w, q, cache["glimpse_key"], cache["glimpse_val"], cache["logit_key"], mask)
+    D, T = cache["_D"], cache["_T"]
+    if S > 1:
+        dist = gather_by_index(D.unsqueeze(1).expand(-1, S, -1, -1), td["current_node"], dim=-2)
+        dur = gather_by_index(T.unsqueeze(1).expand(-1, S, -1, -1), td["current_node"], dim=-2)
+    else:
+        dist = gather_by_index(D, td["current_node"], dim=-2)
+        dur = gather_by_index(T, td["current_node"], dim=-2)
+    bias = w["decoder.alpha"] * dist + w["decoder.beta"] * dur
+    logits = torch.log(torch.exp(logits.to(torch.float32) - bias.to(torch.float32)) + 1e-6)
+    if S > 1:
+        logits = logits.permute(1, 0, 2).reshape(-1, logits.shape[-1])
+        mask = mask.permute(1, 0, 2).reshape(-1, mask.shape[-1])
+    return logits, mask
+
+
+def rcvrptw_policy(w: W, td0: dict, sidx: Tensor, num_starts: int, decode: str = "greedy",
+                   actions: Optional[Tensor] = None, trace: Optional[dict] = None) -> dict:
+    """RRNetPolicy.forward for RCVRPTW; td0 = rmtvrp_reset(...); S = N starts (test.py:129-131)."""
+    feats = torch.cat([td0["time_windows"], td0["service_time"][..., None]], -1)
+    row, col = rcvrp_init_embedding(_tw_init_names(w), td0["locs"], td0["demand_linehaul"][:, 1:], td0["distance_matrix"], sidx, feats)
+    row, col = encoder_net(w, row, col, td0["distance_matrix"], td0["locs"].float(), td0["duration_matrix"].float(), num_layers_of(w))
+    if trace is not None:
+        trace["row_emb"], trace["col_emb"] = row, col
+    B, N1 = td0["action_mask"].shape
+    S = num_starts if num_starts > 1 else 0
+    static = ("locs", "distance_matrix", "duration_matrix", "min_distance", "max_distance")
+    acts, lps = [], []
+    if S >= 1:
+        a0 = torch.arange(S).repeat_interleave(B) % (N1 - 1) + 1      # AllSelectStartNodes selectstartnodes.py:42-50
+        td = batchify_state({k: v for k, v in td0.items() if k not in static}, S)
+        td["distance_matrix"], td["duration_matrix"] = batchify(td0["distance_matrix"], S), batchify(td0["duration_matrix"], S)
+        td["action"] = a0
+        td = rmtvrp_step(td)
+        lps.append(torch.zeros_like(a0, dtype=torch.float32)); acts.append(a0)
+    else:
+        td = {k: v for k, v in td0.items() if k != "locs"}
+    cache = precompute_cache(w, row, col)
+    cache["_D"], cache["_T"] = td0["distance_matrix"], td0["duration_matrix"]
+    k = 0
+    while not td["done"].all():
+        logits, mask = rcvrptw_decoder_step(w, td, cache, S)
+        logp = process_logits(logits, mask)
+        sel = logp.argmax(dim=-1) if decode == "greedy" else actions[:, k]
+        if trace is not None:
+            trace.setdefault("logits", []).append(logits); trace.setdefault("mask", []).append(mask)
+            trace.setdefault("logp", []).append(logp)
+        lps.append(gather_by_index(logp, sel, dim=1)); acts.append(sel)
+        td["action"] = sel
+        td = rmtvrp_step(td)
+        k += 1
+    logprobs, actions_out = torch.stack(lps, 1), torch.stack(acts, 1)
+    R = actions_out.shape[0]
+    ix = torch.arange(R) % B
+    rtd = {"distance_matrix": td0["distance_matrix"][ix], "min_distance": td0["min_distance"][ix], "max_distance": td0["max_distance"][ix]}
+    real, nd = vrp_reward(rtd, actions_out, True)      # rmtvrp/env.py:430-455 (closed routes: the open-route zeroing is inert)
+    return {"reward": real, "normalized_reward": nd, "log_likelihood": logprobs.sum(1), "actions": actions_out,
+            "logprobs": logprobs}
+
+
+def _tw_init_names(w: W) -> W:
+    """rcvrptw.py names the attribute layer `init_embed` (Linear(4,E)) where rcvrp.py has `demand_init`."""
+    out = dict(w)
+    out["encoder.init_embedding.demand_init.weight"] = w["encoder.init_embedding.init_embed.weight"]
+    out["encoder.init_embedding.demand_init.bias"] = w["encoder.init_embedding.init_embed.bias"]
+    return out
+
+
+def rcvrptw_weight_template(embed_dim: int = 128, num_layers: int = 6, ff: int = 512, sample_size: int = 25) -> Dict[str, tuple]:
+    E = embed_dim
+    t = {}
+    for k, v in rcvrp_weight_template(E, num_layers, ff, sample_size, 4, 4).items():
+        if ".angle_distance_fusion." in k:
+            if ".gate.0." in k:
+                continue
+            k = k.replace(".angle_distance_fusion.", ".neural_adaptive_bias.")
+        k = k.replace("encoder.init_embedding.demand_init.", "encoder.init_embedding.init_embed.")
+        t[k] = v
+    for l in range(num_layers):
+        for rc in ("row", "col"):
+            f = f"encoder.net.layers.{l}.{rc}_encoding_block.neural_adaptive_bias"
+            t[f + ".dur_emb.0.weight"] = (E, 1); t[f + ".dur_emb.0.bias"] = (E,)
+            t[f + ".dur_emb.2.weight"] = (E, E); t[f + ".dur_emb.2.bias"] = (E,)
+            t[f + ".gate.0.weight"] = (E, 3 * E); t[f + ".gate.0.bias"] = (E,)
+            t[f + ".gate.2.weight"] = (3, E); t[f + ".gate.2.bias"] = (3,)
+            t[f + ".gate_temperature"] = ()
+    t["decoder.beta"] = (1,)
+    return t
