@@ -37,6 +37,12 @@ typedef struct {                /* ATSPInitEmbedding (rrnco/models/env_embedding
   int nfeat;
 } InitW;
 
+typedef struct {                /* folded DistAngleFusion(use_duration_matrix=True): attn_freenet.py:226-237, 265-286 */
+  const void *mp;               /* pack [9][24][64][4]: [M_d|M_a|M_t] (128x384) + rows co_d/co_a/co_t */
+  const float *ab, *cg, *wg2;   /* first-layer slopes/offsets [2][384], gate constant [128], gate.2 weight [3][128] */
+  float bg2[3], ko[3], inv_tau, bo, alpha;
+} NabDurW;
+
 typedef struct { const void *wk, *wv, *wl, *wca, *wcb; } CacheW;   /* rrnco/models/decoder.py:214-232 + context */
 
 typedef struct {                /* pointer MLP + inductive-bias scalars: rrnco/models/decoder.py:186-198, 272-277 */
@@ -44,8 +50,8 @@ typedef struct {                /* pointer MLP + inductive-bias scalars: rrnco/m
 } DecW;
 
 typedef struct {                /* arguments of the persistent rollout: see csrc/rr_decode.hip */
-  const float *K, *Vt, *L, *ctxA, *ctxB, *D, *Dur, *demand;
-  int64_t *cur, *first; uint8_t *mask, *visited; float *used, *vcap; uint8_t *done;
+  const float *K, *Vt, *L, *ctxA, *ctxB, *D, *Dur, *demand, *tw, *service;
+  int64_t *cur, *first; uint8_t *mask, *visited; float *used, *vcap, *ctime, *rlen; uint8_t *done;
   int64_t *actions; float *logp, *logits_out; const int64_t *actions_in; int *steps_out;
   int Bp, N, S, T, t0, nsteps, mode, use_placeholder, set_first, write_state, logits_only, stagger;
   float tanh_clip, temperature; unsigned long long seed;
@@ -77,8 +83,18 @@ int rr_select(const float* logits, const uint8_t* mask, const int64_t* action_in
 
 /* One Attn_Free_Layer = row block + col block (rrnco/models/nn/attn_freenet.py:472-488). */
 int rr_enc_layer(const EncBlockW* wrow, const EncBlockW* wcol, const float* row_in, const float* col_in,
-                 float* row_out, float* col_out, const float* D, const float* locs, int Bp, int N,
-                 float* dbg, hipStream_t stream);
+                 float* row_out, float* col_out, const float* D, const float* locs, const float* bias_pre,
+                 int Bp, int N, float* dbg, hipStream_t stream);
+
+/* Neural Adaptive Bias with the duration matrix for the row and col block of one layer
+ * (rrnco/models/nn/attn_freenet.py:226-237, 265-286, x alpha :427-429) -> bias_out [Bp][2][N*N], fed to rr_enc_layer. */
+int rr_nab_dur(const NabDurW* wrow, const NabDurW* wcol, const float* D, const float* T, const float* locs,
+               float* bias_out, int Bp, int N, hipStream_t stream);
+
+/* RMTVRPEnv._step + get_action_mask under the vrptw preset (rrnco/envs/rmtvrp/env.py:155-215, 343-428). */
+int rr_rmtvrp_step(const int64_t* action, const float* D, const float* T, const float* demand_l, const float* tw,
+                   const float* service, const float* vcap, int64_t* cur, float* ctime, float* rlen, float* used_l,
+                   uint8_t* visited, uint8_t* mask, uint8_t* done, int R, int Bp, int N, hipStream_t stream);
 
 /* kind 0: ATSPInitEmbedding.forward (rrnco/models/env_embeddings/atsp.py:69-91);
  * kind 1: RVRPInitEmbedding._embed_with_distance (rcvrp.py:88-102; rcvrptw.py with F=4), node 0 = depot,
@@ -92,7 +108,7 @@ int rr_dec_cache(const CacheW* w, const float* row_emb, const float* col_emb, fl
 
 /* The decode loop of RRNetPolicy.forward (rrnco/models/policy.py:210-228) = RRNetDecoder.forward
  * (decoder.py:151-206) + DecodingStrategy.step (decoding.py:219-270) + env.step, `nsteps` steps in one launch;
- * logits_only = a single pure RRNetDecoder.forward.  prob 0 = ATSP, 1 = RCVRP. */
+ * logits_only = a single pure RRNetDecoder.forward.  prob 0 = ATSP, 1 = RCVRP, 2 = RCVRPTW. */
 int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStream_t stream);
 
 #ifdef __cplusplus

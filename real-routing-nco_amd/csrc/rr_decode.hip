@@ -32,12 +32,14 @@ struct RolloutIO {
   const float *K, *Vt, *L, *ctxA, *ctxB;
   const float *D, *Dur;                  // normalised distance (and duration) matrices [Bp][N][N]
   // problem data
-  const float* demand;                   // RCVRP: [Bp][N-1] customer demands (already / capacity)
+  const float* demand;                   // RCVRP: [Bp][N-1] customer demands (already / capacity); RCVRPTW: demand_linehaul [Bp][N]
+  const float *tw, *service;             // RCVRPTW: time_windows [Bp][N][2], service_time [Bp][N]
   // rollout state, r = s*Bp + b
   int64_t *cur, *first;                  // [R]
   uint8_t *mask;                         // [R][N] action mask, 1 = feasible
   uint8_t *visited;                      // [R][N] (VRP)
   float *used, *vcap;                    // [R] (VRP)
+  float *ctime, *rlen;                   // [R] (RCVRPTW) current_time, current_route_length
   uint8_t *done;                         // [R]
   // outputs
   int64_t* actions; float* logp;         // [R][T]
@@ -374,10 +376,11 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_rollout(DecW w, RolloutIO io
 extern "C" int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStream_t st) {
   if (w == nullptr || io == nullptr) return RR_EINVAL;
   const int N = io->N, S = io->S;
-  if (io->Bp <= 0 || N < 2 || N > RR_MAXN || S < 1 || io->T < 1 || prob < 0 || prob > 1) return RR_EINVAL;
+  if (io->Bp <= 0 || N < 2 || N > RR_MAXN || S < 1 || io->T < 1 || prob < 0 || prob > 2) return RR_EINVAL;
+  if (prob == 2 && (io->Dur == nullptr || io->tw == nullptr || io->service == nullptr || io->ctime == nullptr)) return RR_EINVAL;
   if (io->mode == 2 && io->actions_in == nullptr) return RR_EINVAL;
   static const int variant = getenv("RR_ROLLOUT_VARIANT") ? atoi(getenv("RR_ROLLOUT_VARIANT")) : 1;
-  if (variant == 0) {   // workgroup-per-instance variant (kept for A/B measurements)
+  if (variant == 0 && prob < 2) {   // workgroup-per-instance variant (kept for A/B measurements; ATSP / RCVRP only)
     dim3 grid(io->Bp, (S + ROWS - 1) / ROWS), blk(DEC_THREADS);
     const int need = N > (S < ROWS ? S : ROWS) ? N : (S < ROWS ? S : ROWS);
 #define RR_LAUNCH(NTV)                                                                       \
@@ -404,7 +407,8 @@ extern "C" int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStrea
 #define RR_LAUNCHW(NTV)                                                                      \
   do {                                                                                       \
     if (prob == 0) RR_LAUNCHW2(NTV, 0);                                                      \
-    else RR_LAUNCHW2(NTV, 1);                                                                \
+    else if (prob == 1) RR_LAUNCHW2(NTV, 1);                                                 \
+    else RR_LAUNCHW2(NTV, 2);                                                                \
   } while (0)
   if (N <= 32) RR_LAUNCHW(2);
   else if (N <= 64) RR_LAUNCHW(4);

@@ -88,6 +88,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_enc_block(EncBlockW wr, EncB
                                                               const float* __restrict__ row_in, const float* __restrict__ col_in,
                                                               float* __restrict__ row_out, float* __restrict__ col_out,
                                                               const float* __restrict__ D, const float* __restrict__ locs,
+                                                              const float* __restrict__ bias_pre,
                                                               int N, float* __restrict__ dbg) {
   __shared__ __attribute__((aligned(16))) float smem[3 * BUF_FLOATS];
   float* A = smem;                   // r = IN1(x)
@@ -140,9 +141,13 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_enc_block(EncBlockW wr, EncB
         int jj = lane + 64 * q;
         bs[q] = -INFINITY;
         if (jj < N) {
-          float d = is_col ? Db[jj * N + i] : Db[i * N + jj];
-          float th = atan2f(yi - yj[q], xi - xj[q]);
-          bs[q] = nab_edge(w.nab, d, th);
+          if (bias_pre != nullptr) {   // NAB with duration: computed by k_nab_dur (MFMA), already scaled by alpha
+            bs[q] = bias_pre[((size_t)(b * 2 + is_col) * N + i) * N + jj];
+          } else {
+            float d = is_col ? Db[jj * N + i] : Db[i * N + jj];
+            float th = atan2f(yi - yj[q], xi - xj[q]);
+            bs[q] = nab_edge(w.nab, d, th);
+          }
         }
       }
       float m = rr_wave_max(fmaxf(bs[0], bs[1]));
@@ -276,13 +281,119 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_enc_block(EncBlockW wr, EncB
 }
 
 extern "C" int rr_enc_layer(const EncBlockW* wrow, const EncBlockW* wcol, const float* row_in, const float* col_in,
-                            float* row_out, float* col_out, const float* D, const float* locs, int Bp, int N,
-                            float* dbg, hipStream_t st) {
+                            float* row_out, float* col_out, const float* D, const float* locs, const float* bias_pre,
+                            int Bp, int N, float* dbg, hipStream_t st) {
   if (Bp <= 0 || N < 2 || N > RR_MAXN || wrow == nullptr || wcol == nullptr) return RR_EINVAL;
   dim3 grid(Bp, 2), blk(ENC_THREADS);
-  if (N <= 32) hipLaunchKernelGGL(k_enc_block<2>, grid, blk, 0, st, *wrow, *wcol, row_in, col_in, row_out, col_out, D, locs, N, dbg);
-  else if (N <= 64) hipLaunchKernelGGL(k_enc_block<4>, grid, blk, 0, st, *wrow, *wcol, row_in, col_in, row_out, col_out, D, locs, N, dbg);
-  else hipLaunchKernelGGL(k_enc_block<7>, grid, blk, 0, st, *wrow, *wcol, row_in, col_in, row_out, col_out, D, locs, N, dbg);
+  if (N <= 32) hipLaunchKernelGGL(k_enc_block<2>, grid, blk, 0, st, *wrow, *wcol, row_in, col_in, row_out, col_out, D, locs, bias_pre, N, dbg);
+  else if (N <= 64) hipLaunchKernelGGL(k_enc_block<4>, grid, blk, 0, st, *wrow, *wcol, row_in, col_in, row_out, col_out, D, locs, bias_pre, N, dbg);
+  else hipLaunchKernelGGL(k_enc_block<7>, grid, blk, 0, st, *wrow, *wcol, row_in, col_in, row_out, col_out, D, locs, bias_pre, N, dbg);
+  return rr_check(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// NAB with duration (DistAngleFusion(use_duration_matrix=True), attn_freenet.py:226-237, 265-286) for one layer.
+//   u,v,w = MLP_{d,theta,t}(x) ; z = SiLU(Wg0 [u;v;w] + bg0) ; g = softmax((Wg2 z + bg2) / exp(tau))
+//   bias  = wo.(g0 u + g1 v + g2 w) + bo
+// Folding the second MLP layers into their consumers (host, float64) leaves per edge
+//   z_pre = [M_d | M_a | M_t] (128 x 384) . [h_d; h_a; h_t] + c   with h_x = relu(a_x x + b_x)  (a REAL E x 3E contraction),
+//   po_x  = co_x . h_x + ko_x
+// which runs on MFMA with the 16 edges of a tile on the lane axis: 8 feature tiles of z plus a 9th tile whose rows
+// 0..2 are co_d / co_a / co_t; the hidden vectors are generated in registers (never stored).  One wave = 64 edges.
+// ------------------------------------------------------------------------------------------------
+struct NabDurW {
+  const float4* mp;     // packed A operand [9 tiles][24 kk][64][4]
+  const float* ab;      // [2][384]: a (slopes) then b (offsets) of the three first layers, order d | theta | t
+  const float* cg;      // [128] constant of the gate pre-activation
+  const float* wg2;     // [3][128] gate.2 weight
+  float bg2[3], ko[3];
+  float inv_tau, bo, alpha;
+};
+
+#define NAB_ET 4       // edge tiles (of 16 edges) per wave
+
+__global__ __launch_bounds__(256, 2) void k_nab_dur(NabDurW wr, NabDurW wc, const float* __restrict__ D,
+                                                    const float* __restrict__ T, const float* __restrict__ locs,
+                                                    float* __restrict__ bias_out, int N) {
+  const int b = blockIdx.y, is_col = blockIdx.z;
+  const NabDurW& w = is_col ? wc : wr;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int NN = N * N;
+  const int e0 = (blockIdx.x * 4 + wave) * (16 * NAB_ET);
+  if (e0 >= NN) return;
+  const float* Db = D + (size_t)b * NN;
+  const float* Tb = T + (size_t)b * NN;
+  const float* lc = locs + (size_t)b * N * 2;
+  float xin[NAB_ET][3];
+#pragma unroll
+  for (int et = 0; et < NAB_ET; ++et) {
+    int e = e0 + et * 16 + j; e = e < NN ? e : NN - 1;
+    const int i = e / N, jj = e - i * N;
+    xin[et][0] = is_col ? Db[jj * N + i] : Db[e];
+    xin[et][2] = is_col ? Tb[jj * N + i] : Tb[e];
+    xin[et][1] = atan2f(lc[i * 2 + 1] - lc[jj * 2 + 1], lc[i * 2] - lc[jj * 2]);
+  }
+  f32x4 acc[NAB_ET][9];
+#pragma unroll
+  for (int et = 0; et < NAB_ET; ++et)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[et][t] = rr_zero4();
+#pragma unroll 1
+  for (int kk = 0; kk < 24; ++kk) {
+    const int src = kk >> 3;                                  // 0 d, 1 theta, 2 t
+    const float4 a4 = rr_ld4(w.ab + kk * 16 + 4 * g), b4 = rr_ld4(w.ab + 384 + kk * 16 + 4 * g);
+    float4 af[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) af[t] = w.mp[(size_t)(t * 24 + kk) * 64 + lane];
+#pragma unroll
+    for (int et = 0; et < NAB_ET; ++et) {
+      const float x = src == 0 ? xin[et][0] : src == 1 ? xin[et][1] : xin[et][2];
+      const float h0 = fmaxf(fmaf(a4.x, x, b4.x), 0.f), h1 = fmaxf(fmaf(a4.y, x, b4.y), 0.f);
+      const float h2 = fmaxf(fmaf(a4.z, x, b4.z), 0.f), h3 = fmaxf(fmaf(a4.w, x, b4.w), 0.f);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        acc[et][t] = rr_mfma(af[t].x, h0, acc[et][t]); acc[et][t] = rr_mfma(af[t].y, h1, acc[et][t]);
+        acc[et][t] = rr_mfma(af[t].z, h2, acc[et][t]); acc[et][t] = rr_mfma(af[t].w, h3, acc[et][t]);
+      }
+    }
+  }
+  // epilogue per edge tile: SiLU, 3-way gate, softmax with temperature, blend of the three projected scalars
+#pragma unroll
+  for (int et = 0; et < NAB_ET; ++et) {
+    float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float4 c4 = rr_ld4(w.cg + 16 * t + 4 * g);
+      const float4 g0 = rr_ld4(w.wg2 + 16 * t + 4 * g), g1 = rr_ld4(w.wg2 + 128 + 16 * t + 4 * g), g2 = rr_ld4(w.wg2 + 256 + 16 * t + 4 * g);
+      const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
+      const float g0v[4] = {g0.x, g0.y, g0.z, g0.w}, g1v[4] = {g1.x, g1.y, g1.z, g1.w}, g2v[4] = {g2.x, g2.y, g2.z, g2.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float zp = acc[et][t][r] + cv[r];
+        const float zs = zp * rr_sigmoid(zp);                  // SiLU
+        l0 = fmaf(g0v[r], zs, l0); l1 = fmaf(g1v[r], zs, l1); l2 = fmaf(g2v[r], zs, l2);
+      }
+    }
+    l0 = (rr_sum_g(l0) + w.bg2[0]) * w.inv_tau; l1 = (rr_sum_g(l1) + w.bg2[1]) * w.inv_tau; l2 = (rr_sum_g(l2) + w.bg2[2]) * w.inv_tau;
+    const float m = fmaxf(l0, fmaxf(l1, l2));
+    const float e0x = rr_exp(l0 - m), e1x = rr_exp(l1 - m), e2x = rr_exp(l2 - m);
+    const float inv = 1.0f / (e0x + e1x + e2x);
+    // rows 0..2 of tile 8 (lane group g == 0, regs 0..2) hold co_d.h_d, co_a.h_a, co_t.h_t
+    const float bias = (e0x * inv) * (acc[et][8][0] + w.ko[0]) + (e1x * inv) * (acc[et][8][1] + w.ko[1]) +
+                       (e2x * inv) * (acc[et][8][2] + w.ko[2]) + w.bo;
+    const int e = e0 + et * 16 + j;
+    if (g == 0 && e < NN) bias_out[(size_t)(b * 2 + is_col) * NN + e] = bias * w.alpha;
+  }
+}
+
+extern "C" int rr_nab_dur(const NabDurW* wrow, const NabDurW* wcol, const float* D, const float* T, const float* locs,
+                          float* bias_out, int Bp, int N, hipStream_t st) {
+  if (Bp <= 0 || N < 2 || wrow == nullptr || wcol == nullptr) return RR_EINVAL;
+  const int per_wg = 4 * 16 * NAB_ET;
+  dim3 grid((N * N + per_wg - 1) / per_wg, Bp, 2), blk(256);
+  hipLaunchKernelGGL(k_nab_dur, grid, blk, 0, st, *wrow, *wcol, D, T, locs, bias_out, N);
   return rr_check(hipGetLastError());
 }
 

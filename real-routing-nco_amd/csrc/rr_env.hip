@@ -238,3 +238,71 @@ extern "C" int rr_select(const float* logits, const uint8_t* mask, const int64_t
                      logp_all, R, N, tanh_clip, temperature, mode, seed, step);
   return rr_check(hipGetLastError());
 }
+
+// ------------------------------------------------------------------------------------------------
+// RMTVRPEnv._step + get_action_mask under the vrptw preset (rmtvrp/env.py:155-215, 343-428): backhaul demands are
+// zero, routes closed, no distance limit, backhaul class 1 — those terms are inert and not evaluated.
+// One wave per rollout; rollout r uses instance r % Bp; N counts the depot.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rmtvrp_step(const int64_t* __restrict__ action, const float* __restrict__ D,
+                                                     const float* __restrict__ T, const float* __restrict__ dem_l,
+                                                     const float* __restrict__ tw, const float* __restrict__ service,
+                                                     const float* __restrict__ vcap, int64_t* __restrict__ cur_io,
+                                                     float* __restrict__ ctime, float* __restrict__ rlen,
+                                                     float* __restrict__ used_l, uint8_t* __restrict__ visited,
+                                                     uint8_t* __restrict__ mask, uint8_t* __restrict__ done,
+                                                     int R, int Bp, int N) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const int b = r % Bp;
+  const float* Db = D + (size_t)b * N * N;
+  const float* Tb = T + (size_t)b * N * N;
+  const float* twb = tw + (size_t)b * N * 2;
+  const float* svb = service + (size_t)b * N;
+  const float* dl = dem_l + (size_t)b * N;
+  const int prev = (int)cur_io[r], a = (int)action[r];
+  const float nz = a != 0 ? 1.0f : 0.0f;
+  const float t1 = nz * (fmaxf(ctime[r] + Tb[prev * N + a], twb[a * 2]) + svb[a]);
+  const float len1 = nz * (rlen[r] + Db[prev * N + a]);
+  const float u1 = nz * (used_l[r] + dl[a]);
+  const float cap = vcap[r], late0 = twb[1];
+  uint8_t* vis = visited + (size_t)r * N;
+  uint8_t* mk = mask + (size_t)r * N;
+  int nvis = 0, missing = 0;
+  for (int k = lane; k < N; k += 64) {
+    uint8_t v = vis[k];
+    if (k == a) v = 1;
+    vis[k] = v;
+    nvis += (v != 0);
+    missing |= (v == 0 && dl[k] > 0.f);
+  }
+  nvis = (int)rr_wave_sum((float)nvis);
+  missing = __any(missing);
+  int nfree = 0;
+  for (int k = lane; k < N; k += 64) {
+    const bool v = vis[k] != 0;
+    const float arrival = t1 + Tb[a * N + k];
+    const bool reach = arrival < twb[k * 2 + 1];
+    const bool back = (fmaxf(arrival, twb[k * 2]) + svb[k] + Tb[k * N]) < late0;
+    const bool capok = !(dl[k] + u1 > cap) && dl[k] > 0.f;
+    const bool can = missing && reach && back && capok && !v;
+    if (k >= 1) { mk[k] = can; nfree += can; }
+  }
+  nfree = (int)rr_wave_sum((float)nfree);
+  if (lane == 0) {
+    mk[0] = !((a == 0) && nfree > 0);
+    cur_io[r] = a; ctime[r] = t1; rlen[r] = len1; used_l[r] = u1;
+    done[r] = (nvis == N);
+  }
+}
+
+extern "C" int rr_rmtvrp_step(const int64_t* action, const float* D, const float* T, const float* demand_l,
+                              const float* tw, const float* service, const float* vcap, int64_t* cur, float* ctime,
+                              float* rlen, float* used_l, uint8_t* visited, uint8_t* mask, uint8_t* done,
+                              int R, int Bp, int N, hipStream_t st) {
+  if (R <= 0 || N < 2 || Bp <= 0) return RR_EINVAL;
+  hipLaunchKernelGGL(k_rmtvrp_step, dim3((R + 3) / 4), dim3(256), 0, st, action, D, T, demand_l, tw, service, vcap, cur,
+                     ctime, rlen, used_l, visited, mask, done, R, Bp, N);
+  return rr_check(hipGetLastError());
+}

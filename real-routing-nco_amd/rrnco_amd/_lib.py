@@ -36,10 +36,15 @@ class DecW(C.Structure):
     _fields_ = [(n, vp) for n in ("w1", "w2", "b1", "b2", "q0", "wstate")] + [("alpha", f32), ("beta", f32)]
 
 
+class NabDurW(C.Structure):
+    _fields_ = [(n, vp) for n in ("mp", "ab", "cg", "wg2")] + [("bg2", f32 * 3), ("ko", f32 * 3),
+                                                                ("inv_tau", f32), ("bo", f32), ("alpha", f32)]
+
+
 class RolloutIO(C.Structure):
     _fields_ = [(n, vp) for n in (
-        "K", "Vt", "L", "ctxA", "ctxB", "D", "Dur", "demand", "cur", "first", "mask", "visited", "used", "vcap",
-        "done", "actions", "logp", "logits_out", "actions_in", "steps_out")] + \
+        "K", "Vt", "L", "ctxA", "ctxB", "D", "Dur", "demand", "tw", "service", "cur", "first", "mask", "visited", "used",
+        "vcap", "ctime", "rlen", "done", "actions", "logp", "logits_out", "actions_in", "steps_out")] + \
         [(n, i32) for n in ("Bp", "N", "S", "T", "t0", "nsteps", "mode", "use_placeholder", "set_first",
                             "write_state", "logits_only", "stagger")] + \
         [("tanh_clip", f32), ("temperature", f32), ("seed", u64)]
@@ -51,7 +56,9 @@ _SIGS = {
     "rr_rcvrp_step": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "rr_tour_cost": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "rr_select": [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, u64, u32, vp],
-    "rr_enc_layer": [C.POINTER(EncBlockW), C.POINTER(EncBlockW), vp, vp, vp, vp, vp, vp, i32, i32, vp, vp],
+    "rr_enc_layer": [C.POINTER(EncBlockW), C.POINTER(EncBlockW), vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp],
+    "rr_nab_dur": [C.POINTER(NabDurW), C.POINTER(NabDurW), vp, vp, vp, vp, i32, i32, vp],
+    "rr_rmtvrp_step": [vp] * 14 + [i32, i32, i32, vp],
     "rr_init_embed": [C.POINTER(InitW), i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "rr_dec_cache": [C.POINTER(CacheW), vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "rr_rollout": [C.POINTER(DecW), C.POINTER(RolloutIO), i32, vp],

@@ -1,0 +1,169 @@
+"""RCVRPTW environment — drop-in for rrnco.envs.rmtvrp.RMTVRPEnv with `variant_preset: vrptw`
+(rrnco/envs/rmtvrp/env.py, configs/env/rcvrptw.yaml).  The HIP kernels evaluate the vrptw preset: linehaul demands,
+time windows, closed routes; instances carrying backhauls / open routes / distance limits are rejected."""
+from __future__ import annotations
+
+import torch
+
+from .. import _lib as L
+from ..tensordict_lite import TensorDict
+from .base import EnvBase
+
+
+def vrptw_capacity(n: int) -> float:
+    return 30.0 + (n // 5 if n > 20 else 0)          # rmtvrp/generator.py:20-33
+
+
+class RMTVRPGenerator:
+    """Synthetic VRPTW instances: LazyRMTVRPGenerator(variant_preset='vrptw') synthetic branch
+    (rmtvrp/generator_lazy.py:302-348, generator.py:445-513) plus explicit asymmetric distance / duration matrices."""
+
+    def __init__(self, num_loc: int = 20, max_time: float = 4.6, variant_preset: str = "vrptw", device="cuda", **unused):
+        if variant_preset != "vrptw":
+            raise NotImplementedError("rrnco_amd implements the vrptw preset (configs/env/rcvrptw.yaml)")
+        self.num_loc, self.max_time, self.device = num_loc, max_time, device
+
+    def __call__(self, batch_size, generator=None):
+        bs = [batch_size] if isinstance(batch_size, int) else list(batch_size)
+        n, dev, B = self.num_loc, self.device, bs[0]
+        rnd = lambda *s: torch.rand(*s, device=dev, generator=generator)  # noqa: E731
+        locs = rnd(B, n + 1, 2)
+        cd = torch.cdist(locs, locs)
+        D, T = cd * (1 + 0.2 * rnd(B, n + 1, n + 1)), cd * (1 + 0.3 * rnd(B, n + 1, n + 1))
+        ar = torch.arange(n + 1, device=dev)
+        D[:, ar, ar] = 0; T[:, ar, ar] = 0
+        tmn, tmx = T.amin(dim=(1, 2), keepdim=True), T.amax(dim=(1, 2), keepdim=True)
+        T = (T - tmn) / (tmx - tmn)
+        demand = (rnd(B, n) * 9).int().add(1).float() / vrptw_capacity(n)
+        a, b, c = 0.15, 0.18, 0.2
+        service = a + (b - a) * rnd(B, n)
+        tw_len = b + (c - b) * rnd(B, n)
+        d0 = (locs[:, 0:1] - locs[:, 1:]).norm(p=2, dim=-1)
+        h_max = (self.max_time - service - tw_len) / d0 - 1
+        tw_start = (1 + (h_max - 1) * rnd(B, n)) * d0
+        z, full = torch.zeros(B, 1, device=dev), torch.full((B, 1), self.max_time, device=dev)
+        tw = torch.stack((torch.cat((z, tw_start), -1), torch.cat((full, tw_start + tw_len), -1)), dim=-1)
+        return TensorDict({"locs": locs, "distance_matrix": D, "duration_matrix": T, "demand_linehaul": demand,
+                           "time_windows": tw, "service_time": torch.cat((z, service), -1)}, batch_size=bs)
+
+
+class RMTVRPEnv(EnvBase):
+    name = "rcvrptw"
+
+    def __init__(self, generator=None, generator_params: dict = {}, select_start_nodes_fn="all", normalize: bool = True,
+                 check_solution: bool = False, **kwargs):
+        super().__init__(check_solution=check_solution, **kwargs)
+        if generator is None:
+            generator = RMTVRPGenerator(**{k: v for k, v in dict(generator_params).items() if k != "_target_"})
+        if select_start_nodes_fn != "all":
+            raise NotImplementedError("only the 'all' start-node selector (selectstartnodes.py:42-50) is implemented")
+        self.generator, self.normalize = generator, normalize
+
+    def get_num_starts(self, td):                      # selectstartnodes.py: AllSelectStartNodes -> num_loc
+        return td["action_mask"].shape[-1] - 1
+
+    def select_start_nodes(self, td, num_starts):      # selectstartnodes.py:42-50
+        n = td["locs"].shape[-2] - 1
+        return torch.arange(num_starts, device=td.device).repeat_interleave(td.shape[0]) % n + 1
+
+    def _reset(self, td, batch_size=None) -> TensorDict:
+        """env.py:217-341."""
+        for k, bad in (("demand_backhaul", lambda v: bool((v != 0).any())), ("open_route", lambda v: bool(v.any())),
+                       ("distance_limit", lambda v: bool(torch.isfinite(v).any()))):
+            if k in td and bad(td[k]):
+                raise NotImplementedError(f"rrnco_amd RMTVRPEnv evaluates the vrptw preset only ('{k}' is set)")
+        L.require_gpu(td["locs"])
+        dev, B = td["locs"].device, td["locs"].shape[0]
+        dl = torch.cat([torch.zeros_like(td["demand_linehaul"][..., :1]), td["demand_linehaul"]], dim=1)
+        D = td["distance_matrix"] if "distance_matrix" in td else torch.cdist(td["locs"], td["locs"], p=2)
+        n1 = D.shape[-1]
+        out = {}
+        if self.normalize:
+            D = D.contiguous().float()
+            norm, mn, mx = torch.empty_like(D), torch.empty(B, device=dev), torch.empty(B, device=dev)
+            L.check(L.lib().rr_minmax_normalize(L.ptr(D), L.ptr(norm), L.ptr(mn), L.ptr(mx), B, n1 * n1, L.stream()),
+                    "rr_minmax_normalize")
+            D = norm
+            out.update(min_distance=mn, max_distance=mx)
+        ones = torch.ones_like(dl[..., :1])
+        tw = td.get("time_windows", None)
+        if tw is None:
+            tw = torch.zeros_like(td["locs"]); tw[..., 1] = float("inf")
+        out.update(
+            locs=td["locs"], distance_matrix=D, duration_matrix=td["duration_matrix"] if "duration_matrix" in td else D / ones[:, None],
+            demand_backhaul=torch.zeros_like(dl), demand_linehaul=dl,
+            backhaul_class=torch.full((*batch_size, 1), 1, dtype=torch.int32, device=dev),
+            distance_limit=torch.full_like(ones, float("inf")), service_time=td.get("service_time", torch.zeros_like(dl)),
+            open_route=torch.zeros_like(ones, dtype=torch.bool), time_windows=tw, speed=ones.clone(),
+            vehicle_capacity=ones.clone(), capacity_original=ones.clone(),
+            current_node=torch.zeros((*batch_size,), dtype=torch.long, device=dev),
+            current_route_length=torch.zeros((*batch_size, 1), device=dev), current_time=torch.zeros((*batch_size, 1), device=dev),
+            used_capacity_backhaul=torch.zeros((*batch_size, 1), device=dev),
+            used_capacity_linehaul=torch.zeros((*batch_size, 1), device=dev),
+            visited=torch.zeros((*batch_size, n1), dtype=torch.bool, device=dev))
+        if td.get("sample_idx", None) is not None:
+            out["sample_idx"] = td["sample_idx"]
+        res = TensorDict(out, batch_size=batch_size, meta={"i": 0})
+        res.set("action_mask", self.get_action_mask(res))
+        return res
+
+    @staticmethod
+    def get_action_mask(td) -> torch.Tensor:
+        """env.py:343-428 in torch ops (reset-time only; per-step masks come from rr_rmtvrp_step / the rollout kernel)."""
+        rep = td.static_repeat
+        ex = (lambda v: v.repeat(rep, *([1] * (v.dim() - 1)))) if rep > 1 else (lambda v: v)
+        cur = td["current_node"]
+        R = cur.shape[0]
+        bi = torch.arange(R, device=cur.device)
+        D, T = ex(td["distance_matrix"]), ex(td["duration_matrix"])
+        tw, sv, dl = ex(td["time_windows"]), ex(td["service_time"]), ex(td["demand_linehaul"])
+        dur_ij, dur_j0 = T[bi, cur, :], T[:, :, 0]
+        early, late = tw[..., 0], tw[..., 1]
+        arrival = td["current_time"] + dur_ij
+        reach = arrival < late
+        back = (torch.max(arrival, early) + sv + dur_j0) < late[..., 0:1]
+        ex_l = dl + td["used_capacity_linehaul"] > td["vehicle_capacity"]
+        missing = ((dl * ~td["visited"]).sum(-1) > 0)[..., None]
+        can = reach & back & (missing & ~ex_l & (dl > 0)) & ~td["visited"]
+        can[:, 0] = ~((cur == 0) & (can[:, 1:].sum(-1) > 0))
+        return can
+
+    def _step(self, td: TensorDict) -> TensorDict:
+        """env.py:155-215 on rr_rmtvrp_step."""
+        action = td["action"].contiguous()
+        R = action.shape[0]
+        D, T = td["distance_matrix"].contiguous(), td["duration_matrix"].float().contiguous()
+        dl, tw, sv = td["demand_linehaul"].contiguous(), td["time_windows"].contiguous(), td["service_time"].contiguous()
+        vcap = td["vehicle_capacity"].reshape(-1).contiguous()
+        if vcap.shape[0] != R:
+            vcap = vcap.repeat(R // vcap.shape[0])
+        cur = td["current_node"].reshape(-1).contiguous().clone()
+        ctime, rlen = td["current_time"].contiguous().clone(), td["current_route_length"].contiguous().clone()
+        used, vis = td["used_capacity_linehaul"].contiguous().clone(), td["visited"].contiguous().clone()
+        mask = torch.empty(R, vis.shape[-1], dtype=torch.bool, device=action.device)
+        done = torch.empty(R, dtype=torch.bool, device=action.device)
+        L.check(L.lib().rr_rmtvrp_step(L.ptr(action), L.ptr(D), L.ptr(T), L.ptr(dl), L.ptr(tw), L.ptr(sv), L.ptr(vcap),
+                                       L.ptr(cur), L.ptr(ctime), L.ptr(rlen), L.ptr(used), L.ptr(vis), L.ptr(mask),
+                                       L.ptr(done), R, D.shape[0], D.shape[-1], L.stream()), "rr_rmtvrp_step")
+        td.update({"current_node": cur, "current_route_length": rlen, "current_time": ctime, "done": done,
+                   "reward": torch.zeros(R, device=action.device), "used_capacity_linehaul": used, "visited": vis,
+                   "action_mask": mask})
+        td.meta["i"] = td.meta.get("i", 0) + 1
+        return td
+
+    def _get_reward(self, td, actions):
+        """env.py:430-455 (closed routes: the open-route zeroing of column 0 is inert)."""
+        D = td["distance_matrix"].contiguous()
+        actions = actions.contiguous()
+        R, T = actions.shape
+        nd = torch.empty(R, device=D.device, dtype=torch.float32)
+        real = torch.empty_like(nd)
+        mn = td["min_distance"].contiguous() if self.normalize else None
+        mx = td["max_distance"].contiguous() if self.normalize else None
+        L.check(L.lib().rr_tour_cost(L.ptr(D), L.ptr(actions), L.ptr(mn), L.ptr(mx), L.ptr(nd), L.ptr(real),
+                                     R, D.shape[0], D.shape[-1], T, 1, L.stream()), "rr_tour_cost")
+        return (real, nd) if self.normalize else nd
+
+    @staticmethod
+    def check_solution_validity(td, actions):
+        raise NotImplementedError("unimplemented in the reference as well (rmtvrp/env.py:457-461)")

@@ -48,27 +48,39 @@ class _TransformerFFN(nn.Module):  # attn_freenet.py:330-357
         self.ops = nn.ModuleDict({"norm1": _Norm(E), "ffn": _FFN(E, ff), "norm2": _Norm(E)})
 
 
+class _DistAngleDurFusion(nn.Module):   # attn_freenet.py:201-240 with use_duration_matrix=True
+    def __init__(self, E):
+        super().__init__()
+        self.dist_emb, self.angle_emb, self.dur_emb = _MLP1(E), _MLP1(E), _MLP1(E)
+        self.gate = nn.Sequential(nn.Linear(3 * E, E), nn.SiLU(), nn.Linear(E, 3))
+        self.gate_temperature = nn.Parameter(torch.tensor(5.0))
+        self.out_lin = nn.Linear(E, 1)
+
+
 class _Block(nn.Module):         # AttnFree_Block attn_freenet.py:360-415
-    def __init__(self, E, ff):
+    def __init__(self, E, ff, use_duration=False):
         super().__init__()
         self.alpha = nn.Parameter(torch.ones(1))
         self.attn_free = _AFT(E)
         self.multi_head_combine = nn.Linear(E, E)
-        self.angle_distance_fusion = _DistAngleFusion(E)
+        if use_duration:
+            self.neural_adaptive_bias = _DistAngleDurFusion(E)     # :379-383
+        else:
+            self.angle_distance_fusion = _DistAngleFusion(E)       # :384-389
         self.feed_forward = _TransformerFFN(E, ff)
         self.norm1, self.norm2, self.norm3 = _Norm(E), _Norm(E), _Norm(E)
 
 
 class _Layer(nn.Module):         # Attn_Free_Layer attn_freenet.py:444-470
-    def __init__(self, E, ff):
+    def __init__(self, E, ff, use_duration=False):
         super().__init__()
-        self.row_encoding_block, self.col_encoding_block = _Block(E, ff), _Block(E, ff)
+        self.row_encoding_block, self.col_encoding_block = _Block(E, ff, use_duration), _Block(E, ff, use_duration)
 
 
 class AttnFreeNet(nn.Module):    # attn_freenet.py:491-515
-    def __init__(self, embed_dim=128, feedforward_hidden=512, num_layers=3, **unused):
+    def __init__(self, embed_dim=128, feedforward_hidden=512, num_layers=3, use_duration_matrix=False, **unused):
         super().__init__()
-        self.layers = nn.ModuleList([_Layer(embed_dim, feedforward_hidden) for _ in range(num_layers)])
+        self.layers = nn.ModuleList([_Layer(embed_dim, feedforward_hidden, use_duration_matrix) for _ in range(num_layers)])
 
 
 class _Gating(nn.Module):        # ContextualGating env_embeddings/atsp.py:108-121
@@ -119,7 +131,8 @@ class RRNetEncoder(nn.Module):
         else:
             from .vrp_embeddings import make_vrp_init_embedding
             self.init_embedding = make_vrp_init_embedding(self.env_name, embed_dim, **kw)
-        self.net = AttnFreeNet(embed_dim, feedforward_hidden, num_layers) if net is None else net
+        self.net = AttnFreeNet(embed_dim, feedforward_hidden, num_layers,
+                               use_duration_matrix=self.env_name not in ("atsp", "rcvrp")) if net is None else net   # encoder.py:63-66
 
     def forward(self, td, phase: str = "val", mask=None, packed=None):
         """-> (row_emb, col_emb) [B,N,E].  `packed` = packing.pack_policy(...) (the policy caches it)."""
@@ -150,8 +163,16 @@ class RRNetEncoder(nn.Module):
         self._last_init = (row, col)
         row2, col2 = torch.empty_like(row), torch.empty_like(col)
         dbg = getattr(self, "_debug_buffer", None)
+        use_dur = len(packed["nabdur"]) > 0          # encoder.py:98-106: duration matrix only for rcvrptw
+        if use_dur:
+            T = td["duration_matrix"].float().contiguous()
+            bias = torch.empty(Bp, 2, N * N, device=dev, dtype=torch.float32)
         for l, (wr, wc) in enumerate(packed["blocks"]):
+            if use_dur:
+                nr, nc = packed["nabdur"][l]
+                L.check(lib.rr_nab_dur(nr, nc, L.ptr(D), L.ptr(T), L.ptr(locs), L.ptr(bias), Bp, N, L.stream()), "rr_nab_dur")
             L.check(lib.rr_enc_layer(wr, wc, L.ptr(row), L.ptr(col), L.ptr(row2), L.ptr(col2), L.ptr(D), L.ptr(locs),
+                                     L.ptr(bias) if use_dur else None,
                                      Bp, N, L.ptr(dbg) if (dbg is not None and l == 0) else None, L.stream()),
                     "rr_enc_layer")
             if l == 0 and dbg is not None:

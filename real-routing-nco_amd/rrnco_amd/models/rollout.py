@@ -5,7 +5,7 @@ import torch
 
 from .. import _lib as L
 
-PROB_ID = {"atsp": 0, "rcvrp": 1}
+PROB_ID = {"atsp": 0, "rcvrp": 1, "rcvrptw": 2}
 MODE_ID = {"greedy": 0, "sampling": 1, "evaluate": 2}
 import os
 STAGGER = int(os.environ.get("RR_STAGGER", "0"))   # initial delay of the second wave of every SIMD (units of ~8k cycles)
@@ -45,6 +45,17 @@ def launch_rollout(env_name, packed, cache, td, num_starts, *, actions=None, log
         used, vcap = td["used_capacity"].reshape(-1).contiguous(), td["vehicle_capacity"].reshape(-1).contiguous()
         io.demand, io.visited, io.used, io.vcap = L.ptr(dem), L.ptr(vis), L.ptr(used), L.ptr(vcap)
         keep += [dem, vis, used, vcap]
+    if env_name == "rcvrptw":
+        T_ = td["duration_matrix"].float().contiguous()
+        dem, vis = td["demand_linehaul"].contiguous(), td["visited"].contiguous()
+        tw, sv = td["time_windows"].contiguous(), td["service_time"].contiguous()
+        used, vcap = td["used_capacity_linehaul"].reshape(-1).contiguous(), td["vehicle_capacity"].reshape(-1).contiguous()
+        ctime, rlen = td["current_time"].reshape(-1).contiguous(), td["current_route_length"].reshape(-1).contiguous()
+        if vcap.shape[0] != R:
+            vcap = vcap.repeat(R // vcap.shape[0])
+        io.Dur, io.demand, io.tw, io.service = L.ptr(T_), L.ptr(dem), L.ptr(tw), L.ptr(sv)
+        io.visited, io.used, io.vcap, io.ctime, io.rlen = L.ptr(vis), L.ptr(used), L.ptr(vcap), L.ptr(ctime), L.ptr(rlen)
+        keep += [T_, dem, vis, tw, sv, used, vcap, ctime, rlen]
     done = td["done"].reshape(-1).contiguous() if "done" in td and td["done"].numel() == R else None
     io.done = L.ptr(done)
     io.actions, io.logp = L.ptr(actions), L.ptr(logp)

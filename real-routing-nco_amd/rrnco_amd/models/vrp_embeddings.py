@@ -51,6 +51,11 @@ class RVRPInitEmbedding(nn.Module):
 class RVRPTWInitEmbedding(RVRPInitEmbedding):
     demand_feats = 4
 
+    def __init__(self, embed_dim, **kw):
+        super().__init__(embed_dim, **kw)
+        self.init_embed = self.demand_init          # rcvrptw.py:44: the attribute layer is called `init_embed`
+        del self.demand_init
+
     def node_features(self, td):
         """(demand_linehaul, tw_start, tw_end, service_time), all already depot-padded (rcvrptw.py:51-56)."""
         return torch.cat([td["demand_linehaul"][..., None], td["time_windows"], td["service_time"][..., None]], -1).float()

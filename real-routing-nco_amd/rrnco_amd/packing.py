@@ -39,6 +39,40 @@ def fold_nab(sd, p: str, alpha: torch.Tensor) -> torch.Tensor:
     return torch.cat([torch.cat(rows), tail]).float()
 
 
+def fold_nab_dur(sd, p: str, alpha: torch.Tensor, ar) -> "L.NabDurW":
+    """DistAngleFusion with duration (attn_freenet.py:226-237, 265-286): fold every second MLP layer into the gate's
+    first Linear (M_x = Wg0_x W2_x) and into out_lin (co_x = W2_x^T wo), in float64; see csrc/rr_encoder.hip:k_nab_dur."""
+    d = lambda k: sd[p + k].detach().double().cpu()  # noqa: E731
+    wo, bo = d(".out_lin.weight")[0], d(".out_lin.bias")[0]
+    Wg0, bg0 = d(".gate.0.weight"), d(".gate.0.bias")
+    Ms, cos, kos, a_, b_ = [], [], [], [], []
+    cg = bg0.clone()
+    for i, nm in enumerate(("dist_emb", "angle_emb", "dur_emb")):
+        W2, b2 = d(f".{nm}.2.weight"), d(f".{nm}.2.bias")
+        Wgx = Wg0[:, i * E:(i + 1) * E]
+        Ms.append(Wgx @ W2)
+        cg += Wgx @ b2
+        cos.append(W2.t() @ wo)
+        kos.append(float(wo @ b2))
+        a_.append(d(f".{nm}.0.weight")[:, 0]); b_.append(d(f".{nm}.0.bias"))
+    Mcat = torch.zeros(9 * 16, 3 * E, dtype=torch.float64)
+    Mcat[:E] = torch.cat(Ms, dim=1)
+    for i in range(3):
+        Mcat[E + i, i * E:(i + 1) * E] = cos[i]
+    w = L.NabDurW()
+    w.mp = ar.put(pack_a(Mcat.float()))
+    w.ab = ar.put(torch.cat(a_ + b_).float())
+    w.cg = ar.put(cg.float())
+    w.wg2 = ar.put(d(".gate.2.weight").float().contiguous())
+    bg2 = d(".gate.2.bias")
+    for i in range(3):
+        w.bg2[i] = float(bg2[i]); w.ko[i] = kos[i]
+    w.inv_tau = float(torch.exp(-d(".gate_temperature")))
+    w.bo = float(bo)
+    w.alpha = float(alpha.detach().double().cpu().reshape(()))
+    return w
+
+
 class _Arena:
     """Keeps every packed tensor alive and hands out raw device pointers."""
 
@@ -56,7 +90,7 @@ def pack_policy(sd: dict, env_name: str, device) -> dict:
     """state_dict (reference names) -> ctypes structs for the kernels."""
     ar = _Arena(device)
     nl = 1 + max(int(k.split(".")[3]) for k in sd if k.startswith("encoder.net.layers."))
-    blocks = []
+    blocks, nabdur = [], {}
     nabname = "angle_distance_fusion" if env_name in ("atsp", "rcvrp") else "neural_adaptive_bias"
     for l in range(nl):
         pair = []
@@ -72,11 +106,15 @@ def pack_policy(sd: dict, env_name: str, device) -> dict:
                          ("1", "feed_forward.ops.ffn.W1"), ("2", "feed_forward.ops.ffn.W2")):
                 setattr(w, "w" + f, ar.put(pack_a(sd[f"{b}.{k}.weight"].detach().float())))
                 setattr(w, "b" + f, ar.put(sd[f"{b}.{k}.bias"]))
-            w.nab = ar.put(fold_nab(sd, f"{b}.{nabname}", sd[f"{b}.alpha"]))
+            if nabname == "angle_distance_fusion":
+                w.nab = ar.put(fold_nab(sd, f"{b}.{nabname}", sd[f"{b}.alpha"]))
+            else:
+                w.nab = None
+                nabdur.setdefault(l, []).append(fold_nab_dur(sd, f"{b}.{nabname}", sd[f"{b}.alpha"], ar))
             pair.append(w)
         blocks.append(tuple(pair))
 
-    out = {"arena": ar, "blocks": blocks, "num_layers": nl}
+    out = {"arena": ar, "blocks": blocks, "num_layers": nl, "nabdur": [tuple(nabdur[l]) for l in sorted(nabdur)]}
     p = "encoder.init_embedding"
     if env_name == "atsp":
         iw = L.InitW()
@@ -98,8 +136,9 @@ def pack_policy(sd: dict, env_name: str, device) -> dict:
         iw.wi, iw.bi = ar.put(sd[p + ".coord_expert.init_embed.weight"]), ar.put(sd[p + ".coord_expert.init_embed.bias"])
         iw.wr, iw.br = ar.put(sd[p + ".distance_expert.row_embed.weight"]), ar.put(sd[p + ".distance_expert.row_embed.bias"])
         iw.wcl, iw.bcl = ar.put(sd[p + ".distance_expert.col_embed.weight"]), ar.put(sd[p + ".distance_expert.col_embed.bias"])
-        iw.wdm, iw.bdm = ar.put(sd[p + ".demand_init.weight"]), ar.put(sd[p + ".demand_init.bias"])
-        iw.nfeat = sd[p + ".demand_init.weight"].shape[1]
+        dm = ".demand_init" if (p + ".demand_init.weight") in sd else ".init_embed"   # rcvrptw.py:44 names it init_embed
+        iw.wdm, iw.bdm = ar.put(sd[p + dm + ".weight"]), ar.put(sd[p + dm + ".bias"])
+        iw.nfeat = sd[p + dm + ".weight"].shape[1]
         for rc, s in (("row", "r"), ("col", "c")):
             q = f"{p}.gating_network_{rc}.gating_fc"
             setattr(iw, "g0" + s, ar.put(pack_a(sd[q + ".0.weight"].detach().float())))

@@ -61,3 +61,11 @@ def rcvrp_weights(fx):
 
 def rcvrp_instance(fx):
     return {k: fx[k] for k in ("locs", "depot", "distance_matrix", "demand")}
+
+
+def rcvrptw_weights(fx):
+    return restate.make_weights(restate.rcvrptw_weight_template(128, fx["layers"], 512, fx["sample_size"]), fx["seed"])
+
+
+def rcvrptw_instance(fx):
+    return {k: fx[k] for k in ("locs", "distance_matrix", "duration_matrix", "demand_linehaul", "time_windows", "service_time")}

@@ -1,0 +1,90 @@
+"""`-m gpu` parity tests for RCVRPTW (RMTVRPEnv, vrptw preset; BASELINE configs[3] shape at N=100) against the golden
+vectors of the real reference: NAB with the duration matrix (MFMA kernel), time-window masks, duration inductive bias."""
+import pytest
+import torch
+
+from oracle import restate
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+ENC_ATOL, LL_RTOL, LL_ATOL, COST_ATOL, GAP_TOL = 5e-4, 2e-5, 4e-3, 1e-4, 1e-3
+FIXTURES = ["rcvrptw_n20_b4_pomo", "rcvrptw_n20_b4_greedy", "rcvrptw_n100_b2_pomo"]
+
+
+def _setup(name):
+    from rrnco_amd import TensorDict
+    from rrnco_amd.envs import RMTVRPEnv
+    fx = H.load_fixture(name)
+    w = H.rcvrptw_weights(fx)
+    pol = H.make_policy(w, env_name="rcvrptw")
+    inst = H.rcvrptw_instance(fx)
+    env = RMTVRPEnv(generator_params=dict(num_loc=fx["N"]))
+    td_in = TensorDict({k: v.cuda() for k, v in inst.items()}, batch_size=[fx["B"]])
+    td_in["sample_idx"] = fx["sample_idx"].cuda()
+    return fx, w, pol, inst, env, td_in
+
+
+def test_rmtvrp_env_step_and_time_window_mask_match_oracle():
+    from rrnco_amd.ops import batchify
+    fx, w, pol, inst, env, td_in = _setup("rcvrptw_n20_b4_pomo")
+    S = fx["S"]
+    td0 = env.reset(td_in)
+    o0 = restate.rmtvrp_reset(inst)
+    assert torch.equal(td0["distance_matrix"].cpu(), fx["norm_distance"]) and torch.equal(td0["action_mask"].cpu(), o0["action_mask"])
+    assert env.get_num_starts(td0) == fx["N"] and torch.equal(env.select_start_nodes(td0, S).cpu(), fx["actions"][:, 0])
+    td = batchify(td0, S)
+    otd = restate.batchify_state({k: v for k, v in o0.items() if k not in ("locs", "min_distance", "max_distance")}, S)
+    for t in range(fx["actions"].shape[1]):
+        a = fx["actions"][:, t]
+        td.set("action", a.cuda()); td = env.step(td)["next"]
+        otd["action"] = a; otd = restate.rmtvrp_step(otd)
+        assert torch.equal(td["action_mask"].cpu(), otd["action_mask"]), t          # TW / capacity feasibility, bit-exact
+        assert torch.equal(td["visited"].cpu(), otd["visited"]) and torch.equal(td["done"].cpu(), otd["done"])
+        assert torch.equal(td["current_time"].cpu(), otd["current_time"])           # same fp32 op order: exact
+        assert torch.equal(td["used_capacity_linehaul"].cpu(), otd["used_capacity_linehaul"])
+        assert torch.equal(td["current_route_length"].cpu(), otd["current_route_length"])
+    assert td["done"].all()
+    real, nd = env.get_reward(td, fx["actions"].cuda())
+    assert torch.allclose(real.cpu(), fx["reward"], atol=COST_ATOL)
+
+
+def test_rmtvrp_rejects_variants_outside_the_vrptw_preset():
+    fx, w, pol, inst, env, td_in = _setup("rcvrptw_n20_b4_greedy")
+    td_in["open_route"] = torch.ones(fx["B"], 1, dtype=torch.bool, device="cuda")
+    with pytest.raises(NotImplementedError):
+        env.reset(td_in)
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_rcvrptw_encoder_with_duration_nab_matches_reference(name):
+    fx, w, pol, inst, env, td_in = _setup(name)
+    row, col = pol.encoder(env.reset(td_in), packed=pol.packed(torch.device("cuda")))
+    assert torch.allclose(row.cpu(), fx["row_emb"], atol=ENC_ATOL) and torch.allclose(col.cpu(), fx["col_emb"], atol=ENC_ATOL)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("name", FIXTURES)
+def test_rcvrptw_policy_greedy_routes_match_reference(name, fused):
+    fx, w, pol, inst, env, td_in = _setup(name)
+    S = fx["S"]
+    out = pol(env.reset(td_in), env, phase="val", decode_type="multistart_greedy" if S > 1 else "greedy",
+              num_starts=S if S > 1 else None, return_actions=True, fused=fused)
+    acts = out["actions"].cpu()
+    n = fx["N"]
+    cust = acts.sort(1).values[:, -n:]
+    assert (cust == torch.arange(1, n + 1)).all()                     # every customer exactly once
+    T = min(acts.shape[1], fx["actions"].shape[1])
+    frac, first = H.tour_agreement(acts[:, :T], fx["actions"][:, :T])
+    if frac < 1.0:
+        tr = {}
+        with torch.inference_mode():
+            restate.rcvrptw_policy(w, restate.rmtvrp_reset(inst), fx["sample_idx"], S, "greedy", trace=tr)
+        lp = torch.nan_to_num(torch.stack(tr["logp"], 1), neginf=-1e9).topk(2, -1).values
+        gap = lp[..., 0] - lp[..., 1]
+        for r in torch.nonzero(first >= 0).flatten().tolist():
+            t = int(first[r]) - (1 if S > 1 else 0)
+            assert t >= gap.shape[1] or gap[r, t] < GAP_TOL
+    assert frac >= 0.97
+    same = first < 0
+    assert torch.allclose(out["reward"].cpu()[same], fx["reward"][same], atol=COST_ATOL)
+    assert torch.allclose(out["log_likelihood"].cpu()[same], fx["log_likelihood"][same], rtol=LL_RTOL, atol=LL_ATOL)
