@@ -11,6 +11,20 @@
 #define LDA 112     // row stride of the exp(softmax(bias)) matrix (k padded to 7 groups of 16)
 #define BUF_FLOATS (RR_MAXN * LD)
 
+#ifdef RR_STAMP
+__device__ unsigned long long rr_enc_stamps[8];
+#define RR_ET(i)                                                                             \
+  do {                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    unsigned long long _n = __builtin_amdgcn_s_memtime();                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                       \
+    _acc[i] += _n - _t0; _t0 = _n;                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+  } while (0)
+#else
+#define RR_ET(i)
+#endif
+
 struct EncBlockW {
   const float *n1g, *n1b, *n2g, *n2b, *n3g, *n3b, *f1g, *f1b, *f2g, *f2b;  // instance-norm affine [E]
   const float4 *wq, *wk, *wv, *wp, *wc, *w1, *w2;                             // packed A operands
@@ -41,6 +55,33 @@ __device__ __forceinline__ float nab_edge(const float* __restrict__ nab, float d
   float gt = 1.0f / (1.0f + expf(-z));
   float bo = gt * (pod + s[0]) + (1.0f - gt) * (poa + s[2]) + s[5];
   return bo * s[6];
+}
+
+// Piecewise-linear evaluation of the same four scalar functions (tables from packing.fold_nab_pwl, staged in LDS):
+// binary search over the 128 sorted breakpoints, then f(x) = F_m + S_m (x - anchor_m).  Exact in real arithmetic.
+#define NAB_TAB_FLOATS (256 + 2 * 129 * 4 + 8)
+__device__ __forceinline__ void nab_family(const float* t, const float* seg, float x, float& fo, float& fg) {
+  int m = 0;                                          // number of breakpoints <= x
+#pragma unroll
+  for (int s = 128; s >= 1; s >>= 1) {
+    const int idx = m + s - 1;
+    const float tv = t[idx < 128 ? idx : 127];
+    m += (idx < 128 && tv <= x) ? s : 0;
+  }
+  float anchor = t[m > 0 ? m - 1 : 0];
+  anchor = anchor < INFINITY ? anchor : 0.f;
+  const float4 sg = rr_ld4(seg + 4 * m);
+  const float dx = x - anchor;
+  fo = fmaf(sg.x, dx, sg.y);
+  fg = fmaf(sg.z, dx, sg.w);
+}
+__device__ __forceinline__ float nab_edge_pwl(const float* tab, float d, float th) {
+  float od, gd, oa, ga;
+  nab_family(tab, tab + 256, d, od, gd);
+  nab_family(tab + 128, tab + 256 + 516, th, oa, ga);
+  const float* s = tab + 256 + 1032;                  // bg, bo, alpha
+  const float gt = rr_sigmoid(gd + ga + s[0]);
+  return (gt * od + (1.0f - gt) * oa + s[1]) * s[2];
 }
 
 // den/num GEMM: acc[nt] (features 16w.., query nodes 16nt..) += sum_k Z[k][16w+i] * ea[node][k]
@@ -90,10 +131,11 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_enc_block(EncBlockW wr, EncB
                                                               const float* __restrict__ D, const float* __restrict__ locs,
                                                               const float* __restrict__ bias_pre,
                                                               int N, float* __restrict__ dbg) {
-  __shared__ __attribute__((aligned(16))) float smem[3 * BUF_FLOATS];
+  __shared__ __attribute__((aligned(16))) float smem[3 * BUF_FLOATS + NAB_TAB_FLOATS];
   float* A = smem;                   // r = IN1(x)
   float* B = smem + BUF_FLOATS;      // c = IN2(y) -> eK -> Z -> Y -> x1
   float* C = smem + 2 * BUF_FLOATS;  // ea -> P -> H chunks
+  float* nabtab = smem + 3 * BUF_FLOATS;   // piecewise-linear NAB tables (5 KB)
 
   const int b = blockIdx.x, is_col = blockIdx.y;
   const EncBlockW& w = is_col ? wcol : wr;
@@ -105,11 +147,16 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_enc_block(EncBlockW wr, EncB
   const int fb = 16 * wave;  // this wave's feature tile in every 128-wide GEMM
   float* dbgb = dbg ? dbg + (size_t)(b * 2 + is_col) * 8 * N * RR_E : nullptr;
 
+#ifdef RR_STAMP
+  unsigned long long _acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long _t0 = __builtin_amdgcn_s_memtime();
+#endif
   // ---- S0: stage x, y
   for (int i = tid; i < N * (RR_E / 4); i += ENC_THREADS) {
     rr_st4(A + i * 4, rr_ld4(x_in + i * 4));
     rr_st4(B + i * 4, rr_ld4(y_in + i * 4));
   }
+  if (bias_pre == nullptr) for (int i = tid; i < NAB_TAB_FLOATS; i += ENC_THREADS) nabtab[i] = w.nab[i];
   __syncthreads();
 
   // ---- S1: r = norm1(x), c = norm2(y)  (:421-422) — each wave owns 16 features of all nodes
@@ -123,6 +170,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_enc_block(EncBlockW wr, EncB
     rr_store_tiles<NT>(t, B, LD, fb, N, lane);
   }
 
+  RR_ET(0);
   // ---- S2: ea = exp(softmax_j(NAB(D, theta) * alpha))  (:427-429, 318, 320) -> C [N][LDA]
   {
     const float* Db = D + (size_t)b * N * N;
@@ -146,7 +194,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_enc_block(EncBlockW wr, EncB
           } else {
             float d = is_col ? Db[jj * N + i] : Db[i * N + jj];
             float th = atan2f(yi - yj[q], xi - xj[q]);
-            bs[q] = nab_edge(w.nab, d, th);
+            bs[q] = nab_edge_pwl(nabtab, d, th);
           }
         }
       }
@@ -163,6 +211,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_enc_block(EncBlockW wr, EncB
     for (int i = tid; i < N * N; i += ENC_THREADS) dbgb[2 * N * RR_E + i] = C[(i / N) * LDA + (i % N)];
   }
 
+  RR_ET(1);
   // ---- S3: K, V = lin(c)  (:314-315); eK = exp(softmax_nodes(K)) (:319,321); Z = eK * V
   f32x4 num[NT], den[NT];
   {
@@ -203,6 +252,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_enc_block(EncBlockW wr, EncB
     aft_mix<NT>(num, B, C, fb, N, lane);   // num = ea @ (eK*V)  (:321)
   }
 
+  RR_ET(2);
   // ---- S4: Y = sigmoid(Q) * num / den  (:313,316,322-324)
   {
     f32x4 qa[NT];
@@ -252,6 +302,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_enc_block(EncBlockW wr, EncB
   __syncthreads();
   if (dbgb) for (int i = tid; i < N * RR_E; i += ENC_THREADS) dbgb[4 * N * RR_E + i] = B[i];
 
+  RR_ET(3);
   // ---- S7: x2 = ffn.norm2(x1 + W2 relu(W1 x1 + b1) + b2) (:356, 536), hidden in 4 chunks of 128
   {
     f32x4 fa[NT];
@@ -278,6 +329,13 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_enc_block(EncBlockW wr, EncB
     rr_instnorm_tiles<NT>(fa, w.f2g, w.f2b, fb, N, lane);
     rr_store_tiles<NT>(fa, out, RR_E, fb, N, lane);
   }
+  RR_ET(4);
+#ifdef RR_STAMP
+  if (lane == 0) {
+    for (int i = 0; i < 5; ++i) atomicAdd(&rr_enc_stamps[i], _acc[i]);
+    atomicAdd(&rr_enc_stamps[7], 1ull);
+  }
+#endif
 }
 
 extern "C" int rr_enc_layer(const EncBlockW* wrow, const EncBlockW* wcol, const float* row_in, const float* col_in,
@@ -594,3 +652,11 @@ extern "C" int rr_dec_cache(const CacheW* w, const float* row_emb, const float* 
   else hipLaunchKernelGGL(k_dec_cache<7>, grid, blk, 0, st, *w, row_emb, col_emb, K, Vt, L, ctxA, ctxB, N);
   return rr_check(hipGetLastError());
 }
+
+#ifdef RR_STAMP
+extern "C" int rr_debug_enc_stamps(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rr_enc_stamps), sizeof(unsigned long long) * 8) != hipSuccess) return RR_ELAUNCH;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rr_enc_stamps), z, sizeof(z)) != hipSuccess) return RR_ELAUNCH; }
+  return RR_OK;
+}
+#endif

@@ -39,6 +39,67 @@ def fold_nab(sd, p: str, alpha: torch.Tensor) -> torch.Tensor:
     return torch.cat([torch.cat(rows), tail]).float()
 
 
+def fold_nab_pwl(sd, p: str, alpha: torch.Tensor) -> torch.Tensor:
+    """Exact piecewise-linear form of the folded gating NAB (see fold_nab).  Each of the four scalar functions
+        f(x) = sum_k c_k relu(a_k x + b_k) + const       (x = distance or angle; c = W2^T wo or W2^T wg)
+    is piecewise linear in x with breakpoints t_k = -b_k / a_k.  Per sorted segment m we store the slope S_m and the
+    function value F_m at the segment's anchor breakpoint (both accumulated in float64), and the kernel evaluates
+    f(x) = F_m + S_m (x - t_anchor) after a binary search: ~45 VALU ops per edge instead of 1 024, with no cancellation
+    (x - t_anchor is small).  Layout: t_d[128] | t_a[128] | seg_d[129][4] | seg_a[129][4] | (bg, bo, alpha, 0...)[8],
+    seg = (S_out, F_out, S_gate, F_gate); unused breakpoints are +inf."""
+    import numpy as np
+    d = lambda k: sd[p + k].detach().double().cpu().numpy()  # noqa: E731
+    wo, bo = d(".out_lin.weight")[0], float(d(".out_lin.bias")[0])
+    wg, bg = d(".gate.0.weight")[0], float(d(".gate.0.bias")[0])
+    ts, segs = [], []
+    for nm, wgh in (("dist_emb", wg[:E]), ("angle_emb", wg[E:])):
+        a, b = d(f".{nm}.0.weight")[:, 0], d(f".{nm}.0.bias")
+        W2, b2 = d(f".{nm}.2.weight"), d(f".{nm}.2.bias")
+        co, cg, ko, kg = W2.T @ wo, W2.T @ wgh, float(wo @ b2), float(wgh @ b2)
+        nz = a != 0
+        t = np.sort(-b[nz] / a[nz])
+        M = len(t)
+
+        def f(x, c, k0):
+            return float(np.sum(c * np.maximum(a * x + b, 0.0)) + k0)
+        seg = np.zeros((129, 4))
+        for m in range(M + 1):
+            if M == 0:
+                xm, anchor = 0.0, 0.0
+            elif m == 0:
+                xm, anchor = t[0] - 1.0, t[0]
+            elif m == M:
+                xm, anchor = t[M - 1] + 1.0, t[M - 1]
+            else:
+                xm, anchor = 0.5 * (t[m - 1] + t[m]), t[m - 1]
+            act = (a * xm + b) > 0
+            seg[m] = (np.sum((co * a)[act]), f(anchor, co, ko), np.sum((cg * a)[act]), f(anchor, cg, kg))
+        seg[M + 1:] = seg[M]
+        tt = np.full(128, np.inf)
+        tt[:M] = t
+        ts.append(tt); segs.append(seg.reshape(-1))
+    tail = np.zeros(8)
+    tail[0], tail[1], tail[2] = bg, bo, float(alpha.detach().double().cpu().reshape(()))
+    return torch.from_numpy(np.concatenate(ts + segs + [tail])).float()
+
+
+def eval_nab_pwl(tab: torch.Tensor, dmat: torch.Tensor, theta: torch.Tensor) -> torch.Tensor:
+    """float32 emulation of csrc/rr_encoder.hip:nab_edge_pwl (used by the CPU tests to validate the tables)."""
+    def fam(x, t, seg):
+        seg = seg.view(129, 4)
+        m = torch.searchsorted(t.contiguous(), x.contiguous(), right=True)          # number of breakpoints <= x
+        anchor = t[(m - 1).clamp_min(0)]
+        anchor = torch.where(torch.isfinite(anchor), anchor, torch.zeros_like(anchor))
+        s = seg[m]
+        dx = x - anchor
+        return s[..., 1] + s[..., 0] * dx, s[..., 3] + s[..., 2] * dx
+    od, gd = fam(dmat, tab[0:128], tab[256:256 + 516])
+    oa, ga = fam(theta, tab[128:256], tab[256 + 516:256 + 1032])
+    bg, bo, al = tab[1288], tab[1289], tab[1290]
+    g = torch.sigmoid(gd + ga + bg)
+    return (g * od + (1 - g) * oa + bo) * al
+
+
 def fold_nab_dur(sd, p: str, alpha: torch.Tensor, ar) -> "L.NabDurW":
     """DistAngleFusion with duration (attn_freenet.py:226-237, 265-286): fold every second MLP layer into the gate's
     first Linear (M_x = Wg0_x W2_x) and into out_lin (co_x = W2_x^T wo), in float64; see csrc/rr_encoder.hip:k_nab_dur."""
@@ -107,7 +168,7 @@ def pack_policy(sd: dict, env_name: str, device) -> dict:
                 setattr(w, "w" + f, ar.put(pack_a(sd[f"{b}.{k}.weight"].detach().float())))
                 setattr(w, "b" + f, ar.put(sd[f"{b}.{k}.bias"]))
             if nabname == "angle_distance_fusion":
-                w.nab = ar.put(fold_nab(sd, f"{b}.{nabname}", sd[f"{b}.alpha"]))
+                w.nab = ar.put(fold_nab_pwl(sd, f"{b}.{nabname}", sd[f"{b}.alpha"]))
             else:
                 w.nab = None
                 nabdur.setdefault(l, []).append(fold_nab_dur(sd, f"{b}.{nabname}", sd[f"{b}.alpha"], ar))

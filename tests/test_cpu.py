@@ -112,6 +112,21 @@ def test_nab_fold_matches_unfolded_formula():
     assert torch.allclose(mine, ref, atol=2e-6)
 
 
+def test_nab_piecewise_linear_tables_are_exact():
+    from rrnco_amd.packing import eval_nab_pwl, fold_nab_pwl
+    fx = H.load_fixture("atsp_n100_b2_pomo")
+    w = H.atsp_weights(fx)
+    st0 = restate.atsp_reset(H.fixture_state(fx))
+    D, locs = st0["distance_matrix"], st0["locs"]
+    th = restate.pairwise_angles(locs)
+    for p in ("encoder.net.layers.0.row_encoding_block", "encoder.net.layers.5.col_encoding_block"):
+        tab = fold_nab_pwl(w, p + ".angle_distance_fusion", w[p + ".alpha"])
+        assert tab.numel() == 256 + 2 * 129 * 4 + 8
+        ref = restate.nab_gating(w, p + ".angle_distance_fusion", locs, D, None) * w[p + ".alpha"]
+        mine = eval_nab_pwl(tab, D, th)
+        assert torch.allclose(mine, ref, atol=2e-6), (mine - ref).abs().max()
+
+
 def test_state_dict_names_match_reference_template():
     from rrnco_amd.models import RRNetPolicy
     pol = RRNetPolicy(env_name="atsp", num_encoder_layers=6, normalization="instance", use_graph_context=False,

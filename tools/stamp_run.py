@@ -19,6 +19,9 @@ bench.hot_path_step(pol, env, inst, sidx); torch.cuda.synchronize()
 lib = _lib.lib(); lib.rr_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 out = (ctypes.c_ulonglong * 8)()
 lib.rr_debug_stamps(out, 1)
+lib.rr_debug_enc_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+eout = (ctypes.c_ulonglong * 8)()
+lib.rr_debug_enc_stamps(eout, 1)
 bench.hot_path_step(pol, env, inst, sidx); torch.cuda.synchronize()
 lib.rr_debug_stamps(out, 0)
 names = ["loop-top", "ctx gather", "attention", "MLP", "logits MFMA", "select+step"]
@@ -26,3 +29,10 @@ waves = out[7]; tot = sum(out[i] for i in range(6))
 print(f"waves={waves} total cycles/wave={tot/waves:.3e} per step={tot/waves/99:.0f}")
 for i, n in enumerate(names):
     print(f"  {n:12s} {out[i]/waves/99:10.0f} cycles/step  {100*out[i]/tot:5.1f}%")
+
+lib.rr_debug_enc_stamps(eout, 0)
+en = ["load+norm1/2", "NAB+softmax", "KV,softmaxK,den,num", "Q,Y,P,M,norms", "FFN+norm"]
+ew = eout[7]; et = sum(eout[i] for i in range(5))
+print(f"encoder block: waves={ew} cycles/wave/block={et/ew:.0f}")
+for i, n in enumerate(en):
+    print(f"  {n:22s} {eout[i]/ew:10.0f} cycles  {100*eout[i]/et:5.1f}%")
