@@ -111,6 +111,12 @@ int rr_dec_cache(const CacheW* w, const float* row_emb, const float* col_emb, fl
  * logits_only = a single pure RRNetDecoder.forward.  prob 0 = ATSP, 1 = RCVRP, 2 = RCVRPTW. */
 int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStream_t stream);
 
+/* POMO shared-baseline REINFORCE loss, forward half + d loss / d log-likelihood
+ * (rrnco/models/rl.py:112-128; in-tree formula rrnco/baselines/routefinder/model.py:182-202). reward / ll / adv /
+ * grad_ll are [S*B] with r = s*B + b; bl and partial are [B] workspaces; loss is one float. */
+int rr_reinforce_loss(const float* reward, const float* ll, float* adv, float* grad_ll, float* bl, float* partial,
+                      float* loss, int B, int S, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

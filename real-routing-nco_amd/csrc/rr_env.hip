@@ -306,3 +306,50 @@ extern "C" int rr_rmtvrp_step(const int64_t* action, const float* D, const float
                      ctime, rlen, used_l, visited, mask, done, R, Bp, N);
   return rr_check(hipGetLastError());
 }
+
+// ------------------------------------------------------------------------------------------------
+// POMO shared-baseline REINFORCE loss (rrnco/models/rl.py:112-128; formula in-tree at
+// rrnco/baselines/routefinder/model.py:182-202; rl4co SharedBaseline = mean over the S starts of an instance):
+//   adv[b,s] = R[b,s] - mean_s R[b,s];  loss = -mean_{b,s}(adv * ll);  d loss / d ll = -adv / (B*S)
+// rollout index r = s*B + b.  Stage 1: one wave per instance (partial sum per instance, fixed order);
+// stage 2: one workgroup folds the B partials in a fixed order -> bit-reproducible loss.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_reinforce_stage1(const float* __restrict__ reward, const float* __restrict__ ll,
+                                                          float* __restrict__ adv, float* __restrict__ grad_ll,
+                                                          float* __restrict__ bl, float* __restrict__ partial, int B, int S) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  float s = 0.f;
+  for (int k = lane; k < S; k += 64) s += reward[(size_t)k * B + b];
+  const float mean = rr_wave_sum(s) / (float)S;
+  float acc = 0.f;
+  const float scale = -1.0f / ((float)B * (float)S);
+  for (int k = lane; k < S; k += 64) {
+    const size_t r = (size_t)k * B + b;
+    const float a = reward[r] - mean;
+    adv[r] = a;
+    grad_ll[r] = a * scale;
+    acc += a * ll[r];
+  }
+  acc = rr_wave_sum(acc);
+  if (lane == 0) { bl[b] = mean; partial[b] = acc; }
+}
+
+__global__ __launch_bounds__(256) void k_reinforce_stage2(const float* __restrict__ partial, float* __restrict__ loss, int B, int S) {
+  __shared__ float sm[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < B; i += 256) s += partial[i];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) { if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) loss[0] = -sm[0] / ((float)B * (float)S);
+}
+
+extern "C" int rr_reinforce_loss(const float* reward, const float* ll, float* adv, float* grad_ll, float* bl,
+                                 float* partial, float* loss, int B, int S, hipStream_t st) {
+  if (B <= 0 || S <= 1) return RR_EINVAL;
+  hipLaunchKernelGGL(k_reinforce_stage1, dim3((B + 3) / 4), dim3(256), 0, st, reward, ll, adv, grad_ll, bl, partial, B, S);
+  hipLaunchKernelGGL(k_reinforce_stage2, dim3(1), dim3(256), 0, st, partial, loss, B, S);
+  return rr_check(hipGetLastError());
+}

@@ -59,6 +59,7 @@ _SIGS = {
     "rr_enc_layer": [C.POINTER(EncBlockW), C.POINTER(EncBlockW), vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp],
     "rr_nab_dur": [C.POINTER(NabDurW), C.POINTER(NabDurW), vp, vp, vp, vp, i32, i32, vp],
     "rr_rmtvrp_step": [vp] * 14 + [i32, i32, i32, vp],
+    "rr_reinforce_loss": [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "rr_init_embed": [C.POINTER(InitW), i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "rr_dec_cache": [C.POINTER(CacheW), vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "rr_rollout": [C.POINTER(DecW), C.POINTER(RolloutIO), i32, vp],

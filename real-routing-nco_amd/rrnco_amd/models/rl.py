@@ -1,0 +1,76 @@
+"""RRNet RL module — mirror of rrnco.models.rl.RRNet.shared_step (rrnco/models/rl.py:96-166) without Lightning.
+
+val / test phases are complete (augmentation, multistart, best-of metrics).  The train phase runs the sampling rollout and
+the POMO shared-baseline REINFORCE loss on HIP kernels and returns d loss / d log-likelihood; the backward pass through the
+policy (and with it the RCCL gradient all-reduce of BASELINE configs[4]) is not built yet — see DESIGN.md §6."""
+from __future__ import annotations
+
+import torch
+
+from .. import _lib as L
+from ..ops import gather_by_index, unbatchify
+from .policy import RRNetPolicy
+from .transforms import StateAugmentation
+
+
+def reinforce_loss(reward: torch.Tensor, log_likelihood: torch.Tensor, num_starts: int) -> dict:
+    """reward, log_likelihood: [S*B] (r = s*B + b).  -> loss, bl_val [B], advantage [S*B], grad_ll [S*B]."""
+    L.require_gpu(reward)
+    R = reward.numel()
+    B = R // num_starts
+    reward, ll = reward.contiguous().float(), log_likelihood.contiguous().float()
+    adv, grad = torch.empty_like(reward), torch.empty_like(reward)
+    bl, part = torch.empty(B, device=reward.device), torch.empty(B, device=reward.device)
+    loss = torch.empty(1, device=reward.device)
+    L.check(L.lib().rr_reinforce_loss(L.ptr(reward), L.ptr(ll), L.ptr(adv), L.ptr(grad), L.ptr(bl), L.ptr(part), L.ptr(loss),
+                                      B, num_starts, L.stream()), "rr_reinforce_loss")
+    return {"loss": loss[0], "reinforce_loss": loss[0], "bl_loss": 0, "bl_val": bl, "advantage": adv, "grad_log_likelihood": grad}
+
+
+class RRNet:
+    def __init__(self, env, policy: RRNetPolicy = None, baseline: str = "shared", policy_kwargs: dict = {}, num_augment: int = 8,
+                 augment_fn="dihedral8", first_aug_identity: bool = True, feats=None, num_starts: int = None,
+                 no_aug_coords: bool = True, **unused):
+        assert baseline == "shared", "RRNet only supports shared baseline"          # rl.py:74
+        self.env, self.env_name = env, env.name
+        kw = {"num_encoder_layers": 6, "normalization": "instance", "use_graph_context": False, **policy_kwargs}
+        self.policy = policy if policy is not None else RRNetPolicy(env_name=env.name, **kw)
+        self.num_starts, self.num_augment = num_starts, num_augment
+        self.augment = StateAugmentation(num_augment=num_augment, augment_fn=augment_fn, first_aug_identity=first_aug_identity,
+                                         feats=feats, no_aug_coords=no_aug_coords) if num_augment > 1 else None
+        for phase in ("train", "val", "test"):                                      # rl.py:93-94
+            attr = f"{phase}_decode_type"
+            if "multistart" not in getattr(self.policy, attr):
+                setattr(self.policy, attr, "multistart_" + getattr(self.policy, attr))
+
+    def shared_step(self, batch, batch_idx: int = 0, phase: str = "val", **policy_kw) -> dict:
+        td = self.env.reset(batch)
+        n_aug, n_start = self.num_augment, self.num_starts
+        n_start = self.env.get_num_starts(td) if n_start is None else n_start
+        if phase == "train":
+            n_aug = 0
+        elif n_aug > 1:
+            td = self.augment(td)
+        out = self.policy(td, self.env, phase=phase, num_starts=n_start, **policy_kw)
+        reward = unbatchify(out["reward"], (n_aug, n_start))
+        if phase == "train":
+            assert n_start > 1, "num_starts must be > 1 during training"
+            r = out["normalized_reward"] if self.env.normalize else out["reward"]
+            out.update(reinforce_loss(r, out["log_likelihood"], n_start))
+            out["max_reward"] = reward.max(dim=-1).values
+            return out
+        out.update({"reward": reward, "no_aug_reward": reward[:, [0], :] if n_aug > 1 else reward})
+        max_reward, max_idxs = reward.max(dim=-1)
+        out.update({"max_reward": max_reward})
+        if n_aug > 1:
+            out["no_aug_max_reward"] = max_reward[:, [0]]
+        if out.get("actions", None) is not None:
+            actions = unbatchify(out["actions"], (n_aug, n_start))
+            out["best_multistart_actions"] = gather_by_index(actions, max_idxs, dim=max_idxs.dim())
+            out["actions"] = actions
+        if n_aug > 1:
+            max_aug_reward, aug_idx = max_reward.max(dim=1)
+            out["max_aug_reward"] = max_aug_reward
+            if "best_multistart_actions" in out:
+                out["best_aug_actions"] = gather_by_index(out["best_multistart_actions"], aug_idx)
+        return out

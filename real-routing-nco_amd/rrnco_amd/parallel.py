@@ -23,3 +23,21 @@ def aggregate_throughput(local_units: int, local_seconds: float, distributed: bo
     dist.all_reduce(u, op=dist.ReduceOp.SUM)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return int(round(u.item())), float(t.item())
+
+
+def allreduce_flat_gradients(grads, world: int):
+    """Data-parallel gradient combine as Lightning's DDPStrategy does for the reference (configs/trainer/default.yaml:12-15):
+    ONE flat fp32 buffer (13.5-17.2 MB for RRNet), one sum all-reduce over RCCL / xGMI, then / world (mean).  Parameters
+    without a gradient (decoder.pointer.project_out, decoder.project_fixed_context, W_placeholder under multistart:
+    SURVEY App. D-9) take part as zeros so that every rank reduces the same layout."""
+    import torch.distributed as dist
+    flat = torch.cat([g.reshape(-1).float() for g in grads])
+    if world > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat /= world
+    out, off = [], 0
+    for g in grads:
+        n = g.numel()
+        out.append(flat[off:off + n].view_as(g))
+        off += n
+    return out

@@ -208,3 +208,28 @@ def test_full_size_properties_n100_b64_aug8():
     assert (best >= no_aug - 1e-6).all() and best.shape == (B,)
     out2 = pol(td, env, phase="val", decode_type="multistart_greedy", num_starts=100)   # deterministic
     assert torch.equal(out2["actions"], acts)
+
+
+def test_rl_module_metrics_and_reinforce_loss_match_formula():
+    """rrnco/models/rl.py:96-166: val-phase best-of metrics and the POMO shared-baseline loss (K12)."""
+    from rrnco_amd import TensorDict
+    from rrnco_amd.models.rl import RRNet, reinforce_loss
+    fx, w, pol, st, env, td_in = _setup("atsp_n20_b4_pomo")
+    S, B = fx["S"], fx["B"]
+    model = RRNet(env, policy=pol, num_augment=8, augment_fn="dihedral8", no_aug_coords=False, num_starts=S)
+    raw = TensorDict({"locs": fx["locs"].cuda(), "distance_matrix": fx["distance_matrix"].cuda()}, batch_size=[B])
+    out = model.shared_step(raw, phase="val")
+    assert out["reward"].shape == (B, 8, S) and out["max_reward"].shape == (B, 8) and out["max_aug_reward"].shape == (B,)
+    assert torch.equal(out["max_aug_reward"], out["reward"].amax(dim=(1, 2)))
+    assert out["best_aug_actions"].shape == (B, fx["N"]) and restate.atsp_check(out["best_aug_actions"].cpu())
+    # loss on the golden rollout: adv = R - mean_s R, loss = -mean(adv * ll)
+    R_, ll = fx["normalized_reward"], fx["log_likelihood"]
+    o = reinforce_loss(R_.cuda(), ll.cuda(), S)
+    Rb, lb = restate.unbatchify(R_, S), restate.unbatchify(ll, S)
+    adv = Rb - Rb.mean(1, keepdim=True)
+    assert torch.allclose(o["loss"].cpu(), -(adv * lb).mean(), atol=1e-6)
+    assert torch.allclose(restate.unbatchify(o["advantage"].cpu(), S), adv, atol=1e-6)
+    assert torch.allclose(o["bl_val"].cpu(), Rb.mean(1), atol=1e-6)
+    assert torch.allclose(restate.unbatchify(o["grad_log_likelihood"].cpu(), S), -adv / (B * S), atol=1e-8)
+    tr = model.shared_step(raw, phase="train", seed=3)
+    assert torch.isfinite(tr["loss"]) and tr["actions"].shape == (S * B, fx["N"])
