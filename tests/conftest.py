@@ -11,3 +11,8 @@ for p in (ROOT, os.path.join(ROOT, "real-routing-nco_amd")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a ROCm GPU (run on the MI355X box)")
+
+
+def pytest_sessionstart(session):
+    import torch
+    torch.set_num_threads(min(8, torch.get_num_threads()))   # the oracle's small CPU ops crawl with hundreds of threads

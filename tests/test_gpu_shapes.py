@@ -1,0 +1,93 @@
+"""`-m gpu`: shapes the golden fixtures do not cover — other tile-count templates (N <= 32 / <= 64 / <= 103), ragged
+start counts (S not a multiple of 16, S > 112, S = 1), the N = 103 limit — each against the oracle run on the fly."""
+import pytest
+import torch
+
+from oracle import restate
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(N, B, S, ss, seed, layers=2):
+    from rrnco_amd import TensorDict
+    from rrnco_amd.envs import ATSPEnv
+    w = restate.make_weights(restate.atsp_weight_template(128, layers, 512, ss), seed)
+    pol = H.make_policy(w)
+    inst = restate.atsp_synthetic(B, N, seed)
+    st0 = restate.atsp_reset(inst)
+    sidx = restate.sample_neighbor_indices(st0["distance_matrix"], ss, generator=torch.Generator().manual_seed(seed))
+    tr = {}
+    with torch.inference_mode():
+        ref = restate.atsp_policy(w, st0, sidx, S, "greedy", trace=tr)
+    env = ATSPEnv(generator_params=dict(num_loc=N))
+    td = TensorDict({k: v.cuda() for k, v in inst.items()}, batch_size=[B])
+    td["sample_idx"] = sidx.cuda()
+    outs = [pol(env.reset(td), env, phase="val", decode_type="multistart_greedy" if S > 1 else "greedy",
+                num_starts=S if S > 1 else None, fused=f) for f in (True, False)]
+    for out in outs:
+        acts = out["actions"].cpu()
+        assert acts.shape == ref["actions"].shape and restate.atsp_check(acts)
+        frac, first = H.tour_agreement(acts, ref["actions"])
+        if frac < 1.0:
+            lp = torch.nan_to_num(torch.stack(tr["logp"], 1), neginf=-1e9).topk(2, -1).values
+            gap = lp[..., 0] - lp[..., 1]
+            for r in torch.nonzero(first >= 0).flatten().tolist():
+                assert gap[r, int(first[r]) - (1 if S > 1 else 0)] < 1e-3
+        assert frac >= 0.97
+        same = first < 0
+        assert torch.allclose(out["reward"].cpu()[same], ref["reward"][same], atol=5e-5)
+        assert torch.allclose(out["log_likelihood"].cpu()[same], ref["log_likelihood"][same], rtol=2e-5, atol=3e-3)
+    assert torch.equal(outs[0]["actions"], outs[1]["actions"])          # fused == step-wise
+
+
+@pytest.mark.parametrize("N,B,S,ss", [
+    (50, 3, 50, 25),      # 4-tile template, S not a multiple of 16
+    (64, 2, 7, 25),       # 4-tile template upper edge, one partial rollout tile
+    (33, 3, 33, 20),      # just above the 2-tile template
+    (12, 5, 12, 8),       # small instance, 2-tile template
+    (20, 2, 1, 15),       # num_starts = 1 -> plain greedy path of get_decoding_strategy
+])
+def test_atsp_other_shapes_match_oracle(N, B, S, ss):
+    _run(N, B, S, ss, seed=100 + N + S)
+
+
+def test_atsp_max_nodes_103_and_more_starts_than_a_workgroup_tile_set():
+    _run(103, 2, 103, 25, seed=7)
+
+
+def test_more_than_103_nodes_is_rejected_loudly():
+    from rrnco_amd import TensorDict
+    from rrnco_amd.envs import ATSPEnv
+    w = restate.make_weights(restate.atsp_weight_template(128, 1, 512, 25), 1)
+    pol = H.make_policy(w)
+    inst = restate.atsp_synthetic(1, 104, 1)
+    env = ATSPEnv(generator_params=dict(num_loc=104))
+    td = TensorDict({k: v.cuda() for k, v in inst.items()}, batch_size=[1])
+    with pytest.raises(RuntimeError, match="status -1"):
+        pol(env.reset(td), env, phase="val", decode_type="greedy")
+
+
+def test_rcvrp_generator_instances_roundtrip_properties_n50():
+    """Size-independent properties on generator-made RCVRP instances (no fixture): every customer once, capacity never
+    exceeded, cost equals the recomputed route length, fused == step-wise."""
+    from rrnco_amd.envs import RCVRPEnv
+    w = restate.make_weights(restate.rcvrp_weight_template(128, 2, 512, 20), 5)
+    pol = H.make_policy(w, env_name="rcvrp")
+    env = RCVRPEnv(generator_params=dict(num_loc=50), check_solution=True)
+    td_in = env.generator(6, generator=torch.Generator(device="cuda").manual_seed(2))
+    from rrnco_amd.models.encoder import ATSPInitEmbedding
+    td0 = env.reset(td_in)
+    td_in["sample_idx"] = ATSPInitEmbedding.sample_indices(td0["distance_matrix"], 20)
+    a = pol(env.reset(td_in), env, phase="val", decode_type="multistart_greedy", num_starts=51, fused=True)
+    b = pol(env.reset(td_in), env, phase="val", decode_type="multistart_greedy", num_starts=51, fused=False)
+    assert torch.equal(a["actions"], b["actions"]) and torch.allclose(a["reward"], b["reward"])
+    acts = a["actions"].cpu()
+    R = acts.shape[0]
+    chk = {"demand": td_in["demand"].cpu()[torch.arange(R) % 6], "vehicle_capacity": torch.ones(R, 1)}
+    assert restate.rcvrp_check(chk, acts)
+    D = td0["distance_matrix"].cpu()
+    for r in (0, 17, R - 1):
+        path = torch.cat([torch.zeros(1, dtype=torch.long), acts[r], torch.zeros(1, dtype=torch.long)])
+        cost = D[r % 6, path[:-1], path[1:]].double().sum()
+        assert abs(float(a["normalized_reward"][r]) + float(cost)) < 1e-4
