@@ -142,7 +142,8 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_enc_block(EncBlockW wr, EncB
   const float* x_in = (is_col ? col_in : row_in) + (size_t)b * N * RR_E;
   const float* y_in = (is_col ? row_in : col_in) + (size_t)b * N * RR_E;
   float* out = (is_col ? col_out : row_out) + (size_t)b * N * RR_E;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably uniform: packed-weight bases stay in SGPRs
   const int j = lane & 15, g = lane >> 4;
   const int fb = 16 * wave;  // this wave's feature tile in every 128-wide GEMM
   float* dbgb = dbg ? dbg + (size_t)(b * 2 + is_col) * 8 * N * RR_E : nullptr;
@@ -199,10 +200,11 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_enc_block(EncBlockW wr, EncB
         }
       }
       float m = rr_wave_max(fmaxf(bs[0], bs[1]));
-      float e0 = expf(bs[0] - m), e1 = expf(bs[1] - m);   // exp(-inf) = 0 for padding lanes
+      float e0 = rr_exp(bs[0] - m), e1 = rr_exp(bs[1] - m);   // exp(-inf) = 0 for padding lanes
       float s = rr_wave_sum(e0 + e1);
-      if (lane < LDA) C[i * LDA + lane] = lane < N ? expf(e0 / s) : 0.f;
-      if (lane + 64 < LDA) C[i * LDA + lane + 64] = (lane + 64 < N) ? expf(e1 / s) : 0.f;
+      const float is = __builtin_amdgcn_rcpf(s);
+      if (lane < LDA) C[i * LDA + lane] = lane < N ? rr_exp(e0 * is) : 0.f;
+      if (lane + 64 < LDA) C[i * LDA + lane + 64] = (lane + 64 < N) ? rr_exp(e1 * is) : 0.f;
     }
   }
   __syncthreads();
@@ -231,13 +233,14 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_enc_block(EncBlockW wr, EncB
       float s = 0.f;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        float e = (nt * 16 + j < N) ? expf(ka[nt][r] - m) : 0.f;
+        float e = (nt * 16 + j < N) ? rr_exp(ka[nt][r] - m) : 0.f;
         ka[nt][r] = e; s += e;
       }
       s = rr_sum16(s);
+      const float is = __builtin_amdgcn_rcpf(s);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        float ek = expf(ka[nt][r] / s);
+        float ek = rr_exp(ka[nt][r] * is);
         ka[nt][r] = ek;          // eK
         va[nt][r] = ek * va[nt][r];  // Z
       }
@@ -264,8 +267,8 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_enc_block(EncBlockW wr, EncB
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float sg = 1.0f / (1.0f + expf(-qa[nt][r]));
-        qa[nt][r] = sg * (num[nt][r] / den[nt][r]);
+        float sg = rr_sigmoid(qa[nt][r]);
+        qa[nt][r] = sg * (num[nt][r] * __builtin_amdgcn_rcpf(den[nt][r]));
       }
     __syncthreads();  // all waves done with Z (B) and ea (C)
     rr_store_tiles<NT>(qa, B, LD, fb, N, lane);
@@ -486,22 +489,29 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_init_embed(InitW w, const fl
   float* comb = smem;                      // [N][256] = [node | dist-embedding]
   float* scr = smem + 2 * BUF_FLOATS;      // sorted samples [N][MAXSS], then gate partials [16][112]
   float* gpart = scr + RR_MAXN * MAXSS;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, g = lane >> 4;
   const float* Db = D + (size_t)b * N * N;
   const float* lc = locs + (size_t)b * N * 2;
   const int64_t* sx = sidx + (size_t)b * N * SS;
 
   for (int pass = 0; pass < 2; ++pass) {   // 0: row embedding, 1: col embedding
-    // gather + rank sort (ascending) of the SS sampled distances of every node
+    // gather the SS sampled distances of every node once (unsorted, in the gate-partials scratch area), then rank-sort
+    // them (ascending; ties by sample position) from LDS
+    float* raw = gpart;      // [N][MAXSS] floats = 13.2 KB max; gpart is not live yet
     for (int e = tid; e < N * SS; e += ENC_THREADS) {
-      int i = e / SS, s = e % SS;
-      int k = (int)sx[i * SS + s];
-      float v = pass == 0 ? Db[i * N + k] : Db[k * N + i];
+      int i = e / SS, s = e - i * SS;
+      int k = (int)sx[e];
+      raw[i * MAXSS + s] = pass == 0 ? Db[i * N + k] : Db[k * N + i];
+    }
+    __syncthreads();
+    for (int e = tid; e < N * SS; e += ENC_THREADS) {
+      int i = e / SS, s = e - i * SS;
+      const float v = raw[i * MAXSS + s];
       int rank = 0;
       for (int s2 = 0; s2 < SS; ++s2) {
-        int k2 = (int)sx[i * SS + s2];
-        float v2 = pass == 0 ? Db[i * N + k2] : Db[k2 * N + i];
+        const float v2 = raw[i * MAXSS + s2];
         rank += (v2 < v) || (v2 == v && s2 < s);
       }
       scr[i * MAXSS + rank] = v;
@@ -609,7 +619,8 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_dec_cache(CacheW w, const fl
                                                               float* __restrict__ ctxA, float* __restrict__ ctxB, int N) {
   __shared__ __attribute__((aligned(16))) float smem[2 * BUF_FLOATS];
   float* R = smem; float* Cc = smem + BUF_FLOATS;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, g = lane >> 4, fb = 16 * wave;
   const size_t off = (size_t)b * N * RR_E;
   for (int i = tid; i < N * (RR_E / 4); i += ENC_THREADS) {
