@@ -54,13 +54,18 @@ __device__ __forceinline__ void rr_gemm_wx(f32x4 (&acc)[NT], const float4* __res
     rowoff[nt] = node * ldx + 4 * g + xk0;
   }
   float4 a = wp[(size_t)kk0 * 64 + lane];
+  float4 b[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) b[nt] = rr_ld4(X + rowoff[nt]);
 #pragma unroll 1
   for (int kk = 0; kk < nkk; ++kk) {
-    float4 an = a;
-    if (kk + 1 < nkk) an = wp[(size_t)(kk0 + kk + 1) * 64 + lane];
-    float4 b[NT];
+    // operands of the next k-group (A from L2, B from LDS) are requested before this group's 4*NT MFMAs issue
+    float4 an = a, bn[NT];
+    const int kn = kk + 1 < nkk ? kk + 1 : kk;
+    an = wp[(size_t)(kk0 + kn) * 64 + lane];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) b[nt] = rr_ld4(X + rowoff[nt] + kk * 16);
+    for (int nt = 0; nt < NT; ++nt) bn[nt] = rr_ld4(X + rowoff[nt] + kn * 16);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = rr_mfma(a.x, b[nt].x, acc[nt]);
 #pragma unroll
@@ -69,9 +74,26 @@ __device__ __forceinline__ void rr_gemm_wx(f32x4 (&acc)[NT], const float4* __res
     for (int nt = 0; nt < NT; ++nt) acc[nt] = rr_mfma(a.z, b[nt].z, acc[nt]);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = rr_mfma(a.w, b[nt].w, acc[nt]);
+    __builtin_amdgcn_sched_barrier(0);
     a = an;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = bn[nt];
   }
 }
+
+// ---- raw buffer loads: 128-bit SGPR descriptor + 32-bit per-lane byte offset + SCALAR byte offset.  The uniform part of
+// every operand address (fragment index, head, k-group) then advances with SALU adds and costs no VALU slot — which matters
+// because the fp32 MFMA shares the SIMD's fp32 datapath with the VALU (measured: 2 waves/SIMD gain only 11 % over 1).
+typedef unsigned int rr_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rr_make_buf(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 rr_bld4(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
+  rr_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, soff_bytes, 0);
+  return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
+// exp without the low-order correction of rr_exp: |rel err| <= 6e-8 * |x| * log2(e); used where x is O(10)
+__device__ __forceinline__ float rr_exp_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 
 // add a per-feature bias (feature = fbase + 4g + reg) to every node tile
 template <int NT>
