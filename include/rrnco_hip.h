@@ -82,9 +82,15 @@ int rr_select(const float* logits, const uint8_t* mask, const int64_t* action_in
               uint64_t seed, uint32_t step, hipStream_t stream);
 
 /* One Attn_Free_Layer = row block + col block (rrnco/models/nn/attn_freenet.py:472-488). */
+/* theta [Bp][N][N] = rr_edge_angles(locs) (may be NULL: angles are then recomputed per block, slower);
+ * bias_pre [Bp][2][N*N] = rr_nab_dur output when the encoder uses the duration matrix, else NULL. */
 int rr_enc_layer(const EncBlockW* wrow, const EncBlockW* wcol, const float* row_in, const float* col_in,
-                 float* row_out, float* col_out, const float* D, const float* locs, const float* bias_pre,
-                 int Bp, int N, float* dbg, hipStream_t stream);
+                 float* row_out, float* col_out, const float* D, const float* locs, const float* theta,
+                 const float* bias_pre, int Bp, int N, float* dbg, hipStream_t stream);
+
+/* theta[b][i][j] = atan2(y_i - y_j, x_i - x_j): the angle input of the Neural Adaptive Bias
+ * (rrnco/models/nn/attn_freenet.py:262-264), computed once per instance and shared by every encoder block. */
+int rr_edge_angles(const float* locs, float* theta, int Bp, int N, hipStream_t stream);
 
 /* Neural Adaptive Bias with the duration matrix for the row and col block of one layer
  * (rrnco/models/nn/attn_freenet.py:226-237, 265-286, x alpha :427-429) -> bias_out [Bp][2][N*N], fed to rr_enc_layer. */

@@ -92,6 +92,9 @@ __device__ __forceinline__ float4 rr_bld4(__amdgpu_buffer_rsrc_t r, unsigned vof
   rr_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, soff_bytes, 0);
   return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
 }
+__device__ __forceinline__ float rr_bld1(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff_bytes, soff_bytes, 0));   // out of range -> 0
+}
 // exp without the low-order correction of rr_exp: |rel err| <= 6e-8 * |x| * log2(e); used where x is O(10)
 __device__ __forceinline__ float rr_exp_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 

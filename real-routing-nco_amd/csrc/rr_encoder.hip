@@ -84,6 +84,70 @@ __device__ __forceinline__ float nab_edge_pwl(const float* tab, float d, float t
   return (gt * od + (1.0f - gt) * oa + s[1]) * s[2];
 }
 
+// Grid-accelerated variant for four edges at once (k_enc_block_w).  After the tables above the host appends, per
+// family, NAB_G bytes: for cell c of a uniform grid over the input's range ([0,1] for the min-max-normalised distance,
+// [-pi,pi] for the angle) a conservative lower bound of "number of breakpoints <= x" for every x that lands in c.  The
+// search is then a forward scan from that bound — usually one or two steps instead of the eight of the bisection — and
+// ends at exactly the same segment, so the result is bit-identical to nab_edge_pwl for any x (inputs below the range scan
+// from the first breakpoint, inputs above it from the last cell's bound: correct, just longer).
+#define NAB_G 1024
+#define NAB_TAB2_FLOATS (NAB_TAB_FLOATS + 2 * NAB_G / 4)
+#define NAB_TS_LD 132
+__device__ __forceinline__ void nab_edge4_grid(const float* tab, const float* ts, const float (&d)[4], const float (&th)[4], float (&out)[4]) {
+  const unsigned char* cell = reinterpret_cast<const unsigned char*>(tab + NAB_TAB_FLOATS);
+  float x[8]; int m[8];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    x[q] = fminf(d[q], 3.0e38f); x[4 + q] = fminf(th[q], 3.0e38f);   // the +inf sentinel must stop the scan
+    int cd = (int)(d[q] * (float)NAB_G);
+    int ca = (int)((th[q] + 3.14159265358979f) * ((float)NAB_G / 6.28318530717959f));
+    const int sd = cell[min(max(cd, 0), NAB_G - 1)], sa = cell[NAB_G + min(max(ca, 0), NAB_G - 1)];
+    m[q] = cd < 0 ? 0 : sd; m[4 + q] = ca < 0 ? 0 : sa;       // below the range: scan from the first breakpoint
+  }
+  // forward scan on the sentinel-terminated copies ts[f][0..128] (ts[f][128] = +inf): branch-free, 8 searches in flight
+  int more;
+  do {
+    more = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float tv = ts[(e >= 4 ? NAB_TS_LD : 0) + m[e]];
+      const int adv = tv <= x[e] ? 1 : 0;
+      m[e] += adv; more |= adv;
+    }
+  } while (__any(more));
+  const float* s = tab + 256 + 1032;                  // bg, bo, alpha
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float fo[2], fg[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const int mm = m[4 * f + q];
+      float anchor = tab[128 * f + (mm > 0 ? mm - 1 : 0)];
+      anchor = anchor < INFINITY ? anchor : 0.f;
+      const float4 sg = rr_ld4(tab + 256 + 516 * f + 4 * mm);
+      const float dx = x[4 * f + q] - anchor;
+      fo[f] = fmaf(sg.x, dx, sg.y); fg[f] = fmaf(sg.z, dx, sg.w);
+    }
+    const float gt = rr_sigmoid(fg[0] + fg[1] + s[0]);
+    out[q] = (gt * fo[0] + (1.0f - gt) * fo[1] + s[1]) * s[2];
+  }
+}
+
+// theta[b][i][j] = atan2(y_i - y_j, x_i - x_j) (attn_freenet.py:262-264 computes it per layer; it only depends on the
+// coordinates, so it is computed once per instance and shared by the twelve blocks)
+__global__ void k_edge_angles(const float* __restrict__ locs, float* __restrict__ theta, int N) {
+  const int b = blockIdx.y, e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N * N) return;
+  const float* lc = locs + (size_t)b * N * 2;
+  const int i = e / N, j = e - i * N;
+  theta[(size_t)b * N * N + e] = atan2f(lc[2 * i + 1] - lc[2 * j + 1], lc[2 * i] - lc[2 * j]);
+}
+extern "C" int rr_edge_angles(const float* locs, float* theta, int Bp, int N, hipStream_t st) {
+  if (Bp <= 0 || N < 2 || N > RR_MAXN || locs == nullptr || theta == nullptr) return RR_EINVAL;
+  hipLaunchKernelGGL(k_edge_angles, dim3((N * N + 255) / 256, Bp), dim3(256), 0, st, locs, theta, N);
+  return rr_check(hipGetLastError());
+}
+
 // den/num GEMM: acc[nt] (features 16w.., query nodes 16nt..) += sum_k Z[k][16w+i] * ea[node][k]
 //   Z  : LDS [node][LD]   (A operand, read per element: lane (i,g) needs rows 16kk+4g+m)
 //   ea : LDS [node][LDA]  (B operand, float4 per lane)
@@ -341,11 +405,21 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_enc_block(EncBlockW wr, EncB
 #endif
 }
 
+#include "rr_enc_w.inc"
+
 extern "C" int rr_enc_layer(const EncBlockW* wrow, const EncBlockW* wcol, const float* row_in, const float* col_in,
-                            float* row_out, float* col_out, const float* D, const float* locs, const float* bias_pre,
-                            int Bp, int N, float* dbg, hipStream_t st) {
+                            float* row_out, float* col_out, const float* D, const float* locs, const float* theta,
+                            const float* bias_pre, int Bp, int N, float* dbg, hipStream_t st) {
   if (Bp <= 0 || N < 2 || N > RR_MAXN || wrow == nullptr || wcol == nullptr) return RR_EINVAL;
   dim3 grid(Bp, 2), blk(ENC_THREADS);
+  static const int variant = [] { const char* e = getenv("RR_ENC_VARIANT"); return e ? atoi(e) : 1; }();
+  if (variant == 1 && dbg == nullptr && (theta != nullptr || bias_pre != nullptr)) {
+    EncBlockW2 ws; ws.blk[0] = *wrow; ws.blk[1] = *wcol;   // wave = node tile, register-resident (rr_enc_w.inc); stage dumps use the LDS-staged kernel
+    if (N <= 32) hipLaunchKernelGGL(k_enc_block_w<2>, grid, dim3(128), 0, st, ws, row_in, col_in, row_out, col_out, D, theta, bias_pre, N);
+    else if (N <= 64) hipLaunchKernelGGL(k_enc_block_w<4>, grid, dim3(256), 0, st, ws, row_in, col_in, row_out, col_out, D, theta, bias_pre, N);
+    else hipLaunchKernelGGL(k_enc_block_w<7>, grid, dim3(448), 0, st, ws, row_in, col_in, row_out, col_out, D, theta, bias_pre, N);
+    return rr_check(hipGetLastError());
+  }
   if (N <= 32) hipLaunchKernelGGL(k_enc_block<2>, grid, blk, 0, st, *wrow, *wcol, row_in, col_in, row_out, col_out, D, locs, bias_pre, N, dbg);
   else if (N <= 64) hipLaunchKernelGGL(k_enc_block<4>, grid, blk, 0, st, *wrow, *wcol, row_in, col_in, row_out, col_out, D, locs, bias_pre, N, dbg);
   else hipLaunchKernelGGL(k_enc_block<7>, grid, blk, 0, st, *wrow, *wcol, row_in, col_in, row_out, col_out, D, locs, bias_pre, N, dbg);

@@ -164,15 +164,19 @@ class RRNetEncoder(nn.Module):
         row2, col2 = torch.empty_like(row), torch.empty_like(col)
         dbg = getattr(self, "_debug_buffer", None)
         use_dur = len(packed["nabdur"]) > 0          # encoder.py:98-106: duration matrix only for rcvrptw
+        theta = None
         if use_dur:
             T = td["duration_matrix"].float().contiguous()
             bias = torch.empty(Bp, 2, N * N, device=dev, dtype=torch.float32)
+        else:   # the angle matrix only depends on the coordinates: once per instance, shared by all twelve blocks
+            theta = torch.empty(Bp, N, N, device=dev, dtype=torch.float32)
+            L.check(lib.rr_edge_angles(L.ptr(locs), L.ptr(theta), Bp, N, L.stream()), "rr_edge_angles")
         for l, (wr, wc) in enumerate(packed["blocks"]):
             if use_dur:
                 nr, nc = packed["nabdur"][l]
                 L.check(lib.rr_nab_dur(nr, nc, L.ptr(D), L.ptr(T), L.ptr(locs), L.ptr(bias), Bp, N, L.stream()), "rr_nab_dur")
             L.check(lib.rr_enc_layer(wr, wc, L.ptr(row), L.ptr(col), L.ptr(row2), L.ptr(col2), L.ptr(D), L.ptr(locs),
-                                     L.ptr(bias) if use_dur else None,
+                                     L.ptr(theta) if theta is not None else None, L.ptr(bias) if use_dur else None,
                                      Bp, N, L.ptr(dbg) if (dbg is not None and l == 0) else None, L.stream()),
                     "rr_enc_layer")
             if l == 0 and dbg is not None:

@@ -80,7 +80,30 @@ def fold_nab_pwl(sd, p: str, alpha: torch.Tensor) -> torch.Tensor:
         ts.append(tt); segs.append(seg.reshape(-1))
     tail = np.zeros(8)
     tail[0], tail[1], tail[2] = bg, bo, float(alpha.detach().double().cpu().reshape(()))
-    return torch.from_numpy(np.concatenate(ts + segs + [tail])).float()
+    tab = np.concatenate(ts + segs + [tail]).astype(np.float32)
+    return torch.from_numpy(np.concatenate([tab, nab_grid_cells(tab)]))
+
+
+NAB_G = 1024            # csrc/rr_encoder.hip: NAB_G
+NAB_RANGES = ((0.0, 1.0), (-math.pi, math.pi))   # min-max-normalised distance, atan2 angle
+
+
+def nab_grid_cells(tab):
+    """Start-of-scan tables for csrc/rr_encoder.hip:nab_edge4_grid: per family, for each of the NAB_G uniform cells of
+    the input range, a lower bound (uint8) of "number of float32 breakpoints <= x" valid for every x the kernel maps to
+    that cell.  The kernel computes the cell in float32, so the bound is taken a little below the cell's lower edge.
+    Inputs below the range (negative raw cell index) start their scan at 0 in the kernel; inputs above it land in the
+    last cell and scan on.  Returned packed 4 bytes per float32."""
+    import numpy as np
+    out = []
+    for f, (lo, hi) in enumerate(NAB_RANGES):
+        t = tab[128 * f:128 * (f + 1)].astype(np.float64)
+        t = t[np.isfinite(t)]
+        w = (hi - lo) / NAB_G
+        edges = lo + w * np.arange(NAB_G) - 1e-2 * w - 1e-6
+        start = np.searchsorted(t, edges, side="right")          # breakpoints <= (edge - margin)
+        out.append(np.minimum(start, 128).astype(np.uint8))
+    return np.concatenate(out).view(np.float32)
 
 
 def eval_nab_pwl(tab: torch.Tensor, dmat: torch.Tensor, theta: torch.Tensor) -> torch.Tensor:

@@ -121,7 +121,25 @@ def test_nab_piecewise_linear_tables_are_exact():
     th = restate.pairwise_angles(locs)
     for p in ("encoder.net.layers.0.row_encoding_block", "encoder.net.layers.5.col_encoding_block"):
         tab = fold_nab_pwl(w, p + ".angle_distance_fusion", w[p + ".alpha"])
-        assert tab.numel() == 256 + 2 * 129 * 4 + 8
+        assert tab.numel() == 256 + 2 * 129 * 4 + 8 + 2 * 1024 // 4
+        # grid start tables (nab_edge4_grid): a lower bound of the bisection's result for every input of the cell,
+        # cell computed in float32 exactly as the kernel does
+        from rrnco_amd.packing import NAB_G, NAB_RANGES
+        cells = tab[1296:].numpy().view(np.uint8).astype(np.int64)
+        for f, x in enumerate((D.reshape(-1), th.reshape(-1))):
+            x = torch.cat([x, torch.linspace(NAB_RANGES[f][0], NAB_RANGES[f][1], 20001), torch.tensor([-5.0, 7.0])]).float()
+            if f == 0:
+                c = (x * np.float32(NAB_G)).to(torch.int32)
+            else:
+                c = ((x + np.float32(3.14159265358979)) * np.float32(NAB_G / 6.28318530717959)).to(torch.int32)
+            below = c < 0
+            c = c.clamp(0, NAB_G - 1).long()
+            true_m = torch.searchsorted(tab[128 * f:128 * f + 128].contiguous(), x.contiguous(), right=True)
+            start = torch.from_numpy(cells[NAB_G * f:NAB_G * (f + 1)])[c]
+            start = torch.where(below, torch.zeros_like(start), start)
+            assert bool((start <= true_m).all())
+            steps = (true_m - start)[:-2]
+            assert float(steps.float().mean()) < 1.0 and int(steps.max()) <= 8   # short scans on every in-range input
         ref = restate.nab_gating(w, p + ".angle_distance_fusion", locs, D, None) * w[p + ".alpha"]
         mine = eval_nab_pwl(tab, D, th)
         assert torch.allclose(mine, ref, atol=2e-6), (mine - ref).abs().max()

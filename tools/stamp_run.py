@@ -31,8 +31,11 @@ for i, n in enumerate(names):
     print(f"  {n:12s} {out[i]/waves/99:10.0f} cycles/step  {100*out[i]/tot:5.1f}%")
 
 lib.rr_debug_enc_stamps(eout, 0)
-en = ["load+norm1/2", "NAB+softmax", "KV,softmaxK,den,num", "Q,Y,P,M,norms", "FFN+norm"]
-ew = eout[7]; et = sum(eout[i] for i in range(5))
+en = (["norm2,K,softmaxK,V", "NAB", "norm1,Q,mix", "P,M,norm3,normf1", "FFN+norm"] if os.environ.get("RR_ENC_VARIANT", "1") == "1"
+      else ["load+norm1/2", "NAB+softmax", "KV,softmaxK,den,num", "Q,Y,P,M,norms", "FFN+norm"])
+if os.environ.get("RR_ENC_FINE"):
+    en = ["NAB stage+barrier", "NAB input wait", "NAB eval x7", "NAB softmax", "-", "KV stage", "rest"]
+ew = eout[7]; et = sum(eout[i] for i in range(len(en)))
 print(f"encoder block: waves={ew} cycles/wave/block={et/ew:.0f}")
 for i, n in enumerate(en):
     print(f"  {n:22s} {eout[i]/ew:10.0f} cycles  {100*eout[i]/et:5.1f}%")
