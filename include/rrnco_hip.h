@@ -22,7 +22,7 @@ typedef struct {                /* one AttnFree_Block: rrnco/models/nn/attn_free
   const float *n1g, *n1b, *n2g, *n2b, *n3g, *n3b, *f1g, *f1b, *f2g, *f2b;   /* InstanceNorm1d affine [128] */
   const void *wq, *wk, *wv, *wp, *wc, *w1, *w2;   /* MFMA A-operand packs: [M/16][K/16][64 lanes][4] floats  */
   const float *bq, *bk, *bv, *bp, *bc, *b1, *b2;
-  const float *nab;             /* folded DistAngleFusion (:201-289): 8 rows x 128 + 8 scalars              */
+  const float *nab;             /* folded DistAngleFusion (:201-289): piecewise-linear tables, packing.fold_nab_pwl */
 } EncBlockW;
 
 typedef struct {                /* ATSPInitEmbedding (rrnco/models/env_embeddings/atsp.py:5-121) and
