@@ -27,7 +27,7 @@ typedef struct {                /* one AttnFree_Block: rrnco/models/nn/attn_free
 
 typedef struct {                /* ATSPInitEmbedding (rrnco/models/env_embeddings/atsp.py:5-121) and
                                  * RVRPInitEmbedding / RVRPTWInitEmbedding (rcvrp.py:5-200, rcvrptw.py) */
-  const float *wi, *bi, *wr, *br, *wcl, *bcl;
+  const float *wi, *bi, *wr, *br, *wcl, *bcl;   /* wr / wcl: row_embed / col_embed weights transposed to [SS][E] */
   const void *g0r, *g0c;        /* gating_fc.0 packs [16][16][64][4] */
   const float *g0rb, *g0cb, *g2r, *g2c;
   const float *wdep, *bdep, *wdm, *bdm;   /* VRP: depot Linear(2,E), demand_init Linear(F,E) */

@@ -540,7 +540,7 @@ extern "C" int rr_nab_dur(const NabDurW* wrow, const NabDurW* wcol, const float*
 // ------------------------------------------------------------------------------------------------
 struct InitW {
   const float *wi, *bi;            // init_embed [E,2],[E]
-  const float *wr, *br, *wcl, *bcl;  // row_embed / col_embed [E,SS],[E]
+  const float *wr, *br, *wcl, *bcl;  // row_embed / col_embed weights transposed to [SS,E], bias [E]
   const float4 *g0r, *g0c;         // gating_fc.0 packed [16 tiles][16 kk][64]
   const float *g0rb, *g0cb;        // [2E]
   const float *g2r, *g2c;          // gating_fc.2 weight [2E]
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_init_embed(InitW w, const fl
         comb[i * 256 + f] = fmaf(w.wi[f * 3 + 2], ang, fmaf(w.wi[f * 3 + 1], y, w.wi[f * 3] * x)) + w.bi[f];
       }
       float acc = 0.f;
-      for (int s = 0; s < SS; ++s) acc = fmaf(wd[f * SS + s], scr[i * MAXSS + s], acc);
+      for (int s = 0; s < SS; ++s) acc = fmaf(wd[s * RR_E + f], scr[i * MAXSS + s], acc);   // weights stored [SS][E]
       comb[i * 256 + 128 + f] = acc + bd[f];
     }
     __syncthreads();
@@ -633,11 +633,15 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_init_embed(InitW w, const fl
     __syncthreads();
     float* outp = (pass == 0 ? row_out : col_out) + (size_t)b * N * RR_E;
     const float g2b = pass == 0 ? w.g2rb : w.g2cb;
+    if (tid < N) {            // the gate is a scalar per node (atsp.py:108-121): once per node, not once per feature
+      float z = g2b;
+      for (int t = 0; t < 16; ++t) z += gpart[t * 112 + tid];
+      scr[tid] = 1.0f / (1.0f + expf(-z));     // the sorted samples in scr are dead
+    }
+    __syncthreads();
     for (int e = tid; e < N * RR_E; e += ENC_THREADS) {
       int i = e >> 7, f = e & 127;
-      float z = g2b;
-      for (int t = 0; t < 16; ++t) z += gpart[t * 112 + i];
-      float gt = 1.0f / (1.0f + expf(-z));
+      const float gt = scr[i];
       float gated = gt * comb[i * 256 + f] + (1.0f - gt) * comb[i * 256 + 128 + f];
       if (KIND == 0) outp[e] = gated;
       else {

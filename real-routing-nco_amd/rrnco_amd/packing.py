@@ -203,8 +203,8 @@ def pack_policy(sd: dict, env_name: str, device) -> dict:
     if env_name == "atsp":
         iw = L.InitW()
         iw.wi, iw.bi = ar.put(sd[p + ".init_embed.weight"]), ar.put(sd[p + ".init_embed.bias"])
-        iw.wr, iw.br = ar.put(sd[p + ".row_embed.weight"]), ar.put(sd[p + ".row_embed.bias"])
-        iw.wcl, iw.bcl = ar.put(sd[p + ".col_embed.weight"]), ar.put(sd[p + ".col_embed.bias"])
+        iw.wr, iw.br = ar.put(sd[p + ".row_embed.weight"].t().contiguous()), ar.put(sd[p + ".row_embed.bias"])   # [SS,E]: coalesced over features
+        iw.wcl, iw.bcl = ar.put(sd[p + ".col_embed.weight"].t().contiguous()), ar.put(sd[p + ".col_embed.bias"])
         for rc, s in (("row", "r"), ("col", "c")):
             q = f"{p}.gating_network_{rc}.gating_fc"
             setattr(iw, "g0" + s, ar.put(pack_a(sd[q + ".0.weight"].detach().float())))
@@ -218,8 +218,8 @@ def pack_policy(sd: dict, env_name: str, device) -> dict:
         iw = L.InitW()
         iw.wdep, iw.bdep = ar.put(sd[p + ".coord_expert.init_embed_depot.weight"]), ar.put(sd[p + ".coord_expert.init_embed_depot.bias"])
         iw.wi, iw.bi = ar.put(sd[p + ".coord_expert.init_embed.weight"]), ar.put(sd[p + ".coord_expert.init_embed.bias"])
-        iw.wr, iw.br = ar.put(sd[p + ".distance_expert.row_embed.weight"]), ar.put(sd[p + ".distance_expert.row_embed.bias"])
-        iw.wcl, iw.bcl = ar.put(sd[p + ".distance_expert.col_embed.weight"]), ar.put(sd[p + ".distance_expert.col_embed.bias"])
+        iw.wr, iw.br = ar.put(sd[p + ".distance_expert.row_embed.weight"].t().contiguous()), ar.put(sd[p + ".distance_expert.row_embed.bias"])
+        iw.wcl, iw.bcl = ar.put(sd[p + ".distance_expert.col_embed.weight"].t().contiguous()), ar.put(sd[p + ".distance_expert.col_embed.bias"])
         dm = ".demand_init" if (p + ".demand_init.weight") in sd else ".init_embed"   # rcvrptw.py:44 names it init_embed
         iw.wdm, iw.bdm = ar.put(sd[p + dm + ".weight"]), ar.put(sd[p + dm + ".bias"])
         iw.nfeat = sd[p + dm + ".weight"].shape[1]
