@@ -1,0 +1,165 @@
+"""Gradient path of the REINFORCE step (BASELINE configs[4]) — round-1 form.
+
+The reference differentiates straight through its sampling forward (rrnco/models/rl.py:96-128 under Lightning autograd).
+Here the forward — encoder, sampling rollout, reward, loss and d loss / d log-likelihood — runs on the HIP kernels without a
+graph; the parameter gradient is then obtained by REPLAYING the sampled tours teacher-forced through a differentiable
+formulation of the same policy and calling autograd on it (torch ops on the ROCm device: hipBLAS GEMMs, no hand-written
+backward kernels yet — DESIGN.md §6 says so; this module is the piece later rounds replace).
+
+Two things keep the replay cheap:
+  * with the actions known, every decode step's context (first node, current node, visited set) is known up front, so the
+    N-1 sequential pointer steps become ONE batched evaluation over (instance, start, step);
+  * the Neural Adaptive Bias uses the same algebraic fold as the kernel (wo.u and wg.u are linear in the hidden vector:
+    attn_freenet.py:242-289, csrc/rr_encoder.hip), so no E x E contraction per edge is materialised; gradients reach the
+    original parameters through the fold.
+Instances are independent (instance norm is per instance), so the encoder runs in instance chunks under activation
+checkpointing and the decoder chunks back-propagate into detached copies of the cache; one backward through the encoder
+graph finishes the job.  ATSP only (the config-5 problem).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+from torch.utils.checkpoint import checkpoint
+
+E, HEADS = 128, 8
+
+
+def _lin(P, name, x):
+    return F.linear(x, P[name + ".weight"], P.get(name + ".bias"))
+
+
+def _inorm(P, p, x):
+    """Normalization('instance') attn_freenet.py:104-105."""
+    return F.instance_norm(x.transpose(1, 2), weight=P[p + ".normalizer.weight"], bias=P[p + ".normalizer.bias"],
+                           eps=1e-5).transpose(1, 2)
+
+
+def _nab_folded(P, p, cost, theta):
+    """DistAngleFusion (gating, no duration) attn_freenet.py:242-289 with the second MLP layers folded into out_lin / gate."""
+    wo, bo = P[p + ".out_lin.weight"][0], P[p + ".out_lin.bias"][0]
+    wg, bg = P[p + ".gate.0.weight"][0], P[p + ".gate.0.bias"][0]
+    outs = []
+    for nm, x, wgh in (("dist_emb", cost, wg[:E]), ("angle_emb", theta, wg[E:])):
+        a, b = P[f"{p}.{nm}.0.weight"][:, 0], P[f"{p}.{nm}.0.bias"]
+        W2, b2 = P[f"{p}.{nm}.2.weight"], P[f"{p}.{nm}.2.bias"]
+        h = F.relu(x.unsqueeze(-1) * a + b)                                  # [b,N,N,E]
+        outs.append((h @ (W2.t() @ wo) + wo @ b2, h @ (W2.t() @ wgh) + wgh @ b2))
+    (od, gd), (oa, ga) = outs
+    g = torch.sigmoid(gd + ga + bg)
+    return g * od + (1 - g) * oa + bo
+
+
+def _block(P, p, x, y, cost, theta):
+    """AttnFree_Block.forward attn_freenet.py:417-441 (AFTFull :309-327, TransformerFFN :330-357)."""
+    r = _inorm(P, p + ".norm1", x)
+    c = _inorm(P, p + ".norm2", y)
+    bias = _nab_folded(P, p + ".angle_distance_fusion", cost, theta) * P[p + ".alpha"]
+    q, k, v = _lin(P, p + ".attn_free.to_q", r), _lin(P, p + ".attn_free.to_k", c), _lin(P, p + ".attn_free.to_v", c)
+    ea = torch.exp(torch.softmax(bias, dim=-1))
+    ek = torch.exp(torch.softmax(k, dim=1))
+    mixed = (ea @ (ek * v)) / (ea @ ek)
+    out = _lin(P, p + ".attn_free.project", torch.sigmoid(q) * mixed)
+    out = _inorm(P, p + ".norm3", _lin(P, p + ".multi_head_combine", out))
+    f = p + ".feed_forward.ops"
+    x1 = _inorm(P, f + ".norm1", r + out)
+    return _inorm(P, f + ".norm2", x1 + _lin(P, f + ".ffn.W2", F.relu(_lin(P, f + ".ffn.W1", x1))))
+
+
+def _init_embedding(P, locs, D, sidx):
+    """ATSPInitEmbedding atsp.py:69-91 + ContextualGating :108-121."""
+    p = "encoder.init_embedding"
+    node = _lin(P, p + ".init_embed", locs)
+    rowd = D.gather(2, sidx).sort(dim=-1).values
+    cold = D.transpose(1, 2).gather(2, sidx).sort(dim=-1).values
+    out = []
+    for rc, dist in (("row", _lin(P, p + ".row_embed", rowd)), ("col", _lin(P, p + ".col_embed", cold))):
+        q = f"{p}.gating_network_{rc}.gating_fc"
+        g = torch.sigmoid(_lin(P, q + ".2", F.relu(_lin(P, q + ".0", torch.cat([node, dist], -1)))))
+        out.append(g * node + (1 - g) * dist)
+    return out[0], out[1]
+
+
+def encode(P, locs, D, sidx, num_layers, use_checkpoint=True):
+    """RRNetEncoder.forward encoder.py:80-112 (atsp) -> row_emb, col_emb [b,N,E]."""
+    row, col = _init_embedding(P, locs, D, sidx)
+    d = locs.unsqueeze(2) - locs.unsqueeze(1)
+    theta = torch.atan2(d[..., 1], d[..., 0])                                # attn_freenet.py:254-262
+    Dt = D.transpose(1, 2)
+    for l in range(num_layers):
+        p = f"encoder.net.layers.{l}"
+        if use_checkpoint:
+            r = checkpoint(_block, P, p + ".row_encoding_block", row, col, D, theta, use_reentrant=False)
+            c = checkpoint(_block, P, p + ".col_encoding_block", col, row, Dt, theta, use_reentrant=False)
+        else:
+            r = _block(P, p + ".row_encoding_block", row, col, D, theta)
+            c = _block(P, p + ".col_encoding_block", col, row, Dt, theta)      # attn_freenet.py:480-486: D^T, same angles
+        row, col = r, c
+    return row, col
+
+
+def decode_log_likelihood(P, row_emb, col_emb, D, actions, tanh_clipping=10.0, temperature=1.0):
+    """Teacher-forced RRNetDecoder + process_logits + get_log_likelihood for ATSP under multistart
+    (decoder.py:151-329, decoding.py:311-361, policy.py:240-242), all steps at once.
+    row_emb, col_emb [b,N,E]; D [b,N,N] (normalised); actions [b,S,N] (actions[...,0] = start node) -> ll [b,S]."""
+    b, S, N = actions.shape
+    T = N - 1
+    k, v, lk = F.linear(col_emb, P["decoder.project_node_embeddings.weight"]).chunk(3, dim=-1)      # decoder.py:214-232
+    Wc = P["decoder.context_embedding.project_context.weight"]                                        # TSPContext: Linear(2E,E)
+    ctx_first, ctx_cur = F.linear(row_emb, Wc[:, :E]), F.linear(row_emb, Wc[:, E:])                   # [b,N,E]
+    first = actions[..., 0]
+    prev = actions[..., :T]                                       # current node when step t+1's action is chosen
+    target = actions[..., 1:]
+    idx = lambda t, i: t.gather(1, i.reshape(b, -1, 1).expand(-1, -1, t.size(-1)))                    # noqa: E731
+    q = idx(ctx_first, first).unsqueeze(2) + idx(ctx_cur, prev).view(b, S, T, E)                      # [b,S,T,E]
+    onehot = F.one_hot(prev, N).to(torch.int32)
+    visited = onehot.cumsum(dim=2) > 0                            # nodes visited before each decision (incl. current)
+    mask = ~visited                                               # atsp/env.py:80-105 action_mask
+    q = q.reshape(b, S * T, E)
+    m = mask.reshape(b, 1, S * T, N)
+    heads = lambda t: t.unflatten(-1, (HEADS, -1)).transpose(1, 2)                                    # noqa: E731
+    h = F.scaled_dot_product_attention(heads(q), heads(k), heads(v), attn_mask=m)                     # decoder.py:308-323
+    g = h.transpose(1, 2).flatten(-2) + q                                                             # :294
+    g = g + F.linear(F.relu(F.linear(g, P["decoder.pointer.ffn.lins.0.weight"], P["decoder.pointer.ffn.lins.0.bias"])),
+                     P["decoder.pointer.ffn.lins.1.weight"], P["decoder.pointer.ffn.lins.1.bias"])    # :296
+    logits = torch.bmm(g, lk.transpose(1, 2)) / math.sqrt(E)                                          # :300-302
+    bias = P["decoder.alpha"] * idx(D, prev)                                                          # :187-190
+    logits = torch.log(torch.exp(logits - bias) + 1e-6)                                               # :191-198
+    if tanh_clipping > 0:
+        logits = torch.tanh(logits) * tanh_clipping
+    logits = logits.masked_fill(~mask.reshape(b, S * T, N), float("-inf")) / temperature
+    logp = F.log_softmax(logits, dim=-1).gather(-1, target.reshape(b, S * T, 1)).view(b, S, T)
+    return logp.sum(-1)
+
+
+def replay_backward(policy, td, actions, num_starts, grad_ll, sample_idx, enc_chunk=64, dec_chunk=16):
+    """Accumulate d loss / d theta into policy parameters' .grad, given d loss / d log-likelihood.
+
+    td: the reset state the rollout started from (`locs`, normalised `distance_matrix`); actions [S*B, N] and grad_ll [S*B]
+    in the reference's flattening r = s*B + b.  Returns the replayed log-likelihood [S*B] (for checking against the
+    rollout's)."""
+    if policy.env_name != "atsp":
+        raise NotImplementedError("gradient replay is implemented for ATSP (BASELINE configs[4])")
+    P = dict(policy.named_parameters())
+    nl = 1 + max(int(n.split(".")[3]) for n in P if n.startswith("encoder.net.layers."))
+    D, locs = td["distance_matrix"].float(), td["locs"].float()
+    B, N = D.shape[0], D.shape[-1]
+    S = num_starts
+    acts = actions.view(S, B, N).transpose(0, 1)                  # [B,S,N]
+    gll = grad_ll.view(S, B).transpose(0, 1)
+    ll_out = torch.empty(B, S, device=D.device)
+    with torch.enable_grad():
+        for lo in range(0, B, enc_chunk):
+            hi = min(B, lo + enc_chunk)
+            row, col = encode(P, locs[lo:hi], D[lo:hi], sample_idx[lo:hi], nl)
+            row_d, col_d = row.detach().requires_grad_(), col.detach().requires_grad_()
+            for a in range(lo, hi, dec_chunk):
+                z = min(hi, a + dec_chunk)
+                ll = decode_log_likelihood(P, row_d[a - lo:z - lo], col_d[a - lo:z - lo], D[a:z], acts[a:z],
+                                           policy.tanh_clipping, policy.temperature)
+                ll_out[a:z] = ll.detach()
+                ll.backward(gll[a:z])                             # decoder parameters + the detached embeddings
+            torch.autograd.backward([row, col], [row_d.grad, col_d.grad])
+    return ll_out.transpose(0, 1).reshape(-1)

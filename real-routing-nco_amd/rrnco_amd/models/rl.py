@@ -1,14 +1,18 @@
 """RRNet RL module — mirror of rrnco.models.rl.RRNet.shared_step (rrnco/models/rl.py:96-166) without Lightning.
 
 val / test phases are complete (augmentation, multistart, best-of metrics).  The train phase runs the sampling rollout and
-the POMO shared-baseline REINFORCE loss on HIP kernels and returns d loss / d log-likelihood; the backward pass through the
-policy (and with it the RCCL gradient all-reduce of BASELINE configs[4]) is not built yet — see DESIGN.md §6."""
+the POMO shared-baseline REINFORCE loss on HIP kernels and returns d loss / d log-likelihood; `training_step` turns that into
+parameter gradients by a teacher-forced autograd replay (models/grad_replay.py — torch ops on the device, not HIP kernels
+yet), combines them across ranks with ONE flat RCCL all-reduce (parallel.allreduce_flat_gradients) and steps the optimizer:
+BASELINE configs[4]."""
 from __future__ import annotations
 
 import torch
 
 from .. import _lib as L
 from ..ops import gather_by_index, unbatchify
+from ..parallel import allreduce_flat_gradients
+from .grad_replay import replay_backward
 from .policy import RRNetPolicy
 from .transforms import StateAugmentation
 
@@ -42,6 +46,38 @@ class RRNet:
             attr = f"{phase}_decode_type"
             if "multistart" not in getattr(self.policy, attr):
                 setattr(self.policy, attr, "multistart_" + getattr(self.policy, attr))
+
+    def training_step(self, batch, optimizer=None, world: int = 1, enc_chunk: int = 64, dec_chunk: int = 16, **policy_kw) -> dict:
+        """One REINFORCE step on this rank's shard of instances (rl.py:96-128 + Lightning's DDP mean-reduction):
+        sampling rollout, reward, shared-baseline loss and d loss / d ll on the HIP kernels; parameter gradients by the
+        teacher-forced replay; one flat all-reduce (mean over ranks); optimizer step.  Returns the shared_step dict plus
+        `replay_log_likelihood` (must agree with the rollout's) and `grad_norm`."""
+        if self.env_name != "atsp":
+            raise NotImplementedError("training_step is implemented for ATSP (BASELINE configs[4])")
+        from .encoder import ATSPInitEmbedding
+        td = self.env.reset(batch)
+        if td.get("sample_idx", None) is None:            # the rollout and the replay must see the same neighbour sample
+            td.set("sample_idx", ATSPInitEmbedding.sample_indices(td["distance_matrix"], self.policy.encoder.init_embedding.sample_size))
+        state = {"distance_matrix": td["distance_matrix"], "locs": td["locs"]}
+        sidx = td["sample_idx"]
+        n_start = self.env.get_num_starts(td) if self.num_starts is None else self.num_starts
+        out = self.policy(td, self.env, phase="train", num_starts=n_start, **policy_kw)
+        r = out["normalized_reward"] if self.env.normalize else out["reward"]
+        out.update(reinforce_loss(r, out["log_likelihood"], n_start))
+        out["max_reward"] = unbatchify(out["reward"], (0, n_start)).max(dim=-1).values
+        params = [p for p in self.policy.parameters()]
+        for p in params:
+            p.grad = None
+        out["replay_log_likelihood"] = replay_backward(self.policy, state, out["actions"], n_start, out["grad_log_likelihood"],
+                                                       sidx, enc_chunk=enc_chunk, dec_chunk=dec_chunk)
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
+        grads = allreduce_flat_gradients(grads, world)
+        for p, g in zip(params, grads):
+            p.grad = g
+        out["grad_norm"] = torch.sqrt(sum((g.float() ** 2).sum() for g in grads))
+        if optimizer is not None:
+            optimizer.step()
+        return out
 
     def shared_step(self, batch, batch_idx: int = 0, phase: str = "val", **policy_kw) -> dict:
         td = self.env.reset(batch)

@@ -204,3 +204,47 @@ def test_sharded_bench_logic_gloo_world2(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     got = sorted(open(os.path.join(tmp_path, f"rank{i}.txt")).read() for i in range(2))
     assert got[0].split()[1:] == got[1].split()[1:]        # both ranks agree on the aggregate (max time, total units)
+
+
+def test_gradient_replay_matches_oracle_autograd():
+    """REINFORCE gradient path (BASELINE configs[4]): the teacher-forced, all-steps-at-once replay with the folded NAB
+    (rrnco_amd/models/grad_replay.py) gives the log-likelihoods of the reference's own golden tours and the same parameter
+    gradients as autograd through the op-for-op oracle (sequential decode, unfolded NAB)."""
+    from rrnco_amd.models.grad_replay import replay_backward
+    fx = H.load_fixture("atsp_n20_b4_pomo")
+    w = H.atsp_weights(fx)
+    S, N = fx["S"], fx["N"]
+    st0 = restate.atsp_reset(H.fixture_state(fx))
+    gll = torch.from_numpy(np.random.default_rng(3).standard_normal(fx["actions"].shape[0]).astype(np.float32))
+    wg = {k: v.clone().requires_grad_() for k, v in w.items()}
+    out = restate.atsp_policy(wg, st0, fx["sample_idx"], S, decode="evaluate", actions=fx["actions"][:, 1:])
+    assert torch.allclose(out["log_likelihood"], fx["log_likelihood"], atol=1e-4)
+    (out["log_likelihood"] * gll).sum().backward()
+
+    pol = H.make_policy(w, device="cpu")
+    pol.zero_grad()
+    ll = replay_backward(pol, {"distance_matrix": st0["distance_matrix"], "locs": st0["locs"]}, fx["actions"], S, gll,
+                         fx["sample_idx"], enc_chunk=3, dec_chunk=2)           # ragged chunks on purpose
+    assert torch.allclose(ll, fx["log_likelihood"], rtol=2e-5, atol=2e-4), (ll - fx["log_likelihood"]).abs().max()
+    # Tolerances.  (1) tensors whose true gradient is zero (biases in front of an instance norm, to_k.bias under the
+    # node softmax, out_lin.bias under the row softmax) carry only cancellation noise, in the oracle as well.  (2) the
+    # gradient is discontinuous at ReLU kinks: a pre-activation within ~1e-6 of zero may take the other branch under a
+    # different (equally valid) fp32 association, which moves that hidden unit's row of W1 / lins.0 by one sample's full
+    # contribution and everything upstream of it a little (checked against a float64 run of the same code: exactly one
+    # unit of two layers differs on this fixture).  Hence L2 bounds: per tensor 5 % of its own norm plus 2e-5 of the
+    # whole gradient's norm, and 5e-3 relative for the whole gradient (measured 1e-3) — far below what a wrong formula gives.
+    refs = {n: wg[n].grad for n, _ in pol.named_parameters()}
+    gnorm = sum(float((g ** 2).sum()) for g in refs.values() if g is not None) ** 0.5
+    checked, num = 0, 0.0
+    for name, p in pol.named_parameters():
+        ref = refs[name]
+        if ref is None:                                  # parameters the multistart path never touches (SURVEY App. D-9)
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        assert p.grad is not None, name
+        err = float(((p.grad - ref) ** 2).sum()) ** 0.5
+        assert err <= 5e-2 * float((ref ** 2).sum()) ** 0.5 + 2e-5 * gnorm, (name, err)
+        num += err ** 2
+        checked += 1
+    assert checked > 150
+    assert num ** 0.5 / gnorm < 5e-3, num ** 0.5 / gnorm

@@ -1,0 +1,83 @@
+"""`-m gpu`: the REINFORCE training step of BASELINE configs[4] (ATSP), single rank.
+
+Forward (encoder, sampling rollout, reward, loss, d loss / d ll) on the HIP kernels; parameter gradients by the
+teacher-forced replay (rrnco_amd/models/grad_replay.py).  Checked against autograd through the op-for-op CPU oracle fed
+the SAME sampled tours (evaluate mode) and the same d loss / d ll."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import restate
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(fx):
+    from rrnco_amd import TensorDict
+    from rrnco_amd.envs import ATSPEnv
+    from rrnco_amd.models.rl import RRNet
+    w = H.atsp_weights(fx)
+    pol = H.make_policy(w).train()
+    env = ATSPEnv(generator_params=dict(num_loc=fx["N"]), check_solution=True)
+    model = RRNet(env, policy=pol, num_augment=8)
+    st = H.fixture_state(fx)
+    td_in = TensorDict({k: v.cuda() for k, v in st.items()}, batch_size=[st["locs"].shape[0]])
+    td_in["sample_idx"] = fx["sample_idx"].cuda()
+    return w, pol, model, st, td_in
+
+
+@pytest.mark.parametrize("name", ["atsp_n20_b4_pomo", "atsp_n100_b2_pomo"])
+def test_training_step_gradients_match_oracle_autograd(name):
+    fx = H.load_fixture(name)
+    w, pol, model, st, td_in = _model(fx)
+    out = model.training_step(td_in, seed=11)
+    S, B, N = fx["S"], fx["B"], fx["N"]
+    acts = out["actions"].cpu()
+    assert acts.shape == (S * B, N) and bool((acts.sort(1).values == torch.arange(N)).all())      # sampled tours are permutations
+    # the replay reproduces the rollout's log-likelihood (same tours, different kernels)
+    assert torch.allclose(out["replay_log_likelihood"], out["log_likelihood"], rtol=2e-5, atol=2e-3)
+    # loss / advantage as rl.py:123-128 + REINFORCE shared baseline (routefinder/model.py:189-195)
+    r = out["normalized_reward"].cpu().view(S, B)
+    adv = (r - r.mean(0, keepdim=True)).reshape(-1)
+    assert torch.allclose(out["advantage"].cpu(), adv, atol=1e-5)
+    assert abs(float(out["loss"]) - float(-(adv * out["log_likelihood"].cpu()).mean())) < 1e-4
+    gll = out["grad_log_likelihood"].cpu()
+    assert torch.allclose(gll, -adv / (S * B), atol=1e-7)
+    # oracle: autograd through the sequential CPU restatement on the sampled tours
+    wg = {k: v.clone().requires_grad_() for k, v in w.items()}
+    ref = restate.atsp_policy(wg, restate.atsp_reset(st), fx["sample_idx"], S, decode="evaluate", actions=acts[:, 1:])
+    assert torch.allclose(ref["log_likelihood"], out["log_likelihood"].cpu(), rtol=2e-5, atol=2e-3)
+    (ref["log_likelihood"] * gll).sum().backward()
+    refs = {n: wg[n].grad for n, _ in pol.named_parameters()}
+    gnorm = sum(float((g ** 2).sum()) for g in refs.values() if g is not None) ** 0.5
+    num = 0.0
+    for n, p in pol.named_parameters():
+        g = p.grad.cpu()
+        if refs[n] is None:
+            assert float(g.abs().max()) == 0.0, n          # zero-filled so that every rank all-reduces the same layout
+            continue
+        err = float(((g - refs[n]) ** 2).sum()) ** 0.5
+        assert err <= 5e-2 * float((refs[n] ** 2).sum()) ** 0.5 + 2e-5 * gnorm, (n, err)      # tolerances: tests/test_cpu.py
+        num += err ** 2
+    assert num ** 0.5 / gnorm < 5e-3, num ** 0.5 / gnorm
+    assert abs(float(out["grad_norm"]) - gnorm) / gnorm < 5e-3
+
+
+def test_optimizer_steps_change_the_policy_and_repack():
+    """Three Adam steps: parameters move, the packed (MFMA-ordered) weights are rebuilt, the loss stays finite."""
+    fx = H.load_fixture("atsp_n20_b4_pomo")
+    w, pol, model, st, td_in = _model(fx)
+    opt = torch.optim.Adam(pol.parameters(), lr=1e-4)
+    before = {n: p.detach().clone() for n, p in pol.named_parameters()}
+    key0 = pol.packed(torch.device("cuda")) is pol.packed(torch.device("cuda"))
+    assert key0
+    packed0 = pol.packed(torch.device("cuda"))
+    losses = []
+    for it in range(3):
+        out = model.training_step(td_in, optimizer=opt, seed=100 + it)
+        losses.append(float(out["loss"]))
+    assert all(np.isfinite(losses))
+    moved = sum(int(not torch.equal(before[n], p.detach())) for n, p in pol.named_parameters())
+    assert moved > 150
+    assert pol.packed(torch.device("cuda")) is not packed0

@@ -1,0 +1,50 @@
+"""Throughput of BASELINE configs[4]: ATSP n=100 REINFORCE training step, 512 instances per GPU (S=100 sampled starts),
+data-parallel with one flat RCCL gradient all-reduce.  A parity-test config, not the bench line.
+  python tools/bench_train.py [--batch 512] [--steps 2]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/bench_train.py
+Prints one JSON line (rank 0): instances/s over all ranks, and where the step's time goes."""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "real-routing-nco_amd"))
+import torch
+import bench
+from rrnco_amd.envs import ATSPEnv, ATSPGenerator
+from rrnco_amd.models.rl import RRNet
+from rrnco_amd.parallel import aggregate_throughput
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=512)
+ap.add_argument("--steps", type=int, default=2)
+ap.add_argument("--enc-chunk", type=int, default=64)
+ap.add_argument("--dec-chunk", type=int, default=16)
+args = ap.parse_args()
+world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
+torch.cuda.set_device(local)
+dev = torch.device("cuda", local)
+if world > 1:
+    import torch.distributed as dist
+    dist.init_process_group("nccl", device_id=dev)
+pol, w = bench.make_policy(dev)
+pol.train()
+env = ATSPEnv(generator_params=dict(num_loc=100, device=dev), check_solution=False, device=dev)
+model = RRNet(env, policy=pol)
+opt = torch.optim.Adam(pol.parameters(), lr=1e-4)
+gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+batches = [ATSPGenerator(num_loc=100, device=dev)(args.batch, generator=gen) for _ in range(args.steps + 1)]
+out = model.training_step(batches[0], optimizer=opt, world=world, enc_chunk=args.enc_chunk, dec_chunk=args.dec_chunk, seed=1)
+torch.cuda.synchronize()
+if world > 1:
+    dist.barrier()
+t0 = time.perf_counter()
+for i in range(args.steps):
+    out = model.training_step(batches[i + 1], optimizer=opt, world=world, enc_chunk=args.enc_chunk, dec_chunk=args.dec_chunk, seed=2 + i)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+units, tmax = aggregate_throughput(args.batch * args.steps, dt, world > 1, dev)
+if rank == 0:
+    print(json.dumps({"config": "C5 ATSP n=100 REINFORCE training step, %d instances/GPU, S=100 sampling, %d GPU(s)" % (args.batch, world),
+                      "instances_per_s": units / tmax, "ms_per_step": tmax / args.steps * 1e3, "loss": float(out["loss"]),
+                      "grad_norm": float(out["grad_norm"]), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2**30,
+                      "gradient_path": "teacher-forced autograd replay (torch ops), forward + loss on HIP kernels"}))
+if world > 1:
+    dist.destroy_process_group()
