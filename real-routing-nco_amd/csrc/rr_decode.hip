@@ -394,15 +394,29 @@ extern "C" int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStrea
 #undef RR_LAUNCH
     return rr_check(hipGetLastError());
   }
-  const int ntask = io->Bp * ((S + 15) / 16);
+  // tail packing (rr_rollout_w.inc): the S % 16 left-over rollouts of 16 / (S % 16) consecutive instances share one tile
+  static const int pack = getenv("RR_TAIL_PACK") ? atoi(getenv("RR_TAIL_PACK")) : 1;
+  const int tail_m = S & 15;
+  const int tail_g = (pack && S > 16 && tail_m > 0 && tail_m <= 8 && io->Bp > 1) ? 16 / tail_m : 0;
+  const int ntask = tail_g ? (io->Bp + tail_g - 1) / tail_g + io->Bp * (S / 16) : io->Bp * ((S + 15) / 16);
   dim3 grid((ntask + WWAVES - 1) / WWAVES), blk(WTHREADS);
+  // LDS-staged distance tiles: as many instances (<= 2) as leave room for 160 KB / WTHREADS-sized workgroups per CU
+  const size_t tile = (size_t)N * N * sizeof(float);
+  const size_t per_wg = (size_t)(160 * 1024) / (512 / WTHREADS) - 512;
+  const int lds_inst = 2 * tile <= per_wg ? 2 : (tile <= per_wg ? 1 : 0);
+  const size_t shmem = (size_t)lds_inst * tile;
   const int mode = io->logits_only ? 3 : io->mode;
+#define RR_LAUNCHW3(NTV, P, M)                                                                                \
+  do {                                                                                                       \
+    (void)hipFuncSetAttribute((const void*)k_rollout_w<NTV, P, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+    hipLaunchKernelGGL((k_rollout_w<NTV, P, M>), grid, blk, shmem, st, *w, *io, tail_g, lds_inst);            \
+  } while (0)
 #define RR_LAUNCHW2(NTV, P)                                                                                  \
   do {                                                                                                       \
-    if (mode == 0) hipLaunchKernelGGL((k_rollout_w<NTV, P, 0>), grid, blk, 0, st, *w, *io);                  \
-    else if (mode == 1) hipLaunchKernelGGL((k_rollout_w<NTV, P, 1>), grid, blk, 0, st, *w, *io);             \
-    else if (mode == 2) hipLaunchKernelGGL((k_rollout_w<NTV, P, 2>), grid, blk, 0, st, *w, *io);             \
-    else hipLaunchKernelGGL((k_rollout_w<NTV, P, 3>), grid, blk, 0, st, *w, *io);                            \
+    if (mode == 0) RR_LAUNCHW3(NTV, P, 0);                                                                   \
+    else if (mode == 1) RR_LAUNCHW3(NTV, P, 1);                                                              \
+    else if (mode == 2) RR_LAUNCHW3(NTV, P, 2);                                                              \
+    else RR_LAUNCHW3(NTV, P, 3);                                                                             \
   } while (0)
 #define RR_LAUNCHW(NTV)                                                                      \
   do {                                                                                       \
@@ -414,6 +428,7 @@ extern "C" int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStrea
   else if (N <= 64) RR_LAUNCHW(4);
   else RR_LAUNCHW(7);
 #undef RR_LAUNCHW2
+#undef RR_LAUNCHW3
 #undef RR_LAUNCHW
   return rr_check(hipGetLastError());
 }
