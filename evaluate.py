@@ -1,0 +1,95 @@
+"""Evaluation driver with the command line and the measurement span of the reference's test.py:74-220, on the MI355X engine.
+
+  python evaluate.py --problem atsp --datasets data/atsp/x.npz --checkpoint ckpt/atsp/epoch_199.ckpt [--no_aug] [--batch_size 32]
+
+Per dataset it prints the average cost (best over augmentations x starts, real units), the per-batch and the total policy +
+reward time (device-synchronised, which test.py:191-208 omits).  Without --checkpoint a seeded random-init RRNet is used."""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "real-routing-nco_amd"))
+import torch  # noqa: E402
+
+
+def build(problem, checkpoint, problem_size, device, seed):
+    from rrnco_amd import data
+    from rrnco_amd.envs import ATSPEnv, RCVRPEnv, RMTVRPEnv
+    from rrnco_amd.models import RRNetPolicy
+    kw = dict(env_name=problem, embed_dim=128, num_heads=8, num_encoder_layers=6, normalization="instance",
+              use_graph_context=False, nab_type="gating")
+    if checkpoint is not None:
+        sd = data.load_policy_state_dict(checkpoint)
+        kw.update(data.policy_kwargs_from_state_dict(sd))
+        policy = RRNetPolicy(**kw)
+        policy.load_state_dict(sd, strict=True)
+    else:
+        torch.manual_seed(seed)
+        # 25 sampled neighbours as in configs/experiment/rrnet.yaml; smaller graphs cannot supply that many (atsp.py:55-67)
+        policy = RRNetPolicy(**kw, init_embedding_kwargs=dict(sample_size=min(25, max(1, problem_size - 5))))
+    gp = dict(num_loc=problem_size, device=device)
+    env = {"atsp": lambda: ATSPEnv(check_solution=False, generator_params=gp, device=device),
+           "rcvrp": lambda: RCVRPEnv(check_solution=False, generator_params=gp, device=device),
+           "rcvrptw": lambda: RMTVRPEnv(generator_params=gp, device=device)}[problem]()
+    return policy.to(device).eval(), env
+
+
+def evaluate_dataset(path, problem, policy, env, batch_size, n_aug, n_start, device, log=print):
+    from rrnco_amd import data
+    from rrnco_amd.models.transforms import StateAugmentation
+    from rrnco_amd.ops import unbatchify
+    augment = StateAugmentation(augment_fn="dihedral8", no_aug_coords=False)          # test.py:28
+    td_all = data.prepare_for_env(data.load_npz_to_tensordict(path), problem)
+    costs, times = [], []
+    for batch in data.iter_batches(td_all, batch_size):
+        batch = batch.to(device)
+        if n_aug > 1:
+            batch = augment(batch)
+        td = env.reset(batch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = policy(td, env, phase="val", return_actions=True, num_starts=n_start)       # test.py:192-207 (reward inside)
+        reward = out["reward"]
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+        best = unbatchify(reward, (n_aug if n_aug > 1 else 0, n_start)).max(dim=-1).values
+        best = best.max(dim=-1).values if n_aug > 1 else best
+        costs.append((float(-best.sum()), best.numel()))
+    avg = sum(c for c, _ in costs) / sum(n for _, n in costs)
+    log(f"Average cost:\n{avg:.4f}")
+    log(f"Per step inference time (s):\n{sum(times) / len(times):.4f}")
+    log(f"Total inference time (s):\n{sum(times):.4f}")
+    return avg, times
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--problem", type=str, default="atsp", choices=["atsp", "rcvrp", "rcvrptw"])
+    ap.add_argument("--datasets", nargs="*", default=None, help="npz file(s); default: all under data/{problem}/")
+    ap.add_argument("--decode_type", type=str, default="greedy", choices=["greedy"])
+    ap.add_argument("--batch_size", type=int, default=32)
+    ap.add_argument("--checkpoint", type=str, default=None)
+    ap.add_argument("--device", type=str, default="cuda")
+    ap.add_argument("--no_aug", action="store_true")
+    ap.add_argument("--problem_size", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=1234)
+    o = ap.parse_args(argv)
+    if not torch.cuda.is_available():
+        raise RuntimeError("evaluate.py runs on the HIP path only (no CPU fallback)")
+    device = torch.device("cuda:0")
+    paths = o.datasets if o.datasets else sorted(os.path.join("data", o.problem, f) for f in os.listdir(os.path.join("data", o.problem)))
+    n_aug = 1 if o.no_aug else 8
+    # test.py:129-132 hard-codes 100 (atsp, rcvrptw) / 101 (rcvrp) for its n=100 test sets: one start per node / customer+depot
+    n_start = o.problem_size if o.problem in ("atsp", "rcvrptw") else o.problem_size + 1
+    policy, env = build(o.problem, o.checkpoint, o.problem_size, device, o.seed)
+    results = {}
+    for p in sorted(paths):
+        print(f"Loading {p}")
+        results[p] = evaluate_dataset(p, o.problem, policy, env, o.batch_size, n_aug, n_start, device)[0]
+    return results
+
+
+if __name__ == "__main__":
+    main()

@@ -248,3 +248,33 @@ def test_gradient_replay_matches_oracle_autograd():
         checked += 1
     assert checked > 150
     assert num ** 0.5 / gnorm < 5e-3, num ** 0.5 / gnorm
+
+
+def test_npz_dataset_and_checkpoint_readers(tmp_path):
+    """Host-side I/O of SURVEY §8 f-1: the generate_data.py npz schemas and the Lightning checkpoint layout test.py loads."""
+    from rrnco_amd import data
+    inst = restate.rcvrp_synthetic(5, 20, 3)
+    raw = {k: v.numpy() for k, v in inst.items()}
+    raw["demand"] = raw["demand"] * 50.0                              # generate_data.py stores integer demands + capacity
+    raw["capacity"] = np.full(5, 50.0, dtype=np.float32)
+    p = str(tmp_path / "rcvrp20.npz")
+    np.savez(p, **raw)
+    td = data.prepare_for_env(data.load_npz_to_tensordict(p), "rcvrp")
+    assert td.batch_size[0] == 5 and torch.allclose(td["demand"], inst["demand"]) and bool((td["capacity"] == 1).all())
+    sizes = [b.batch_size[0] for b in data.iter_batches(td, 2)]
+    assert sizes == [2, 2, 1]
+    with pytest.raises(KeyError):
+        data.check_schema(td, "rcvrptw")
+    np.savez(str(tmp_path / "bad.npz"), locs=np.zeros((3, 4, 2), np.float32), distance_matrix=np.zeros((2, 4, 4), np.float32))
+    with pytest.raises(ValueError):
+        data.load_npz_to_tensordict(str(tmp_path / "bad.npz"))
+    # Lightning-style checkpoint: "state_dict" with the policy under `policy.` next to baseline / other entries
+    w = H.atsp_weights(15, layers=2, seed=1)
+    ck = {"state_dict": {**{"policy." + k: v for k, v in w.items()}, "baseline.foo": torch.zeros(1)}, "epoch": 199,
+          "hyper_parameters": {"x": 1}}
+    cp = str(tmp_path / "epoch_199.ckpt")
+    torch.save(ck, cp)
+    sd = data.load_policy_state_dict(cp)
+    assert set(sd) == set(w) and all(torch.equal(sd[k], w[k]) for k in w)
+    kw = data.policy_kwargs_from_state_dict(sd)
+    assert kw == dict(num_encoder_layers=2, init_embedding_kwargs=dict(sample_size=15))
