@@ -1,0 +1,127 @@
+"""`-m gpu`: BASELINE.json's FULL sizes through size-independent properties (no oracle run is affordable there):
+C2 ATSP n=100 B=512 x8 aug S=100 greedy, C3 RCVRP n=100 B=512 S=101 greedy, C4 RCVRPTW n=100 B=256 x8 aug S=100 sampling.
+Every property is recomputed with plain torch ops from the returned action sequences."""
+import pytest
+import torch
+
+from oracle import restate
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _policy(env_name, tmpl, seed=1234):
+    from rrnco_amd.models import RRNetPolicy
+    pol = RRNetPolicy(env_name=env_name, embed_dim=128, num_heads=8, num_encoder_layers=6, normalization="instance",
+                      use_graph_context=False, nab_type="gating", init_embedding_kwargs=dict(sample_size=25))
+    pol.load_state_dict(restate.make_weights(tmpl, seed), strict=True)
+    return pol.to(DEV).eval()
+
+
+def _route_cost(D, acts, b_of_r, closed_by_depot):
+    """sum_t D[b, a_t, a_t+1] recomputed with gathers; VRP routes start and end at the depot (node 0)."""
+    if closed_by_depot:
+        z = torch.zeros(acts.shape[0], 1, dtype=acts.dtype, device=acts.device)
+        path = torch.cat([z, acts, z], 1)
+        frm, to = path[:, :-1], path[:, 1:]
+    else:
+        frm, to = acts, acts.roll(-1, 1)
+    return D[b_of_r[:, None], frm, to].double().sum(1)
+
+
+def test_c2_atsp_full_batch_properties():
+    from rrnco_amd.envs import ATSPEnv, ATSPGenerator
+    from rrnco_amd.models.encoder import ATSPInitEmbedding
+    from rrnco_amd.models.transforms import StateAugmentation
+    from rrnco_amd.ops import unbatchify
+    B, N, S = 512, 100, 100
+    pol = _policy("atsp", restate.atsp_weight_template())
+    env = ATSPEnv(generator_params=dict(num_loc=N, device=DEV), check_solution=False, device=DEV)
+    inst = ATSPGenerator(num_loc=N, device=DEV)(B, generator=torch.Generator(device=DEV).manual_seed(11))
+    td = env.reset(StateAugmentation(augment_fn="dihedral8", no_aug_coords=False)(inst))
+    td["sample_idx"] = ATSPInitEmbedding.sample_indices(td["distance_matrix"], 25)
+    out = pol(td, env, phase="val", decode_type="multistart_greedy", num_starts=S)
+    acts = out["actions"]
+    R = S * 8 * B
+    assert acts.shape == (R, N)
+    assert bool((acts.sort(1).values == torch.arange(N, device=DEV)).all())                          # atsp/env.py:213-220
+    assert torch.equal(acts[:, 0], torch.arange(S, device=DEV).repeat_interleave(8 * B))             # POMO start nodes
+    b_of_r = torch.arange(R, device=DEV) % (8 * B)
+    cost = _route_cost(td["distance_matrix"], acts, b_of_r, closed_by_depot=False)
+    assert float((out["normalized_reward"].double() + cost).abs().max()) < 2e-4                     # atsp/env.py:192-211
+    real = out["normalized_reward"] * (td["max_distance"] - td["min_distance"] + 1e-6)[b_of_r] + 0   # de-normalised edge sum
+    real = real + N * td["min_distance"][b_of_r]
+    assert float((out["reward"] - real).abs().max() / out["reward"].abs().max()) < 1e-5
+    assert bool(torch.isfinite(out["log_likelihood"]).all()) and bool((out["log_likelihood"] <= 0).all())
+    rew = unbatchify(out["reward"], (8, S))
+    assert rew.shape == (B, 8, S) and bool((rew.amax(dim=(1, 2)) >= rew[:, 0].amax(-1)).all())
+
+
+def test_c3_rcvrp_full_batch_feasibility():
+    from rrnco_amd.envs import RCVRPEnv
+    from rrnco_amd.models.encoder import ATSPInitEmbedding
+    B, N, S = 512, 100, 101
+    pol = _policy("rcvrp", restate.rcvrp_weight_template())
+    env = RCVRPEnv(generator_params=dict(num_loc=N, device=DEV), check_solution=False, device=DEV)
+    inst = env.generator(B, generator=torch.Generator(device=DEV).manual_seed(12))
+    td = env.reset(inst)
+    td["sample_idx"] = ATSPInitEmbedding.sample_indices(td["distance_matrix"], 25)
+    out = pol(td, env, phase="val", decode_type="multistart_greedy", num_starts=S)
+    acts = out["actions"]
+    R, T = acts.shape
+    assert R == S * B
+    b_of_r = torch.arange(R, device=DEV) % B
+    # every customer exactly once (rcvrp/env.py:236-249)
+    cnt = torch.zeros(R, N + 1, device=DEV).scatter_add_(1, acts, torch.ones(R, T, device=DEV))
+    assert bool((cnt[:, 1:] == 1).all())
+    # capacity per route: demand accumulated between depot visits never exceeds the (normalised) capacity 1
+    dem = torch.cat([torch.zeros(B, 1, device=DEV), td["demand"]], 1)[b_of_r[:, None], acts]
+    seg = (acts == 0).cumsum(1)
+    load = torch.zeros(R, T + 1, device=DEV).scatter_add_(1, seg, dem)
+    assert float(load.max()) <= 1.0 + 1e-5
+    cost = _route_cost(td["distance_matrix"], acts, b_of_r, closed_by_depot=True)
+    assert float((out["normalized_reward"].double() + cost).abs().max()) < 5e-4                     # rcvrp/env.py:197-219
+
+
+def test_c4_rcvrptw_full_batch_sampling_feasibility():
+    from rrnco_amd.envs import RMTVRPEnv
+    from rrnco_amd.models.encoder import ATSPInitEmbedding
+    from rrnco_amd.models.transforms import StateAugmentation
+    B, N, S = 256, 100, 100
+    pol = _policy("rcvrptw", restate.rcvrptw_weight_template())
+    env = RMTVRPEnv(generator_params=dict(num_loc=N, device=DEV), device=DEV)
+    inst = env.generator(B, generator=torch.Generator(device=DEV).manual_seed(13))
+    td = env.reset(StateAugmentation(augment_fn="dihedral8", no_aug_coords=False)(inst))
+    Bp = 8 * B
+    td["sample_idx"] = ATSPInitEmbedding.sample_indices(td["distance_matrix"], 25)
+    D, Dur = td["distance_matrix"], td["duration_matrix"]
+    tw, service, demand = td["time_windows"], td["service_time"], td["demand_linehaul"]
+    out = pol(td, env, phase="val", decode_type="multistart_sampling", num_starts=S, seed=3)
+    acts = out["actions"]
+    R, T = acts.shape
+    assert R == S * Bp
+    b_of_r = torch.arange(R, device=DEV) % Bp
+    cnt = torch.zeros(R, N + 1, device=DEV).scatter_add_(1, acts, torch.ones(R, T, device=DEV))
+    assert bool((cnt[:, 1:] == 1).all())
+    # replay rmtvrp/env.py:155-215: time, load; every arrival inside its window, every return to the depot before it closes
+    t = torch.zeros(R, device=DEV); load = torch.zeros(R, device=DEV); prev = torch.zeros(R, dtype=torch.long, device=DEV)
+    worst_late, worst_load = -1e9, 0.0
+    for k in range(T):
+        a = acts[:, k]
+        arrival = t + Dur[b_of_r, prev, a]
+        worst_late = max(worst_late, float((arrival - tw[b_of_r, a, 1]).max()))
+        nz = (a != 0).float()
+        t = nz * (torch.maximum(arrival, tw[b_of_r, a, 0]) + service[b_of_r, a])
+        load = nz * (load + demand[b_of_r, a])
+        worst_load = max(worst_load, float(load.max()))
+        prev = a
+    assert worst_late < 1e-5 and worst_load <= 1.0 + 1e-5
+    cost = _route_cost(D, acts, b_of_r, closed_by_depot=True)
+    assert float((out["normalized_reward"].double() + cost).abs().max()) < 1e-3
+    ll = out["log_likelihood"]
+    assert bool(torch.isfinite(ll).all()) and bool((ll <= 0).all())
+    out2 = pol(td, env, phase="val", decode_type="multistart_sampling", num_starts=S, seed=3)        # counter-based generator
+    assert torch.equal(out2["actions"], acts)
+    out3 = pol(td, env, phase="val", decode_type="multistart_sampling", num_starts=S, seed=4)
+    assert not torch.equal(out3["actions"][:, :out2["actions"].shape[1]][: , :10], acts[:, :10])
