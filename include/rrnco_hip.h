@@ -117,6 +117,14 @@ int rr_dec_cache(const CacheW* w, const float* row_emb, const float* col_emb, fl
  * logits_only = a single pure RRNetDecoder.forward.  prob 0 = ATSP, 1 = RCVRP, 2 = RCVRPTW. */
 int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStream_t stream);
 
+/* Training side of the gating Neural Adaptive Bias (rrnco/models/nn/attn_freenet.py:242-289) in its folded 128-unit
+ * form: tab = rows a_d, b_d, co_d, cg_d, a_a, b_a, co_a, cg_a [8][128] + (ko_d, kg_d, ko_a, kg_a, bg, bo, alpha, 0);
+ * xd / xa = distance / angle per edge [M]; out[M] = alpha * bias.  The backward adds d loss / d tab into grad_tab
+ * [8*128+8] (caller zeroes it) given gout = d loss / d out; the chain rule back to the module parameters is the caller's. */
+int rr_nab_train_fwd(const float* tab, const float* xd, const float* xa, float* out, long M, hipStream_t stream);
+int rr_nab_train_bwd(const float* tab, const float* xd, const float* xa, const float* gout, float* grad_tab, long M,
+                     hipStream_t stream);
+
 /* POMO shared-baseline REINFORCE loss, forward half + d loss / d log-likelihood
  * (rrnco/models/rl.py:112-128; in-tree formula rrnco/baselines/routefinder/model.py:182-202). reward / ll / adv /
  * grad_ll are [S*B] with r = s*B + b; bl and partial are [B] workspaces; loss is one float. */

@@ -1,0 +1,119 @@
+// Training-side kernels of the Neural Adaptive Bias (gating DistAngleFusion, attn_freenet.py:242-289): the forward in the
+// folded 128-unit form and its backward with respect to the folded parameters.  The NAB is 90 % of the reference's
+// arithmetic and, differentiated through torch ops, 73 % of the config-5 training step (rocBLAS gemv on
+// [B,N,N,128] tensors); here an edge costs ~1.3 kflop forward and ~3 kflop backward of plain VALU work and no [.,128] tensor
+// is ever materialised.  Used by rrnco_amd/models/grad_replay.py through a torch.autograd.Function; the chain rule from the
+// folded table back to the module parameters (W2^T wo etc.) stays in torch (tiny tensors).
+//
+// Table layout (same as nab_edge in rr_encoder.hip): rows a_d, b_d, co_d, cg_d, a_a, b_a, co_a, cg_a [8][E], then
+// s = (ko_d, kg_d, ko_a, kg_a, bg, bo, alpha, -).   out = alpha * (g O_d + (1-g) O_a + bo),
+//   O_x = co_x . relu(a_x x + b_x) + ko_x,  g = sigmoid(cg_d . h_d + kg_d + cg_a . h_a + kg_a + bg).
+#include "rr_common.h"
+
+#define TR_THREADS 256
+#define TR_TAB (8 * RR_E + 8)
+
+struct NabFwd { float od, oa, g; };
+
+__device__ __forceinline__ NabFwd nab_fwd_edge(const float* __restrict__ tab, float d, float th) {
+  float pod = 0.f, pgd = 0.f, poa = 0.f, pga = 0.f;
+#pragma unroll 8
+  for (int k = 0; k < RR_E; ++k) {
+    const float hd = fmaxf(fmaf(tab[0 * RR_E + k], d, tab[1 * RR_E + k]), 0.f);
+    pod = fmaf(tab[2 * RR_E + k], hd, pod);
+    pgd = fmaf(tab[3 * RR_E + k], hd, pgd);
+    const float ha = fmaxf(fmaf(tab[4 * RR_E + k], th, tab[5 * RR_E + k]), 0.f);
+    poa = fmaf(tab[6 * RR_E + k], ha, poa);
+    pga = fmaf(tab[7 * RR_E + k], ha, pga);
+  }
+  const float* s = tab + 8 * RR_E;
+  NabFwd r;
+  r.od = pod + s[0]; r.oa = poa + s[2];
+  r.g = 1.0f / (1.0f + expf(-((pgd + s[1]) + (pga + s[3]) + s[4])));
+  return r;
+}
+
+__global__ __launch_bounds__(TR_THREADS) void k_nab_train_fwd(const float* __restrict__ tab_g, const float* __restrict__ xd,
+                                                              const float* __restrict__ xa, float* __restrict__ out, long M) {
+  __shared__ float tab[TR_TAB];
+  for (int i = threadIdx.x; i < TR_TAB; i += TR_THREADS) tab[i] = tab_g[i];
+  __syncthreads();
+  const float bo = tab[8 * RR_E + 5], alpha = tab[8 * RR_E + 6];
+  for (long e = (long)blockIdx.x * TR_THREADS + threadIdx.x; e < M; e += (long)gridDim.x * TR_THREADS) {
+    const NabFwd f = nab_fwd_edge(tab, xd[e], xa[e]);
+    out[e] = (f.g * f.od + (1.0f - f.g) * f.oa + bo) * alpha;
+  }
+}
+
+// grad_tab (TR_TAB floats, zeroed by the caller) += d loss / d table, given gout = d loss / d out per edge
+__global__ __launch_bounds__(TR_THREADS) void k_nab_train_bwd(const float* __restrict__ tab_g, const float* __restrict__ xd,
+                                                              const float* __restrict__ xa, const float* __restrict__ gout,
+                                                              float* __restrict__ grad_tab, long M) {
+  __shared__ float tab[TR_TAB];
+  __shared__ float exd[TR_THREADS], exa[TR_THREADS], edod[TR_THREADS], edoa[TR_THREADS], edz[TR_THREADS];
+  const int t = threadIdx.x;
+  for (int i = t; i < TR_TAB; i += TR_THREADS) tab[i] = tab_g[i];
+  __syncthreads();
+  const float bo = tab[8 * RR_E + 5], alpha = tab[8 * RR_E + 6];
+  // phase-B role of this thread: hidden unit k of family f
+  const int f = t >> 7, k = t & 127;
+  const float ak = tab[(4 * f + 0) * RR_E + k], bk = tab[(4 * f + 1) * RR_E + k];
+  const float cok = tab[(4 * f + 2) * RR_E + k], cgk = tab[(4 * f + 3) * RR_E + k];
+  float acc_a = 0.f, acc_b = 0.f, acc_co = 0.f, acc_cg = 0.f;
+  float s_alpha = 0.f, s_bo = 0.f, s_od = 0.f, s_oa = 0.f, s_z = 0.f;     // phase-A scalar sums of this thread's edges
+  const long nchunk = (M + TR_THREADS - 1) / TR_THREADS;
+  for (long c = blockIdx.x; c < nchunk; c += gridDim.x) {
+    const long e = c * TR_THREADS + t;
+    float d = 0.f, th = 0.f, dod = 0.f, doa = 0.f, dz = 0.f;
+    if (e < M) {
+      d = xd[e]; th = xa[e];
+      const NabFwd r = nab_fwd_edge(tab, d, th);
+      const float G = gout[e];
+      const float val = r.g * r.od + (1.0f - r.g) * r.oa + bo;
+      const float Gv = G * alpha;
+      dod = Gv * r.g; doa = Gv * (1.0f - r.g); dz = Gv * (r.od - r.oa) * r.g * (1.0f - r.g);
+      s_alpha += G * val; s_bo += Gv; s_od += dod; s_oa += doa; s_z += dz;
+    }
+    __syncthreads();                       // the previous chunk's phase B is done with the edge arrays
+    exd[t] = d; exa[t] = th; edod[t] = dod; edoa[t] = doa; edz[t] = dz;      // edges past M contribute zeros
+    __syncthreads();
+    const float* ex = f ? exa : exd;
+    const float* eo = f ? edoa : edod;
+#pragma unroll 4
+    for (int i = 0; i < TR_THREADS; ++i) {
+      const float x = ex[i], dO = eo[i], dzv = edz[i];
+      const float pre = fmaf(ak, x, bk);
+      const float h = fmaxf(pre, 0.f);
+      acc_co = fmaf(dO, h, acc_co);
+      acc_cg = fmaf(dzv, h, acc_cg);
+      const float dh = pre > 0.f ? fmaf(dO, cok, dzv * cgk) : 0.f;
+      acc_a = fmaf(dh, x, acc_a);
+      acc_b += dh;
+    }
+  }
+  atomicAdd(&grad_tab[(4 * f + 0) * RR_E + k], acc_a);
+  atomicAdd(&grad_tab[(4 * f + 1) * RR_E + k], acc_b);
+  atomicAdd(&grad_tab[(4 * f + 2) * RR_E + k], acc_co);
+  atomicAdd(&grad_tab[(4 * f + 3) * RR_E + k], acc_cg);
+  s_alpha = rr_wave_sum(s_alpha); s_bo = rr_wave_sum(s_bo); s_od = rr_wave_sum(s_od); s_oa = rr_wave_sum(s_oa); s_z = rr_wave_sum(s_z);
+  if ((t & 63) == 0) {
+    float* gs = grad_tab + 8 * RR_E;
+    atomicAdd(&gs[0], s_od); atomicAdd(&gs[1], s_z); atomicAdd(&gs[2], s_oa); atomicAdd(&gs[3], s_z);
+    atomicAdd(&gs[4], s_z); atomicAdd(&gs[5], s_bo); atomicAdd(&gs[6], s_alpha);
+  }
+}
+
+extern "C" int rr_nab_train_fwd(const float* tab, const float* xd, const float* xa, float* out, long M, hipStream_t st) {
+  if (tab == nullptr || xd == nullptr || xa == nullptr || out == nullptr || M <= 0) return RR_EINVAL;
+  const long want = (M + TR_THREADS - 1) / TR_THREADS;
+  hipLaunchKernelGGL(k_nab_train_fwd, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(TR_THREADS), 0, st, tab, xd, xa, out, M);
+  return rr_check(hipGetLastError());
+}
+
+extern "C" int rr_nab_train_bwd(const float* tab, const float* xd, const float* xa, const float* gout, float* grad_tab, long M,
+                                hipStream_t st) {
+  if (tab == nullptr || xd == nullptr || xa == nullptr || gout == nullptr || grad_tab == nullptr || M <= 0) return RR_EINVAL;
+  const long want = (M + TR_THREADS - 1) / TR_THREADS;
+  hipLaunchKernelGGL(k_nab_train_bwd, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(TR_THREADS), 0, st, tab, xd, xa, gout, grad_tab, M);
+  return rr_check(hipGetLastError());
+}

@@ -3,15 +3,16 @@
 The reference differentiates straight through its sampling forward (rrnco/models/rl.py:96-128 under Lightning autograd).
 Here the forward — encoder, sampling rollout, reward, loss and d loss / d log-likelihood — runs on the HIP kernels without a
 graph; the parameter gradient is then obtained by REPLAYING the sampled tours teacher-forced through a differentiable
-formulation of the same policy and calling autograd on it (torch ops on the ROCm device: hipBLAS GEMMs, no hand-written
-backward kernels yet — DESIGN.md §6 says so; this module is the piece later rounds replace).
+formulation of the same policy and calling autograd on it: torch ops on the ROCm device (hipBLAS GEMMs, MIOpen norms) for
+everything except the Neural Adaptive Bias, whose forward and backward are hand-written HIP (csrc/rr_train.hip) because
+differentiating it through torch ops was 73 % of the step.  The remaining torch-op backward is what later rounds replace.
 
 Two things keep the replay cheap:
   * with the actions known, every decode step's context (first node, current node, visited set) is known up front, so the
     N-1 sequential pointer steps become ONE batched evaluation over (instance, start, step);
-  * the Neural Adaptive Bias uses the same algebraic fold as the kernel (wo.u and wg.u are linear in the hidden vector:
-    attn_freenet.py:242-289, csrc/rr_encoder.hip), so no E x E contraction per edge is materialised; gradients reach the
-    original parameters through the fold.
+  * the Neural Adaptive Bias uses the same algebraic fold as the inference kernel (wo.u and wg.u are linear in the hidden
+    vector: attn_freenet.py:242-289), so no E x E contraction and no [b,N,N,E] tensor is materialised; the kernels return
+    d loss / d (folded table) and autograd carries it through the fold to the module parameters.
 Instances are independent (instance norm is per instance), so the encoder runs in instance chunks under activation
 checkpointing and the decoder chunks back-propagate into detached copies of the cache; one backward through the encoder
 graph finishes the job.  ATSP only (the config-5 problem).
@@ -37,26 +38,65 @@ def _inorm(P, p, x):
                            eps=1e-5).transpose(1, 2)
 
 
-def _nab_folded(P, p, cost, theta):
-    """DistAngleFusion (gating, no duration) attn_freenet.py:242-289 with the second MLP layers folded into out_lin / gate."""
+def _nab_table(P, p):
+    """Folded table of csrc/rr_train.hip (rows a_d, b_d, co_d, cg_d, a_a, b_a, co_a, cg_a + scalars), built with torch
+    ops from the module parameters so that autograd carries d loss / d table back to W2, wo, wg, ... (tiny tensors)."""
     wo, bo = P[p + ".out_lin.weight"][0], P[p + ".out_lin.bias"][0]
     wg, bg = P[p + ".gate.0.weight"][0], P[p + ".gate.0.bias"][0]
-    outs = []
-    for nm, x, wgh in (("dist_emb", cost, wg[:E]), ("angle_emb", theta, wg[E:])):
-        a, b = P[f"{p}.{nm}.0.weight"][:, 0], P[f"{p}.{nm}.0.bias"]
+    rows, ks = [], []
+    for nm, wgh in (("dist_emb", wg[:E]), ("angle_emb", wg[E:])):
         W2, b2 = P[f"{p}.{nm}.2.weight"], P[f"{p}.{nm}.2.bias"]
+        rows += [P[f"{p}.{nm}.0.weight"][:, 0], P[f"{p}.{nm}.0.bias"], W2.t() @ wo, W2.t() @ wgh]
+        ks += [wo @ b2, wgh @ b2]
+    return rows, ks, bg, bo
+
+
+class _NabGatingHip(torch.autograd.Function):
+    """alpha * NAB(x_d, x_a) per edge on the HIP kernels of csrc/rr_train.hip; differentiable w.r.t. the folded table."""
+
+    @staticmethod
+    def forward(ctx, tab, xd, xa):
+        from .. import _lib as L
+        tab, xd, xa = tab.contiguous(), xd.contiguous(), xa.contiguous()
+        out = torch.empty_like(xd)
+        L.check(L.lib().rr_nab_train_fwd(L.ptr(tab), L.ptr(xd), L.ptr(xa), L.ptr(out), xd.numel(), L.stream()), "rr_nab_train_fwd")
+        ctx.save_for_backward(tab, xd, xa)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        from .. import _lib as L
+        tab, xd, xa = ctx.saved_tensors
+        g = torch.zeros_like(tab)
+        L.check(L.lib().rr_nab_train_bwd(L.ptr(tab), L.ptr(xd), L.ptr(xa), L.ptr(gout.contiguous()), L.ptr(g), xd.numel(),
+                                         L.stream()), "rr_nab_train_bwd")
+        return g, None, None
+
+
+def _nab_folded(P, p, cost, theta, alpha):
+    """alpha * DistAngleFusion (gating, no duration) attn_freenet.py:242-289, 427-429, with the second MLP layers folded
+    into out_lin / gate.  On the device: HIP forward / backward kernels (no [b,N,N,E] tensor); on CPU tensors (the unit
+    tests of the gradient math) the same formula in torch ops."""
+    rows, ks, bg, bo = _nab_table(P, p)
+    if cost.is_cuda:
+        z = torch.zeros((), device=cost.device, dtype=cost.dtype)
+        tab = torch.cat([torch.cat(rows), torch.stack([ks[0], ks[1], ks[2], ks[3], bg, bo, alpha.reshape(()), z])]).float()
+        return _NabGatingHip.apply(tab, cost.float(), theta.float())
+    outs = []
+    for f, x in enumerate((cost, theta)):
+        a, b, co, cg = rows[4 * f:4 * f + 4]
         h = F.relu(x.unsqueeze(-1) * a + b)                                  # [b,N,N,E]
-        outs.append((h @ (W2.t() @ wo) + wo @ b2, h @ (W2.t() @ wgh) + wgh @ b2))
+        outs.append((h @ co + ks[2 * f], h @ cg + ks[2 * f + 1]))
     (od, gd), (oa, ga) = outs
     g = torch.sigmoid(gd + ga + bg)
-    return g * od + (1 - g) * oa + bo
+    return (g * od + (1 - g) * oa + bo) * alpha
 
 
 def _block(P, p, x, y, cost, theta):
     """AttnFree_Block.forward attn_freenet.py:417-441 (AFTFull :309-327, TransformerFFN :330-357)."""
     r = _inorm(P, p + ".norm1", x)
     c = _inorm(P, p + ".norm2", y)
-    bias = _nab_folded(P, p + ".angle_distance_fusion", cost, theta) * P[p + ".alpha"]
+    bias = _nab_folded(P, p + ".angle_distance_fusion", cost, theta, P[p + ".alpha"])
     q, k, v = _lin(P, p + ".attn_free.to_q", r), _lin(P, p + ".attn_free.to_k", c), _lin(P, p + ".attn_free.to_v", c)
     ea = torch.exp(torch.softmax(bias, dim=-1))
     ek = torch.exp(torch.softmax(k, dim=1))
@@ -134,7 +174,7 @@ def decode_log_likelihood(P, row_emb, col_emb, D, actions, tanh_clipping=10.0, t
     return logp.sum(-1)
 
 
-def replay_backward(policy, td, actions, num_starts, grad_ll, sample_idx, enc_chunk=64, dec_chunk=16):
+def replay_backward(policy, td, actions, num_starts, grad_ll, sample_idx, enc_chunk=512, dec_chunk=64):
     """Accumulate d loss / d theta into policy parameters' .grad, given d loss / d log-likelihood.
 
     td: the reset state the rollout started from (`locs`, normalised `distance_matrix`); actions [S*B, N] and grad_ll [S*B]

@@ -2,8 +2,8 @@
 
 val / test phases are complete (augmentation, multistart, best-of metrics).  The train phase runs the sampling rollout and
 the POMO shared-baseline REINFORCE loss on HIP kernels and returns d loss / d log-likelihood; `training_step` turns that into
-parameter gradients by a teacher-forced autograd replay (models/grad_replay.py — torch ops on the device, not HIP kernels
-yet), combines them across ranks with ONE flat RCCL all-reduce (parallel.allreduce_flat_gradients) and steps the optimizer:
+parameter gradients by a teacher-forced autograd replay (models/grad_replay.py — torch ops on the device around the HIP
+forward / backward kernels of the Neural Adaptive Bias, csrc/rr_train.hip), combines them across ranks with ONE flat RCCL all-reduce (parallel.allreduce_flat_gradients) and steps the optimizer:
 BASELINE configs[4]."""
 from __future__ import annotations
 
@@ -47,7 +47,7 @@ class RRNet:
             if "multistart" not in getattr(self.policy, attr):
                 setattr(self.policy, attr, "multistart_" + getattr(self.policy, attr))
 
-    def training_step(self, batch, optimizer=None, world: int = 1, enc_chunk: int = 64, dec_chunk: int = 16, **policy_kw) -> dict:
+    def training_step(self, batch, optimizer=None, world: int = 1, enc_chunk: int = 512, dec_chunk: int = 64, **policy_kw) -> dict:
         """One REINFORCE step on this rank's shard of instances (rl.py:96-128 + Lightning's DDP mean-reduction):
         sampling rollout, reward, shared-baseline loss and d loss / d ll on the HIP kernels; parameter gradients by the
         teacher-forced replay; one flat all-reduce (mean over ranks); optimizer step.  Returns the shared_step dict plus

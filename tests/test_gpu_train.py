@@ -81,3 +81,31 @@ def test_optimizer_steps_change_the_policy_and_repack():
     moved = sum(int(not torch.equal(before[n], p.detach())) for n, p in pol.named_parameters())
     assert moved > 150
     assert pol.packed(torch.device("cuda")) is not packed0
+
+
+def test_nab_training_kernels_match_the_torch_formula():
+    """csrc/rr_train.hip: forward value and d loss / d (folded table) of the gating NAB against the same formula in torch ops."""
+    from rrnco_amd import _lib as L
+    from rrnco_amd.models import grad_replay as G
+    fx = H.load_fixture("atsp_n100_b2_pomo")
+    w = H.atsp_weights(fx)
+    P = {k: v.cuda().requires_grad_() for k, v in w.items()}
+    p = "encoder.net.layers.3.col_encoding_block"
+    st0 = restate.atsp_reset(H.fixture_state(fx))
+    D = st0["distance_matrix"].cuda()
+    theta = restate.pairwise_angles(st0["locs"]).cuda()
+    gout = torch.from_numpy(np.random.default_rng(0).standard_normal(tuple(D.shape)).astype(np.float32)).cuda()
+    out_hip = G._nab_folded(P, p + ".angle_distance_fusion", D, theta, P[p + ".alpha"])
+    out_hip.backward(gout)
+    g_hip = {k: v.grad.clone() for k, v in P.items() if v.grad is not None}
+    for v in P.values():
+        v.grad = None
+    Pc = {k: v.detach().cpu().requires_grad_() for k, v in P.items()}
+    out_ref = G._nab_folded(Pc, p + ".angle_distance_fusion", D.cpu(), theta.cpu(), Pc[p + ".alpha"])     # torch-op branch
+    out_ref.backward(gout.cpu())
+    assert torch.allclose(out_hip.detach().cpu(), out_ref.detach(), atol=2e-5)
+    assert set(g_hip) == {k for k, v in Pc.items() if v.grad is not None} and len(g_hip) == 13      # 2 x (Linear(1,E) w,b + Linear(E,E) w,b) + gate w,b + out_lin w,b + alpha
+    for k, g in g_hip.items():
+        ref = Pc[k].grad
+        tol = 1e-3 * float(ref.abs().max()) + 1e-4
+        assert float((g.cpu() - ref).abs().max()) < tol, (k, float((g.cpu() - ref).abs().max()), tol)

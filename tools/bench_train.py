@@ -15,8 +15,8 @@ from rrnco_amd.parallel import aggregate_throughput
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=512)
 ap.add_argument("--steps", type=int, default=2)
-ap.add_argument("--enc-chunk", type=int, default=64)
-ap.add_argument("--dec-chunk", type=int, default=16)
+ap.add_argument("--enc-chunk", type=int, default=512)
+ap.add_argument("--dec-chunk", type=int, default=64)
 args = ap.parse_args()
 world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
 torch.cuda.set_device(local)
@@ -45,6 +45,6 @@ if rank == 0:
     print(json.dumps({"config": "C5 ATSP n=100 REINFORCE training step, %d instances/GPU, S=100 sampling, %d GPU(s)" % (args.batch, world),
                       "instances_per_s": units / tmax, "ms_per_step": tmax / args.steps * 1e3, "loss": float(out["loss"]),
                       "grad_norm": float(out["grad_norm"]), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2**30,
-                      "gradient_path": "teacher-forced autograd replay (torch ops), forward + loss on HIP kernels"}))
+                      "gradient_path": "teacher-forced autograd replay: HIP NAB forward/backward kernels + torch ops; rollout + loss on HIP kernels"}))
 if world > 1:
     dist.destroy_process_group()
