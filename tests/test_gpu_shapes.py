@@ -47,6 +47,8 @@ def _run(N, B, S, ss, seed, layers=2):
     (33, 3, 33, 20),      # just above the 2-tile template
     (12, 5, 12, 8),       # small instance, 2-tile template
     (20, 2, 1, 15),       # num_starts = 1 -> plain greedy path of get_decoding_strategy
+    (20, 9, 20, 15),      # tail packing: 4 left-over rollouts x 4 instances per tile, last tail tile holds one instance
+    (24, 20, 17, 15),     # tail packing at its widest: 1 left-over rollout x 16 instances per tile (16 passes), then 4
 ])
 def test_atsp_other_shapes_match_oracle(N, B, S, ss):
     _run(N, B, S, ss, seed=100 + N + S)
