@@ -117,6 +117,11 @@ int rr_dec_cache(const CacheW* w, const float* row_emb, const float* col_emb, fl
  * logits_only = a single pure RRNetDecoder.forward.  prob 0 = ATSP, 1 = RCVRP, 2 = RCVRPTW. */
 int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStream_t stream);
 
+/* Real-world instance sampling (rrnco/envs/atsp/sampler.py:78-94, rmtvrp/sampler.py:80): B sub-matrices
+ * out[b][i][j] = city[idx[b][i]][idx[b][j]] of one city's [M][M] distance (and, if dur != NULL, duration) matrix. */
+int rr_submatrix_gather(const float* dist, const float* dur, const int64_t* idx, float* out_dist, float* out_dur,
+                        int B, int M, int n, hipStream_t stream);
+
 /* Training side of the gating Neural Adaptive Bias (rrnco/models/nn/attn_freenet.py:242-289) in its folded 128-unit
  * form: tab = rows a_d, b_d, co_d, cg_d, a_a, b_a, co_a, cg_a [8][128] + (ko_d, kg_d, ko_a, kg_a, bg, bo, alpha, 0);
  * xd / xa = distance / angle per edge [M]; out[M] = alpha * bias.  The backward adds d loss / d tab into grad_tab

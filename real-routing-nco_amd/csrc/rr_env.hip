@@ -159,6 +159,33 @@ extern "C" int rr_tour_cost(const float* D, const int64_t* actions, const float*
 }
 
 // ------------------------------------------------------------------------------------------------
+// Real-world instance sampling (rrnco/envs/*/sampler.py:78-94): out[b][i][j] = city[idx[b][i]][idx[b][j]] for the
+// distance and (optionally) the duration matrix of one city in a single pass.  One workgroup per (instance, row):
+// the row's source address is wave-uniform, the column indices are read once, the output row is written coalesced.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_submatrix_gather(const float* __restrict__ dist, const float* __restrict__ dur,
+                                                          const int64_t* __restrict__ idx, float* __restrict__ out_dist,
+                                                          float* __restrict__ out_dur, int M, int n) {
+  const int b = blockIdx.y, i = blockIdx.x;
+  const int64_t* ib = idx + (size_t)b * n;
+  const size_t src = (size_t)ib[i] * M;
+  const size_t dst = ((size_t)b * n + i) * n;
+  for (int j = threadIdx.x; j < n; j += 128) {
+    const size_t c = (size_t)ib[j];
+    out_dist[dst + j] = dist[src + c];
+    if (dur != nullptr) out_dur[dst + j] = dur[src + c];
+  }
+}
+
+extern "C" int rr_submatrix_gather(const float* dist, const float* dur, const int64_t* idx, float* out_dist, float* out_dur,
+                                   int B, int M, int n, hipStream_t st) {
+  if (B <= 0 || M <= 0 || n <= 0 || n > M || dist == nullptr || idx == nullptr || out_dist == nullptr) return RR_EINVAL;
+  if ((dur == nullptr) != (out_dur == nullptr)) return RR_EINVAL;
+  hipLaunchKernelGGL(k_submatrix_gather, dim3(n, B), dim3(128), 0, st, dist, dur, idx, out_dist, out_dur, M, n);
+  return rr_check(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
 // logits -> (action, logp): process_logits + greedy / sampling / evaluate
 // (rrnco/models/decoding.py:311-361, 272-298, 266).  One wave per row, N <= 128.
 // mode: 0 greedy (first index on ties), 1 sampling (inverse-CDF on a counter-based uniform),

@@ -64,6 +64,7 @@ _SIGS = {
     "rr_init_embed": [C.POINTER(InitW), i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "rr_dec_cache": [C.POINTER(CacheW), vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "rr_rollout": [C.POINTER(DecW), C.POINTER(RolloutIO), i32, vp],
+    "rr_submatrix_gather": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "rr_nab_train_fwd": [vp, vp, vp, vp, C.c_long, vp],
     "rr_nab_train_bwd": [vp, vp, vp, vp, vp, C.c_long, vp],
 }

@@ -278,3 +278,27 @@ def test_npz_dataset_and_checkpoint_readers(tmp_path):
     assert set(sd) == set(w) and all(torch.equal(sd[k], w[k]) for k in w)
     kw = data.policy_kwargs_from_state_dict(sd)
     assert kw == dict(num_encoder_layers=2, init_embedding_kwargs=dict(sample_size=15))
+
+
+def test_real_world_sampler_host_logic():
+    """rrnco/envs/atsp/sampler.py:41-60, 98-150 restated for the device sampler: index sets and the outlier filter."""
+    from rrnco_amd.envs.sampler import RealWorldSampler
+    g = torch.Generator().manual_seed(0)
+    idx = RealWorldSampler.uniform_indices(7, 50, 20, "cpu", g)
+    assert idx.shape == (7, 20) and all(len(set(r.tolist())) == 20 for r in idx) and int(idx.max()) < 50
+    pts = torch.rand(50, 2, generator=g)
+    clu = RealWorldSampler.single_cluster_indices(pts, 3, 10, g)
+    assert clu.shape == (3, 10) and torch.equal(clu[0], clu[2])
+    c0 = pts[clu[0, 0]]                                               # the centre is its own nearest point
+    far = (pts - c0).norm(dim=1).argsort()[:10]
+    assert set(far.tolist()) == set(clu[0].tolist())
+    mix = RealWorldSampler().mixed_indices(pts, 5, 12, g)
+    assert mix.shape == (5, 12) and int(mix.max()) < 50
+    # outlier filter: point 3 is unreachable (its row and column are 1e6) -> dropped, the rest kept in order
+    M = 12
+    d = torch.rand(M, M, generator=g)
+    d[3, :] = 1e6; d[:, 3] = 1e6; d[3, 3] = 0
+    out = RealWorldSampler.filter_outliers({"points": torch.arange(M * 2.0).view(M, 2), "distance": d, "duration": d.clone()})
+    keep = [i for i in range(M) if i != 3]
+    assert out["distance"].shape == (M - 1, M - 1) and torch.equal(out["points"], torch.arange(M * 2.0).view(M, 2)[keep])
+    assert torch.equal(out["distance"], d[keep][:, keep]) and float(out["distance"].max()) < 1e5

@@ -59,3 +59,33 @@ def test_evaluate_cli_with_checkpoint_and_augmentation(tmp_path):
     assert list(res) == [path] and np.isfinite(res[path])
     res_na = evaluate.main(["--problem", "atsp", "--datasets", path, "--checkpoint", ck, "--problem_size", "20", "--no_aug"])
     assert res[path] <= res_na[path] + 1e-2                       # best-of-8 augmentations cannot be (noticeably) worse
+
+
+def test_device_sampler_matches_reference_indexing_bit_exact():
+    """rr_submatrix_gather == data[key][idx[:, :, None], idx[:, None, :]] (atsp/sampler.py:83-90, rmtvrp/sampler.py:80)."""
+    from rrnco_amd.envs import ATSPEnv, RealWorldSampler
+    g = torch.Generator().manual_seed(4)
+    M, B, n = 700, 33, 100
+    city = {"points": torch.rand(M, 2, generator=g).numpy(), "distance": (torch.rand(M, M, generator=g) * 5e3).numpy(),
+            "duration": (torch.rand(M, M, generator=g) * 9e2).numpy()}
+    smp = RealWorldSampler(with_duration=True)
+    smp.load_city(city)
+    out = smp.sample(B, n, "uniform", generator=torch.Generator(device="cuda").manual_seed(1))
+    # recover the indices from the points (all distinct) and redo the slicing the reference's way on the host
+    pts = torch.from_numpy(city["points"])
+    idx = torch.cdist(out["points"].cpu().reshape(-1, 2), pts).argmin(1).view(B, n)
+    assert all(len(set(r.tolist())) == n for r in idx)
+    assert torch.equal(out["points"].cpu(), pts[idx])
+    for key in ("distance", "duration"):
+        ref = torch.from_numpy(city[key])[idx[:, :, None], idx[:, None, :]]
+        assert torch.equal(out[key + "_matrix"].cpu(), ref)
+    for mode in ("mixed", "single_cluster"):
+        o = smp.sample(5, 20, mode, generator=torch.Generator(device="cuda").manual_seed(2))
+        assert o["distance_matrix"].shape == (5, 20, 20) and bool((torch.diagonal(o["distance_matrix"], dim1=1, dim2=2) >= 0).all())
+    # the sampled batch feeds the env directly
+    from rrnco_amd import TensorDict
+    td = ATSPEnv(generator_params=dict(num_loc=n)).reset(
+        TensorDict({"locs": out["points"], "distance_matrix": out["distance_matrix"]}, batch_size=[B]))
+    assert td["distance_matrix"].shape == (B, n, n) and float(td["distance_matrix"].max()) <= 1.0
+    with pytest.raises(ValueError):
+        smp.sample(2, M + 1)
