@@ -97,6 +97,16 @@ int rr_edge_angles(const float* locs, float* theta, int Bp, int N, hipStream_t s
 int rr_nab_dur(const NabDurW* wrow, const NabDurW* wcol, const float* D, const float* T, const float* locs,
                float* bias_out, int Bp, int N, hipStream_t stream);
 
+/* Ablation bias modules, nab_type "heuristic" (kind 0, rrnco/models/nn/attn_freenet.py:119-167) and "naive" (kind 1,
+ * :170-199; needs T and locs), for the row and col block of one layer -> bias_out [Bp][2][N*N] (x alpha), fed to
+ * rr_enc_layer as bias_pre. */
+typedef struct {
+  const float *w0, *b0, *w2;    /* naive: mlp.0 weight [E][3], bias [E]; mlp.2 weight [E] */
+  float b2, alpha, dw, tw;      /* naive: mlp.2 bias; block alpha; heuristic: distance_weight, duration_weight */
+} NabSimpleW;
+int rr_nab_simple(const NabSimpleW* wrow, const NabSimpleW* wcol, int kind, const float* D, const float* T,
+                  const float* locs, float* bias_out, int Bp, int N, hipStream_t stream);
+
 /* RMTVRPEnv._step + get_action_mask under the vrptw preset (rrnco/envs/rmtvrp/env.py:155-215, 343-428). */
 int rr_rmtvrp_step(const int64_t* action, const float* D, const float* T, const float* demand_l, const float* tw,
                    const float* service, const float* vcap, int64_t* cur, float* ctime, float* rlen, float* used_l,

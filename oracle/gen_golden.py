@@ -55,19 +55,22 @@ def _np(d):
     return {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in d.items()}
 
 
-def gen_atsp(tag, B, N, S, sample_size, seed, layers=6, aug=False, keep_trace=True):
+def gen_atsp(tag, B, N, S, sample_size, seed, layers=6, aug=False, keep_trace=True, nab_type="gating"):
     from rrnco.envs.atsp.env import ATSPEnv
     from rrnco.models.policy import RRNetPolicy
 
     torch.manual_seed(seed)
     inst = restate.atsp_synthetic(B, N, seed)
     env = ATSPEnv(generator=_Gen(N), check_solution=True)
-    kw = dict(POLICY_KW, num_encoder_layers=layers)
+    kw = dict(POLICY_KW, num_encoder_layers=layers, nab_type=nab_type)
     pol = RRNetPolicy(env_name="atsp", init_embedding_kwargs=dict(
         use_coords=True, use_polar_feats=True, use_dist=True, use_matnet_init=False,
         sample_type="prob", sample_size=sample_size), **kw).eval()
     tmpl = {k: tuple(v.shape) for k, v in pol.state_dict().items()}
-    assert tmpl == restate.atsp_weight_template(128, layers, 512, sample_size), "state_dict template drift"
+    mine_t = restate.atsp_weight_template(128, layers, 512, sample_size)
+    if nab_type != "gating":
+        mine_t = restate.ablation_template(mine_t, nab_type, use_duration=False)
+    assert tmpl == mine_t, "state_dict template drift"
     w = restate.make_weights(tmpl, seed)
     pol.load_state_dict(w, strict=True)
 
@@ -115,7 +118,7 @@ def gen_atsp(tag, B, N, S, sample_size, seed, layers=6, aug=False, keep_trace=Tr
         assert torch.allclose(ev["log_likelihood"], out["log_likelihood"], atol=1e-5)
 
     fx = dict(
-        kind="atsp", B=B, N=N, S=S, sample_size=sample_size, seed=seed, layers=layers, aug=int(aug),
+        kind="atsp", B=B, N=N, S=S, sample_size=sample_size, seed=seed, layers=layers, aug=int(aug), nab_type=nab_type,
         locs=inst["locs"], distance_matrix=inst["distance_matrix"], sample_idx=sidx,
         norm_distance=td["distance_matrix"], min_distance=td["min_distance"], max_distance=td["max_distance"],
         row_emb=out["hidden"][0], col_emb=out["hidden"][1],
@@ -198,7 +201,7 @@ def gen_rcvrp(tag, B, N, S, sample_size, seed, capacity, layers=6, keep_trace=Tr
     print(f"wrote {path}  ({os.path.getsize(path)/1e3:.0f} kB) T={out['actions'].shape[1]} reward[:3]={out['reward'][:3].tolist()}")
 
 
-def gen_rcvrptw(tag, B, N, S, sample_size, seed, layers=6, keep_trace=True):
+def gen_rcvrptw(tag, B, N, S, sample_size, seed, layers=6, keep_trace=True, nab_type="gating"):
     from rrnco.envs.rmtvrp.env import RMTVRPEnv
     from rrnco.models.policy import RRNetPolicy
 
@@ -207,9 +210,11 @@ def gen_rcvrptw(tag, B, N, S, sample_size, seed, layers=6, keep_trace=True):
     env = RMTVRPEnv(generator=_Gen(N), check_solution=False)
     pol = RRNetPolicy(env_name="rcvrptw", init_embedding_kwargs=dict(
         use_coords=True, use_polar_feats=True, use_dist=True, use_matnet_init=False,
-        sample_type="prob", sample_size=sample_size), **dict(POLICY_KW, num_encoder_layers=layers)).eval()
+        sample_type="prob", sample_size=sample_size), **dict(POLICY_KW, num_encoder_layers=layers, nab_type=nab_type)).eval()
     tmpl = {k: tuple(v.shape) for k, v in pol.state_dict().items()}
     mine_t = restate.rcvrptw_weight_template(128, layers, 512, sample_size)
+    if nab_type != "gating":
+        mine_t = restate.ablation_template(mine_t, nab_type, use_duration=True)
     assert tmpl == mine_t, (set(tmpl) ^ set(mine_t), [k for k in tmpl if k in mine_t and tmpl[k] != mine_t[k]])
     w = restate.make_weights(tmpl, seed)
     pol.load_state_dict(w, strict=True)
@@ -243,7 +248,7 @@ def gen_rcvrptw(tag, B, N, S, sample_size, seed, layers=6, keep_trace=True):
     assert torch.allclose(mine["log_likelihood"][same], out["log_likelihood"][same], atol=5e-4)
     assert torch.allclose(trace["row_emb"], enc_out[0][0], atol=1e-4) and torch.allclose(trace["col_emb"], enc_out[0][1], atol=1e-4)
     print(f"  tours identical on {float(same.float().mean())*100:.2f}% of rollouts")
-    fx = dict(kind="rcvrptw", B=B, N=N, S=S, sample_size=sample_size, seed=seed, layers=layers,
+    fx = dict(kind="rcvrptw", B=B, N=N, S=S, sample_size=sample_size, seed=seed, layers=layers, nab_type=nab_type,
               **{k: inst[k] for k in inst}, sample_idx=sidx, norm_distance=td["distance_matrix"],
               min_distance=td["min_distance"], max_distance=td["max_distance"], row_emb=enc_out[0][0], col_emb=enc_out[0][1],
               actions=out["actions"], reward=out["reward"], normalized_reward=out["normalized_reward"],
@@ -272,3 +277,7 @@ if __name__ == "__main__":
         gen_rcvrptw("rcvrptw_n20_b4_pomo", B=4, N=20, S=20, sample_size=15, seed=31)
         gen_rcvrptw("rcvrptw_n20_b4_greedy", B=4, N=20, S=0, sample_size=15, seed=32)
         gen_rcvrptw("rcvrptw_n100_b2_pomo", B=2, N=100, S=100, sample_size=25, seed=33, keep_trace=False)
+    if "ablation" in which:      # nab_type ablations (configs/experiment/rrnet_naive.yaml, rrnet_heuristic.yaml)
+        gen_atsp("atsp_n20_b4_pomo_heuristic", B=4, N=20, S=20, sample_size=15, seed=41, keep_trace=False, nab_type="heuristic")
+        gen_rcvrptw("rcvrptw_n20_b4_pomo_heuristic", B=4, N=20, S=20, sample_size=15, seed=42, keep_trace=False, nab_type="heuristic")
+        gen_rcvrptw("rcvrptw_n20_b4_pomo_naive", B=4, N=20, S=20, sample_size=15, seed=43, keep_trace=False, nab_type="naive")

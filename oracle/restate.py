@@ -231,11 +231,59 @@ def aft_full(w: W, p: str, x: Tensor, y: Tensor, bias: Tensor) -> Tensor:
     return lin(w, p + ".project", torch.mul(torch.sigmoid(Q), weighted))
 
 
+def nab_heuristic(w: W, p: str, cost: Tensor, dur: Optional[Tensor]) -> Tensor:
+    """HeuristicNeuralAdaptiveBias.forward attn_freenet.py:138-167: -log2(N) * d_ij (the module's own `alpha` is unused)."""
+    log2n = torch.log2(torch.tensor(cost.size(-1), dtype=cost.dtype))
+    if dur is not None and (p + ".distance_weight") in w:
+        d = w[p + ".distance_weight"] * cost + w[p + ".duration_weight"] * dur
+    else:
+        d = cost
+    return -log2n * d
+
+
+def nab_naive(w: W, p: str, coords: Tensor, cost: Tensor, dur: Optional[Tensor]) -> Tensor:
+    """NaiveNeuralAdaptiveBias.forward attn_freenet.py:182-199 (needs the duration matrix: torch.cat fails on None)."""
+    if dur is None:
+        raise TypeError("NaiveNeuralAdaptiveBias concatenates duration_mat; the reference raises without it")
+    x = torch.stack([pairwise_angles(coords), cost, dur], dim=-1)
+    return lin(w, p + ".mlp.2", F.silu(lin(w, p + ".mlp.0", x))).squeeze(-1)
+
+
+def nab_any(w: W, p: str, nab_name: str, coords: Tensor, cost: Tensor, dur) -> Tensor:
+    """AttnFree_Block's choice of bias module (attn_freenet.py:379-405), recognised by the parameters present."""
+    q = p + ".neural_adaptive_bias"
+    if (q + ".mlp.0.weight") in w:
+        return nab_naive(w, q, coords, cost, dur)
+    if (q + ".alpha") in w:
+        return nab_heuristic(w, q, cost, dur)
+    return nab_gating(w, p + "." + nab_name, coords, cost, dur)
+
+
+def ablation_template(template: Dict[str, tuple], nab_type: str, use_duration: bool, embed_dim: int = 128) -> Dict[str, tuple]:
+    """state_dict template of the same policy built with nab_type in {'naive', 'heuristic'} (configs/experiment/
+    rrnet_naive.yaml, rrnet_heuristic.yaml): the gating fusion's parameters are replaced by the ablation module's."""
+    t = {k: v for k, v in template.items() if ".angle_distance_fusion." not in k and ".neural_adaptive_bias." not in k}
+    blocks = sorted({k.rsplit(".alpha", 1)[0] for k in template if k.endswith("_encoding_block.alpha")})
+    for b in blocks:
+        q = b + ".neural_adaptive_bias"
+        if nab_type == "naive":
+            c = 3 if use_duration else 2
+            t[q + ".mlp.0.weight"] = (embed_dim, c); t[q + ".mlp.0.bias"] = (embed_dim,)
+            t[q + ".mlp.2.weight"] = (1, embed_dim); t[q + ".mlp.2.bias"] = (1,)
+        elif nab_type == "heuristic":
+            t[q + ".alpha"] = (1,)
+            if use_duration:
+                t[q + ".distance_weight"] = (1,); t[q + ".duration_weight"] = (1,)
+        else:
+            raise ValueError(nab_type)
+    return t
+
+
 def block(w: W, p: str, row: Tensor, col: Tensor, cost: Tensor, coords: Tensor, dur, nab_name: str) -> Tensor:
     """AttnFree_Block.forward attn_freenet.py:417-441."""
     row = instance_norm(w, p + ".norm1", row)
     col = instance_norm(w, p + ".norm2", col)
-    bias = nab_gating(w, p + "." + nab_name, coords, cost, dur) * w[p + ".alpha"]
+    bias = nab_any(w, p, nab_name, coords, cost, dur) * w[p + ".alpha"]
     out = aft_full(w, p + ".attn_free", row, col, bias)
     out = instance_norm(w, p + ".norm3", lin(w, p + ".multi_head_combine", out))
     f = p + ".feed_forward.ops"
@@ -415,7 +463,7 @@ def make_weights(template: Dict[str, tuple], seed: int) -> W:
             a = 1.0 + 0.1 * rng.standard_normal(shape)
         elif name.endswith("normalizer.bias"):
             a = 0.1 * rng.standard_normal(shape)
-        elif name.endswith(".alpha") or name.endswith(".beta"):
+        elif name.endswith(".alpha") or name.endswith(".beta") or name.endswith("distance_weight") or name.endswith("duration_weight"):
             a = 1.0 + 0.1 * rng.standard_normal(shape)
         elif name.endswith("gate_temperature"):
             a = np.full(shape, 5.0) + 0.1 * rng.standard_normal(shape)

@@ -533,6 +533,64 @@ extern "C" int rr_nab_dur(const NabDurW* wrow, const NabDurW* wcol, const float*
 }
 
 // ------------------------------------------------------------------------------------------------
+// Ablation bias modules (nab_type = "heuristic" / "naive", configs/experiment/rrnet_heuristic.yaml, rrnet_naive.yaml)
+// for the row and col block of one layer -> bias_out [Bp][2][N*N], already multiplied by the block's alpha, fed to
+// rr_enc_layer as bias_pre.
+//   kind 0  HeuristicNeuralAdaptiveBias (attn_freenet.py:119-167): -log2(N) * (dw * d + tw * t)   (dw = 1, tw = 0 without T)
+//   kind 1  NaiveNeuralAdaptiveBias (:170-199): Linear(E,1)(SiLU(Linear(3,E)([theta, d, t])))
+// The col block sees D^T / T^T and the un-transposed angles (:480-486).
+// ------------------------------------------------------------------------------------------------
+struct NabSimpleW {
+  const float *w0, *b0, *w2;     // naive: Linear(3,E) weight [E][3] and bias [E], Linear(E,1) weight [E]
+  float b2, alpha, dw, tw;       // naive: Linear(E,1) bias; block alpha; heuristic: distance / duration weights
+};
+
+__global__ __launch_bounds__(256) void k_nab_simple(NabSimpleW wr, NabSimpleW wc, int kind, const float* __restrict__ D,
+                                                    const float* __restrict__ T, const float* __restrict__ locs,
+                                                    float* __restrict__ bias_out, int N) {
+  __shared__ float tab[5 * RR_E];
+  const int b = blockIdx.y, is_col = blockIdx.z;
+  const NabSimpleW& w = is_col ? wc : wr;
+  if (kind == 1) {
+    for (int i = threadIdx.x; i < RR_E; i += 256) {
+      tab[i] = w.w0[i * 3]; tab[RR_E + i] = w.w0[i * 3 + 1]; tab[2 * RR_E + i] = w.w0[i * 3 + 2];
+      tab[3 * RR_E + i] = w.b0[i]; tab[4 * RR_E + i] = w.w2[i];
+    }
+    __syncthreads();
+  }
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= N * N) return;
+  const int i = e / N, j = e - i * N;
+  const size_t base = (size_t)b * N * N;
+  const int src = is_col ? j * N + i : e;
+  const float d = D[base + src];
+  const float t = T != nullptr ? T[base + src] : 0.f;
+  float out;
+  if (kind == 0) {
+    out = -log2f((float)N) * (T != nullptr ? w.dw * d + w.tw * t : d);
+  } else {
+    const float* lc = locs + (size_t)b * N * 2;
+    const float th = atan2f(lc[i * 2 + 1] - lc[j * 2 + 1], lc[i * 2] - lc[j * 2]);
+    float acc = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < RR_E; ++k) {
+      const float z = fmaf(tab[k], th, fmaf(tab[RR_E + k], d, fmaf(tab[2 * RR_E + k], t, tab[3 * RR_E + k])));
+      acc = fmaf(tab[4 * RR_E + k], z * rr_sigmoid(z), acc);          // SiLU
+    }
+    out = acc + w.b2;
+  }
+  bias_out[((size_t)(b * 2 + is_col) * N) * N + e] = out * w.alpha;
+}
+
+extern "C" int rr_nab_simple(const NabSimpleW* wrow, const NabSimpleW* wcol, int kind, const float* D, const float* T,
+                             const float* locs, float* bias_out, int Bp, int N, hipStream_t st) {
+  if (Bp <= 0 || N < 2 || wrow == nullptr || wcol == nullptr || D == nullptr || bias_out == nullptr) return RR_EINVAL;
+  if (kind < 0 || kind > 1 || (kind == 1 && (T == nullptr || locs == nullptr || wrow->w0 == nullptr))) return RR_EINVAL;
+  hipLaunchKernelGGL(k_nab_simple, dim3((N * N + 255) / 256, Bp, 2), dim3(256), 0, st, *wrow, *wcol, kind, D, T, locs, bias_out, N);
+  return rr_check(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
 // ATSP init embedding (rrnco/models/env_embeddings/atsp.py:69-91, 108-121).
 //   node = Lin(2,E)(locs); rowd/cold = sorted sampled D[i,idx] / D[idx,i]; row/col = Lin(S,E)(sorted);
 //   out = g*node + (1-g)*dist  with  g = sigmoid(Lin(2E,1)(relu(Lin(2E,2E)([node;dist]))))  (scalar gate)

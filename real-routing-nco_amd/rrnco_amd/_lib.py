@@ -41,6 +41,10 @@ class NabDurW(C.Structure):
                                                                 ("inv_tau", f32), ("bo", f32), ("alpha", f32)]
 
 
+class NabSimpleW(C.Structure):
+    _fields_ = [(n, vp) for n in ("w0", "b0", "w2")] + [(n, f32) for n in ("b2", "alpha", "dw", "tw")]
+
+
 class RolloutIO(C.Structure):
     _fields_ = [(n, vp) for n in (
         "K", "Vt", "L", "ctxA", "ctxB", "D", "Dur", "demand", "tw", "service", "cur", "first", "mask", "visited", "used",
@@ -59,6 +63,7 @@ _SIGS = {
     "rr_enc_layer": [C.POINTER(EncBlockW), C.POINTER(EncBlockW), vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp],
     "rr_edge_angles": [vp, vp, i32, i32, vp],
     "rr_nab_dur": [C.POINTER(NabDurW), C.POINTER(NabDurW), vp, vp, vp, vp, i32, i32, vp],
+    "rr_nab_simple": [C.POINTER(NabSimpleW), C.POINTER(NabSimpleW), i32, vp, vp, vp, vp, i32, i32, vp],
     "rr_rmtvrp_step": [vp] * 14 + [i32, i32, i32, vp],
     "rr_reinforce_loss": [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "rr_init_embed": [C.POINTER(InitW), i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],

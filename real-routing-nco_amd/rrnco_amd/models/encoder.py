@@ -57,13 +57,33 @@ class _DistAngleDurFusion(nn.Module):   # attn_freenet.py:201-240 with use_durat
         self.out_lin = nn.Linear(E, 1)
 
 
+class _HeuristicNAB(nn.Module):  # HeuristicNeuralAdaptiveBias attn_freenet.py:119-167 (its own alpha is never used in forward)
+    def __init__(self, use_duration):
+        super().__init__()
+        self.alpha = nn.Parameter(torch.ones(1))
+        if use_duration:
+            self.distance_weight, self.duration_weight = nn.Parameter(torch.ones(1)), nn.Parameter(torch.ones(1))
+
+
+class _NaiveNAB(nn.Module):      # NaiveNeuralAdaptiveBias attn_freenet.py:170-199
+    def __init__(self, E, use_duration):
+        super().__init__()
+        self.mlp = nn.Sequential(nn.Linear(3 if use_duration else 2, E), nn.SiLU(), nn.Linear(E, 1))
+
+
 class _Block(nn.Module):         # AttnFree_Block attn_freenet.py:360-415
-    def __init__(self, E, ff, use_duration=False):
+    def __init__(self, E, ff, use_duration=False, nab_type="gating"):
         super().__init__()
         self.alpha = nn.Parameter(torch.ones(1))
         self.attn_free = _AFT(E)
         self.multi_head_combine = nn.Linear(E, E)
-        if use_duration:
+        if nab_type == "naive":
+            self.neural_adaptive_bias = _NaiveNAB(E, use_duration)  # :391-395
+        elif nab_type == "heuristic":
+            self.neural_adaptive_bias = _HeuristicNAB(use_duration)  # :396-400
+        elif nab_type != "gating":
+            raise ValueError(f"Unknown nab_type: {nab_type}. Supported types: 'gating', 'naive', 'heuristic'")
+        elif use_duration:
             self.neural_adaptive_bias = _DistAngleDurFusion(E)     # :379-383
         else:
             self.angle_distance_fusion = _DistAngleFusion(E)       # :384-389
@@ -72,15 +92,15 @@ class _Block(nn.Module):         # AttnFree_Block attn_freenet.py:360-415
 
 
 class _Layer(nn.Module):         # Attn_Free_Layer attn_freenet.py:444-470
-    def __init__(self, E, ff, use_duration=False):
+    def __init__(self, E, ff, use_duration=False, nab_type="gating"):
         super().__init__()
-        self.row_encoding_block, self.col_encoding_block = _Block(E, ff, use_duration), _Block(E, ff, use_duration)
+        self.row_encoding_block, self.col_encoding_block = _Block(E, ff, use_duration, nab_type), _Block(E, ff, use_duration, nab_type)
 
 
 class AttnFreeNet(nn.Module):    # attn_freenet.py:491-515
-    def __init__(self, embed_dim=128, feedforward_hidden=512, num_layers=3, use_duration_matrix=False, **unused):
+    def __init__(self, embed_dim=128, feedforward_hidden=512, num_layers=3, use_duration_matrix=False, nab_type="gating", **unused):
         super().__init__()
-        self.layers = nn.ModuleList([_Layer(embed_dim, feedforward_hidden, use_duration_matrix) for _ in range(num_layers)])
+        self.layers = nn.ModuleList([_Layer(embed_dim, feedforward_hidden, use_duration_matrix, nab_type) for _ in range(num_layers)])
 
 
 class _Gating(nn.Module):        # ContextualGating env_embeddings/atsp.py:108-121
@@ -120,8 +140,8 @@ class RRNetEncoder(nn.Module):
         super().__init__()
         if embed_dim != 128 or feedforward_hidden != 512:
             raise NotImplementedError("rrnco_amd kernels are specialised for embed_dim=128, feedforward_hidden=512")
-        if normalization != "instance" or nab_type != "gating":
-            raise NotImplementedError("rrnco_amd implements normalization='instance', nab_type='gating' (configs/experiment/rrnet.yaml)")
+        if normalization != "instance":
+            raise NotImplementedError("rrnco_amd implements normalization='instance' (configs/experiment/rrnet.yaml)")
         self.env_name = getattr(env_name, "name", env_name)
         kw = dict(init_embedding_kwargs or {})
         if init_embedding is not None:
@@ -131,7 +151,7 @@ class RRNetEncoder(nn.Module):
         else:
             from .vrp_embeddings import make_vrp_init_embedding
             self.init_embedding = make_vrp_init_embedding(self.env_name, embed_dim, **kw)
-        self.net = AttnFreeNet(embed_dim, feedforward_hidden, num_layers,
+        self.net = AttnFreeNet(embed_dim, feedforward_hidden, num_layers, nab_type=nab_type,
                                use_duration_matrix=self.env_name not in ("atsp", "rcvrp")) if net is None else net   # encoder.py:63-66
 
     def forward(self, td, phase: str = "val", mask=None, packed=None):
@@ -163,16 +183,22 @@ class RRNetEncoder(nn.Module):
         self._last_init = (row, col)
         row2, col2 = torch.empty_like(row), torch.empty_like(col)
         dbg = getattr(self, "_debug_buffer", None)
-        use_dur = len(packed["nabdur"]) > 0          # encoder.py:98-106: duration matrix only for rcvrptw
+        has_dur = self.env_name not in ("atsp", "rcvrp")   # encoder.py:98-106: duration matrix only for rcvrptw
+        simple = packed.get("nab_kind", "gating") != "gating"
+        use_dur = len(packed["nabdur"]) > 0 or simple         # "bias_pre" path: NAB evaluated by a kernel of its own
         theta = None
+        T = td["duration_matrix"].float().contiguous() if has_dur else None
         if use_dur:
-            T = td["duration_matrix"].float().contiguous()
             bias = torch.empty(Bp, 2, N * N, device=dev, dtype=torch.float32)
         else:   # the angle matrix only depends on the coordinates: once per instance, shared by all twelve blocks
             theta = torch.empty(Bp, N, N, device=dev, dtype=torch.float32)
             L.check(lib.rr_edge_angles(L.ptr(locs), L.ptr(theta), Bp, N, L.stream()), "rr_edge_angles")
         for l, (wr, wc) in enumerate(packed["blocks"]):
-            if use_dur:
+            if simple:
+                nr, nc = packed["nabsimple"][l]
+                L.check(lib.rr_nab_simple(nr, nc, 1 if packed["nab_kind"] == "naive" else 0, L.ptr(D), L.ptr(T), L.ptr(locs),
+                                          L.ptr(bias), Bp, N, L.stream()), "rr_nab_simple")
+            elif use_dur:
                 nr, nc = packed["nabdur"][l]
                 L.check(lib.rr_nab_dur(nr, nc, L.ptr(D), L.ptr(T), L.ptr(locs), L.ptr(bias), Bp, N, L.stream()), "rr_nab_dur")
             L.check(lib.rr_enc_layer(wr, wc, L.ptr(row), L.ptr(col), L.ptr(row2), L.ptr(col2), L.ptr(D), L.ptr(locs),

@@ -174,8 +174,10 @@ def pack_policy(sd: dict, env_name: str, device) -> dict:
     """state_dict (reference names) -> ctypes structs for the kernels."""
     ar = _Arena(device)
     nl = 1 + max(int(k.split(".")[3]) for k in sd if k.startswith("encoder.net.layers."))
-    blocks, nabdur = [], {}
+    blocks, nabdur, nabsimple = [], {}, {}
     nabname = "angle_distance_fusion" if env_name in ("atsp", "rcvrp") else "neural_adaptive_bias"
+    q0 = "encoder.net.layers.0.row_encoding_block.neural_adaptive_bias"
+    nab_kind = "naive" if (q0 + ".mlp.0.weight") in sd else "heuristic" if (q0 + ".alpha") in sd else "gating"
     for l in range(nl):
         pair = []
         for rc in ("row", "col"):
@@ -190,7 +192,21 @@ def pack_policy(sd: dict, env_name: str, device) -> dict:
                          ("1", "feed_forward.ops.ffn.W1"), ("2", "feed_forward.ops.ffn.W2")):
                 setattr(w, "w" + f, ar.put(pack_a(sd[f"{b}.{k}.weight"].detach().float())))
                 setattr(w, "b" + f, ar.put(sd[f"{b}.{k}.bias"]))
-            if nabname == "angle_distance_fusion":
+            if nab_kind != "gating":          # ablation modules: bias computed by rr_nab_simple, fed as bias_pre
+                w.nab = None
+                q, sw = f"{b}.neural_adaptive_bias", L.NabSimpleW()
+                sw.alpha = float(sd[f"{b}.alpha"])
+                if nab_kind == "naive":
+                    if sd[q + ".mlp.0.weight"].shape[1] != 3:
+                        raise NotImplementedError("NaiveNeuralAdaptiveBias needs the duration matrix (the reference raises "
+                                                  "without it, attn_freenet.py:193-195): rcvrptw only")
+                    sw.w0, sw.b0 = ar.put(sd[q + ".mlp.0.weight"]), ar.put(sd[q + ".mlp.0.bias"])
+                    sw.w2, sw.b2 = ar.put(sd[q + ".mlp.2.weight"].reshape(-1)), float(sd[q + ".mlp.2.bias"])
+                else:
+                    sw.dw = float(sd[q + ".distance_weight"]) if (q + ".distance_weight") in sd else 1.0
+                    sw.tw = float(sd[q + ".duration_weight"]) if (q + ".duration_weight") in sd else 0.0
+                nabsimple.setdefault(l, []).append(sw)
+            elif nabname == "angle_distance_fusion":
                 w.nab = ar.put(fold_nab_pwl(sd, f"{b}.{nabname}", sd[f"{b}.alpha"]))
             else:
                 w.nab = None
@@ -198,7 +214,8 @@ def pack_policy(sd: dict, env_name: str, device) -> dict:
             pair.append(w)
         blocks.append(tuple(pair))
 
-    out = {"arena": ar, "blocks": blocks, "num_layers": nl, "nabdur": [tuple(nabdur[l]) for l in sorted(nabdur)]}
+    out = {"arena": ar, "blocks": blocks, "num_layers": nl, "nabdur": [tuple(nabdur[l]) for l in sorted(nabdur)],
+           "nab_kind": nab_kind, "nabsimple": [tuple(nabsimple[l]) for l in sorted(nabsimple)]}
     p = "encoder.init_embedding"
     if env_name == "atsp":
         iw = L.InitW()

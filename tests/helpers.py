@@ -25,15 +25,20 @@ def atsp_weights(fx_or_ss, layers=6, seed=None):
         ss, layers, seed = fx_or_ss["sample_size"], fx_or_ss["layers"], fx_or_ss["seed"]
     else:
         ss = fx_or_ss
-    return restate.make_weights(restate.atsp_weight_template(128, layers, 512, ss), seed)
+    t = restate.atsp_weight_template(128, layers, 512, ss)
+    if isinstance(fx_or_ss, dict) and fx_or_ss.get("nab_type", "gating") != "gating":
+        t = restate.ablation_template(t, fx_or_ss["nab_type"], use_duration=False)
+    return restate.make_weights(t, seed)
 
 
 def make_policy(w, env_name="atsp", device="cuda"):
     from rrnco_amd.models import RRNetPolicy
     layers = restate.num_layers_of(w)
     ss = [v for k, v in w.items() if k.endswith(".row_embed.weight")][0].shape[1]
+    q0 = "encoder.net.layers.0.row_encoding_block.neural_adaptive_bias"
+    nab_type = "naive" if (q0 + ".mlp.0.weight") in w else "heuristic" if (q0 + ".alpha") in w else "gating"
     pol = RRNetPolicy(env_name=env_name, embed_dim=128, num_heads=8, num_encoder_layers=layers,
-                      normalization="instance", use_graph_context=False, nab_type="gating",
+                      normalization="instance", use_graph_context=False, nab_type=nab_type,
                       init_embedding_kwargs=dict(use_coords=True, use_polar_feats=True, use_dist=True,
                                                  use_matnet_init=False, sample_type="prob", sample_size=ss))
     pol.load_state_dict(w, strict=True)
@@ -64,7 +69,10 @@ def rcvrp_instance(fx):
 
 
 def rcvrptw_weights(fx):
-    return restate.make_weights(restate.rcvrptw_weight_template(128, fx["layers"], 512, fx["sample_size"]), fx["seed"])
+    t = restate.rcvrptw_weight_template(128, fx["layers"], 512, fx["sample_size"])
+    if fx.get("nab_type", "gating") != "gating":
+        t = restate.ablation_template(t, fx["nab_type"], use_duration=True)
+    return restate.make_weights(t, fx["seed"])
 
 
 def rcvrptw_instance(fx):
