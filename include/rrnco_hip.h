@@ -76,10 +76,11 @@ int rr_tour_cost(const float* D, const int64_t* actions, const float* mn, const 
                  float* real_out, int R, int Bp, int N, int T, int mode, hipStream_t stream);
 
 /* process_logits + Greedy/Sampling/Evaluate._step + logp gather (rrnco/models/decoding.py:311-361, 272-298, 266).
- * mode 0 greedy, 1 sampling (Gumbel-max on a counter-based generator), 2 evaluate (action_in). */
+ * mode 0 greedy, 1 sampling (Gumbel-max on a counter-based generator), 2 evaluate (action_in).
+ * top_k > 0 / 0 < top_p < 1: the filters of decoding.py:37-63 applied after masking and temperature (0 = off). */
 int rr_select(const float* logits, const uint8_t* mask, const int64_t* action_in, int64_t* action_out,
               float* logp_out, float* logp_all, int R, int N, float tanh_clip, float temperature, int mode,
-              uint64_t seed, uint32_t step, hipStream_t stream);
+              uint64_t seed, uint32_t step, int top_k, float top_p, hipStream_t stream);
 
 /* One Attn_Free_Layer = row block + col block (rrnco/models/nn/attn_freenet.py:472-488). */
 /* theta [Bp][N][N] = rr_edge_angles(locs) (may be NULL: angles are then recomputed per block, slower);

@@ -377,13 +377,23 @@ def atsp_decoder_step(w: W, td_flat: dict, cache: dict, S: int):
     return logits, mask
 
 
-def process_logits(logits: Tensor, mask: Tensor, temperature: float = 1.0, tanh_clipping: float = 10.0) -> Tensor:
-    """decoding.py:311-361 (top-k/top-p off)."""
+def process_logits(logits: Tensor, mask: Tensor, temperature: float = 1.0, tanh_clipping: float = 10.0,
+                   top_p: float = 0.0, top_k: int = 0) -> Tensor:
+    """decoding.py:311-361, with the top-k (:37-42) and top-p (:45-63) filters."""
     if tanh_clipping > 0:
         logits = torch.tanh(logits) * tanh_clipping
     logits = logits.clone()
     logits[~mask] = float("-inf")
     logits = logits / temperature
+    if top_k > 0:
+        k = min(top_k, logits.size(-1))
+        logits = logits.masked_fill(logits < torch.topk(logits, k)[0][..., -1, None], float("-inf"))
+    if top_p > 0:
+        assert top_p <= 1.0
+        if 0.0 < top_p < 1.0:
+            sl, si = torch.sort(logits, descending=False)
+            rm = sl.softmax(dim=-1).cumsum(dim=-1) <= (1 - top_p)
+            logits = logits.masked_fill(rm.scatter(-1, si, rm), float("-inf"))
     return F.log_softmax(logits, dim=-1)
 
 

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
                                                 const int64_t* __restrict__ action_in, int64_t* __restrict__ action_out,
                                                 float* __restrict__ logp_out, float* __restrict__ logp_all,
                                                 int R, int N, float tanh_clip, float temperature, int mode,
-                                                uint64_t seed, uint32_t step) {
+                                                uint64_t seed, uint32_t step, int top_k, float top_p) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= R) return;
@@ -211,6 +211,38 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
       v = v * (1.0f / temperature);
     }
     x[q] = v;
+  }
+  if (top_k > 0 && top_k < N) {
+    // modify_logits_for_top_k_filtering (decoding.py:37-42): drop everything below the k-th largest value, counted with
+    // multiplicity as torch.topk does.  Peel off the current maximum and its copies until k values are covered.
+    float bound = INFINITY, thr = -INFINITY;
+    int covered = 0;
+    for (int it = 0; it < top_k; ++it) {
+      const float c0 = x[0] < bound ? x[0] : -INFINITY, c1 = x[1] < bound ? x[1] : -INFINITY;
+      const float cur = rr_wave_max(fmaxf(c0, c1));
+      covered += __popcll(__ballot(lane < N && x[0] == cur)) + __popcll(__ballot(lane + 64 < N && x[1] == cur));
+      thr = cur; bound = cur;
+      if (covered >= top_k || cur == -INFINITY) break;
+    }
+    if (x[0] < thr) x[0] = -INFINITY;
+    if (x[1] < thr) x[1] = -INFINITY;
+  }
+  if (top_p > 0.f && top_p < 1.f) {
+    // modify_logits_for_top_p_filtering (decoding.py:45-63): remove the lower tail whose cumulative probability, summed
+    // from the smallest logit upwards, is <= 1 - top_p.  Without sorting: cum_i = sum of p_j over the elements that a
+    // stable ascending sort places at or before i (x_j < x_i, or x_j == x_i and j <= i; ties are common once tanh saturates).
+    const float mm = rr_wave_max(fmaxf(x[0], x[1]));
+    const float p0 = (lane < N) ? rr_exp(x[0] - mm) : 0.f, p1 = (lane + 64 < N) ? rr_exp(x[1] - mm) : 0.f;
+    const float inv = 1.0f / rr_wave_sum(p0 + p1);
+    float c0 = 0.f, c1 = 0.f;
+    for (int j = 0; j < N; ++j) {
+      const float xj = (j & 64) ? __shfl(x[1], j & 63) : __shfl(x[0], j & 63);
+      const float pj = ((j & 64) ? __shfl(p1, j & 63) : __shfl(p0, j & 63)) * inv;
+      c0 += (xj < x[0] || (xj == x[0] && j <= lane)) ? pj : 0.f;
+      c1 += (xj < x[1] || (xj == x[1] && j <= lane + 64)) ? pj : 0.f;
+    }
+    if (c0 <= 1.0f - top_p) x[0] = -INFINITY;
+    if (c1 <= 1.0f - top_p) x[1] = -INFINITY;
   }
   float m = rr_wave_max(fmaxf(x[0], x[1]));
   float e0 = (lane < N) ? rr_exp(x[0] - m) : 0.f;
@@ -258,11 +290,11 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
 
 extern "C" int rr_select(const float* logits, const uint8_t* mask, const int64_t* action_in, int64_t* action_out,
                          float* logp_out, float* logp_all, int R, int N, float tanh_clip, float temperature,
-                         int mode, uint64_t seed, uint32_t step, hipStream_t st) {
-  if (R <= 0 || N <= 0 || N > 128 || temperature <= 0.f) return RR_EINVAL;
+                         int mode, uint64_t seed, uint32_t step, int top_k, float top_p, hipStream_t st) {
+  if (R <= 0 || N <= 0 || N > 128 || temperature <= 0.f || top_k < 0 || top_p < 0.f || top_p > 1.f) return RR_EINVAL;
   if (mode == 2 && action_in == nullptr) return RR_EINVAL;
   hipLaunchKernelGGL(k_select, dim3((R + 3) / 4), dim3(256), 0, st, logits, mask, action_in, action_out, logp_out,
-                     logp_all, R, N, tanh_clip, temperature, mode, seed, step);
+                     logp_all, R, N, tanh_clip, temperature, mode, seed, step, top_k, top_p);
   return rr_check(hipGetLastError());
 }
 

@@ -26,8 +26,12 @@ class DecodingStrategy:
     def __init__(self, temperature=1.0, top_p=0.0, top_k=0, mask_logits=True, tanh_clipping=0, num_samples=None,
                  multisample=False, num_starts=None, multistart=False, select_start_nodes_fn=None,
                  improvement_method_mode=False, select_best=False, store_all_logp=False, seed=0, **kwargs):
-        if top_p > 0 or top_k > 0 or select_best or improvement_method_mode:
-            raise NotImplementedError("top-k / top-p / select_best are outside the MI355X hot path")
+        if select_best or improvement_method_mode:
+            raise NotImplementedError("select_best / improvement_method_mode are outside the MI355X hot path")
+        if not 0.0 <= top_p <= 1.0:
+            raise AssertionError("top-p should be in (0, 1].")                      # decoding.py:357
+        # decoding.py:352-358 filters; evaluated by rr_select in the step-wise loop (the fused rollout has no sort)
+        self.top_p, self.top_k = float(top_p), int(top_k)
         self.temperature, self.mask_logits, self.tanh_clipping = temperature, mask_logits, tanh_clipping
         assert not (multistart and multisample)
         if num_samples is not None:
@@ -80,7 +84,7 @@ class DecodingStrategy:
         act_in = action.contiguous() if action is not None else None
         L.check(L.lib().rr_select(L.ptr(logits), L.ptr(m), L.ptr(act_in), L.ptr(sel), L.ptr(lp), L.ptr(lp_all), R, N,
                                   float(self.tanh_clipping), float(self.temperature), mode, int(self.seed),
-                                  len(self.actions), L.stream()), "rr_select")
+                                  len(self.actions), self.top_k, self.top_p, L.stream()), "rr_select")
         td.set("action", sel)
         self.actions.append(sel)
         self.logprobs.append(lp_all if self.store_all_logp else lp)
