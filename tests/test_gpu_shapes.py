@@ -93,3 +93,55 @@ def test_rcvrp_generator_instances_roundtrip_properties_n50():
         path = torch.cat([torch.zeros(1, dtype=torch.long), acts[r], torch.zeros(1, dtype=torch.long)])
         cost = D[r % 6, path[:-1], path[1:]].double().sum()
         assert abs(float(a["normalized_reward"][r]) + float(cost)) < 1e-4
+
+
+def _run_vrp(problem, N, B, S, ss, seed, layers=2):
+    """RCVRP / RCVRPTW at shapes the fixtures do not cover, against the oracle run on the fly (tolerances of the
+    fixture tests: every divergence must sit at an oracle decision gap < 1e-3)."""
+    from rrnco_amd import TensorDict
+    from rrnco_amd.envs import RCVRPEnv, RMTVRPEnv
+    if problem == "rcvrp":
+        w = restate.make_weights(restate.rcvrp_weight_template(128, layers, 512, ss), seed)
+        inst = restate.rcvrp_synthetic(B, N, seed, capacity=restate.vrptw_capacity(N))
+        st0 = restate.rcvrp_reset(inst)
+        env, run = RCVRPEnv(generator_params=dict(num_loc=N)), restate.rcvrp_policy
+    else:
+        w = restate.make_weights(restate.rcvrptw_weight_template(128, layers, 512, ss), seed)
+        inst = restate.rcvrptw_synthetic(B, N, seed)
+        st0 = restate.rmtvrp_reset(inst)
+        env, run = RMTVRPEnv(generator_params=dict(num_loc=N)), restate.rcvrptw_policy
+    pol = H.make_policy(w, env_name=problem)
+    sidx = restate.sample_neighbor_indices(st0["distance_matrix"], ss, generator=torch.Generator().manual_seed(seed))
+    tr = {}
+    with torch.inference_mode():
+        ref = run(w, st0, sidx, S, "greedy", trace=tr)
+    td = TensorDict({k: v.cuda() for k, v in inst.items()}, batch_size=[B])
+    td["sample_idx"] = sidx.cuda()
+    outs = [pol(env.reset(td), env, phase="val", decode_type="multistart_greedy", num_starts=S, fused=f) for f in (True, False)]
+    assert torch.equal(outs[0]["actions"], outs[1]["actions"])                     # fused == step-wise
+    acts = outs[0]["actions"].cpu()
+    assert bool((acts.sort(1).values[:, -N:] == torch.arange(1, N + 1)).all())     # every customer exactly once
+    T = min(acts.shape[1], ref["actions"].shape[1])
+    frac, first = H.tour_agreement(acts[:, :T], ref["actions"][:, :T])
+    if frac < 1.0:
+        lp = torch.nan_to_num(torch.stack(tr["logp"], 1), neginf=-1e9).topk(2, -1).values
+        gap = lp[..., 0] - lp[..., 1]
+        for r in torch.nonzero(first >= 0).flatten().tolist():
+            t = int(first[r]) - 1
+            assert t >= gap.shape[1] or gap[r, t] < 1e-3
+    assert frac >= 0.95
+    same = first < 0
+    assert torch.allclose(outs[0]["reward"].cpu()[same], ref["reward"][same], atol=1e-4)
+    assert torch.allclose(outs[0]["log_likelihood"].cpu()[same], ref["log_likelihood"][same], rtol=2e-5, atol=4e-3)
+
+
+@pytest.mark.parametrize("problem,N,B,S,ss", [
+    ("rcvrp", 37, 3, 38, 20),       # 38 nodes: 4-tile template, ragged S, odd batch
+    ("rcvrp", 63, 2, 64, 25),       # 64 nodes: upper edge of the 4-tile template, S a multiple of 16 (no tail tile)
+    ("rcvrp", 102, 2, 50, 25),      # 103 nodes: the kernels' maximum
+    ("rcvrptw", 37, 3, 37, 20),
+    ("rcvrptw", 70, 2, 70, 25),     # 71 nodes: 7-tile template below 100
+    ("rcvrptw", 102, 1, 33, 25),    # 103 nodes, one instance (tail packing needs two: disabled)
+])
+def test_vrp_other_shapes_match_oracle(problem, N, B, S, ss):
+    _run_vrp(problem, N, B, S, ss, seed=300 + N)
