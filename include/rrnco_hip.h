@@ -41,6 +41,7 @@ typedef struct {                /* folded DistAngleFusion(use_duration_matrix=Tr
   const void *mp;               /* pack [9][24][64][4]: [M_d|M_a|M_t] (128x384) + rows co_d/co_a/co_t */
   const float *ab, *cg, *wg2;   /* first-layer slopes/offsets [2][384], gate constant [128], gate.2 weight [3][128] */
   float bg2[3], ko[3], inv_tau, bo, alpha;
+  const float *pwl;             /* vector-valued piecewise-linear tables of the gate pre-activation (packing.fold_nab_dur_pwl) */
 } NabDurW;
 
 typedef struct { const void *wk, *wv, *wl, *wca, *wcb; } CacheW;   /* rrnco/models/decoder.py:214-232 + context */

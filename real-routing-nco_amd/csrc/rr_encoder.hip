@@ -443,6 +443,7 @@ struct NabDurW {
   const float* wg2;     // [3][128] gate.2 weight
   float bg2[3], ko[3];
   float inv_tau, bo, alpha;
+  const float* pwl;     // vector-valued piecewise-linear tables (k_nab_dur_pwl), packing.fold_nab_dur_pwl
 };
 
 #define NAB_ET 4       // edge tiles (of 16 edges) per wave
@@ -523,12 +524,141 @@ __global__ __launch_bounds__(256, 2) void k_nab_dur(NabDurW wr, NabDurW wc, cons
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same bias through the vector-valued piecewise-linear form (packing.fold_nab_dur_pwl): the gate pre-activation
+// z = cg + sum_x M_x relu(a_x x + b_x) is linear in each scalar input between that family's 128 breakpoints, so per edge
+// it is six 512-byte table rows (value at the segment's anchor + slope, three families) instead of a 128 x 384
+// contraction: no MFMA at all, ~0.8 kflop of fma + the SiLU / gate epilogue per edge.  Same wave geometry and epilogue
+// as k_nab_dur (lane (j,g): edge j of an edge tile, gate units 16t+4g..+3), rows gathered from L2 (792 KB per layer).
+// ------------------------------------------------------------------------------------------------
+#define NABD_TS 132
+#define NABD_SEG 129
+#define NABD_ANC (3 * NABD_TS)
+#define NABD_OSC (2 * 3 * NABD_TS)
+#define NABD_CELL (NABD_OSC + 3 * NABD_SEG * 2 + 2)
+#define NABD_ROWS (NABD_CELL + 3 * NAB_G / 4)
+
+__global__ __launch_bounds__(256, 2) void k_nab_dur_pwl(NabDurW wr, NabDurW wc, const float* __restrict__ D,
+                                                        const float* __restrict__ T, const float* __restrict__ locs,
+                                                        float* __restrict__ bias_out, int N) {
+  __shared__ __attribute__((aligned(16))) float head[NABD_ROWS];
+  const int b = blockIdx.y, is_col = blockIdx.z;
+  const NabDurW& w = is_col ? wc : wr;
+  for (int i = threadIdx.x; i < NABD_ROWS; i += 256) head[i] = w.pwl[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int NN = N * N;
+  const int e0 = (blockIdx.x * 4 + wave) * (16 * NAB_ET);
+  if (e0 >= NN) return;
+  const float* Db = D + (size_t)b * NN;
+  const float* Tb = T + (size_t)b * NN;
+  const float* lc = locs + (size_t)b * N * 2;
+  const unsigned char* cell = reinterpret_cast<const unsigned char*>(head + NABD_CELL);
+  const float* rows = w.pwl + NABD_ROWS;
+  // per edge tile: segment of each family, distance to its anchor, the out_lin scalars
+  unsigned roff[NAB_ET][3];
+  float dx[NAB_ET][3], ox[NAB_ET][3];
+#pragma unroll
+  for (int et = 0; et < NAB_ET; ++et) {
+    int e = e0 + et * 16 + j; e = e < NN ? e : NN - 1;
+    const int i = e / N, jj = e - i * N;
+    float x[3];
+    x[0] = is_col ? Db[jj * N + i] : Db[e];
+    x[2] = is_col ? Tb[jj * N + i] : Tb[e];
+    x[1] = atan2f(lc[i * 2 + 1] - lc[jj * 2 + 1], lc[i * 2] - lc[jj * 2]);
+    int m[3];
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+      x[f] = fminf(x[f], 3.0e38f);
+      const int c = f == 1 ? (int)((x[1] + 3.14159265358979f) * ((float)NAB_G / 6.28318530717959f)) : (int)(x[f] * (float)NAB_G);
+      const int s0 = cell[f * NAB_G + min(max(c, 0), NAB_G - 1)];
+      m[f] = c < 0 ? 0 : s0;
+    }
+    int more;
+    do {                                                   // forward scan to the segment (sentinel +inf at index 128)
+      more = 0;
+#pragma unroll
+      for (int f = 0; f < 3; ++f) {
+        const int adv = head[f * NABD_TS + m[f]] <= x[f] ? 1 : 0;
+        m[f] += adv; more |= adv;
+      }
+    } while (__any(more));
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+      dx[et][f] = x[f] - head[NABD_ANC + f * NABD_TS + m[f]];
+      const float* os = head + NABD_OSC + (f * NABD_SEG + m[f]) * 2;
+      ox[et][f] = fmaf(os[1], dx[et][f], os[0]);
+      roff[et][f] = (unsigned)((f * NABD_SEG + m[f]) * 2 * RR_E + 4 * g);
+    }
+  }
+  float l[NAB_ET][3];
+#pragma unroll
+  for (int et = 0; et < NAB_ET; ++et) l[et][0] = l[et][1] = l[et][2] = 0.f;
+  // two edge tiles at a time; the 12 row fragments of unit tile t+1 are in flight while tile t is evaluated
+#pragma unroll
+  for (int eh = 0; eh < NAB_ET; eh += 2) {
+    float4 F[2][3], S[2][3];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int f = 0; f < 3; ++f) { F[q][f] = rr_ld4(rows + roff[eh + q][f]); S[q][f] = rr_ld4(rows + roff[eh + q][f] + RR_E); }
+#pragma unroll 1
+    for (int t = 0; t < 8; ++t) {
+      const float4 g0 = rr_ld4(w.wg2 + 16 * t + 4 * g), g1 = rr_ld4(w.wg2 + 128 + 16 * t + 4 * g), g2 = rr_ld4(w.wg2 + 256 + 16 * t + 4 * g);
+      float4 Fn[2][3], Sn[2][3];
+      const int tn = t + 1 < 8 ? t + 1 : 0;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int f = 0; f < 3; ++f) { Fn[q][f] = rr_ld4(rows + roff[eh + q][f] + 16 * tn); Sn[q][f] = rr_ld4(rows + roff[eh + q][f] + RR_E + 16 * tn); }
+      __builtin_amdgcn_sched_barrier(0);
+      const float g0v[4] = {g0.x, g0.y, g0.z, g0.w}, g1v[4] = {g1.x, g1.y, g1.z, g1.w}, g2v[4] = {g2.x, g2.y, g2.z, g2.w};
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int et = eh + q;
+        float z[4];
+        z[0] = fmaf(S[q][0].x, dx[et][0], F[q][0].x) + fmaf(S[q][1].x, dx[et][1], F[q][1].x) + fmaf(S[q][2].x, dx[et][2], F[q][2].x);
+        z[1] = fmaf(S[q][0].y, dx[et][0], F[q][0].y) + fmaf(S[q][1].y, dx[et][1], F[q][1].y) + fmaf(S[q][2].y, dx[et][2], F[q][2].y);
+        z[2] = fmaf(S[q][0].z, dx[et][0], F[q][0].z) + fmaf(S[q][1].z, dx[et][1], F[q][1].z) + fmaf(S[q][2].z, dx[et][2], F[q][2].z);
+        z[3] = fmaf(S[q][0].w, dx[et][0], F[q][0].w) + fmaf(S[q][1].w, dx[et][1], F[q][1].w) + fmaf(S[q][2].w, dx[et][2], F[q][2].w);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float zs = z[r] * rr_sigmoid(z[r]);            // SiLU
+          l[et][0] = fmaf(g0v[r], zs, l[et][0]); l[et][1] = fmaf(g1v[r], zs, l[et][1]); l[et][2] = fmaf(g2v[r], zs, l[et][2]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int f = 0; f < 3; ++f) { F[q][f] = Fn[q][f]; S[q][f] = Sn[q][f]; }
+    }
+  }
+#pragma unroll
+  for (int et = 0; et < NAB_ET; ++et) {
+    const float l0 = (rr_sum_g(l[et][0]) + w.bg2[0]) * w.inv_tau, l1 = (rr_sum_g(l[et][1]) + w.bg2[1]) * w.inv_tau;
+    const float l2 = (rr_sum_g(l[et][2]) + w.bg2[2]) * w.inv_tau;
+    const float m = fmaxf(l0, fmaxf(l1, l2));
+    const float e0x = rr_exp(l0 - m), e1x = rr_exp(l1 - m), e2x = rr_exp(l2 - m);
+    const float inv = 1.0f / (e0x + e1x + e2x);
+    const float bias = (e0x * inv) * ox[et][0] + (e1x * inv) * ox[et][1] + (e2x * inv) * ox[et][2] + w.bo;
+    const int e = e0 + et * 16 + j;
+    if (g == 0 && e < NN) bias_out[(size_t)(b * 2 + is_col) * NN + e] = bias * w.alpha;
+  }
+}
+
 extern "C" int rr_nab_dur(const NabDurW* wrow, const NabDurW* wcol, const float* D, const float* T, const float* locs,
                           float* bias_out, int Bp, int N, hipStream_t st) {
   if (Bp <= 0 || N < 2 || wrow == nullptr || wcol == nullptr) return RR_EINVAL;
   const int per_wg = 4 * 16 * NAB_ET;
   dim3 grid((N * N + per_wg - 1) / per_wg, Bp, 2), blk(256);
-  hipLaunchKernelGGL(k_nab_dur, grid, blk, 0, st, *wrow, *wcol, D, T, locs, bias_out, N);
+  static const int variant = [] { const char* e = getenv("RR_NABDUR_VARIANT"); return e ? atoi(e) : 1; }();
+  if (variant == 1 && wrow->pwl != nullptr && wcol->pwl != nullptr)
+    hipLaunchKernelGGL(k_nab_dur_pwl, grid, blk, 0, st, *wrow, *wcol, D, T, locs, bias_out, N);
+  else   // MFMA contraction (first generation; kept for A/B)
+    hipLaunchKernelGGL(k_nab_dur, grid, blk, 0, st, *wrow, *wcol, D, T, locs, bias_out, N);
   return rr_check(hipGetLastError());
 }
 

@@ -38,7 +38,8 @@ class DecW(C.Structure):
 
 class NabDurW(C.Structure):
     _fields_ = [(n, vp) for n in ("mp", "ab", "cg", "wg2")] + [("bg2", f32 * 3), ("ko", f32 * 3),
-                                                                ("inv_tau", f32), ("bo", f32), ("alpha", f32)]
+                                                                ("inv_tau", f32), ("bo", f32), ("alpha", f32),
+                                                                ("pwl", vp)]
 
 
 class NabSimpleW(C.Structure):
