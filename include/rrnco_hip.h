@@ -56,6 +56,11 @@ typedef struct {                /* arguments of the persistent rollout: see csrc
   int64_t *actions; float *logp, *logits_out; const int64_t *actions_in; int *steps_out;
   int Bp, N, S, T, t0, nsteps, mode, use_placeholder, set_first, write_state, logits_only, stagger;
   float tanh_clip, temperature; unsigned long long seed;
+  /* MTVRP variants, decoder context only (env_embeddings/context.py:51-70); NULL = vrptw preset.  The fused env.step of the
+   * rollout covers the vrptw preset; with these set the caller runs one decoder.forward per launch (logits_only). */
+  const float *used_b;          /* [R] used_capacity_backhaul */
+  const uint8_t *open_route;    /* [Bp] */
+  const float *dist_limit;      /* [Bp] */
 } RolloutIO;
 
 /* ATSPEnv._reset / RCVRPEnv._reset / RMTVRPEnv._reset min-max normalisation
@@ -74,7 +79,8 @@ int rr_rcvrp_step(const int64_t* action, const float* demand, const float* vcap,
 /* _get_reward: mode 0 closed tour (rrnco/envs/atsp/env.py:192-211), mode 1 depot-prefixed route list
  * (rrnco/envs/rcvrp/env.py:197-219, rmtvrp/env.py:430-455).  norm_out = -sum, real_out de-normalised. */
 int rr_tour_cost(const float* D, const int64_t* actions, const float* mn, const float* mx, float* norm_out,
-                 float* real_out, int R, int Bp, int N, int T, int mode, hipStream_t stream);
+                 float* real_out, int R, int Bp, int N, int T, int mode, const uint8_t* open_route /* [Bp] or NULL:
+                 rmtvrp/env.py:433 zeroes the arcs into the depot of open routes */, hipStream_t stream);
 
 /* process_logits + Greedy/Sampling/Evaluate._step + logp gather (rrnco/models/decoding.py:311-361, 272-298, 266).
  * mode 0 greedy, 1 sampling (Gumbel-max on a counter-based generator), 2 evaluate (action_in).
@@ -109,10 +115,20 @@ typedef struct {
 int rr_nab_simple(const NabSimpleW* wrow, const NabSimpleW* wcol, int kind, const float* D, const float* T,
                   const float* locs, float* bias_out, int Bp, int N, hipStream_t stream);
 
-/* RMTVRPEnv._step + get_action_mask under the vrptw preset (rrnco/envs/rmtvrp/env.py:155-215, 343-428). */
+/* RMTVRPEnv._step + get_action_mask (rrnco/envs/rmtvrp/env.py:155-215, 343-428).  extra == NULL evaluates the vrptw
+ * preset (linehaul demands, time windows, closed routes); with extra the backhaul (classes 1 / 2), open-route and
+ * distance-limit terms of the multi-task env are active. */
+typedef struct {
+  const float* demand_b;        /* [Bp][N] demand_backhaul incl. the depot zero */
+  float* used_b;                /* [R] used_capacity_backhaul, updated */
+  const uint8_t* open_route;    /* [Bp] */
+  const float* dist_limit;      /* [Bp], +inf = none */
+  const int32_t* bclass;        /* [Bp] backhaul class 1 or 2 */
+} MtvrpExtra;
 int rr_rmtvrp_step(const int64_t* action, const float* D, const float* T, const float* demand_l, const float* tw,
                    const float* service, const float* vcap, int64_t* cur, float* ctime, float* rlen, float* used_l,
-                   uint8_t* visited, uint8_t* mask, uint8_t* done, int R, int Bp, int N, hipStream_t stream);
+                   uint8_t* visited, uint8_t* mask, uint8_t* done, int R, int Bp, int N, const MtvrpExtra* extra,
+                   hipStream_t stream);
 
 /* kind 0: ATSPInitEmbedding.forward (rrnco/models/env_embeddings/atsp.py:69-91);
  * kind 1: RVRPInitEmbedding._embed_with_distance (rcvrp.py:88-102; rcvrptw.py with F=4), node 0 = depot,

@@ -767,6 +767,23 @@ def rcvrptw_synthetic(batch: int, n: int, seed: int, max_time: float = 4.6) -> d
             "time_windows": tw, "service_time": service}
 
 
+def rmtvrp_variant_synthetic(batch: int, n: int, seed: int) -> dict:
+    """A mixed-variant MTVRP batch on top of rcvrptw_synthetic: about a quarter of the customers are backhauls, backhaul
+    class 1 (classical) or 2 (mixed) per instance, open routes on some instances, a finite distance limit on some (>= 2.2 on
+    the normalised matrix, so every customer can be served on a route of its own)."""
+    inst = rcvrptw_synthetic(batch, n, seed)
+    g = torch.Generator().manual_seed(seed + 7919)
+    back = torch.rand(batch, n, generator=g) < 0.25
+    dem = inst["demand_linehaul"]
+    inst["demand_backhaul"] = torch.where(back, dem, torch.zeros_like(dem))
+    inst["demand_linehaul"] = torch.where(back, torch.zeros_like(dem), dem)
+    inst["backhaul_class"] = torch.randint(1, 3, (batch, 1), generator=g).to(torch.int32)
+    inst["open_route"] = torch.rand(batch, 1, generator=g) < 0.5
+    lim = 2.2 + 1.3 * torch.rand(batch, 1, generator=g)
+    inst["distance_limit"] = torch.where(torch.rand(batch, 1, generator=g) < 0.5, lim, torch.full_like(lim, float("inf")))
+    return inst
+
+
 def rmtvrp_action_mask(td: dict) -> Tensor:
     """rmtvrp/env.py:343-428 (all 16-variant terms computed; O/L/B/MB are inert under the vrptw preset)."""
     cur = td["current_node"]
@@ -808,9 +825,12 @@ def rmtvrp_reset(td: dict, normalize: bool = True) -> dict:
     speed = torch.ones_like(dl[..., :1])
     out.update(
         locs=td["locs"], distance_matrix=D, duration_matrix=td.get("duration_matrix", D / speed[:, None]),
-        demand_backhaul=db, demand_linehaul=dl, backhaul_class=torch.full((B, 1), 1, dtype=torch.int32),
-        distance_limit=torch.full_like(dl[..., :1], float("inf")), service_time=td["service_time"],
-        open_route=torch.zeros_like(dl[..., :1], dtype=torch.bool), time_windows=td["time_windows"], speed=speed,
+        demand_backhaul=db, demand_linehaul=dl,
+        backhaul_class=td.get("backhaul_class", torch.full((B, 1), 1, dtype=torch.int32)),                # env.py:236-243
+        distance_limit=td.get("distance_limit", torch.full_like(dl[..., :1], float("inf"))),             # :254-257
+        service_time=td["service_time"],
+        open_route=td.get("open_route", torch.zeros_like(dl[..., :1], dtype=torch.bool)),                # :249-252
+        time_windows=td["time_windows"], speed=speed,
         vehicle_capacity=torch.ones_like(dl[..., :1]), capacity_original=torch.ones_like(dl[..., :1]),
         current_node=torch.zeros(B, dtype=torch.long), current_route_length=torch.zeros(B, 1),
         current_time=torch.zeros(B, 1), used_capacity_backhaul=torch.zeros(B, 1), used_capacity_linehaul=torch.zeros(B, 1),
@@ -913,8 +933,10 @@ def rcvrptw_policy(w: W, td0: dict, sidx: Tensor, num_starts: int, decode: str =
     logprobs, actions_out = torch.stack(lps, 1), torch.stack(acts, 1)
     R = actions_out.shape[0]
     ix = torch.arange(R) % B
-    rtd = {"distance_matrix": td0["distance_matrix"][ix], "min_distance": td0["min_distance"][ix], "max_distance": td0["max_distance"][ix]}
-    real, nd = vrp_reward(rtd, actions_out, True)      # rmtvrp/env.py:430-455 (closed routes: the open-route zeroing is inert)
+    Dr = td0["distance_matrix"].clone()
+    Dr[:, :, 0] = Dr[:, :, 0] * ~td0["open_route"]     # rmtvrp/env.py:430-434: arcs into the depot are free on open routes
+    rtd = {"distance_matrix": Dr[ix], "min_distance": td0["min_distance"][ix], "max_distance": td0["max_distance"][ix]}
+    real, nd = vrp_reward(rtd, actions_out, True)      # rmtvrp/env.py:435-455
     return {"reward": real, "normalized_reward": nd, "log_likelihood": logprobs.sum(1), "actions": actions_out,
             "logprobs": logprobs}
 

@@ -170,7 +170,7 @@ extern "C" int rr_rcvrp_step(const int64_t* action, const float* demand, const f
 __global__ __launch_bounds__(256) void k_tour_cost(const float* __restrict__ D, const int64_t* __restrict__ actions,
                                                    const float* __restrict__ mn, const float* __restrict__ mx,
                                                    float* __restrict__ norm_out, float* __restrict__ real_out,
-                                                   int R, int Bp, int N, int T, int mode) {
+                                                   int R, int Bp, int N, int T, int mode, const uint8_t* __restrict__ open_route) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= R) return;
@@ -185,10 +185,12 @@ __global__ __launch_bounds__(256) void k_tour_cost(const float* __restrict__ D, 
     }
   } else {
     // edges: (0 -> a_0), (a_t -> a_{t+1}), (a_{T-1} -> 0)
+    // rmtvrp/env.py:430-434: on an open route every arc INTO the depot is free (column 0 of the cost matrix is zeroed)
+    const bool open = open_route != nullptr && open_route[b] != 0;
     for (int t = lane; t <= T; t += 64) {
       int u = t == 0 ? 0 : (int)act[t - 1];
       int v = t == T ? 0 : (int)act[t];
-      s += Db[u * N + v];
+      s += (open && v == 0) ? 0.f : Db[u * N + v];
     }
   }
   s = rr_wave_sum(s);
@@ -201,9 +203,11 @@ __global__ __launch_bounds__(256) void k_tour_cost(const float* __restrict__ D, 
 }
 
 extern "C" int rr_tour_cost(const float* D, const int64_t* actions, const float* mn, const float* mx,
-                            float* norm_out, float* real_out, int R, int Bp, int N, int T, int mode, hipStream_t st) {
+                            float* norm_out, float* real_out, int R, int Bp, int N, int T, int mode,
+                            const uint8_t* open_route, hipStream_t st) {
   if (R <= 0 || N <= 0 || T <= 0 || Bp <= 0) return RR_EINVAL;
-  hipLaunchKernelGGL(k_tour_cost, dim3((R + 3) / 4), dim3(256), 0, st, D, actions, mn, mx, norm_out, real_out, R, Bp, N, T, mode);
+  hipLaunchKernelGGL(k_tour_cost, dim3((R + 3) / 4), dim3(256), 0, st, D, actions, mn, mx, norm_out, real_out, R, Bp, N, T, mode,
+                     open_route);
   return rr_check(hipGetLastError());
 }
 
@@ -377,6 +381,15 @@ extern "C" int rr_select(const float* logits, const uint8_t* mask, const int64_t
 // zero, routes closed, no distance limit, backhaul class 1 — those terms are inert and not evaluated.
 // One wave per rollout; rollout r uses instance r % Bp; N counts the depot.
 // ------------------------------------------------------------------------------------------------
+// Optional per-variant data of the multi-task VRP (backhauls B / MB, open routes O, distance limits L); NULL = vrptw preset.
+struct MtvrpExtra {
+  const float* demand_b;      // [Bp][N] demand_backhaul incl. the depot zero
+  float* used_b;              // [R] used_capacity_backhaul (updated)
+  const uint8_t* open_route;  // [Bp]
+  const float* dist_limit;    // [Bp] (+inf = none)
+  const int32_t* bclass;      // [Bp] backhaul class 1 (classical) / 2 (mixed)
+};
+
 __global__ __launch_bounds__(256) void k_rmtvrp_step(const int64_t* __restrict__ action, const float* __restrict__ D,
                                                      const float* __restrict__ T, const float* __restrict__ dem_l,
                                                      const float* __restrict__ tw, const float* __restrict__ service,
@@ -384,7 +397,7 @@ __global__ __launch_bounds__(256) void k_rmtvrp_step(const int64_t* __restrict__
                                                      float* __restrict__ ctime, float* __restrict__ rlen,
                                                      float* __restrict__ used_l, uint8_t* __restrict__ visited,
                                                      uint8_t* __restrict__ mask, uint8_t* __restrict__ done,
-                                                     int R, int Bp, int N) {
+                                                     int R, int Bp, int N, MtvrpExtra ex, int has_ex) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= R) return;
@@ -394,12 +407,18 @@ __global__ __launch_bounds__(256) void k_rmtvrp_step(const int64_t* __restrict__
   const float* twb = tw + (size_t)b * N * 2;
   const float* svb = service + (size_t)b * N;
   const float* dl = dem_l + (size_t)b * N;
+  const float* db = has_ex ? ex.demand_b + (size_t)b * N : nullptr;
   const int prev = (int)cur_io[r], a = (int)action[r];
   const float nz = a != 0 ? 1.0f : 0.0f;
-  const float t1 = nz * (fmaxf(ctime[r] + Tb[prev * N + a], twb[a * 2]) + svb[a]);
-  const float len1 = nz * (rlen[r] + Db[prev * N + a]);
-  const float u1 = nz * (used_l[r] + dl[a]);
+  const float t1 = nz * (fmaxf(ctime[r] + Tb[prev * N + a], twb[a * 2]) + svb[a]);      // env.py:170-172
+  const float len1 = nz * (rlen[r] + Db[prev * N + a]);                                // :175-177
+  const float u1 = nz * (used_l[r] + dl[a]);                                           // :189-191
+  const float ub1 = has_ex ? nz * (ex.used_b[r] + db[a]) : 0.f;                        // :192-194
   const float cap = vcap[r], late0 = twb[1];
+  const float closed = (has_ex && ex.open_route[b]) ? 0.f : 1.f;                       // `* ~open_route`
+  const float limit = has_ex ? ex.dist_limit[b] : INFINITY;
+  const int bclass = has_ex ? ex.bclass[b] : 1;
+  const bool carrying_b = has_ex && db[a] > 0.f;                                       // :388-396
   uint8_t* vis = visited + (size_t)r * N;
   uint8_t* mk = mask + (size_t)r * N;
   int nvis = 0, missing = 0;
@@ -408,7 +427,7 @@ __global__ __launch_bounds__(256) void k_rmtvrp_step(const int64_t* __restrict__
     if (k == a) v = 1;
     vis[k] = v;
     nvis += (v != 0);
-    missing |= (v == 0 && dl[k] > 0.f);
+    missing |= (v == 0 && dl[k] > 0.f);                                                // linehauls_missing :384-386
   }
   nvis = (int)rr_wave_sum((float)nvis);
   missing = __any(missing);
@@ -416,16 +435,22 @@ __global__ __launch_bounds__(256) void k_rmtvrp_step(const int64_t* __restrict__
   for (int k = lane; k < N; k += 64) {
     const bool v = vis[k] != 0;
     const float arrival = t1 + Tb[a * N + k];
-    const bool reach = arrival < twb[k * 2 + 1];
-    const bool back = (fmaxf(arrival, twb[k * 2]) + svb[k] + Tb[k * N]) < late0;
-    const bool capok = !(dl[k] + u1 > cap) && dl[k] > 0.f;
-    const bool can = missing && reach && back && capok && !v;
+    const bool reach = arrival < twb[k * 2 + 1];                                       // :361
+    const bool back = ((fmaxf(arrival, twb[k * 2]) + svb[k] + Tb[k * N]) * closed) < late0;          // :364-366
+    const bool far = (len1 + Db[a * N + k] + Db[k * N] * closed) > limit;              // :369-372
+    const float dlk = dl[k], dbk = has_ex ? db[k] : 0.f;
+    const bool ex_l = dlk + u1 > cap, ex_b = dbk + ub1 > cap;                          // :375-380
+    const bool ok1 = (missing && !ex_l && !carrying_b && dlk > 0.f) || (!ex_b && dbk > 0.f);         // :397-402
+    const bool ok2 = !ex_l && !ex_b && !(dlk > cap - ub1);                             // :407-412
+    const bool ok = bclass == 1 ? ok1 : (bclass == 2 ? ok2 : false);                   // :415-417
+    const bool can = reach && back && ok && !far && !v;                                // :420-426
     if (k >= 1) { mk[k] = can; nfree += can; }
   }
   nfree = (int)rr_wave_sum((float)nfree);
   if (lane == 0) {
-    mk[0] = !((a == 0) && nfree > 0);
+    mk[0] = !((a == 0) && nfree > 0);                                                  // :429
     cur_io[r] = a; ctime[r] = t1; rlen[r] = len1; used_l[r] = u1;
+    if (has_ex) ex.used_b[r] = ub1;
     done[r] = (nvis == N);
   }
 }
@@ -433,10 +458,15 @@ __global__ __launch_bounds__(256) void k_rmtvrp_step(const int64_t* __restrict__
 extern "C" int rr_rmtvrp_step(const int64_t* action, const float* D, const float* T, const float* demand_l,
                               const float* tw, const float* service, const float* vcap, int64_t* cur, float* ctime,
                               float* rlen, float* used_l, uint8_t* visited, uint8_t* mask, uint8_t* done,
-                              int R, int Bp, int N, hipStream_t st) {
+                              int R, int Bp, int N, const MtvrpExtra* extra, hipStream_t st) {
   if (R <= 0 || N < 2 || Bp <= 0) return RR_EINVAL;
+  MtvrpExtra ex = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (extra != nullptr) {
+    ex = *extra;
+    if (!ex.demand_b || !ex.used_b || !ex.open_route || !ex.dist_limit || !ex.bclass) return RR_EINVAL;
+  }
   hipLaunchKernelGGL(k_rmtvrp_step, dim3((R + 3) / 4), dim3(256), 0, st, action, D, T, demand_l, tw, service, vcap, cur,
-                     ctime, rlen, used_l, visited, mask, done, R, Bp, N);
+                     ctime, rlen, used_l, visited, mask, done, R, Bp, N, ex, extra != nullptr ? 1 : 0);
   return rr_check(hipGetLastError());
 }
 

@@ -52,20 +52,24 @@ class RolloutIO(C.Structure):
         "vcap", "ctime", "rlen", "done", "actions", "logp", "logits_out", "actions_in", "steps_out")] + \
         [(n, i32) for n in ("Bp", "N", "S", "T", "t0", "nsteps", "mode", "use_placeholder", "set_first",
                             "write_state", "logits_only", "stagger")] + \
-        [("tanh_clip", f32), ("temperature", f32), ("seed", u64)]
+        [("tanh_clip", f32), ("temperature", f32), ("seed", u64)] + [(n, vp) for n in ("used_b", "open_route", "dist_limit")]
+
+
+class MtvrpExtra(C.Structure):
+    _fields_ = [(n, vp) for n in ("demand_b", "used_b", "open_route", "dist_limit", "bclass")]
 
 
 _SIGS = {
     "rr_minmax_normalize": [vp, vp, vp, vp, i32, i32, vp],
     "rr_atsp_step": [vp, vp, vp, vp, i32, i32, vp],
     "rr_rcvrp_step": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
-    "rr_tour_cost": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "rr_tour_cost": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp],
     "rr_select": [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, u64, u32, i32, f32, vp],
     "rr_enc_layer": [C.POINTER(EncBlockW), C.POINTER(EncBlockW), vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp],
     "rr_edge_angles": [vp, vp, i32, i32, vp],
     "rr_nab_dur": [C.POINTER(NabDurW), C.POINTER(NabDurW), vp, vp, vp, vp, i32, i32, vp],
     "rr_nab_simple": [C.POINTER(NabSimpleW), C.POINTER(NabSimpleW), i32, vp, vp, vp, vp, i32, i32, vp],
-    "rr_rmtvrp_step": [vp] * 14 + [i32, i32, i32, vp],
+    "rr_rmtvrp_step": [vp] * 14 + [i32, i32, i32, C.POINTER(MtvrpExtra), vp],
     "rr_reinforce_loss": [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "rr_init_embed": [C.POINTER(InitW), i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "rr_dec_cache": [C.POINTER(CacheW), vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],

@@ -99,7 +99,7 @@ class ATSPEnv(EnvBase):
         mn = td["min_distance"].contiguous() if self.normalize else None
         mx = td["max_distance"].contiguous() if self.normalize else None
         L.check(L.lib().rr_tour_cost(L.ptr(D), L.ptr(actions), L.ptr(mn), L.ptr(mx), L.ptr(nd), L.ptr(real),
-                                     R, Bp, n, T, 0, L.stream()), "rr_tour_cost")
+                                     R, Bp, n, T, 0, None, L.stream()), "rr_tour_cost")
         return (real, nd) if self.normalize else nd
 
     @staticmethod

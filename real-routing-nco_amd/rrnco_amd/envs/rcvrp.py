@@ -106,7 +106,7 @@ class RCVRPEnv(EnvBase):
         mn = td["min_distance"].contiguous() if self.normalize else None
         mx = td["max_distance"].contiguous() if self.normalize else None
         L.check(L.lib().rr_tour_cost(L.ptr(D), L.ptr(actions), L.ptr(mn), L.ptr(mx), L.ptr(nd), L.ptr(real),
-                                     R, D.shape[0], D.shape[-1], T, 1, L.stream()), "rr_tour_cost")
+                                     R, D.shape[0], D.shape[-1], T, 1, None, L.stream()), "rr_tour_cost")
         return (real, nd) if self.normalize else nd
 
     @staticmethod

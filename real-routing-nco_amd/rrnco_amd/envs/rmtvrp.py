@@ -1,6 +1,9 @@
-"""RCVRPTW environment — drop-in for rrnco.envs.rmtvrp.RMTVRPEnv with `variant_preset: vrptw`
-(rrnco/envs/rmtvrp/env.py, configs/env/rcvrptw.yaml).  The HIP kernels evaluate the vrptw preset: linehaul demands,
-time windows, closed routes; instances carrying backhauls / open routes / distance limits are rejected."""
+"""RCVRPTW environment — drop-in for rrnco.envs.rmtvrp.RMTVRPEnv (rrnco/envs/rmtvrp/env.py, configs/env/rcvrptw.yaml).
+
+The vrptw preset (linehaul demands, time windows, closed routes: BASELINE configs[3]) runs on the fused rollout kernel.
+Instances that carry the other multi-task features — backhauls (classes 1 / 2), open routes, distance limits — are
+evaluated by the general step kernel (rr_rmtvrp_step with MtvrpExtra) in the step-wise decode loop; `td.meta["mtvrp_variant"]`
+tells the policy which path applies."""
 from __future__ import annotations
 
 import torch
@@ -68,10 +71,6 @@ class RMTVRPEnv(EnvBase):
 
     def _reset(self, td, batch_size=None) -> TensorDict:
         """env.py:217-341."""
-        for k, bad in (("demand_backhaul", lambda v: bool((v != 0).any())), ("open_route", lambda v: bool(v.any())),
-                       ("distance_limit", lambda v: bool(torch.isfinite(v).any()))):
-            if k in td and bad(td[k]):
-                raise NotImplementedError(f"rrnco_amd RMTVRPEnv evaluates the vrptw preset only ('{k}' is set)")
         L.require_gpu(td["locs"])
         dev, B = td["locs"].device, td["locs"].shape[0]
         dl = torch.cat([torch.zeros_like(td["demand_linehaul"][..., :1]), td["demand_linehaul"]], dim=1)
@@ -86,15 +85,23 @@ class RMTVRPEnv(EnvBase):
             D = norm
             out.update(min_distance=mn, max_distance=mx)
         ones = torch.ones_like(dl[..., :1])
+        # env.py:225-257: optional multi-task features with their defaults
+        db = td.get("demand_backhaul", None)
+        db = torch.zeros_like(dl) if db is None else torch.cat([torch.zeros_like(dl[..., :1]), db.float()], dim=1)
+        bclass = td.get("backhaul_class", None)
+        bclass = torch.full((*batch_size, 1), 1, dtype=torch.int32, device=dev) if bclass is None else bclass.to(torch.int32).reshape(-1, 1)
+        limit = td.get("distance_limit", None)
+        limit = torch.full_like(ones, float("inf")) if limit is None else limit.float().reshape(-1, 1)
+        open_route = td.get("open_route", None)
+        open_route = torch.zeros_like(ones, dtype=torch.bool) if open_route is None else open_route.bool().reshape(-1, 1)
+        variant = bool((db != 0).any() or open_route.any() or torch.isfinite(limit).any() or (bclass != 1).any())
         tw = td.get("time_windows", None)
         if tw is None:
             tw = torch.zeros_like(td["locs"]); tw[..., 1] = float("inf")
         out.update(
             locs=td["locs"], distance_matrix=D, duration_matrix=td["duration_matrix"] if "duration_matrix" in td else D / ones[:, None],
-            demand_backhaul=torch.zeros_like(dl), demand_linehaul=dl,
-            backhaul_class=torch.full((*batch_size, 1), 1, dtype=torch.int32, device=dev),
-            distance_limit=torch.full_like(ones, float("inf")), service_time=td.get("service_time", torch.zeros_like(dl)),
-            open_route=torch.zeros_like(ones, dtype=torch.bool), time_windows=tw, speed=ones.clone(),
+            demand_backhaul=db, demand_linehaul=dl, backhaul_class=bclass, distance_limit=limit,
+            service_time=td.get("service_time", torch.zeros_like(dl)), open_route=open_route, time_windows=tw, speed=ones.clone(),
             vehicle_capacity=ones.clone(), capacity_original=ones.clone(),
             current_node=torch.zeros((*batch_size,), dtype=torch.long, device=dev),
             current_route_length=torch.zeros((*batch_size, 1), device=dev), current_time=torch.zeros((*batch_size, 1), device=dev),
@@ -103,7 +110,7 @@ class RMTVRPEnv(EnvBase):
             visited=torch.zeros((*batch_size, n1), dtype=torch.bool, device=dev))
         if td.get("sample_idx", None) is not None:
             out["sample_idx"] = td["sample_idx"]
-        res = TensorDict(out, batch_size=batch_size, meta={"i": 0})
+        res = TensorDict(out, batch_size=batch_size, meta={"i": 0, "mtvrp_variant": variant})
         res.set("action_mask", self.get_action_mask(res))
         return res
 
@@ -116,15 +123,23 @@ class RMTVRPEnv(EnvBase):
         R = cur.shape[0]
         bi = torch.arange(R, device=cur.device)
         D, T = ex(td["distance_matrix"]), ex(td["duration_matrix"])
-        tw, sv, dl = ex(td["time_windows"]), ex(td["service_time"]), ex(td["demand_linehaul"])
+        tw, sv, dl, db = ex(td["time_windows"]), ex(td["service_time"]), ex(td["demand_linehaul"]), ex(td["demand_backhaul"])
+        opn, limit, bclass = ex(td["open_route"]), ex(td["distance_limit"]), ex(td["backhaul_class"])
+        dist_ij, dist_j0 = D[bi, cur, :], D[:, :, 0]
         dur_ij, dur_j0 = T[bi, cur, :], T[:, :, 0]
         early, late = tw[..., 0], tw[..., 1]
         arrival = td["current_time"] + dur_ij
         reach = arrival < late
-        back = (torch.max(arrival, early) + sv + dur_j0) < late[..., 0:1]
+        back = (torch.max(arrival, early) + sv + dur_j0) * ~opn < late[..., 0:1]
+        far = td["current_route_length"] + dist_ij + (dist_j0 * ~opn) > limit
         ex_l = dl + td["used_capacity_linehaul"] > td["vehicle_capacity"]
+        ex_b = db + td["used_capacity_backhaul"] > td["vehicle_capacity"]
         missing = ((dl * ~td["visited"]).sum(-1) > 0)[..., None]
-        can = reach & back & (missing & ~ex_l & (dl > 0)) & ~td["visited"]
+        carrying_b = db.gather(1, cur[:, None]) > 0
+        ok1 = (missing & ~ex_l & ~carrying_b & (dl > 0)) | (~ex_b & (db > 0))
+        ok2 = ~ex_l & ~ex_b & ~(dl > td["vehicle_capacity"] - td["used_capacity_backhaul"])
+        ok = ((bclass == 1) & ok1) | ((bclass == 2) & ok2)
+        can = reach & back & ok & ~far & ~td["visited"]
         can[:, 0] = ~((cur == 0) & (can[:, 1:].sum(-1) > 0))
         return can
 
@@ -142,17 +157,27 @@ class RMTVRPEnv(EnvBase):
         used, vis = td["used_capacity_linehaul"].contiguous().clone(), td["visited"].contiguous().clone()
         mask = torch.empty(R, vis.shape[-1], dtype=torch.bool, device=action.device)
         done = torch.empty(R, dtype=torch.bool, device=action.device)
+        extra, keep = None, None
+        used_b = td["used_capacity_backhaul"]
+        if td.meta.get("mtvrp_variant", False):
+            used_b = used_b.contiguous().clone()
+            keep = (td["demand_backhaul"].float().contiguous(), td["open_route"].reshape(-1).to(torch.uint8).contiguous(),
+                    td["distance_limit"].float().reshape(-1).contiguous(), td["backhaul_class"].reshape(-1).to(torch.int32).contiguous())
+            extra = L.MtvrpExtra()
+            extra.demand_b, extra.used_b = L.ptr(keep[0]), L.ptr(used_b)
+            extra.open_route, extra.dist_limit, extra.bclass = L.ptr(keep[1]), L.ptr(keep[2]), L.ptr(keep[3])
         L.check(L.lib().rr_rmtvrp_step(L.ptr(action), L.ptr(D), L.ptr(T), L.ptr(dl), L.ptr(tw), L.ptr(sv), L.ptr(vcap),
                                        L.ptr(cur), L.ptr(ctime), L.ptr(rlen), L.ptr(used), L.ptr(vis), L.ptr(mask),
-                                       L.ptr(done), R, D.shape[0], D.shape[-1], L.stream()), "rr_rmtvrp_step")
+                                       L.ptr(done), R, D.shape[0], D.shape[-1], extra, L.stream()), "rr_rmtvrp_step")
         td.update({"current_node": cur, "current_route_length": rlen, "current_time": ctime, "done": done,
-                   "reward": torch.zeros(R, device=action.device), "used_capacity_linehaul": used, "visited": vis,
-                   "action_mask": mask})
+                   "reward": torch.zeros(R, device=action.device), "used_capacity_linehaul": used,
+                   "used_capacity_backhaul": used_b, "visited": vis, "action_mask": mask})
         td.meta["i"] = td.meta.get("i", 0) + 1
         return td
 
     def _get_reward(self, td, actions):
-        """env.py:430-455 (closed routes: the open-route zeroing of column 0 is inert)."""
+        """env.py:430-455; on open routes the arcs into the depot cost nothing (:433, done inside the kernel instead of
+        overwriting column 0 of the caller's matrix)."""
         D = td["distance_matrix"].contiguous()
         actions = actions.contiguous()
         R, T = actions.shape
@@ -160,8 +185,9 @@ class RMTVRPEnv(EnvBase):
         real = torch.empty_like(nd)
         mn = td["min_distance"].contiguous() if self.normalize else None
         mx = td["max_distance"].contiguous() if self.normalize else None
+        opn = td["open_route"].reshape(-1).to(torch.uint8).contiguous() if td.meta.get("mtvrp_variant", False) else None
         L.check(L.lib().rr_tour_cost(L.ptr(D), L.ptr(actions), L.ptr(mn), L.ptr(mx), L.ptr(nd), L.ptr(real),
-                                     R, D.shape[0], D.shape[-1], T, 1, L.stream()), "rr_tour_cost")
+                                     R, D.shape[0], D.shape[-1], T, 1, L.ptr(opn), L.stream()), "rr_tour_cost")
         return (real, nd) if self.normalize else nd
 
     @staticmethod

@@ -76,4 +76,6 @@ def rcvrptw_weights(fx):
 
 
 def rcvrptw_instance(fx):
-    return {k: fx[k] for k in ("locs", "distance_matrix", "duration_matrix", "demand_linehaul", "time_windows", "service_time")}
+    keys = ("locs", "distance_matrix", "duration_matrix", "demand_linehaul", "time_windows", "service_time")
+    opt = ("demand_backhaul", "backhaul_class", "open_route", "distance_limit")            # multi-task variants
+    return {k: fx[k] for k in keys + tuple(o for o in opt if o in fx)}

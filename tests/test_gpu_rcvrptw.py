@@ -48,11 +48,60 @@ def test_rmtvrp_env_step_and_time_window_mask_match_oracle():
     assert torch.allclose(real.cpu(), fx["reward"], atol=COST_ATOL)
 
 
-def test_rmtvrp_rejects_variants_outside_the_vrptw_preset():
-    fx, w, pol, inst, env, td_in = _setup("rcvrptw_n20_b4_greedy")
-    td_in["open_route"] = torch.ones(fx["B"], 1, dtype=torch.bool, device="cuda")
-    with pytest.raises(NotImplementedError):
-        env.reset(td_in)
+VARIANTS = "rmtvrp_n20_b8_pomo_variants"     # backhauls (classes 1 and 2), open routes, distance limits, mixed per instance
+
+
+def test_rmtvrp_variant_env_step_and_masks_bit_exact_vs_oracle():
+    """rmtvrp/env.py:155-215, 343-428 beyond the vrptw preset (rr_rmtvrp_step with MtvrpExtra) along the reference's tours."""
+    from rrnco_amd.ops import batchify
+    fx, w, pol, inst, env, td_in = _setup(VARIANTS)
+    assert bool(fx["open_route"].any()) and bool(torch.isfinite(fx["distance_limit"]).any()) and bool((fx["demand_backhaul"] > 0).any())
+    assert set(fx["backhaul_class"].flatten().tolist()) == {1, 2}
+    S = fx["S"]
+    td0 = env.reset(td_in)
+    assert td0.meta["mtvrp_variant"] is True
+    o0 = restate.rmtvrp_reset(inst)
+    assert torch.equal(td0["action_mask"].cpu(), o0["action_mask"])
+    td = batchify(td0, S)
+    otd = restate.batchify_state({k: v for k, v in o0.items() if k not in ("locs", "min_distance", "max_distance")}, S)
+    for t in range(fx["actions"].shape[1]):
+        a = fx["actions"][:, t]
+        td.set("action", a.cuda()); td = env.step(td)["next"]
+        otd["action"] = a; otd = restate.rmtvrp_step(otd)
+        assert torch.equal(td["action_mask"].cpu(), otd["action_mask"]), t
+        assert torch.equal(td["visited"].cpu(), otd["visited"]) and torch.equal(td["done"].cpu(), otd["done"])
+        for k in ("current_time", "used_capacity_linehaul", "used_capacity_backhaul", "current_route_length"):
+            assert torch.equal(td[k].cpu(), otd[k]), (k, t)
+    assert td["done"].all()
+    real, nd = env.get_reward(td, fx["actions"].cuda())                    # open routes: arcs into the depot are free
+    assert torch.allclose(real.cpu(), fx["reward"], atol=COST_ATOL) and torch.allclose(nd.cpu(), fx["normalized_reward"], atol=COST_ATOL)
+
+
+def test_rmtvrp_variant_policy_routes_match_reference():
+    """Greedy multistart decode on the mixed-variant batch: the policy leaves the fused rollout by itself (general step
+    kernel, MTVRP context with open-route flag / remaining distance / backhaul load) and reproduces the reference's tours."""
+    fx, w, pol, inst, env, td_in = _setup(VARIANTS)
+    S = fx["S"]
+    out = pol(env.reset(td_in), env, phase="val", decode_type="multistart_greedy", num_starts=S, return_actions=True)
+    acts = out["actions"].cpu()
+    T = min(acts.shape[1], fx["actions"].shape[1])
+    frac, first = H.tour_agreement(acts[:, :T], fx["actions"][:, :T])
+    if frac < 1.0:
+        tr = {}
+        with torch.inference_mode():
+            restate.rcvrptw_policy(w, restate.rmtvrp_reset(inst), fx["sample_idx"], S, "greedy", trace=tr)
+        lp = torch.nan_to_num(torch.stack(tr["logp"], 1), neginf=-1e9).topk(2, -1).values
+        gap = lp[..., 0] - lp[..., 1]
+        for r in torch.nonzero(first >= 0).flatten().tolist():
+            t = int(first[r]) - 1
+            assert t >= gap.shape[1] or gap[r, t] < GAP_TOL
+    assert frac >= 0.97
+    same = first < 0
+    assert torch.allclose(out["reward"].cpu()[same], fx["reward"][same], atol=COST_ATOL)
+    assert torch.allclose(out["log_likelihood"].cpu()[same], fx["log_likelihood"][same], rtol=LL_RTOL, atol=LL_ATOL)
+    # asking for the fused rollout changes nothing: variants are routed to the step-wise loop
+    out_f = pol(env.reset(td_in), env, phase="val", decode_type="multistart_greedy", num_starts=S, return_actions=True, fused=True)
+    assert torch.equal(out_f["actions"], out["actions"])
 
 
 @pytest.mark.parametrize("name", FIXTURES)
