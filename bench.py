@@ -33,15 +33,17 @@ PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: fp32 matrix peak
 ROLLOUT_TRAFFIC_BYTES_DEFAULT = (2 * 1.9710e8 + 4.0036e6) * 1024
 
 
-def make_policy(device):
-    from oracle import restate                      # only for the deterministic random-init weight vectors
+def make_policy(device, seed=1234):
+    """Random-init RRNet of configs/experiment/rrnet.yaml (torch's default layer initialisation under a fixed seed; no
+    checkpoint can be fetched here).  Returns the policy and a CPU copy of its weights — the latter only feeds the
+    cpu_baseline leg, so that the oracle times the very same network."""
     from rrnco_amd.models import RRNetPolicy
-    w = restate.make_weights(restate.atsp_weight_template(128, 6, 512, 25), 1234)
+    torch.manual_seed(seed)
     pol = RRNetPolicy(env_name="atsp", embed_dim=128, num_heads=8, num_encoder_layers=6, normalization="instance",
                       use_graph_context=False, nab_type="gating",
                       init_embedding_kwargs=dict(use_coords=True, use_polar_feats=True, use_dist=True,
                                                  use_matnet_init=False, sample_type="prob", sample_size=25))
-    pol.load_state_dict(w, strict=True)
+    w = {k: v.detach().clone() for k, v in pol.state_dict().items()}
     return pol.to(device).eval(), w
 
 

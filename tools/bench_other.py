@@ -4,7 +4,6 @@ import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "real-routing-nco_amd"))
 import torch
-from oracle import restate
 from rrnco_amd.envs import RCVRPEnv, RMTVRPEnv
 from rrnco_amd.models import RRNetPolicy
 from rrnco_amd.models.encoder import ATSPInitEmbedding
@@ -15,10 +14,10 @@ from rrnco_amd import TensorDict
 dev = torch.device("cuda")
 
 
-def policy(env_name, tmpl):
+def policy(env_name):
+    torch.manual_seed(1234)
     pol = RRNetPolicy(env_name=env_name, embed_dim=128, num_heads=8, num_encoder_layers=6, normalization="instance",
                       use_graph_context=False, nab_type="gating", init_embedding_kwargs=dict(sample_size=25))
-    pol.load_state_dict(restate.make_weights(tmpl, 1234), strict=True)
     return pol.to(dev).eval()
 
 
@@ -50,8 +49,8 @@ def run(name, env, pol, B, S, aug, decode, steps=2):
 
 if __name__ == "__main__":
     env = RCVRPEnv(generator_params=dict(num_loc=100, device=dev), check_solution=False, device=dev)
-    run("C3 RCVRP n=100 B=512 POMO S=101 greedy", env, policy("rcvrp", restate.rcvrp_weight_template()), 512, 101, False, "multistart_greedy")
+    run("C3 RCVRP n=100 B=512 POMO S=101 greedy", env, policy("rcvrp"), 512, 101, False, "multistart_greedy")
     env = RMTVRPEnv(generator_params=dict(num_loc=100, device=dev), device=dev)
-    pol = policy("rcvrptw", restate.rcvrptw_weight_template())
+    pol = policy("rcvrptw")
     run("C4 RCVRPTW n=100 B=256 x8 aug S=100 sampling", env, pol, 256, 100, True, "multistart_sampling")
     run("C4' RCVRPTW n=100 B=256 x8 aug S=100 greedy", env, pol, 256, 100, True, "multistart_greedy")
