@@ -265,3 +265,27 @@ def test_select_kernel_top_k_top_p_filters_match_process_logits(top_k, top_p):
     a = td["action"].cpu()
     assert bool(torch.isfinite(lp[torch.arange(R), a]).all())          # only kept actions are ever drawn
     assert int(a[5]) == 17
+
+
+def test_gumbel_max_sampling_draws_from_the_softmax_distribution():
+    """Sampling (decoding.py:283-298 uses torch.multinomial) is implemented as Gumbel-max on a counter-based generator:
+    over many rollouts the empirical action frequencies must match softmax(masked, clipped logits)."""
+    from rrnco_amd.models.decoding import get_decoding_strategy
+    from rrnco_amd import TensorDict
+    R, N = 400_000, 12
+    g = torch.Generator().manual_seed(0)
+    row = torch.randn(N, generator=g) * 1.5
+    mk_row = torch.ones(N, dtype=torch.bool); mk_row[3] = False
+    lg, mk = row.repeat(R, 1).cuda(), mk_row.repeat(R, 1).cuda()
+    p = restate.process_logits(row[None], mk_row[None], temperature=0.8, tanh_clipping=10.0).exp()[0]
+    strat = get_decoding_strategy("sampling", tanh_clipping=10.0, temperature=0.8, seed=123)
+    a = strat.step(lg, mk, TensorDict({}, batch_size=[R]))["action"].cpu()
+    freq = torch.bincount(a, minlength=N).double() / R
+    assert freq[3] == 0
+    sigma = (p * (1 - p) / R).sqrt().clamp_min(1e-6)
+    assert float(((freq - p).abs() / sigma).max()) < 5.0            # every category within 5 standard errors
+    lp = strat.logprobs[0].cpu()
+    assert torch.allclose(lp, p.log()[a].float(), atol=3e-6)        # the reported log-prob is the chosen action's
+    a2 = get_decoding_strategy("sampling", tanh_clipping=10.0, temperature=0.8, seed=124).step(lg, mk, TensorDict({}, batch_size=[R]))["action"].cpu()
+    # a different seed is an independent stream: two draws differ with probability 1 - sum p^2
+    assert abs(float((a2 != a).float().mean()) - float(1 - (p * p).sum())) < 5e-3
