@@ -96,11 +96,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     dist = world > 1
+    # RR_DIST_BACKEND=gloo lets the multi-process path be exercised on a box with fewer GPUs than ranks (ranks share devices)
+    backend = os.environ.get("RR_DIST_BACKEND", "nccl")
+    local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if dist:
         import torch.distributed as td_
-        td_.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            td_.init_process_group("nccl", device_id=dev)
+        else:
+            td_.init_process_group(backend)
 
     from rrnco_amd.envs import ATSPEnv, ATSPGenerator
     from rrnco_amd.models import rollout as R
@@ -132,7 +138,7 @@ def main():
     kern_ms = [a.elapsed_time(b) for a, b in R.TIMING]
     R.TIMING = None
     from rrnco_amd.parallel import aggregate_throughput
-    total_inst, dt = aggregate_throughput(args.batch * args.steps, dt, dist, dev)
+    total_inst, dt = aggregate_throughput(args.batch * args.steps, dt, dist, dev if backend == "nccl" else torch.device("cpu"))
 
     if rank == 0:
         rollout_steps = args.batch * AUG * STARTS * (N_NODES - 1)

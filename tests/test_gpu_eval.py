@@ -89,3 +89,21 @@ def test_device_sampler_matches_reference_indexing_bit_exact():
     assert td["distance_matrix"].shape == (B, n, n) and float(td["distance_matrix"].max()) <= 1.0
     with pytest.raises(ValueError):
         smp.sample(2, M + 1)
+
+
+def test_bench_multi_process_contract_two_ranks_on_one_gpu(tmp_path):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one JSON line from rank 0, aggregate over ranks),
+    with two ranks sharing this box's GPU over gloo (RR_DIST_BACKEND): exercises barrier / SUM-of-units / MAX-of-time."""
+    import json
+    import subprocess
+    port = 29600 + os.getpid() % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "64"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env={**os.environ, "RR_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                            # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 1 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["unit"] == "instances/s" and out["value"] > 0 and abs(out["value"] * out["ms_per_step"] / 1e3 - 128) < 1e-6 * 128
+    assert out["roofline"]["bound"] == "mfma" and "cpu_baseline" not in out
