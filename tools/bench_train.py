@@ -19,11 +19,17 @@ ap.add_argument("--enc-chunk", type=int, default=512)
 ap.add_argument("--dec-chunk", type=int, default=64)
 args = ap.parse_args()
 world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
+backend = os.environ.get("RR_DIST_BACKEND", "nccl")      # gloo: ranks may share a GPU (single-GPU boxes)
+if backend != "nccl":
+    local = local % max(torch.cuda.device_count(), 1)
 torch.cuda.set_device(local)
 dev = torch.device("cuda", local)
 if world > 1:
     import torch.distributed as dist
-    dist.init_process_group("nccl", device_id=dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(backend)
 pol, w = bench.make_policy(dev)
 pol.train()
 env = ATSPEnv(generator_params=dict(num_loc=100, device=dev), check_solution=False, device=dev)
@@ -40,7 +46,7 @@ for i in range(args.steps):
     out = model.training_step(batches[i + 1], optimizer=opt, world=world, enc_chunk=args.enc_chunk, dec_chunk=args.dec_chunk, seed=2 + i)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-units, tmax = aggregate_throughput(args.batch * args.steps, dt, world > 1, dev)
+units, tmax = aggregate_throughput(args.batch * args.steps, dt, world > 1, dev if backend == "nccl" else torch.device("cpu"))
 if rank == 0:
     print(json.dumps({"config": "C5 ATSP n=100 REINFORCE training step, %d instances/GPU, S=100 sampling, %d GPU(s)" % (args.batch, world),
                       "instances_per_s": units / tmax, "ms_per_step": tmax / args.steps * 1e3, "loss": float(out["loss"]),
