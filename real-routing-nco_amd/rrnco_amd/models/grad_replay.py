@@ -15,7 +15,8 @@ Two things keep the replay cheap:
     d loss / d (folded table) and autograd carries it through the fold to the module parameters.
 Instances are independent (instance norm is per instance), so the encoder runs in instance chunks under activation
 checkpointing and the decoder chunks back-propagate into detached copies of the cache; one backward through the encoder
-graph finishes the job.  ATSP only (the config-5 problem).
+graph finishes the job.  ATSP (the config-5 problem) and RCVRP; RCVRPTW would additionally need the backward of the
+duration NAB.
 """
 from __future__ import annotations
 
@@ -122,9 +123,29 @@ def _init_embedding(P, locs, D, sidx):
     return out[0], out[1]
 
 
-def encode(P, locs, D, sidx, num_layers, use_checkpoint=True):
-    """RRNetEncoder.forward encoder.py:80-112 (atsp) -> row_emb, col_emb [b,N,E]."""
-    row, col = _init_embedding(P, locs, D, sidx)
+def _init_embedding_vrp(P, locs, demand, D, sidx):
+    """RVRPInitEmbedding._embed_with_distance rcvrp.py:88-102 (CoordinateExpert :105-124, DistanceExpert :127-150).
+    locs [b,N+1,2] with the depot first, demand [b,N]."""
+    p = "encoder.init_embedding"
+    depot, cities = locs[:, :1, :], locs[:, 1:, :]
+    c = cities - depot
+    ang = torch.atan2(c[..., 1:], c[..., :1])
+    node = torch.cat([_lin(P, p + ".coord_expert.init_embed_depot", depot),
+                      _lin(P, p + ".coord_expert.init_embed", torch.cat([cities, ang], dim=-1))], dim=-2)
+    rowd = D.gather(2, sidx).sort(dim=-1).values
+    cold = D.transpose(1, 2).gather(2, sidx).sort(dim=-1).values
+    de = _lin(P, p + ".demand_init", torch.cat([torch.zeros_like(demand[:, :1]), demand], dim=1)[..., None])
+    out = []
+    for rc, dist in (("row", _lin(P, p + ".distance_expert.row_embed", rowd)), ("col", _lin(P, p + ".distance_expert.col_embed", cold))):
+        q = f"{p}.gating_network_{rc}.gating_fc"
+        g = torch.sigmoid(_lin(P, q + ".2", F.relu(_lin(P, q + ".0", torch.cat([node, dist], -1)))))
+        out.append(_lin(P, f"{p}.combine_{rc}_embed", torch.cat([g * node + (1 - g) * dist, de], -1)))
+    return out[0], out[1]
+
+
+def encode(P, locs, D, sidx, num_layers, use_checkpoint=True, demand=None):
+    """RRNetEncoder.forward encoder.py:80-112 (atsp; rcvrp when `demand` is given) -> row_emb, col_emb [b,N,E]."""
+    row, col = _init_embedding(P, locs, D, sidx) if demand is None else _init_embedding_vrp(P, locs, demand, D, sidx)
     d = locs.unsqueeze(2) - locs.unsqueeze(1)
     theta = torch.atan2(d[..., 1], d[..., 0])                                # attn_freenet.py:254-262
     Dt = D.transpose(1, 2)
@@ -174,31 +195,89 @@ def decode_log_likelihood(P, row_emb, col_emb, D, actions, tanh_clipping=10.0, t
     return logp.sum(-1)
 
 
+@torch.no_grad()
+def rcvrp_replay_states(demand, actions, cap=1.0):
+    """RCVRPEnv._step / get_action_mask (rcvrp/env.py:90-122, 183-195) replayed along given routes, in the reference's own
+    operation order (the capacity test compares float sums).  demand [b,N], actions [b,S,T] -> remaining capacity [b,S,T-1]
+    and action masks [b,S,T-1,N+1] seen when actions[..., 1:] were chosen."""
+    b, S, T = actions.shape
+    N1 = demand.shape[1] + 1
+    dem0 = torch.cat([torch.zeros_like(demand[:, :1]), demand], 1)             # demand by node id, 0 at the depot
+    dem_s = dem0[:, None, :].expand(b, S, N1)
+    used = torch.zeros(b, S, device=demand.device)
+    visited = torch.zeros(b, S, N1, dtype=torch.bool, device=demand.device)
+    rem, masks = [], []
+    for t in range(T - 1):
+        a = actions[..., t]
+        used = (used + dem_s.gather(2, a[..., None])[..., 0]) * (a != 0).float()
+        visited = visited.scatter(2, a[..., None], True)
+        exceeds = dem_s[..., 1:] + used[..., None] > cap
+        mask_loc = visited[..., 1:] | exceeds
+        mask_depot = (a == 0) & (~mask_loc).any(-1)
+        masks.append(~torch.cat([mask_depot[..., None], mask_loc], -1))
+        rem.append(cap - used)
+    return torch.stack(rem, 2), torch.stack(masks, 2)
+
+
+def decode_log_likelihood_rcvrp(P, row_emb, col_emb, D, demand, actions, tanh_clipping=10.0, temperature=1.0):
+    """Teacher-forced decoder for RCVRP (rl4co VRPContext: Linear(E+1,E)([emb[cur]; capacity - used]); routes of different
+    lengths are padded with depot visits, whose log-probability is 0 once everything is served).  actions [b,S,T]."""
+    b, S, T = actions.shape
+    N1 = row_emb.shape[1]
+    Td = T - 1
+    rem, mask = rcvrp_replay_states(demand, actions)
+    k, v, lk = F.linear(col_emb, P["decoder.project_node_embeddings.weight"]).chunk(3, dim=-1)
+    Wc = P["decoder.context_embedding.project_context.weight"]                  # [E, E+1]
+    ctx_cur = F.linear(row_emb, Wc[:, :E])
+    prev, target = actions[..., :Td], actions[..., 1:]
+    idx = lambda t, i: t.gather(1, i.reshape(b, -1, 1).expand(-1, -1, t.size(-1)))                    # noqa: E731
+    q = idx(ctx_cur, prev).view(b, S, Td, E) + rem[..., None] * Wc[:, E]
+    q = q.reshape(b, S * Td, E)
+    heads = lambda t: t.unflatten(-1, (HEADS, -1)).transpose(1, 2)                                    # noqa: E731
+    h = F.scaled_dot_product_attention(heads(q), heads(k), heads(v), attn_mask=mask.reshape(b, 1, S * Td, N1))
+    g = h.transpose(1, 2).flatten(-2) + q
+    g = g + F.linear(F.relu(F.linear(g, P["decoder.pointer.ffn.lins.0.weight"], P["decoder.pointer.ffn.lins.0.bias"])),
+                     P["decoder.pointer.ffn.lins.1.weight"], P["decoder.pointer.ffn.lins.1.bias"])
+    logits = torch.bmm(g, lk.transpose(1, 2)) / math.sqrt(E)
+    logits = torch.log(torch.exp(logits - P["decoder.alpha"] * idx(D, prev)) + 1e-6)
+    if tanh_clipping > 0:
+        logits = torch.tanh(logits) * tanh_clipping
+    logits = logits.masked_fill(~mask.reshape(b, S * Td, N1), float("-inf")) / temperature
+    logp = F.log_softmax(logits, dim=-1).gather(-1, target.reshape(b, S * Td, 1)).view(b, S, Td)
+    return logp.sum(-1)
+
+
 def replay_backward(policy, td, actions, num_starts, grad_ll, sample_idx, enc_chunk=512, dec_chunk=64):
     """Accumulate d loss / d theta into policy parameters' .grad, given d loss / d log-likelihood.
 
     td: the reset state the rollout started from (`locs`, normalised `distance_matrix`); actions [S*B, N] and grad_ll [S*B]
     in the reference's flattening r = s*B + b.  Returns the replayed log-likelihood [S*B] (for checking against the
     rollout's)."""
-    if policy.env_name != "atsp":
-        raise NotImplementedError("gradient replay is implemented for ATSP (BASELINE configs[4])")
+    if policy.env_name not in ("atsp", "rcvrp"):
+        raise NotImplementedError("gradient replay is implemented for ATSP (BASELINE configs[4]) and RCVRP")
+    vrp = policy.env_name == "rcvrp"
     P = dict(policy.named_parameters())
     nl = 1 + max(int(n.split(".")[3]) for n in P if n.startswith("encoder.net.layers."))
     D, locs = td["distance_matrix"].float(), td["locs"].float()
+    demand = td["demand"].float() if vrp else None
     B, N = D.shape[0], D.shape[-1]
     S = num_starts
-    acts = actions.view(S, B, N).transpose(0, 1)                  # [B,S,N]
+    acts = actions.view(S, B, actions.shape[-1]).transpose(0, 1)  # [B,S,T]
     gll = grad_ll.view(S, B).transpose(0, 1)
     ll_out = torch.empty(B, S, device=D.device)
     with torch.enable_grad():
         for lo in range(0, B, enc_chunk):
             hi = min(B, lo + enc_chunk)
-            row, col = encode(P, locs[lo:hi], D[lo:hi], sample_idx[lo:hi], nl)
+            row, col = encode(P, locs[lo:hi], D[lo:hi], sample_idx[lo:hi], nl, demand=demand[lo:hi] if vrp else None)
             row_d, col_d = row.detach().requires_grad_(), col.detach().requires_grad_()
             for a in range(lo, hi, dec_chunk):
                 z = min(hi, a + dec_chunk)
-                ll = decode_log_likelihood(P, row_d[a - lo:z - lo], col_d[a - lo:z - lo], D[a:z], acts[a:z],
-                                           policy.tanh_clipping, policy.temperature)
+                if vrp:
+                    ll = decode_log_likelihood_rcvrp(P, row_d[a - lo:z - lo], col_d[a - lo:z - lo], D[a:z], demand[a:z], acts[a:z],
+                                                     policy.tanh_clipping, policy.temperature)
+                else:
+                    ll = decode_log_likelihood(P, row_d[a - lo:z - lo], col_d[a - lo:z - lo], D[a:z], acts[a:z],
+                                               policy.tanh_clipping, policy.temperature)
                 ll_out[a:z] = ll.detach()
                 ll.backward(gll[a:z])                             # decoder parameters + the detached embeddings
             torch.autograd.backward([row, col], [row_d.grad, col_d.grad])

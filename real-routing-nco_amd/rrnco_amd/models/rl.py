@@ -52,13 +52,15 @@ class RRNet:
         sampling rollout, reward, shared-baseline loss and d loss / d ll on the HIP kernels; parameter gradients by the
         teacher-forced replay; one flat all-reduce (mean over ranks); optimizer step.  Returns the shared_step dict plus
         `replay_log_likelihood` (must agree with the rollout's) and `grad_norm`."""
-        if self.env_name != "atsp":
-            raise NotImplementedError("training_step is implemented for ATSP (BASELINE configs[4])")
+        if self.env_name not in ("atsp", "rcvrp"):
+            raise NotImplementedError("training_step is implemented for ATSP (BASELINE configs[4]) and RCVRP")
         from .encoder import ATSPInitEmbedding
         td = self.env.reset(batch)
         if td.get("sample_idx", None) is None:            # the rollout and the replay must see the same neighbour sample
             td.set("sample_idx", ATSPInitEmbedding.sample_indices(td["distance_matrix"], self.policy.encoder.init_embedding.sample_size))
         state = {"distance_matrix": td["distance_matrix"], "locs": td["locs"]}
+        if self.env_name == "rcvrp":
+            state["demand"] = td["demand"]
         sidx = td["sample_idx"]
         n_start = self.env.get_num_starts(td) if self.num_starts is None else self.num_starts
         out = self.policy(td, self.env, phase="train", num_starts=n_start, **policy_kw)

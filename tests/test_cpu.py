@@ -314,3 +314,34 @@ def test_real_world_sampler_host_logic():
     keep = [i for i in range(M) if i != 3]
     assert out["distance"].shape == (M - 1, M - 1) and torch.equal(out["points"], torch.arange(M * 2.0).view(M, 2)[keep])
     assert torch.equal(out["distance"], d[keep][:, keep]) and float(out["distance"].max()) < 1e5
+
+
+def test_gradient_replay_rcvrp_matches_oracle_autograd():
+    """RCVRP: routes of different lengths padded with depot visits, capacity context, masks replayed in the env's own
+    operation order; same tolerances as the ATSP test above."""
+    from rrnco_amd.models.grad_replay import replay_backward
+    fx = H.load_fixture("rcvrp_n20_b4_pomo")
+    w = H.rcvrp_weights(fx)
+    S = fx["S"]
+    st0 = restate.rcvrp_reset(H.rcvrp_instance(fx))
+    gll = torch.from_numpy(np.random.default_rng(4).standard_normal(fx["actions"].shape[0]).astype(np.float32))
+    wg = {k: v.clone().requires_grad_() for k, v in w.items()}
+    out = restate.rcvrp_policy(wg, st0, fx["sample_idx"], S, decode="evaluate", actions=fx["actions"][:, 1:])
+    assert torch.equal(out["actions"], fx["actions"])
+    (out["log_likelihood"] * gll).sum().backward()
+    pol = H.make_policy(w, env_name="rcvrp", device="cpu")
+    pol.zero_grad()
+    state = {"distance_matrix": st0["distance_matrix"], "locs": st0["locs"], "demand": st0["demand"]}
+    ll = replay_backward(pol, state, fx["actions"], S, gll, fx["sample_idx"], enc_chunk=3, dec_chunk=2)
+    assert torch.allclose(ll, out["log_likelihood"].detach(), rtol=2e-5, atol=3e-4), (ll - out["log_likelihood"]).abs().max()
+    refs = {n: wg[n].grad for n, _ in pol.named_parameters()}
+    gnorm = sum(float((g ** 2).sum()) for g in refs.values() if g is not None) ** 0.5
+    num, checked = 0.0, 0
+    for name, p in pol.named_parameters():
+        if refs[name] is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        err = float(((p.grad - refs[name]) ** 2).sum()) ** 0.5
+        assert err <= 5e-2 * float((refs[name] ** 2).sum()) ** 0.5 + 2e-5 * gnorm, (name, err)
+        num += err ** 2; checked += 1
+    assert checked > 150 and num ** 0.5 / gnorm < 5e-3, num ** 0.5 / gnorm
