@@ -15,8 +15,8 @@ Two things keep the replay cheap:
     d loss / d (folded table) and autograd carries it through the fold to the module parameters.
 Instances are independent (instance norm is per instance), so the encoder runs in instance chunks under activation
 checkpointing and the decoder chunks back-propagate into detached copies of the cache; one backward through the encoder
-graph finishes the job.  ATSP (the config-5 problem) and RCVRP; RCVRPTW would additionally need the backward of the
-duration NAB.
+graph finishes the job.  ATSP (the config-5 problem), RCVRP and RCVRPTW (vrptw preset; its duration NAB runs on torch
+GEMMs in the module's unfolded form).
 """
 from __future__ import annotations
 
@@ -93,11 +93,27 @@ def _nab_folded(P, p, cost, theta, alpha):
     return (g * od + (1 - g) * oa + bo) * alpha
 
 
-def _block(P, p, x, y, cost, theta):
+def _nab_duration(P, p, cost, theta, dur, alpha):
+    """alpha * DistAngleFusion(use_duration_matrix=True) attn_freenet.py:226-237, 265-286, in the module's own (unfolded)
+    form: its Linear(E,E) / Linear(3E,E) layers are proper GEMMs over the b*N*N edges, which hipBLAS handles well — unlike
+    the gating variant's matrix-vector products, which is why that one has its own kernels."""
+    def mlp(q, x):
+        return _lin(P, q + ".2", F.relu(_lin(P, q + ".0", x.unsqueeze(-1))))
+    de, ae, du = mlp(p + ".dist_emb", cost), mlp(p + ".angle_emb", theta), mlp(p + ".dur_emb", dur)
+    logits = _lin(P, p + ".gate.2", F.silu(_lin(P, p + ".gate.0", torch.cat([de, ae, du], dim=-1))))
+    g = F.softmax(logits / P[p + ".gate_temperature"].exp(), dim=-1)
+    fused = g[..., [0]] * de + g[..., [1]] * ae + g[..., [2]] * du
+    return _lin(P, p + ".out_lin", fused).squeeze(-1) * alpha
+
+
+def _block(P, p, x, y, cost, theta, dur=None):
     """AttnFree_Block.forward attn_freenet.py:417-441 (AFTFull :309-327, TransformerFFN :330-357)."""
     r = _inorm(P, p + ".norm1", x)
     c = _inorm(P, p + ".norm2", y)
-    bias = _nab_folded(P, p + ".angle_distance_fusion", cost, theta, P[p + ".alpha"])
+    if dur is None:
+        bias = _nab_folded(P, p + ".angle_distance_fusion", cost, theta, P[p + ".alpha"])
+    else:
+        bias = _nab_duration(P, p + ".neural_adaptive_bias", cost, theta, dur, P[p + ".alpha"])
     q, k, v = _lin(P, p + ".attn_free.to_q", r), _lin(P, p + ".attn_free.to_k", c), _lin(P, p + ".attn_free.to_v", c)
     ea = torch.exp(torch.softmax(bias, dim=-1))
     ek = torch.exp(torch.softmax(k, dim=1))
@@ -123,7 +139,7 @@ def _init_embedding(P, locs, D, sidx):
     return out[0], out[1]
 
 
-def _init_embedding_vrp(P, locs, demand, D, sidx):
+def _init_embedding_vrp(P, locs, demand, D, sidx, extra=None, attr="demand_init"):
     """RVRPInitEmbedding._embed_with_distance rcvrp.py:88-102 (CoordinateExpert :105-124, DistanceExpert :127-150).
     locs [b,N+1,2] with the depot first, demand [b,N]."""
     p = "encoder.init_embedding"
@@ -134,7 +150,10 @@ def _init_embedding_vrp(P, locs, demand, D, sidx):
                       _lin(P, p + ".coord_expert.init_embed", torch.cat([cities, ang], dim=-1))], dim=-2)
     rowd = D.gather(2, sidx).sort(dim=-1).values
     cold = D.transpose(1, 2).gather(2, sidx).sort(dim=-1).values
-    de = _lin(P, p + ".demand_init", torch.cat([torch.zeros_like(demand[:, :1]), demand], dim=1)[..., None])
+    feats = torch.cat([torch.zeros_like(demand[:, :1]), demand], dim=1)[..., None]
+    if extra is not None:                # rcvrptw.py:51-56: (demand, tw_start, tw_end, service), attribute layer `init_embed`
+        feats = torch.cat([feats, extra], -1)
+    de = _lin(P, p + "." + attr, feats)
     out = []
     for rc, dist in (("row", _lin(P, p + ".distance_expert.row_embed", rowd)), ("col", _lin(P, p + ".distance_expert.col_embed", cold))):
         q = f"{p}.gating_network_{rc}.gating_fc"
@@ -143,20 +162,25 @@ def _init_embedding_vrp(P, locs, demand, D, sidx):
     return out[0], out[1]
 
 
-def encode(P, locs, D, sidx, num_layers, use_checkpoint=True, demand=None):
-    """RRNetEncoder.forward encoder.py:80-112 (atsp; rcvrp when `demand` is given) -> row_emb, col_emb [b,N,E]."""
-    row, col = _init_embedding(P, locs, D, sidx) if demand is None else _init_embedding_vrp(P, locs, demand, D, sidx)
+def encode(P, locs, D, sidx, num_layers, use_checkpoint=True, demand=None, extra=None, dur=None):
+    """RRNetEncoder.forward encoder.py:80-112 -> row_emb, col_emb [b,N,E].  atsp; rcvrp when `demand` is given; rcvrptw
+    when also `extra` (time windows, service time) and `dur` (duration matrix) are."""
+    if demand is None:
+        row, col = _init_embedding(P, locs, D, sidx)
+    else:
+        row, col = _init_embedding_vrp(P, locs, demand, D, sidx, extra, "demand_init" if extra is None else "init_embed")
     d = locs.unsqueeze(2) - locs.unsqueeze(1)
     theta = torch.atan2(d[..., 1], d[..., 0])                                # attn_freenet.py:254-262
     Dt = D.transpose(1, 2)
+    Tt = None if dur is None else dur.transpose(1, 2)
     for l in range(num_layers):
         p = f"encoder.net.layers.{l}"
         if use_checkpoint:
-            r = checkpoint(_block, P, p + ".row_encoding_block", row, col, D, theta, use_reentrant=False)
-            c = checkpoint(_block, P, p + ".col_encoding_block", col, row, Dt, theta, use_reentrant=False)
+            r = checkpoint(_block, P, p + ".row_encoding_block", row, col, D, theta, dur, use_reentrant=False)
+            c = checkpoint(_block, P, p + ".col_encoding_block", col, row, Dt, theta, Tt, use_reentrant=False)
         else:
-            r = _block(P, p + ".row_encoding_block", row, col, D, theta)
-            c = _block(P, p + ".col_encoding_block", col, row, Dt, theta)      # attn_freenet.py:480-486: D^T, same angles
+            r = _block(P, p + ".row_encoding_block", row, col, D, theta, dur)
+            c = _block(P, p + ".col_encoding_block", col, row, Dt, theta, Tt)  # attn_freenet.py:480-486: D^T, Dur^T, same angles
         row, col = r, c
     return row, col
 
@@ -247,19 +271,89 @@ def decode_log_likelihood_rcvrp(P, row_emb, col_emb, D, demand, actions, tanh_cl
     return logp.sum(-1)
 
 
+@torch.no_grad()
+def rcvrptw_replay_states(D, Dur, demand_l, tw, service, actions, cap=1.0):
+    """RMTVRPEnv._step / get_action_mask under the vrptw preset (rmtvrp/env.py:155-215, 343-428), replayed along given
+    routes in the env's operation order.  demand_l / service [b,N+1] (depot first), tw [b,N+1,2], actions [b,S,T] ->
+    (remaining load, current time) [b,S,T-1] and masks [b,S,T-1,N+1] seen when actions[..., 1:] were chosen."""
+    b, S, T = actions.shape
+    N1 = D.shape[-1]
+    dev = D.device
+    bi = torch.arange(b, device=dev)[:, None].expand(b, S)
+    ex = lambda v: v[:, None].expand(b, S, *v.shape[1:])                                             # noqa: E731
+    dl, sv, early, late = ex(demand_l), ex(service), ex(tw[..., 0]), ex(tw[..., 1])
+    dur_j0 = ex(Dur[:, :, 0])
+    t = torch.zeros(b, S, device=dev); used = torch.zeros(b, S, device=dev)
+    prev = torch.zeros(b, S, dtype=torch.long, device=dev)
+    visited = torch.zeros(b, S, N1, dtype=torch.bool, device=dev)
+    rems, times, masks = [], [], []
+    for k in range(T - 1):
+        a = actions[..., k]
+        nz = (a != 0).float()
+        t = nz * (torch.maximum(t + Dur[bi, prev, a], early.gather(2, a[..., None])[..., 0]) + sv.gather(2, a[..., None])[..., 0])
+        used = nz * (used + dl.gather(2, a[..., None])[..., 0])
+        visited = visited.scatter(2, a[..., None], True)
+        arrival = t[..., None] + Dur[bi, a]                                  # [b,S,N1]
+        reach = arrival < late
+        back = (torch.maximum(arrival, early) + sv + dur_j0) < late[..., 0:1]
+        ex_l = dl + used[..., None] > cap
+        missing = ((dl * ~visited).sum(-1) > 0)[..., None]
+        can = reach & back & (missing & ~ex_l & (dl > 0)) & ~visited
+        can[..., 0] = ~((a == 0) & (can[..., 1:].sum(-1) > 0))
+        masks.append(can); rems.append(cap - used); times.append(t)
+        prev = a
+    return torch.stack(rems, 2), torch.stack(times, 2), torch.stack(masks, 2)
+
+
+def decode_log_likelihood_rcvrptw(P, row_emb, col_emb, D, Dur, demand_l, tw, service, actions, tanh_clipping=10.0, temperature=1.0):
+    """Teacher-forced decoder for RCVRPTW: MTVRPContextEmbedding (context.py:34-70: [emb[cur]; available load, current time,
+    open route = 0, remaining distance = 10 without a limit]), bias alpha*D[cur] + beta*Dur[cur] (decoder.py:187-190)."""
+    b, S, T = actions.shape
+    N1 = row_emb.shape[1]
+    Td = T - 1
+    rem, tm, mask = rcvrptw_replay_states(D, Dur, demand_l, tw, service, actions)
+    k, v, lk = F.linear(col_emb, P["decoder.project_node_embeddings.weight"]).chunk(3, dim=-1)
+    Wc = P["decoder.context_embedding.project_context.weight"]                  # [E, E+4]
+    ctx_cur = F.linear(row_emb, Wc[:, :E])
+    prev, target = actions[..., :Td], actions[..., 1:]
+    idx = lambda t, i: t.gather(1, i.reshape(b, -1, 1).expand(-1, -1, t.size(-1)))                    # noqa: E731
+    q = idx(ctx_cur, prev).view(b, S, Td, E) + rem[..., None] * Wc[:, E] + tm[..., None] * Wc[:, E + 1] + 10.0 * Wc[:, E + 3]
+    q = q.reshape(b, S * Td, E)
+    heads = lambda t: t.unflatten(-1, (HEADS, -1)).transpose(1, 2)                                    # noqa: E731
+    h = F.scaled_dot_product_attention(heads(q), heads(k), heads(v), attn_mask=mask.reshape(b, 1, S * Td, N1))
+    g = h.transpose(1, 2).flatten(-2) + q
+    g = g + F.linear(F.relu(F.linear(g, P["decoder.pointer.ffn.lins.0.weight"], P["decoder.pointer.ffn.lins.0.bias"])),
+                     P["decoder.pointer.ffn.lins.1.weight"], P["decoder.pointer.ffn.lins.1.bias"])
+    logits = torch.bmm(g, lk.transpose(1, 2)) / math.sqrt(E)
+    bias = P["decoder.alpha"] * idx(D, prev) + P["decoder.beta"] * idx(Dur, prev)
+    logits = torch.log(torch.exp(logits - bias) + 1e-6)
+    if tanh_clipping > 0:
+        logits = torch.tanh(logits) * tanh_clipping
+    logits = logits.masked_fill(~mask.reshape(b, S * Td, N1), float("-inf")) / temperature
+    logp = F.log_softmax(logits, dim=-1).gather(-1, target.reshape(b, S * Td, 1)).view(b, S, Td)
+    return logp.sum(-1)
+
+
 def replay_backward(policy, td, actions, num_starts, grad_ll, sample_idx, enc_chunk=512, dec_chunk=64):
     """Accumulate d loss / d theta into policy parameters' .grad, given d loss / d log-likelihood.
 
     td: the reset state the rollout started from (`locs`, normalised `distance_matrix`); actions [S*B, N] and grad_ll [S*B]
     in the reference's flattening r = s*B + b.  Returns the replayed log-likelihood [S*B] (for checking against the
     rollout's)."""
-    if policy.env_name not in ("atsp", "rcvrp"):
-        raise NotImplementedError("gradient replay is implemented for ATSP (BASELINE configs[4]) and RCVRP")
-    vrp = policy.env_name == "rcvrp"
+    if policy.env_name not in ("atsp", "rcvrp", "rcvrptw"):
+        raise NotImplementedError(f"gradient replay for env '{policy.env_name}'")
+    vrp, vtw = policy.env_name == "rcvrp", policy.env_name == "rcvrptw"
+    if vtw and getattr(td, "meta", {}).get("mtvrp_variant", False):
+        raise NotImplementedError("gradient replay covers the vrptw preset of RMTVRPEnv")
     P = dict(policy.named_parameters())
     nl = 1 + max(int(n.split(".")[3]) for n in P if n.startswith("encoder.net.layers."))
     D, locs = td["distance_matrix"].float(), td["locs"].float()
     demand = td["demand"].float() if vrp else None
+    if vtw:
+        Dur, dl_full = td["duration_matrix"].float(), td["demand_linehaul"].float()      # [B,N+1] with the depot zero
+        tw, service = td["time_windows"].float(), td["service_time"].float()
+        demand = dl_full[:, 1:]
+        extra = torch.cat([tw, service[..., None]], -1)
     B, N = D.shape[0], D.shape[-1]
     S = num_starts
     acts = actions.view(S, B, actions.shape[-1]).transpose(0, 1)  # [B,S,T]
@@ -268,11 +362,15 @@ def replay_backward(policy, td, actions, num_starts, grad_ll, sample_idx, enc_ch
     with torch.enable_grad():
         for lo in range(0, B, enc_chunk):
             hi = min(B, lo + enc_chunk)
-            row, col = encode(P, locs[lo:hi], D[lo:hi], sample_idx[lo:hi], nl, demand=demand[lo:hi] if vrp else None)
+            row, col = encode(P, locs[lo:hi], D[lo:hi], sample_idx[lo:hi], nl, demand=demand[lo:hi] if (vrp or vtw) else None,
+                              extra=extra[lo:hi] if vtw else None, dur=Dur[lo:hi] if vtw else None)
             row_d, col_d = row.detach().requires_grad_(), col.detach().requires_grad_()
             for a in range(lo, hi, dec_chunk):
                 z = min(hi, a + dec_chunk)
-                if vrp:
+                if vtw:
+                    ll = decode_log_likelihood_rcvrptw(P, row_d[a - lo:z - lo], col_d[a - lo:z - lo], D[a:z], Dur[a:z], dl_full[a:z],
+                                                       tw[a:z], service[a:z], acts[a:z], policy.tanh_clipping, policy.temperature)
+                elif vrp:
                     ll = decode_log_likelihood_rcvrp(P, row_d[a - lo:z - lo], col_d[a - lo:z - lo], D[a:z], demand[a:z], acts[a:z],
                                                      policy.tanh_clipping, policy.temperature)
                 else:

@@ -52,8 +52,8 @@ class RRNet:
         sampling rollout, reward, shared-baseline loss and d loss / d ll on the HIP kernels; parameter gradients by the
         teacher-forced replay; one flat all-reduce (mean over ranks); optimizer step.  Returns the shared_step dict plus
         `replay_log_likelihood` (must agree with the rollout's) and `grad_norm`."""
-        if self.env_name not in ("atsp", "rcvrp"):
-            raise NotImplementedError("training_step is implemented for ATSP (BASELINE configs[4]) and RCVRP")
+        if self.env_name not in ("atsp", "rcvrp", "rcvrptw"):
+            raise NotImplementedError(f"training_step for env '{self.env_name}'")
         from .encoder import ATSPInitEmbedding
         td = self.env.reset(batch)
         if td.get("sample_idx", None) is None:            # the rollout and the replay must see the same neighbour sample
@@ -61,6 +61,10 @@ class RRNet:
         state = {"distance_matrix": td["distance_matrix"], "locs": td["locs"]}
         if self.env_name == "rcvrp":
             state["demand"] = td["demand"]
+        elif self.env_name == "rcvrptw":
+            if td.meta.get("mtvrp_variant", False):
+                raise NotImplementedError("training_step covers the vrptw preset of RMTVRPEnv")
+            state.update({k: td[k] for k in ("duration_matrix", "demand_linehaul", "time_windows", "service_time")})
         sidx = td["sample_idx"]
         n_start = self.env.get_num_starts(td) if self.num_starts is None else self.num_starts
         out = self.policy(td, self.env, phase="train", num_starts=n_start, **policy_kw)

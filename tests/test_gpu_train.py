@@ -148,3 +148,41 @@ def test_rcvrp_training_step_gradients_match_oracle_autograd():
         assert err <= 5e-2 * float((refs[n] ** 2).sum()) ** 0.5 + 2e-5 * gnorm, (n, err)
         num += err ** 2
     assert num ** 0.5 / gnorm < 5e-3
+
+
+def test_rcvrptw_training_step_gradients_match_oracle_autograd():
+    """... and for RCVRPTW (vrptw preset): duration NAB, time-window masks, MTVRP context."""
+    from rrnco_amd import TensorDict
+    from rrnco_amd.envs import RMTVRPEnv
+    from rrnco_amd.models.rl import RRNet
+    fx = H.load_fixture("rcvrptw_n20_b4_pomo")
+    w = H.rcvrptw_weights(fx)
+    pol = H.make_policy(w, env_name="rcvrptw").train()
+    env = RMTVRPEnv(generator_params=dict(num_loc=fx["N"]))
+    model = RRNet(env, policy=pol)
+    inst = H.rcvrptw_instance(fx)
+    td_in = TensorDict({k: v.cuda() for k, v in inst.items()}, batch_size=[fx["B"]])
+    td_in["sample_idx"] = fx["sample_idx"].cuda()
+    out = model.training_step(td_in, seed=31)
+    S, B = fx["S"], fx["B"]
+    acts = out["actions"].cpu()
+    assert acts.shape[0] == S * B
+    assert torch.allclose(out["replay_log_likelihood"], out["log_likelihood"], rtol=2e-5, atol=4e-3)
+    gll = out["grad_log_likelihood"].cpu()
+    wg = {k: v.clone().requires_grad_() for k, v in w.items()}
+    ref = restate.rcvrptw_policy(wg, restate.rmtvrp_reset(inst), fx["sample_idx"], S, decode="evaluate", actions=acts[:, 1:])
+    T = min(ref["actions"].shape[1], acts.shape[1])
+    assert torch.equal(ref["actions"][:, :T], acts[:, :T])
+    (ref["log_likelihood"] * gll).sum().backward()
+    refs = {n: wg[n].grad for n, _ in pol.named_parameters()}
+    gnorm = sum(float((g ** 2).sum()) for g in refs.values() if g is not None) ** 0.5
+    num = 0.0
+    for n, p in pol.named_parameters():
+        g = p.grad.cpu()
+        if refs[n] is None:
+            assert float(g.abs().max()) == 0.0, n
+            continue
+        err = float(((g - refs[n]) ** 2).sum()) ** 0.5
+        assert err <= 5e-2 * float((refs[n] ** 2).sum()) ** 0.5 + 2e-5 * gnorm, (n, err)
+        num += err ** 2
+    assert num ** 0.5 / gnorm < 5e-3
