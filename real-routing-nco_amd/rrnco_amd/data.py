@@ -68,5 +68,5 @@ def load_policy_state_dict(path: str) -> dict:
 def policy_kwargs_from_state_dict(sd: dict) -> dict:
     """Architecture hyper-parameters recoverable from the tensors themselves (layers, sample size)."""
     layers = 1 + max(int(k.split(".")[3]) for k in sd if k.startswith("encoder.net.layers."))
-    ss = [v.shape[1] for k, v in sd.items() if k.endswith("row_embed.weight")][0]
+    ss = [v.shape[1] for k, v in sd.items() if k.endswith(".row_embed.weight")][0]      # not combine_row_embed
     return dict(num_encoder_layers=layers, init_embedding_kwargs=dict(sample_size=ss))

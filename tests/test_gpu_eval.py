@@ -107,3 +107,26 @@ def test_bench_multi_process_contract_two_ranks_on_one_gpu(tmp_path):
     assert out["n_gpus"] == 2 and out["steps"] == 1 and out["warmup"] == 1 and out["scaling"] == "weak"
     assert out["unit"] == "instances/s" and out["value"] > 0 and abs(out["value"] * out["ms_per_step"] / 1e3 - 128) < 1e-6 * 128
     assert out["roofline"]["bound"] == "mfma" and "cpu_baseline" not in out
+
+
+@pytest.mark.parametrize("problem", ["atsp", "rcvrp", "rcvrptw"])
+def test_train_driver_writes_checkpoints_that_evaluate_reads(tmp_path, problem):
+    """train.py (configs/experiment/rrnet.yaml hyper-parameters, tiny sizes) -> Lightning-layout checkpoint -> resume ->
+    evaluate.py on an npz set; the policy must have moved and the loop must stay finite."""
+    import evaluate
+    import train
+    ck = str(tmp_path / "ck")
+    common = ["--problem", problem, "--problem_size", "20", "--batch_size", "8", "--train_data_size", "32", "--val_data_size", "8",
+              "--checkpoint_dir", ck, "--log_every", "2"]
+    v1 = train.main(common + ["--epochs", "1"])
+    last = os.path.join(ck, problem, "last.ckpt")
+    blob = torch.load(last, map_location="cpu", weights_only=False)
+    assert blob["epoch"] == 0 and all(k.startswith("policy.") for k in blob["state_dict"]) and np.isfinite(v1)
+    v2 = train.main(common + ["--epochs", "2", "--resume", last])                  # continues at epoch 1
+    assert torch.load(last, map_location="cpu", weights_only=False)["epoch"] == 1 and np.isfinite(v2)
+    moved = sum(int(not torch.equal(blob["state_dict"][k], v)) for k, v in
+                torch.load(last, map_location="cpu", weights_only=False)["state_dict"].items())
+    assert moved > 100
+    path = _write(tmp_path, problem, 20, 4)
+    res = evaluate.main(["--problem", problem, "--datasets", path, "--checkpoint", last, "--problem_size", "20", "--batch_size", "4", "--no_aug"])
+    assert np.isfinite(res[path])
