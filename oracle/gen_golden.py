@@ -55,14 +55,14 @@ def _np(d):
     return {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in d.items()}
 
 
-def gen_atsp(tag, B, N, S, sample_size, seed, layers=6, aug=False, keep_trace=True, nab_type="gating"):
+def gen_atsp(tag, B, N, S, sample_size, seed, layers=6, aug=False, keep_trace=True, nab_type="gating", normalization="instance"):
     from rrnco.envs.atsp.env import ATSPEnv
     from rrnco.models.policy import RRNetPolicy
 
     torch.manual_seed(seed)
     inst = restate.atsp_synthetic(B, N, seed)
     env = ATSPEnv(generator=_Gen(N), check_solution=True)
-    kw = dict(POLICY_KW, num_encoder_layers=layers, nab_type=nab_type)
+    kw = dict(POLICY_KW, num_encoder_layers=layers, nab_type=nab_type, normalization=normalization)
     pol = RRNetPolicy(env_name="atsp", init_embedding_kwargs=dict(
         use_coords=True, use_polar_feats=True, use_dist=True, use_matnet_init=False,
         sample_type="prob", sample_size=sample_size), **kw).eval()
@@ -70,6 +70,8 @@ def gen_atsp(tag, B, N, S, sample_size, seed, layers=6, aug=False, keep_trace=Tr
     mine_t = restate.atsp_weight_template(128, layers, 512, sample_size)
     if nab_type != "gating":
         mine_t = restate.ablation_template(mine_t, nab_type, use_duration=False)
+    if normalization == "batch":
+        mine_t = restate.batchnorm_template(mine_t)
     assert tmpl == mine_t, "state_dict template drift"
     w = restate.make_weights(tmpl, seed)
     pol.load_state_dict(w, strict=True)
@@ -119,6 +121,7 @@ def gen_atsp(tag, B, N, S, sample_size, seed, layers=6, aug=False, keep_trace=Tr
 
     fx = dict(
         kind="atsp", B=B, N=N, S=S, sample_size=sample_size, seed=seed, layers=layers, aug=int(aug), nab_type=nab_type,
+        normalization=normalization,
         locs=inst["locs"], distance_matrix=inst["distance_matrix"], sample_idx=sidx,
         norm_distance=td["distance_matrix"], min_distance=td["min_distance"], max_distance=td["max_distance"],
         row_emb=out["hidden"][0], col_emb=out["hidden"][1],
@@ -288,6 +291,8 @@ if __name__ == "__main__":
         gen_atsp("atsp_n20_b4_pomo_heuristic", B=4, N=20, S=20, sample_size=15, seed=41, keep_trace=False, nab_type="heuristic")
         gen_rcvrptw("rcvrptw_n20_b4_pomo_heuristic", B=4, N=20, S=20, sample_size=15, seed=42, keep_trace=False, nab_type="heuristic")
         gen_rcvrptw("rcvrptw_n20_b4_pomo_naive", B=4, N=20, S=20, sample_size=15, seed=43, keep_trace=False, nab_type="naive")
+    if "batchnorm" in which:     # normalization="batch" (the constructor default of RRNetPolicy), eval mode, 3 layers (default too)
+        gen_atsp("atsp_n20_b4_pomo_batchnorm", B=4, N=20, S=20, sample_size=15, seed=61, layers=3, keep_trace=False, normalization="batch")
     if "variant" in which:       # RMTVRPEnv beyond the vrptw preset: backhauls (classes 1, 2), open routes, distance limits
         gen_rcvrptw("rmtvrp_n20_b8_pomo_variants", B=8, N=20, S=20, sample_size=15, seed=51, variant=True)
         # (at N=50 the reference and its restatement already part ways on 11 % of the rollouts, each at a decision gap

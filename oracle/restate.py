@@ -189,9 +189,25 @@ def atsp_init_embedding(w: W, locs: Tensor, distance: Tensor, sidx: Tensor):
 # Encoder net (rrnco/models/nn/attn_freenet.py)
 # ----------------------------------------------------------------------------------------------
 def instance_norm(w: W, p: str, x: Tensor) -> Tensor:
-    """Normalization('instance') attn_freenet.py:104-105: InstanceNorm1d(E, affine) over nodes."""
+    """Normalization attn_freenet.py:101-105: InstanceNorm1d(E, affine) over nodes, or — when the weights carry running
+    statistics (normalization='batch', the constructor default) — BatchNorm1d in eval mode over the flattened B*N rows."""
+    if (p + ".normalizer.running_mean") in w:
+        return F.batch_norm(x.reshape(-1, x.size(-1)), w[p + ".normalizer.running_mean"], w[p + ".normalizer.running_var"],
+                            weight=w[p + ".normalizer.weight"], bias=w[p + ".normalizer.bias"], training=False,
+                            eps=1e-5).view(*x.size())
     return F.instance_norm(x.permute(0, 2, 1), weight=w[p + ".normalizer.weight"],
                            bias=w[p + ".normalizer.bias"], eps=1e-5).permute(0, 2, 1)
+
+
+def batchnorm_template(template: Dict[str, tuple]) -> Dict[str, tuple]:
+    """state_dict template of the same policy built with normalization='batch': BatchNorm1d buffers next to every affine."""
+    t = {}
+    for k, v in template.items():
+        t[k] = v
+        if k.endswith(".normalizer.bias"):
+            base = k[: -len("bias")]
+            t[base + "running_mean"] = v; t[base + "running_var"] = v; t[base + "num_batches_tracked"] = ()
+    return t
 
 
 def pairwise_angles(coords: Tensor) -> Tensor:
@@ -471,8 +487,12 @@ def make_weights(template: Dict[str, tuple], seed: int) -> W:
         rng = np.random.default_rng([seed, zlib.crc32(name.encode())])
         if name.endswith("normalizer.weight"):
             a = 1.0 + 0.1 * rng.standard_normal(shape)
-        elif name.endswith("normalizer.bias"):
+        elif name.endswith("normalizer.bias") or name.endswith("normalizer.running_mean"):
             a = 0.1 * rng.standard_normal(shape)
+        elif name.endswith("normalizer.running_var"):
+            a = 1.0 + 0.3 * np.abs(rng.standard_normal(shape))
+        elif name.endswith("num_batches_tracked"):
+            a = np.asarray(100.0)
         elif name.endswith(".alpha") or name.endswith(".beta") or name.endswith("distance_weight") or name.endswith("duration_weight"):
             a = 1.0 + 0.1 * rng.standard_normal(shape)
         elif name.endswith("gate_temperature"):

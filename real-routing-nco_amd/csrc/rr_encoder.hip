@@ -409,15 +409,17 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_enc_block(EncBlockW wr, EncB
 
 extern "C" int rr_enc_layer(const EncBlockW* wrow, const EncBlockW* wcol, const float* row_in, const float* col_in,
                             float* row_out, float* col_out, const float* D, const float* locs, const float* theta,
-                            const float* bias_pre, int Bp, int N, float* dbg, hipStream_t st) {
+                            const float* bias_pre, int Bp, int N, int norm_affine_only, float* dbg, hipStream_t st) {
   if (Bp <= 0 || N < 2 || N > RR_MAXN || wrow == nullptr || wcol == nullptr) return RR_EINVAL;
+  // BatchNorm (eval) as a per-feature affine map is implemented in the register-resident block only
+  if (norm_affine_only && (dbg != nullptr || (theta == nullptr && bias_pre == nullptr))) return RR_EINVAL;
   dim3 grid(Bp, 2), blk(ENC_THREADS);
   static const int variant = [] { const char* e = getenv("RR_ENC_VARIANT"); return e ? atoi(e) : 1; }();
-  if (variant == 1 && dbg == nullptr && (theta != nullptr || bias_pre != nullptr)) {
+  if ((variant == 1 || norm_affine_only) && dbg == nullptr && (theta != nullptr || bias_pre != nullptr)) {
     EncBlockW2 ws; ws.blk[0] = *wrow; ws.blk[1] = *wcol;   // wave = node tile, register-resident (rr_enc_w.inc); stage dumps use the LDS-staged kernel
-    if (N <= 32) hipLaunchKernelGGL(k_enc_block_w<2>, grid, dim3(128), 0, st, ws, row_in, col_in, row_out, col_out, D, theta, bias_pre, N);
-    else if (N <= 64) hipLaunchKernelGGL(k_enc_block_w<4>, grid, dim3(256), 0, st, ws, row_in, col_in, row_out, col_out, D, theta, bias_pre, N);
-    else hipLaunchKernelGGL(k_enc_block_w<7>, grid, dim3(448), 0, st, ws, row_in, col_in, row_out, col_out, D, theta, bias_pre, N);
+    if (N <= 32) hipLaunchKernelGGL(k_enc_block_w<2>, grid, dim3(128), 0, st, ws, row_in, col_in, row_out, col_out, D, theta, bias_pre, N, norm_affine_only);
+    else if (N <= 64) hipLaunchKernelGGL(k_enc_block_w<4>, grid, dim3(256), 0, st, ws, row_in, col_in, row_out, col_out, D, theta, bias_pre, N, norm_affine_only);
+    else hipLaunchKernelGGL(k_enc_block_w<7>, grid, dim3(448), 0, st, ws, row_in, col_in, row_out, col_out, D, theta, bias_pre, N, norm_affine_only);
     return rr_check(hipGetLastError());
   }
   if (N <= 32) hipLaunchKernelGGL(k_enc_block<2>, grid, blk, 0, st, *wrow, *wcol, row_in, col_in, row_out, col_out, D, locs, bias_pre, N, dbg);

@@ -11,10 +11,13 @@ import torch.nn as nn
 from .. import _lib as L
 
 
-class _Norm(nn.Module):          # Normalization('instance') attn_freenet.py:78-116 -> `.normalizer.{weight,bias}`
+NORMALIZATION = "instance"       # set by RRNetEncoder while it builds its module tree ("instance" | "batch")
+
+
+class _Norm(nn.Module):          # Normalization attn_freenet.py:78-116 -> `.normalizer.{weight,bias}` (+ running stats for "batch")
     def __init__(self, E):
         super().__init__()
-        self.normalizer = nn.InstanceNorm1d(E, affine=True)
+        self.normalizer = nn.BatchNorm1d(E, affine=True) if NORMALIZATION == "batch" else nn.InstanceNorm1d(E, affine=True)
 
 
 class _MLP1(nn.Sequential):      # nn.Sequential(Linear(1,E), ReLU, Linear(E,E))  attn_freenet.py:216-225
@@ -140,8 +143,11 @@ class RRNetEncoder(nn.Module):
         super().__init__()
         if embed_dim != 128 or feedforward_hidden != 512:
             raise NotImplementedError("rrnco_amd kernels are specialised for embed_dim=128, feedforward_hidden=512")
-        if normalization != "instance":
-            raise NotImplementedError("rrnco_amd implements normalization='instance' (configs/experiment/rrnet.yaml)")
+        if normalization not in ("instance", "batch"):
+            raise NotImplementedError("rrnco_amd implements normalization='instance' (configs/experiment/rrnet.yaml) and 'batch'")
+        self.normalization = normalization
+        global NORMALIZATION
+        NORMALIZATION = normalization
         self.env_name = getattr(env_name, "name", env_name)
         kw = dict(init_embedding_kwargs or {})
         if init_embedding is not None:
@@ -153,10 +159,15 @@ class RRNetEncoder(nn.Module):
             self.init_embedding = make_vrp_init_embedding(self.env_name, embed_dim, **kw)
         self.net = AttnFreeNet(embed_dim, feedforward_hidden, num_layers, nab_type=nab_type,
                                use_duration_matrix=self.env_name not in ("atsp", "rcvrp")) if net is None else net   # encoder.py:63-66
+        NORMALIZATION = "instance"
 
     def forward(self, td, phase: str = "val", mask=None, packed=None):
         """-> (row_emb, col_emb) [B,N,E].  `packed` = packing.pack_policy(...) (the policy caches it)."""
         assert packed is not None, "RRNetEncoder.forward needs packed weights (call through RRNetPolicy or pass packed=)"
+        bn = self.normalization == "batch"
+        if bn and self.training:
+            raise NotImplementedError("normalization='batch' is evaluated with running statistics (module.eval()); batch "
+                                      "statistics across instances (train mode) are not implemented")
         D = td["distance_matrix"].contiguous()
         L.require_gpu(D)
         locs = td["locs"].float().contiguous()
@@ -203,7 +214,7 @@ class RRNetEncoder(nn.Module):
                 L.check(lib.rr_nab_dur(nr, nc, L.ptr(D), L.ptr(T), L.ptr(locs), L.ptr(bias), Bp, N, L.stream()), "rr_nab_dur")
             L.check(lib.rr_enc_layer(wr, wc, L.ptr(row), L.ptr(col), L.ptr(row2), L.ptr(col2), L.ptr(D), L.ptr(locs),
                                      L.ptr(theta) if theta is not None else None, L.ptr(bias) if use_dur else None,
-                                     Bp, N, L.ptr(dbg) if (dbg is not None and l == 0) else None, L.stream()),
+                                     Bp, N, int(bn), L.ptr(dbg) if (dbg is not None and l == 0) else None, L.stream()),
                     "rr_enc_layer")
             if l == 0 and dbg is not None:
                 row, col, row2, col2 = row2, col2, torch.empty_like(row), torch.empty_like(col)

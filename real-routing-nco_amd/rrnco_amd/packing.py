@@ -245,8 +245,13 @@ def pack_policy(sd: dict, env_name: str, device) -> dict:
             w = L.EncBlockW()
             for f, k in (("n1", "norm1"), ("n2", "norm2"), ("n3", "norm3"),
                          ("f1", "feed_forward.ops.norm1"), ("f2", "feed_forward.ops.norm2")):
-                setattr(w, f + "g", ar.put(sd[f"{b}.{k}.normalizer.weight"]))
-                setattr(w, f + "b", ar.put(sd[f"{b}.{k}.normalizer.bias"]))
+                gam, bet = sd[f"{b}.{k}.normalizer.weight"].detach().double(), sd[f"{b}.{k}.normalizer.bias"].detach().double()
+                if f"{b}.{k}.normalizer.running_mean" in sd:      # BatchNorm1d (eval): fold the running statistics
+                    rm, rv = sd[f"{b}.{k}.normalizer.running_mean"].double(), sd[f"{b}.{k}.normalizer.running_var"].double()
+                    gam = gam / torch.sqrt(rv + 1e-5)
+                    bet = bet - rm * gam
+                setattr(w, f + "g", ar.put(gam.float()))
+                setattr(w, f + "b", ar.put(bet.float()))
             for f, k in (("q", "attn_free.to_q"), ("k", "attn_free.to_k"), ("v", "attn_free.to_v"),
                          ("p", "attn_free.project"), ("c", "multi_head_combine"),
                          ("1", "feed_forward.ops.ffn.W1"), ("2", "feed_forward.ops.ffn.W2")):

@@ -13,7 +13,8 @@ from oracle import restate
 from tests import helpers as H
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ATSP_FIXTURES = ["atsp_n20_b4_greedy", "atsp_n20_b4_pomo", "atsp_n20_b2_pomo_aug8", "atsp_n100_b2_pomo", "atsp_n20_b4_pomo_heuristic"]
+ATSP_FIXTURES = ["atsp_n20_b4_greedy", "atsp_n20_b4_pomo", "atsp_n20_b2_pomo_aug8", "atsp_n100_b2_pomo", "atsp_n20_b4_pomo_heuristic",
+                 "atsp_n20_b4_pomo_batchnorm"]
 
 
 # ---------------------------------------------------------------- oracle vs golden (reference outputs)

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 ENC_ATOL, LL_RTOL, LL_ATOL, COST_ATOL, GAP_TOL = 5e-4, 2e-5, 4e-3, 1e-4, 1e-3
 
 
-def _run(name):
+def _run_plain(name):
     from rrnco_amd import TensorDict
     from rrnco_amd.envs import ATSPEnv, RMTVRPEnv
     fx = H.load_fixture(name)
@@ -21,10 +21,15 @@ def _run(name):
         w, inst = H.rcvrptw_weights(fx), H.rcvrptw_instance(fx)
         env, env_name = RMTVRPEnv(generator_params=dict(num_loc=fx["N"])), "rcvrptw"
     pol = H.make_policy(w, env_name=env_name)
-    assert pol.encoder.net.layers[0].row_encoding_block.neural_adaptive_bias.__class__.__name__ in ("_HeuristicNAB", "_NaiveNAB")
     td_in = TensorDict({k: v.cuda() for k, v in inst.items()}, batch_size=[fx["B"]])
     td_in["sample_idx"] = fx["sample_idx"].cuda()
     return fx, w, pol, inst, env, td_in
+
+
+def _run(name):
+    out = _run_plain(name)
+    assert out[2].encoder.net.layers[0].row_encoding_block.neural_adaptive_bias.__class__.__name__ in ("_HeuristicNAB", "_NaiveNAB")
+    return out
 
 
 @pytest.mark.parametrize("name", ["atsp_n20_b4_pomo_heuristic", "rcvrptw_n20_b4_pomo_heuristic", "rcvrptw_n20_b4_pomo_naive"])
@@ -52,3 +57,18 @@ def test_naive_nab_without_duration_matrix_is_rejected_like_the_reference():
     pol = H.make_policy(restate.make_weights(t, 3))
     with pytest.raises(NotImplementedError, match="duration matrix"):
         pol.packed(torch.device("cuda"))
+
+
+def test_batchnorm_eval_policy_matches_reference_and_train_mode_is_rejected():
+    """normalization='batch' (the constructor default of RRNetPolicy, 3 layers): running statistics folded into per-feature
+    affine maps; golden vectors from the reference in eval mode.  Batch statistics (train mode) are not implemented."""
+    fx, w, pol, inst, env, td_in = _run_plain("atsp_n20_b4_pomo_batchnorm")
+    assert pol.encoder.normalization == "batch" and len(pol.encoder.net.layers) == 3
+    row, col = pol.encoder(env.reset(td_in), packed=pol.packed(torch.device("cuda")))
+    assert torch.allclose(row.cpu(), fx["row_emb"], atol=ENC_ATOL) and torch.allclose(col.cpu(), fx["col_emb"], atol=ENC_ATOL)
+    out = pol(env.reset(td_in), env, phase="val", decode_type="multistart_greedy", num_starts=fx["S"], return_actions=True)
+    assert torch.equal(out["actions"].cpu(), fx["actions"])
+    assert torch.allclose(out["reward"].cpu(), fx["reward"], atol=COST_ATOL)
+    pol.train()
+    with pytest.raises(NotImplementedError, match="running statistics"):
+        pol(env.reset(td_in), env, phase="train", num_starts=fx["S"])
