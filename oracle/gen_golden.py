@@ -137,6 +137,36 @@ def gen_atsp(tag, B, N, S, sample_size, seed, layers=6, aug=False, keep_trace=Tr
     print(f"wrote {path}  ({os.path.getsize(path)/1e3:.0f} kB)  reward[:3]={out['reward'][:3].tolist()}")
 
 
+def gen_atsp_beam(tag, B, N, W, sample_size, seed, layers=6):
+    """decode_type='beam_search' (decoding.py:402-554) through the reference policy; the restatement must reproduce it."""
+    from rrnco.envs.atsp.env import ATSPEnv
+    from rrnco.models.policy import RRNetPolicy
+    torch.manual_seed(seed)
+    inst = restate.atsp_synthetic(B, N, seed)
+    env = ATSPEnv(generator=_Gen(N), check_solution=True)
+    pol = RRNetPolicy(env_name="atsp", init_embedding_kwargs=dict(
+        use_coords=True, use_polar_feats=True, use_dist=True, use_matnet_init=False,
+        sample_type="prob", sample_size=sample_size), **dict(POLICY_KW, num_encoder_layers=layers)).eval()
+    w = restate.make_weights({k: tuple(v.shape) for k, v in pol.state_dict().items()}, seed)
+    pol.load_state_dict(w, strict=True)
+    td = env.reset(TensorDict({k: v.clone() for k, v in inst.items()}, batch_size=[B]))
+    with torch.inference_mode(), _CaptureMultinomial() as cap:
+        # select_best=True is unusable in the reference with these envs (`get_reward` returns a tuple under normalize=True and
+        # _select_best_beam calls .unsqueeze on it, decoding.py:499-503): all beams are returned instead
+        out = pol(td.clone(), env, phase="val", decode_type="beam_search", beam_width=W, select_best=False, return_actions=True)
+    sidx = cap.calls[0].reshape(B, N, sample_size)
+    with torch.inference_mode():
+        mine = restate.atsp_beam_search(w, restate.atsp_reset(dict(inst)), sidx, W, select_best=False)
+    assert torch.equal(mine["actions"], out["actions"]), "restatement beams differ from reference"
+    assert torch.allclose(mine["reward"], out["reward"], atol=1e-6) and torch.allclose(mine["log_likelihood"], out["log_likelihood"], atol=1e-5)
+    fx = dict(kind="atsp", B=B, N=N, S=W, sample_size=sample_size, seed=seed, layers=layers, aug=0, locs=inst["locs"],
+              distance_matrix=inst["distance_matrix"], sample_idx=sidx, actions=out["actions"], reward=out["reward"],
+              log_likelihood=out["log_likelihood"])
+    path = os.path.join(GOLD, f"{tag}.npz")
+    np.savez_compressed(path, **_np(fx))
+    print(f"wrote {path}  ({os.path.getsize(path)/1e3:.0f} kB)  reward={out['reward'].tolist()}")
+
+
 def gen_rcvrp(tag, B, N, S, sample_size, seed, capacity, layers=6, keep_trace=True):
     from rrnco.envs.rcvrp.env import RCVRPEnv
     from rrnco.models.policy import RRNetPolicy
@@ -291,6 +321,9 @@ if __name__ == "__main__":
         gen_atsp("atsp_n20_b4_pomo_heuristic", B=4, N=20, S=20, sample_size=15, seed=41, keep_trace=False, nab_type="heuristic")
         gen_rcvrptw("rcvrptw_n20_b4_pomo_heuristic", B=4, N=20, S=20, sample_size=15, seed=42, keep_trace=False, nab_type="heuristic")
         gen_rcvrptw("rcvrptw_n20_b4_pomo_naive", B=4, N=20, S=20, sample_size=15, seed=43, keep_trace=False, nab_type="naive")
+    if "beam" in which:
+        gen_atsp_beam("atsp_n20_b4_beam5", B=4, N=20, W=5, sample_size=15, seed=71)
+        gen_atsp_beam("atsp_n20_b3_beam20", B=3, N=20, W=20, sample_size=15, seed=72, layers=2)
     if "batchnorm" in which:     # normalization="batch" (the constructor default of RRNetPolicy), eval mode, 3 layers (default too)
         gen_atsp("atsp_n20_b4_pomo_batchnorm", B=4, N=20, S=20, sample_size=15, seed=61, layers=3, keep_trace=False, normalization="batch")
     if "variant" in which:       # RMTVRPEnv beyond the vrptw preset: backhauls (classes 1, 2), open routes, distance limits

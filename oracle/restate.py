@@ -471,6 +471,56 @@ def atsp_policy(w: W, td0: dict, sidx: Tensor, num_starts: int, decode: str = "g
     return out
 
 
+def atsp_beam_search(w: W, td0: dict, sidx: Tensor, beam_width: int, select_best: bool = True) -> dict:
+    """RRNetPolicy.forward with decode_type='beam_search' (decoding.py:402-554: BeamSearch with select_best=True) for ATSP."""
+    row, col = atsp_encoder(w, td0, sidx)
+    B, N = td0["action_mask"].shape
+    W_ = beam_width
+    a0 = torch.arange(W_).repeat_interleave(B) % N
+    td = batchify_state({k: v for k, v in td0.items() if k not in ("locs",)}, W_)
+    td["action"] = a0
+    td = atsp_step(td)
+    lp0 = torch.zeros_like(td["action_mask"], dtype=torch.float32)
+    logps, acts, path = [lp0], [a0], [torch.zeros(B * W_, dtype=torch.int32)]
+    parent_lp = lp0.gather(1, a0[..., None])
+    cache = precompute_cache(w, row, col)
+    cache["_D"] = td0["distance_matrix"]
+    seq = torch.arange(B).repeat(W_)
+    while not td["done"].all():
+        logits, mask = atsp_decoder_step(w, td, cache, W_)
+        logp = process_logits(logits, mask)
+        stacked = torch.cat((logp + parent_lp).split(B), dim=1)
+        top_lp, top_ix = torch.topk(stacked, W_, dim=1)
+        parent_lp = torch.hstack(torch.unbind(top_lp, 1)).unsqueeze(1)
+        top_ix = torch.hstack(torch.unbind(top_ix, 1))
+        sel, par = top_ix % N, (top_ix // N).int()
+        idx = seq + par * B
+        path.append(par)
+        td = {k: v[idx] for k, v in td.items()}
+        assert not (~mask[idx]).gather(1, sel.unsqueeze(-1)).any()
+        logps.append(logp[idx]); acts.append(sel)
+        td["action"] = sel
+        td = atsp_step(td)
+    actions, logprobs = torch.stack(acts, 1), torch.stack(logps, 1)
+    cur = path[-1]
+    seqs, lps = [actions[:, -1]], [logprobs[:, -1]]
+    for k in reversed(range(len(path) - 1)):
+        idx = seq + cur * B
+        seqs.append(actions[idx, k]); lps.append(logprobs[idx, k])
+        cur = path[k][idx]
+    actions, logprobs = torch.stack(list(reversed(seqs)), 1), torch.stack(list(reversed(lps)), 1)
+    tdb = dict(td)
+    if select_best:          # decoding.py:499-505 (on the real reward; the reference itself trips over the tuple here)
+        real, nd = atsp_reward(tdb, actions, True)
+        _, best = torch.cat(real.unsqueeze(1).split(B), 1).max(1)
+        flat = torch.arange(B) + best * B
+        actions, logprobs = actions[flat], logprobs[flat]
+        tdb = {k: v[flat] for k, v in td.items()}
+    real, nd = atsp_reward(tdb, actions, True)
+    ll = logprobs.gather(-1, actions.unsqueeze(-1)).squeeze(-1).sum(1)
+    return {"reward": real, "normalized_reward": nd, "log_likelihood": ll, "actions": actions}
+
+
 # ----------------------------------------------------------------------------------------------
 # Deterministic weights (inputs shared by oracle, reference and the HIP path)
 # ----------------------------------------------------------------------------------------------

@@ -9,11 +9,9 @@ from ..ops import batchify
 
 
 def get_decoding_strategy(decoding_strategy, **config):
-    """rrnco/models/decoding.py:16-34 (beam_search is out of scope: unused by the reference configs)."""
+    """rrnco/models/decoding.py:16-34."""
     registry = {"greedy": Greedy, "sampling": Sampling, "multistart_greedy": Greedy,
-                "multistart_sampling": Sampling, "evaluate": Evaluate}
-    if decoding_strategy == "beam_search":
-        raise NotImplementedError("beam_search is not part of the MI355X hot path")
+                "multistart_sampling": Sampling, "evaluate": Evaluate, "beam_search": BeamSearch}
     if "multistart" in decoding_strategy:
         config["multistart"] = True
     return registry.get(decoding_strategy, Sampling)(**config)
@@ -101,3 +99,87 @@ class Sampling(DecodingStrategy):
 
 class Evaluate(DecodingStrategy):
     name, mode = "evaluate", "evaluate"
+
+
+class BeamSearch(DecodingStrategy):
+    """rrnco/models/decoding.py:402-554.  The per-step log-probabilities come from rr_select (all-logp output); the beam
+    bookkeeping (top-k over the stacked beams, parent pointers, back-tracking, best-beam selection) is index arithmetic on
+    [B, W] tensors and stays in torch ops on the device.  Runs in the step-wise loop (the fused rollout has no beams)."""
+    name, mode = "beam_search", "greedy"
+
+    def __init__(self, beam_width=None, select_best=True, **kwargs):
+        kwargs["store_all_logp"] = True
+        kwargs.pop("select_best", None)
+        super().__init__(**kwargs)
+        self.beam_width, self.select_best_beam = beam_width, select_best
+        self.parent_beam_logprobs, self.beam_path = None, []
+        self.is_beam_search = True
+
+    def pre_decoder_hook(self, td, env, action=None):
+        """:429-454."""
+        if self.beam_width is None:
+            self.beam_width = env.get_num_starts(td)
+        assert self.beam_width > 1, "beam width must be larger than 1"
+        action = (self.select_start_nodes_fn(td, env, self.beam_width) if self.select_start_nodes_fn
+                  else env.select_start_nodes(td, num_starts=self.beam_width))
+        td = batchify(td, self.beam_width)
+        td.set("action", action)
+        td = env.step(td)["next"]
+        logprobs = torch.zeros_like(td["action_mask"], dtype=torch.float32)
+        self.logprobs.append(logprobs)
+        self.actions.append(action)
+        self.parent_beam_logprobs = logprobs.gather(1, action[..., None])
+        self.beam_path.append(torch.zeros(logprobs.size(0), device=td.device, dtype=torch.int32))
+        self.num_starts = self.beam_width
+        return td, env, self.beam_width
+
+    def step(self, logits, mask, td=None, action=None, **kwargs):
+        """:219-270 with BeamSearch._step (:414-427) and _make_beam_step (:507-554)."""
+        logits = logits.contiguous()
+        R, N = logits.shape
+        m = mask.contiguous() if (self.mask_logits and mask is not None) else None
+        sel = torch.empty(R, dtype=torch.int64, device=logits.device)
+        lp = torch.empty(R, dtype=torch.float32, device=logits.device)
+        lp_all = torch.empty(R, N, dtype=torch.float32, device=logits.device)
+        L.check(L.lib().rr_select(L.ptr(logits), L.ptr(m), None, L.ptr(sel), L.ptr(lp), L.ptr(lp_all), R, N,
+                                  float(self.tanh_clipping), float(self.temperature), 0, 0, len(self.actions),
+                                  self.top_k, self.top_p, L.stream()), "rr_select")
+        B = R // self.beam_width
+        seq = torch.arange(B, device=logits.device).repeat(self.beam_width)
+        stacked = torch.cat((lp_all + self.parent_beam_logprobs).split(B), dim=1)           # [B, W*N]
+        top_lp, top_ix = torch.topk(stacked, self.beam_width, dim=1)
+        self.parent_beam_logprobs = torch.hstack(torch.unbind(top_lp, 1)).unsqueeze(1)
+        top_ix = torch.hstack(torch.unbind(top_ix, 1))
+        selected = top_ix % N
+        parent = (top_ix // N).int()
+        idx = seq + parent * B
+        self.beam_path.append(parent)
+        td = td.index_rollouts(idx)
+        lp_all = lp_all[idx]
+        assert not (~mask[idx]).gather(1, selected.unsqueeze(-1)).any(), "infeasible action selected"
+        td.set("action", selected)
+        self.actions.append(selected)
+        self.logprobs.append(lp_all)
+        return td
+
+    def post_decoder_hook(self, td, env):
+        """:456-505."""
+        actions, logprobs = torch.stack(self.actions, 1), torch.stack(self.logprobs, 1)
+        assert actions.size(1) == len(self.beam_path), "action idx shape and beam path shape dont match"
+        cur = self.beam_path[-1]
+        seqs, lps = [actions[:, -1]], [logprobs[:, -1]]
+        R = actions.size(0)
+        B = R // self.beam_width
+        seq = torch.arange(B, device=actions.device).repeat(self.beam_width)
+        for k in reversed(range(len(self.beam_path) - 1)):
+            idx = seq + cur * B
+            seqs.append(actions[idx, k]); lps.append(logprobs[idx, k])
+            cur = self.beam_path[k][idx]
+        actions, logprobs = torch.stack(list(reversed(seqs)), 1), torch.stack(list(reversed(lps)), 1)
+        if not self.select_best_beam:
+            return logprobs, actions, td, env
+        rewards = env.get_reward(td, actions)
+        rewards = rewards[0] if isinstance(rewards, tuple) else rewards
+        _, best = torch.cat(rewards.unsqueeze(1).split(B), 1).max(1)
+        flat = torch.arange(B, device=rewards.device) + best * B
+        return logprobs[flat], actions[flat], td.index_rollouts(flat), env

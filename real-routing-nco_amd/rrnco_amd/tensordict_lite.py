@@ -58,6 +58,16 @@ class TensorDict:
         self._d.update(other._d if isinstance(other, TensorDict) else other)
         return self
 
+    def index_rollouts(self, idx):
+        """td[idx] for a batchified state (beam search: decoding.py:418): rows of the per-rollout keys are re-indexed, the
+        per-instance keys stay as they are — valid as long as idx keeps every rollout on its own instance (r % B)."""
+        if self.static_repeat == 1:
+            return self[idx]
+        out = {k: (v if self.is_static(k) else v[idx]) for k, v in self._d.items()}
+        bs = [int(idx.shape[0]), *self.batch_size[1:]]
+        return TensorDict(out, batch_size=bs, static_repeat=max(int(idx.shape[0]) // max(self.batch_size[0] // self.static_repeat, 1), 1),
+                          meta=self.meta)
+
     def keys(self, *a, **k):
         return self._d.keys()
 

@@ -377,3 +377,13 @@ def test_gradient_replay_rcvrptw_matches_oracle_autograd():
         assert err <= 5e-2 * float((refs[name] ** 2).sum()) ** 0.5 + 2e-5 * gnorm, (name, err)
         num += err ** 2; checked += 1
     assert checked > 200 and num ** 0.5 / gnorm < 5e-3, num ** 0.5 / gnorm
+
+
+@pytest.mark.parametrize("name", ["atsp_n20_b4_beam5", "atsp_n20_b3_beam20"])
+def test_oracle_beam_search_reproduces_reference_golden(name):
+    fx = H.load_fixture(name)
+    w = H.atsp_weights(fx)
+    with torch.inference_mode():
+        out = restate.atsp_beam_search(w, restate.atsp_reset(H.fixture_state(fx)), fx["sample_idx"], fx["S"], select_best=False)
+    assert torch.equal(out["actions"], fx["actions"]) and torch.allclose(out["reward"], fx["reward"], atol=1e-5)
+    assert torch.allclose(out["log_likelihood"], fx["log_likelihood"], atol=1e-4)

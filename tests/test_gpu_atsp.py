@@ -289,3 +289,30 @@ def test_gumbel_max_sampling_draws_from_the_softmax_distribution():
     a2 = get_decoding_strategy("sampling", tanh_clipping=10.0, temperature=0.8, seed=124).step(lg, mk, TensorDict({}, batch_size=[R]))["action"].cpu()
     # a different seed is an independent stream: two draws differ with probability 1 - sum p^2
     assert abs(float((a2 != a).float().mean()) - float(1 - (p * p).sum())) < 5e-3
+
+
+@pytest.mark.parametrize("name", ["atsp_n20_b4_beam5", "atsp_n20_b3_beam20"])
+def test_beam_search_matches_reference_beams(name):
+    """decode_type='beam_search' (decoding.py:402-554) against the reference run with select_best=False (its select_best=True
+    path cannot run with these envs: `_select_best_beam` calls .unsqueeze on the (real, normalised) reward tuple)."""
+    fx, w, pol, st, env, td_in = _setup(name)
+    W = fx["S"]
+    out = pol(env.reset(td_in), env, phase="val", decode_type="beam_search", beam_width=W, select_best=False, return_actions=True)
+    acts = out["actions"].cpu()
+    assert acts.shape == fx["actions"].shape and restate.atsp_check(acts)
+    # beams are ranked by summed log-probability: fp32 noise may swap two beams of (nearly) equal score, so compare the
+    # beam sets per instance, and the scores
+    B = fx["B"]
+    same = (acts == fx["actions"]).all(1)
+    for b in range(B):
+        mine = {tuple(r.tolist()) for r in acts[b::B]}
+        ref = {tuple(r.tolist()) for r in fx["actions"][b::B]}
+        assert len(mine & ref) >= len(ref) - 1, (b, len(mine & ref))
+    assert float(same.float().mean()) >= 0.8
+    assert torch.allclose(out["reward"].cpu()[same], fx["reward"][same], atol=COST_ATOL)
+    assert torch.allclose(out["log_likelihood"].cpu()[same], fx["log_likelihood"][same], rtol=LL_RTOL, atol=LL_ATOL)
+    # select_best=True (works here: the tuple is handled) returns, per instance, the best of exactly those beams
+    best = pol(env.reset(td_in), env, phase="val", decode_type="beam_search", beam_width=W, return_actions=True)
+    assert best["actions"].shape == (B, fx["N"])
+    ref_best = out["reward"].view(W, B).max(0).values
+    assert torch.allclose(best["reward"], ref_best, atol=COST_ATOL)
