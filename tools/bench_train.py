@@ -13,6 +13,7 @@ from rrnco_amd.models.rl import RRNet
 from rrnco_amd.parallel import aggregate_throughput
 
 ap = argparse.ArgumentParser()
+ap.add_argument("--problem", default="atsp", choices=["atsp", "rcvrp", "rcvrptw"])
 ap.add_argument("--batch", type=int, default=512)
 ap.add_argument("--steps", type=int, default=2)
 ap.add_argument("--enc-chunk", type=int, default=512)
@@ -30,13 +31,22 @@ if world > 1:
         dist.init_process_group("nccl", device_id=dev)
     else:
         dist.init_process_group(backend)
-pol, w = bench.make_policy(dev)
+if args.problem == "atsp":
+    pol, w = bench.make_policy(dev)
+    env = ATSPEnv(generator_params=dict(num_loc=100, device=dev), check_solution=False, device=dev)
+else:
+    from rrnco_amd.envs import RCVRPEnv, RMTVRPEnv
+    from rrnco_amd.models import RRNetPolicy
+    torch.manual_seed(1234)
+    pol = RRNetPolicy(env_name=args.problem, embed_dim=128, num_heads=8, num_encoder_layers=6, normalization="instance",
+                      use_graph_context=False, nab_type="gating", init_embedding_kwargs=dict(sample_size=25)).to(dev)
+    gp = dict(num_loc=100, device=dev)
+    env = RCVRPEnv(generator_params=gp, check_solution=False, device=dev) if args.problem == "rcvrp" else RMTVRPEnv(generator_params=gp, device=dev)
 pol.train()
-env = ATSPEnv(generator_params=dict(num_loc=100, device=dev), check_solution=False, device=dev)
 model = RRNet(env, policy=pol)
 opt = torch.optim.Adam(pol.parameters(), lr=1e-4)
 gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-batches = [ATSPGenerator(num_loc=100, device=dev)(args.batch, generator=gen) for _ in range(args.steps + 1)]
+batches = [env.generator(args.batch, generator=gen) for _ in range(args.steps + 1)]
 out = model.training_step(batches[0], optimizer=opt, world=world, enc_chunk=args.enc_chunk, dec_chunk=args.dec_chunk, seed=1)
 torch.cuda.synchronize()
 if world > 1:
@@ -48,7 +58,7 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 units, tmax = aggregate_throughput(args.batch * args.steps, dt, world > 1, dev if backend == "nccl" else torch.device("cpu"))
 if rank == 0:
-    print(json.dumps({"config": "C5 ATSP n=100 REINFORCE training step, %d instances/GPU, S=100 sampling, %d GPU(s)" % (args.batch, world),
+    print(json.dumps({"config": "%s n=100 REINFORCE training step, %d instances/GPU, multistart sampling, %d GPU(s)" % (args.problem.upper(), args.batch, world),
                       "instances_per_s": units / tmax, "ms_per_step": tmax / args.steps * 1e3, "loss": float(out["loss"]),
                       "grad_norm": float(out["grad_norm"]), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2**30,
                       "gradient_path": "teacher-forced autograd replay: HIP NAB forward/backward kernels + torch ops; rollout + loss on HIP kernels"}))
