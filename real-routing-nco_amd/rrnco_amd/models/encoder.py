@@ -11,13 +11,10 @@ import torch.nn as nn
 from .. import _lib as L
 
 
-NORMALIZATION = "instance"       # set by RRNetEncoder while it builds its module tree ("instance" | "batch")
-
-
 class _Norm(nn.Module):          # Normalization attn_freenet.py:78-116 -> `.normalizer.{weight,bias}` (+ running stats for "batch")
-    def __init__(self, E):
+    def __init__(self, E, normalization="instance"):
         super().__init__()
-        self.normalizer = nn.BatchNorm1d(E, affine=True) if NORMALIZATION == "batch" else nn.InstanceNorm1d(E, affine=True)
+        self.normalizer = nn.BatchNorm1d(E, affine=True) if normalization == "batch" else nn.InstanceNorm1d(E, affine=True)
 
 
 class _MLP1(nn.Sequential):      # nn.Sequential(Linear(1,E), ReLU, Linear(E,E))  attn_freenet.py:216-225
@@ -46,9 +43,9 @@ class _FFN(nn.Module):           # FeedForward attn_freenet.py:524-536
 
 
 class _TransformerFFN(nn.Module):  # attn_freenet.py:330-357
-    def __init__(self, E, ff):
+    def __init__(self, E, ff, normalization="instance"):
         super().__init__()
-        self.ops = nn.ModuleDict({"norm1": _Norm(E), "ffn": _FFN(E, ff), "norm2": _Norm(E)})
+        self.ops = nn.ModuleDict({"norm1": _Norm(E, normalization), "ffn": _FFN(E, ff), "norm2": _Norm(E, normalization)})
 
 
 class _DistAngleDurFusion(nn.Module):   # attn_freenet.py:201-240 with use_duration_matrix=True
@@ -75,7 +72,7 @@ class _NaiveNAB(nn.Module):      # NaiveNeuralAdaptiveBias attn_freenet.py:170-1
 
 
 class _Block(nn.Module):         # AttnFree_Block attn_freenet.py:360-415
-    def __init__(self, E, ff, use_duration=False, nab_type="gating"):
+    def __init__(self, E, ff, use_duration=False, nab_type="gating", normalization="instance"):
         super().__init__()
         self.alpha = nn.Parameter(torch.ones(1))
         self.attn_free = _AFT(E)
@@ -90,20 +87,23 @@ class _Block(nn.Module):         # AttnFree_Block attn_freenet.py:360-415
             self.neural_adaptive_bias = _DistAngleDurFusion(E)     # :379-383
         else:
             self.angle_distance_fusion = _DistAngleFusion(E)       # :384-389
-        self.feed_forward = _TransformerFFN(E, ff)
-        self.norm1, self.norm2, self.norm3 = _Norm(E), _Norm(E), _Norm(E)
+        self.feed_forward = _TransformerFFN(E, ff, normalization)
+        self.norm1, self.norm2, self.norm3 = _Norm(E, normalization), _Norm(E, normalization), _Norm(E, normalization)
 
 
 class _Layer(nn.Module):         # Attn_Free_Layer attn_freenet.py:444-470
-    def __init__(self, E, ff, use_duration=False, nab_type="gating"):
+    def __init__(self, E, ff, use_duration=False, nab_type="gating", normalization="instance"):
         super().__init__()
-        self.row_encoding_block, self.col_encoding_block = _Block(E, ff, use_duration, nab_type), _Block(E, ff, use_duration, nab_type)
+        self.row_encoding_block = _Block(E, ff, use_duration, nab_type, normalization)
+        self.col_encoding_block = _Block(E, ff, use_duration, nab_type, normalization)
 
 
 class AttnFreeNet(nn.Module):    # attn_freenet.py:491-515
-    def __init__(self, embed_dim=128, feedforward_hidden=512, num_layers=3, use_duration_matrix=False, nab_type="gating", **unused):
+    def __init__(self, embed_dim=128, feedforward_hidden=512, num_layers=3, use_duration_matrix=False, nab_type="gating",
+                 normalization="instance", **unused):
         super().__init__()
-        self.layers = nn.ModuleList([_Layer(embed_dim, feedforward_hidden, use_duration_matrix, nab_type) for _ in range(num_layers)])
+        self.layers = nn.ModuleList([_Layer(embed_dim, feedforward_hidden, use_duration_matrix, nab_type, normalization)
+                                     for _ in range(num_layers)])
 
 
 class _Gating(nn.Module):        # ContextualGating env_embeddings/atsp.py:108-121
@@ -146,8 +146,6 @@ class RRNetEncoder(nn.Module):
         if normalization not in ("instance", "batch"):
             raise NotImplementedError("rrnco_amd implements normalization='instance' (configs/experiment/rrnet.yaml) and 'batch'")
         self.normalization = normalization
-        global NORMALIZATION
-        NORMALIZATION = normalization
         self.env_name = getattr(env_name, "name", env_name)
         kw = dict(init_embedding_kwargs or {})
         if init_embedding is not None:
@@ -157,9 +155,8 @@ class RRNetEncoder(nn.Module):
         else:
             from .vrp_embeddings import make_vrp_init_embedding
             self.init_embedding = make_vrp_init_embedding(self.env_name, embed_dim, **kw)
-        self.net = AttnFreeNet(embed_dim, feedforward_hidden, num_layers, nab_type=nab_type,
+        self.net = AttnFreeNet(embed_dim, feedforward_hidden, num_layers, nab_type=nab_type, normalization=normalization,
                                use_duration_matrix=self.env_name not in ("atsp", "rcvrp")) if net is None else net   # encoder.py:63-66
-        NORMALIZATION = "instance"
 
     def forward(self, td, phase: str = "val", mask=None, packed=None):
         """-> (row_emb, col_emb) [B,N,E].  `packed` = packing.pack_policy(...) (the policy caches it)."""
