@@ -20,7 +20,7 @@ typedef struct ihipStream_t* hipStream_t;
 /* ---- packed-weight descriptors (built by rrnco_amd/packing.py; host structs holding device pointers) ---- */
 typedef struct {                /* one AttnFree_Block: rrnco/models/nn/attn_freenet.py:360-441 */
   const float *n1g, *n1b, *n2g, *n2b, *n3g, *n3b, *f1g, *f1b, *f2g, *f2b;   /* InstanceNorm1d affine [128] */
-  const void *wq, *wk, *wv, *wp, *wc, *w1, *w2;   /* MFMA A-operand packs: [M/16][K/16][64 lanes][4] floats  */
+  const void *wq, *wk, *wv, *wp, *wc, *w1, *w2;   /* MFMA A-operand packs [M/16][K/16][64 lanes][4]; wp = Wc Wp (project and multi_head_combine folded), wc unused */
   const float *bq, *bk, *bv, *bp, *bc, *b1, *b2;
   const float *nab;             /* folded DistAngleFusion (:201-289): piecewise-linear tables, packing.fold_nab_pwl */
 } EncBlockW;

@@ -27,7 +27,7 @@ __device__ unsigned long long rr_enc_stamps[8];
 
 struct EncBlockW {
   const float *n1g, *n1b, *n2g, *n2b, *n3g, *n3b, *f1g, *f1b, *f2g, *f2b;  // instance-norm affine [E]
-  const float4 *wq, *wk, *wv, *wp, *wc, *w1, *w2;                             // packed A operands
+  const float4 *wq, *wk, *wv, *wp, *wc, *w1, *w2;                             // packed A operands; wp = Wc Wp (folded), wc unused
   const float *bq, *bk, *bv, *bp, *bc, *b1, *b2;
   const float* nab;  // folded NAB: rows a_d,b_d,co_d,cg_d,a_a,b_a,co_a,cg_a [8][E] + 8 scalars
 };
@@ -340,31 +340,23 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_enc_block(EncBlockW wr, EncB
   __syncthreads();
   if (dbgb) for (int i = tid; i < N * RR_E; i += ENC_THREADS) dbgb[3 * N * RR_E + i] = B[i];
 
-  // ---- S5: P = project(Y) (:325) -> C
-  {
-    f32x4 pa[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) pa[nt] = rr_zero4();
-    rr_gemm_wx<NT>(pa, w.wp + (size_t)wave * 8 * 64, 0, 8, B, LD, 0, N, lane);
-    rr_add_bias<NT>(pa, w.bp, fb, lane);
-    rr_store_tiles<NT>(pa, C, LD, fb, N, lane);
-  }
-  __syncthreads();
-
-  // ---- S6: out = norm3(combine(P)) (:435-436); x1 = ffn.norm1(r + out) (:355)
+  // ---- S5+S6: out = norm3(combine(project(Y))) (:325, 435-436) — project and multi_head_combine are two Linear layers
+  // with nothing in between, folded on the host into one (packing.pack_policy: wp := Wc Wp, bp := Wc bp + bc);
+  // x1 = ffn.norm1(r + out) (:355)
   f32x4 x1[NT];
   {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) x1[nt] = rr_zero4();
-    rr_gemm_wx<NT>(x1, w.wc + (size_t)wave * 8 * 64, 0, 8, C, LD, 0, N, lane);
-    rr_add_bias<NT>(x1, w.bc, fb, lane);
+    rr_gemm_wx<NT>(x1, w.wp + (size_t)wave * 8 * 64, 0, 8, B, LD, 0, N, lane);
+    rr_add_bias<NT>(x1, w.bp, fb, lane);
     rr_instnorm_tiles<NT>(x1, w.n3g, w.n3b, fb, N, lane);
     f32x4 rt[NT];
     rr_load_tiles<NT>(rt, A, LD, fb, N, lane);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) x1[nt] = rt[nt] + x1[nt];
     rr_instnorm_tiles<NT>(x1, w.f1g, w.f1b, fb, N, lane);
-    rr_store_tiles<NT>(x1, B, LD, fb, N, lane);   // B (Y) is dead: every wave passed the S5 barrier
+    __syncthreads();                              // every wave has finished reading Y from B
+    rr_store_tiles<NT>(x1, B, LD, fb, N, lane);
   }
   __syncthreads();
   if (dbgb) for (int i = tid; i < N * RR_E; i += ENC_THREADS) dbgb[4 * N * RR_E + i] = B[i];

@@ -253,10 +253,14 @@ def pack_policy(sd: dict, env_name: str, device) -> dict:
                 setattr(w, f + "g", ar.put(gam.float()))
                 setattr(w, f + "b", ar.put(bet.float()))
             for f, k in (("q", "attn_free.to_q"), ("k", "attn_free.to_k"), ("v", "attn_free.to_v"),
-                         ("p", "attn_free.project"), ("c", "multi_head_combine"),
                          ("1", "feed_forward.ops.ffn.W1"), ("2", "feed_forward.ops.ffn.W2")):
                 setattr(w, "w" + f, ar.put(pack_a(sd[f"{b}.{k}.weight"].detach().float())))
                 setattr(w, "b" + f, ar.put(sd[f"{b}.{k}.bias"]))
+            # AFTFull.project (attn_freenet.py:325) feeds multi_head_combine (:435) directly: one Linear, folded in float64
+            Wp, bp = sd[f"{b}.attn_free.project.weight"].detach().double(), sd[f"{b}.attn_free.project.bias"].detach().double()
+            Wc, bc = sd[f"{b}.multi_head_combine.weight"].detach().double(), sd[f"{b}.multi_head_combine.bias"].detach().double()
+            w.wp, w.bp = ar.put(pack_a((Wc @ Wp).float())), ar.put((Wc @ bp + bc).float())
+            w.wc, w.bc = None, None
             if nab_kind != "gating":          # ablation modules: bias computed by rr_nab_simple, fed as bias_pre
                 w.nab = None
                 q, sw = f"{b}.neural_adaptive_bias", L.NabSimpleW()
