@@ -643,13 +643,150 @@ __global__ __launch_bounds__(256, 2) void k_nab_dur_pwl(NabDurW wr, NabDurW wc, 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Third generation: the same piecewise-linear rows served from LDS.  k_nab_dur_pwl gathers 3 KB of table rows per edge
+// from L2 and runs at the L2 gather rate; here a workgroup owns (a chunk of) one instance's edges, one edge per lane and
+// NABL_ET edges per thread, and walks the 128 gate units in four slices of 32: the slice's rows of all three families
+// (3 x 129 rows of 32 x {F, S}) are copied into LDS once (99 KB) and every edge of the chunk reads its three rows from
+// there with ds_read_b64 — 39 B of L2 traffic per edge instead of 3 KB.  A row is padded to 66 words so that row m starts
+// on bank 2m mod 64: lanes on one segment broadcast, lanes on different segments (closer than 32 apart) use different
+// banks.  Per-edge state kept across slices: packed segment indices, the three anchor distances, three gate logits.
+// Table layout in global memory (packing.fold_nab_dur_pwl, after the [3][129][2][128] rows): [4 slices][3][129][16 unit pairs]
+// (F_u, F_u+1, S_u, S_u+1), so that the evaluation runs two units per v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define NABL_THREADS 1024
+#define NABL_RS 68
+#define NABL_SLICE (3 * NABD_SEG * 64)
+#define NABL_HEAD ((NABD_ROWS + 3) & ~3)
+#define NABL_LDS_BYTES ((NABL_HEAD + 3 * NABD_SEG * NABL_RS) * 4)
+
+template <int ET>
+__global__ __launch_bounds__(NABL_THREADS) void k_nab_dur_lds(NabDurW wr, NabDurW wc, const float* __restrict__ D,
+                                                              const float* __restrict__ T, const float* __restrict__ locs,
+                                                              float* __restrict__ bias_out, int N) {
+  extern __shared__ __attribute__((aligned(16))) float nabl_sm[];
+  float* head = nabl_sm;
+  float* tab = nabl_sm + NABL_HEAD;
+  const int b = blockIdx.y, is_col = blockIdx.z;
+  const NabDurW& w = is_col ? wc : wr;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < NABD_ROWS; i += NABL_THREADS) head[i] = w.pwl[i];
+  __syncthreads();
+  const int NN = N * N;
+  const int e0 = blockIdx.x * (NABL_THREADS * ET);
+  const float* Db = D + (size_t)b * NN;
+  const float* Tb = T + (size_t)b * NN;
+  const float* lc = locs + (size_t)b * N * 2;
+  const unsigned char* cell = reinterpret_cast<const unsigned char*>(head + NABD_CELL);
+  unsigned seg[ET];
+  float dx[ET][3], l[ET][3];
+#pragma unroll
+  for (int et = 0; et < ET; ++et) {
+    int e = e0 + et * NABL_THREADS + tid; e = e < NN ? e : NN - 1;
+    const int i = e / N, jj = e - i * N;
+    float x[3];
+    x[0] = is_col ? Db[jj * N + i] : Db[e];
+    x[2] = is_col ? Tb[jj * N + i] : Tb[e];
+    x[1] = atan2f(lc[i * 2 + 1] - lc[jj * 2 + 1], lc[i * 2] - lc[jj * 2]);
+    int m[3];
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+      x[f] = fminf(x[f], 3.0e38f);
+      const int c = f == 1 ? (int)((x[1] + 3.14159265358979f) * ((float)NAB_G / 6.28318530717959f)) : (int)(x[f] * (float)NAB_G);
+      const int s0 = cell[f * NAB_G + min(max(c, 0), NAB_G - 1)];
+      m[f] = c < 0 ? 0 : s0;
+    }
+    int more;
+    do {                                                   // forward scan to the segment (sentinel +inf at index 128)
+      more = 0;
+#pragma unroll
+      for (int f = 0; f < 3; ++f) {
+        const int adv = head[f * NABD_TS + m[f]] <= x[f] ? 1 : 0;
+        m[f] += adv; more |= adv;
+      }
+    } while (__any(more));
+#pragma unroll
+    for (int f = 0; f < 3; ++f) dx[et][f] = x[f] - head[NABD_ANC + f * NABD_TS + m[f]];
+    seg[et] = (unsigned)m[0] | ((unsigned)m[1] << 8) | ((unsigned)m[2] << 16);
+    l[et][0] = l[et][1] = l[et][2] = 0.f;
+  }
+  const float* rows = w.pwl + NABD_ROWS + 3 * NABD_SEG * 2 * RR_E;
+#pragma unroll 1
+  for (int s = 0; s < 4; ++s) {
+    __syncthreads();                                       // everyone is done with the previous slice
+    const float4* src = reinterpret_cast<const float4*>(rows + (size_t)s * NABL_SLICE);
+    for (int i = tid; i < NABL_SLICE / 4; i += NABL_THREADS) {
+      const float4 v = src[i];
+      const int row = i >> 4, c = (i & 15) * 4;
+      *reinterpret_cast<float4*>(tab + row * NABL_RS + c) = v;
+    }
+    __syncthreads();
+    const float* g0 = w.wg2 + 32 * s;
+#pragma unroll
+    for (int et = 0; et < ET; ++et) {
+      // a row holds 16 unit pairs as (F_u, F_u+1, S_u, S_u+1): two units per packed-fp32 instruction
+      const float4* r0 = reinterpret_cast<const float4*>(tab) + (seg[et] & 255u) * (NABL_RS / 4);
+      const float4* r1 = reinterpret_cast<const float4*>(tab) + (NABD_SEG + ((seg[et] >> 8) & 255u)) * (NABL_RS / 4);
+      const float4* r2 = reinterpret_cast<const float4*>(tab) + (2 * NABD_SEG + (seg[et] >> 16)) * (NABL_RS / 4);
+      const f32x2 d0 = {dx[et][0], dx[et][0]}, d1 = {dx[et][1], dx[et][1]}, d2 = {dx[et][2], dx[et][2]};
+      f32x2 c0 = {0.f, 0.f}, c1 = {0.f, 0.f}, c2 = {0.f, 0.f};
+#pragma unroll 4
+      for (int p = 0; p < 16; ++p) {
+        const float4 q0 = r0[p], q1 = r1[p], q2 = r2[p];
+        const f32x2 F0 = {q0.x, q0.y}, S0 = {q0.z, q0.w}, F1 = {q1.x, q1.y}, S1 = {q1.z, q1.w}, F2 = {q2.x, q2.y}, S2 = {q2.z, q2.w};
+        const f32x2 z = (S0 * d0 + F0) + (S1 * d1 + F1) + (S2 * d2 + F2);
+        const f32x2 t = z * -1.44269504088896341f;
+        f32x2 ex = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};   // SiLU; |z| is O(10): a plain exp2 keeps ~1e-6 relative
+        ex = ex + 1.0f;
+        const f32x2 rc = {__builtin_amdgcn_rcpf(ex.x), __builtin_amdgcn_rcpf(ex.y)};
+        const f32x2 zs = z * rc;
+        const f32x2 w0 = {g0[2 * p], g0[2 * p + 1]}, w1 = {g0[128 + 2 * p], g0[128 + 2 * p + 1]}, w2 = {g0[256 + 2 * p], g0[256 + 2 * p + 1]};
+        c0 = w0 * zs + c0; c1 = w1 * zs + c1; c2 = w2 * zs + c2;
+      }
+      const float a0 = c0.x + c0.y, a1 = c1.x + c1.y, a2 = c2.x + c2.y;
+      l[et][0] += a0; l[et][1] += a1; l[et][2] += a2;
+    }
+  }
+#pragma unroll
+  for (int et = 0; et < ET; ++et) {
+    const int e = e0 + et * NABL_THREADS + tid;
+    const int mf[3] = {(int)(seg[et] & 255u), (int)((seg[et] >> 8) & 255u), (int)(seg[et] >> 16)};
+    float ox[3];
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+      const float* os = head + NABD_OSC + (f * NABD_SEG + mf[f]) * 2;
+      ox[f] = fmaf(os[1], dx[et][f], os[0]);
+    }
+    const float l0 = (l[et][0] + w.bg2[0]) * w.inv_tau, l1 = (l[et][1] + w.bg2[1]) * w.inv_tau, l2 = (l[et][2] + w.bg2[2]) * w.inv_tau;
+    const float m = fmaxf(l0, fmaxf(l1, l2));
+    const float e0x = rr_exp(l0 - m), e1x = rr_exp(l1 - m), e2x = rr_exp(l2 - m);
+    const float inv = 1.0f / (e0x + e1x + e2x);
+    const float bias = (e0x * inv) * ox[0] + (e1x * inv) * ox[1] + (e2x * inv) * ox[2] + w.bo;
+    if (e < NN) bias_out[(size_t)(b * 2 + is_col) * NN + e] = bias * w.alpha;
+  }
+}
+
 extern "C" int rr_nab_dur(const NabDurW* wrow, const NabDurW* wcol, const float* D, const float* T, const float* locs,
                           float* bias_out, int Bp, int N, hipStream_t st) {
   if (Bp <= 0 || N < 2 || wrow == nullptr || wcol == nullptr) return RR_EINVAL;
   const int per_wg = 4 * 16 * NAB_ET;
   dim3 grid((N * N + per_wg - 1) / per_wg, Bp, 2), blk(256);
-  static const int variant = [] { const char* e = getenv("RR_NABDUR_VARIANT"); return e ? atoi(e) : 1; }();
-  if (variant == 1 && wrow->pwl != nullptr && wcol->pwl != nullptr)
+  const char* ev = getenv("RR_NABDUR_VARIANT");           // 1 (default) LDS-resident rows, 2 rows gathered from L2, 0 MFMA contraction
+  const int variant = ev ? atoi(ev) : 1;
+  const bool has_pwl = wrow->pwl != nullptr && wcol->pwl != nullptr;
+  const int NN = N * N;
+  if (variant == 1 && has_pwl && NN >= 2048) {           // rows from LDS; below ~2k edges the 396 KB table copy per workgroup does not pay
+#define RR_NABL(ETV)                                                                                                   \
+  do {                                                                                                                 \
+    (void)hipFuncSetAttribute((const void*)k_nab_dur_lds<ETV>, hipFuncAttributeMaxDynamicSharedMemorySize, NABL_LDS_BYTES); \
+    hipLaunchKernelGGL(k_nab_dur_lds<ETV>, dim3((NN + NABL_THREADS * ETV - 1) / (NABL_THREADS * ETV), Bp, 2), dim3(NABL_THREADS), \
+                       NABL_LDS_BYTES, st, *wrow, *wcol, D, T, locs, bias_out, N);                                     \
+  } while (0)
+    if (NN <= 3 * NABL_THREADS) RR_NABL(3);          // 5 edges per thread is what 128 VGPRs (16 waves per CU) hold without spilling
+    else RR_NABL(5);
+#undef RR_NABL
+  } else if ((variant == 1 || variant == 2) && has_pwl)
     hipLaunchKernelGGL(k_nab_dur_pwl, grid, blk, 0, st, *wrow, *wcol, D, T, locs, bias_out, N);
   else   // MFMA contraction (first generation; kept for A/B)
     hipLaunchKernelGGL(k_nab_dur, grid, blk, 0, st, *wrow, *wcol, D, T, locs, bias_out, N);

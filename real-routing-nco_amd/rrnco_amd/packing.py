@@ -176,7 +176,8 @@ def fold_nab_dur_pwl(Ms, cg, cos, kos, a_, b_) -> torch.Tensor:
       anchor  [3][132]   anchor of segment m (0 where the family has no breakpoint to anchor on)
       osc     [3][129][2] (+2 pad)  (F_o, S_o) of co_x . h_x + ko_x
       cells   [3][1024] u8 grid-start bounds (nab_grid_cells semantics), packed 4 per word
-      rows    [3][129][2][128]  F then S of the 128 gate units; the constant cg is folded into family 0's F."""
+      rows    [3][129][2][128]  F then S of the 128 gate units; the constant cg is folded into family 0's F.
+      sliced  [4][3][129][16][2][2] the same rows per 32-unit slice as unit pairs (F_u, F_u+1, S_u, S_u+1) (k_nab_dur_lds copies a slice to LDS)."""
     import numpy as np
     ts = np.full((3, NABD_TS), np.inf)
     anc = np.zeros((3, NABD_TS))
@@ -214,7 +215,10 @@ def fold_nab_dur_pwl(Ms, cg, cos, kos, a_, b_) -> torch.Tensor:
         cells.append(np.minimum(np.searchsorted(t32, edges, side="right"), 128).astype(np.uint8))
     head = np.concatenate([ts.reshape(-1), anc.reshape(-1), osc.reshape(-1)]).astype(np.float32)
     cellw = np.concatenate(cells).view(np.float32)
-    return torch.from_numpy(np.concatenate([head, cellw, rows.reshape(-1).astype(np.float32)]))
+    # the same rows again as [4 unit slices][3][129][16 unit pairs](F, F, S, S) for the LDS-resident kernel (k_nab_dur_lds)
+    sliced = rows.reshape(3, NABD_SEG, 2, 4, 16, 2).transpose(3, 0, 1, 4, 2, 5)
+    return torch.from_numpy(np.concatenate([head, cellw, rows.reshape(-1).astype(np.float32),
+                                            np.ascontiguousarray(sliced).reshape(-1).astype(np.float32)]))
 
 
 class _Arena:

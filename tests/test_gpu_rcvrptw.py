@@ -111,6 +111,33 @@ def test_rcvrptw_encoder_with_duration_nab_matches_reference(name):
     assert torch.allclose(row.cpu(), fx["row_emb"], atol=ENC_ATOL) and torch.allclose(col.cpu(), fx["col_emb"], atol=ENC_ATOL)
 
 
+@pytest.mark.parametrize("n_nodes", [51, 72, 101, 110])
+def test_duration_nab_three_kernel_generations_agree(n_nodes, monkeypatch):
+    """rr_nab_dur: the LDS-resident piecewise-linear kernel (default for N*N >= 2048), the L2-gather one and the MFMA
+    contraction evaluate the same folded formula; they may differ by fp32 association only."""
+    from rrnco_amd import _lib as L
+    fx, w, pol, inst, env, td_in = _setup("rcvrptw_n20_b4_pomo")
+    packed = pol.packed(torch.device("cuda"))
+    g = torch.Generator().manual_seed(n_nodes)
+    Bp, N = 3, n_nodes
+    D = torch.rand(Bp, N, N, generator=g).cuda(); T = torch.rand(Bp, N, N, generator=g).cuda()
+    D[0, 0, :5] = 0.0; T[1, 2, :5] = 1.0
+    locs = torch.rand(Bp, N, 2, generator=g).cuda()
+    outs = []
+    for variant in ("1", "2", "0"):
+        monkeypatch.setenv("RR_NABDUR_VARIANT", variant)
+        bias = torch.full((Bp, 2, N * N), float("nan"), device="cuda")
+        for nr, nc in packed["nabdur"]:
+            L.check(L.lib().rr_nab_dur(nr, nc, L.ptr(D), L.ptr(T), L.ptr(locs), L.ptr(bias), Bp, N, L.stream()), "rr_nab_dur")
+            outs.append(bias.clone())
+    nl = len(packed["nabdur"])
+    for l in range(nl):
+        a, b, c = outs[l], outs[nl + l], outs[2 * nl + l]
+        assert torch.isfinite(a).all()
+        assert (a - b).abs().max() < 1e-5 * (1 + b.abs().max())
+        assert (a - c).abs().max() < 2e-5 * (1 + c.abs().max())
+
+
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("name", FIXTURES)
 def test_rcvrptw_policy_greedy_routes_match_reference(name, fused):
