@@ -52,10 +52,10 @@ __global__ __launch_bounds__(256) void k_atsp_step(const int64_t* __restrict__ a
   if (lane == 0) done[r] = (cnt <= 0);
 }
 
-// Vectorised form for N % 2 == 0 and 8 N <= 1024: a wave owns 8 consecutive rows = 8 N contiguous bytes (a multiple of
+// First vectorised form (kept for A/B, RR_STEP_VARIANT=0), N % 2 == 0 and 8 N <= 1024: a wave owns 8 consecutive rows = 8 N contiguous bytes (a multiple of
 // 16), each lane moves one 16-byte chunk.  The byte-per-lane kernel above keeps 64 B per load instruction in flight and
 // reaches 13 % of the HBM roofline; this one issues 8N B per wave with one load and one store per lane.
-__global__ __launch_bounds__(256) void k_atsp_step_v(const int64_t* __restrict__ action, const uint8_t* __restrict__ mask_in,
+__global__ __launch_bounds__(256) void k_atsp_step_v0(const int64_t* __restrict__ action, const uint8_t* __restrict__ mask_in,
                                                      uint8_t* __restrict__ mask_out, uint8_t* __restrict__ done, int R, int N) {
   const int lane = threadIdx.x & 63;
   const long r0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
@@ -97,12 +97,131 @@ __global__ __launch_bounds__(256) void k_atsp_step_v(const int64_t* __restrict__
   }
 }
 
+// Vectorised form for N % 2 == 0, 16 <= N <= 128: a wave owns 8 consecutive rows = 8 N contiguous bytes (a multiple of
+// 16), each lane moves one 16-byte chunk.  The
+// byte-per-lane kernel above keeps 64 B per load instruction in flight and reaches 13 % of the HBM roofline.  The action
+// byte of a row is cleared word-wise, `done` comes from one ballot per row (no per-byte loop, no shuffle reductions).
+template <int STEPV_CHUNKS>          // 16-byte chunks per lane, 8 rows per chunk
+__global__ __launch_bounds__(256) void k_atsp_step_v(const int64_t* __restrict__ action, const uint8_t* __restrict__ mask_in,
+                                                     uint8_t* __restrict__ mask_out, uint8_t* __restrict__ done, int R, int N) {
+  const int lane = threadIdx.x & 63;
+  constexpr int STEPV_ROWS = 8 * STEPV_CHUNKS;
+  const long r0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * STEPV_ROWS;
+  if (r0 >= R) return;
+  const int rows = (int)(R - r0 < STEPV_ROWS ? R - r0 : STEPV_ROWS);
+  const int nbytes = rows * N;
+  // both loads unconditional on always-valid addresses: guarded loads made hipcc wait for the action before issuing the
+  // mask load (two memory latencies per wave)
+  uint4 v[STEPV_CHUNKS];
+#pragma unroll
+  for (int h = 0; h < STEPV_CHUNKS; ++h) {
+    const int base = (lane + 64 * h) * 16;
+    v[h] = *reinterpret_cast<const uint4*>(mask_in + r0 * N + (base + 16 <= nbytes ? base : 0));
+  }
+  int myact = (int)action[r0 + (lane < rows ? lane : 0)];
+  myact = lane < rows ? myact : -1;
+#pragma unroll
+  for (int h = 0; h < STEPV_CHUNKS; ++h) {
+    const int base = (lane + 64 * h) * 16;
+    if (base + 16 > nbytes) {                                     // last wave only: a partial or absent chunk
+      v[h] = make_uint4(0, 0, 0, 0);
+      if (base < nbytes) {
+        const uint8_t* src = mask_in + r0 * N + base;
+        uint32_t t[4] = {0, 0, 0, 0};
+        for (int q = 0; q < nbytes - base; ++q) t[q >> 2] |= (uint32_t)src[q] << (8 * (q & 3));
+        v[h] = make_uint4(t[0], t[1], t[2], t[3]);
+      }
+    }
+  }
+  uint32_t left = 0;
+#pragma unroll
+  for (int h = 0; h < STEPV_CHUNKS; ++h) {
+    const int base = (lane + 64 * h) * 16;
+    const bool active = base < nbytes;
+    // the chunk [base, base+16) touches rows ra = base / N and (possibly) ra + 1
+    const int ra = base / N, split = (ra + 1) * N - base;          // bytes [0, split) belong to row ra
+    const int act_a = __shfl(myact, ra & 63), act_b = __shfl(myact, (ra + 1) & 63);
+    const int clr_a = act_a - (base - ra * N);                      // byte position of row ra's action inside this chunk
+    const int clr_b = act_b + split;
+    uint32_t w[4] = {v[h].x, v[h].y, v[h].z, v[h].w};
+    const int valid = min(max(nbytes - base, 0), 16);             // bytes of this chunk that exist
+    const int sa = min(split, valid);                             // bytes [0, sa) belong to row ra, [sa, valid) to row ra + 1
+    const int ca = (clr_a >= 0 && clr_a < sa) ? clr_a : -1;
+    const int cb = (clr_b >= sa && clr_b < valid) ? clr_b : -1;
+    uint32_t any_a = 0, any_b = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      uint32_t keepm = 0xffffffffu;
+      if ((ca >> 2) == k) keepm &= ~(0xffu << (8 * (ca & 3)));
+      if ((cb >> 2) == k) keepm &= ~(0xffu << (8 * (cb & 3)));
+      w[k] &= keepm;
+      // byte-range masks of word k: bytes with chunk index < n
+      const int ta = min(max(sa - 4 * k, 0), 4), tv = min(max(valid - 4 * k, 0), 4);
+      const uint32_t ma = ta == 4 ? 0xffffffffu : ((1u << (8 * ta)) - 1u), mv = tv == 4 ? 0xffffffffu : ((1u << (8 * tv)) - 1u);
+      any_a |= w[k] & ma; any_b |= w[k] & mv & ~ma;
+    }
+    uint8_t* dst = mask_out + r0 * N + base;
+    if (base + 16 <= nbytes) *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+    else if (active) { const uint8_t* pw = reinterpret_cast<const uint8_t*>(w); for (int q = 0; q < nbytes - base; ++q) dst[q] = pw[q]; }
+    // rows with a byte left set: one ballot per row
+#pragma unroll
+    for (int rr = 0; rr < STEPV_ROWS; ++rr) {
+      const bool mine = active && ((ra == rr && any_a != 0) || (ra + 1 == rr && any_b != 0));
+      left |= (__ballot(mine) != 0ull ? 1u : 0u) << rr;
+    }
+  }
+  if (lane < rows) done[r0 + lane] = ((left >> lane) & 1u) == 0;
+}
+
+// Third form, N % 4 == 0 and 16 <= N <= 128: eight lanes per row, lane s of a row moves the 16-byte window starting at
+// byte min(16 s, N - 16) with one dword-aligned access — the last window is pulled back to end at the row's end, so it
+// overlaps its neighbour and both write the same updated bytes.  No window straddles two rows: no row arithmetic, no
+// shuffle, no per-byte work, no divergent load (hipcc waits for all outstanding loads at a divergent one): ~50
+// instructions per wave against ~450 in k_atsp_step_v, which was VALU-bound at a third of the plain-copy rate.  `done` is
+// one ballot per pass.  STEPR_PASSES x 8 rows per wave, every load issued before the first use.
+typedef uint32_t rr_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+#define STEPR_PASSES 2
+__global__ __launch_bounds__(256) void k_atsp_step_r(const int64_t* __restrict__ action, const uint8_t* __restrict__ mask_in,
+                                                     uint8_t* __restrict__ mask_out, uint8_t* __restrict__ done, int R, int N) {
+  const int lane = threadIdx.x & 63, s = lane & 7, rl = lane >> 3;
+  const long rbase = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (8 * STEPR_PASSES);
+  const int ws = min(16 * s, N - 16);
+  const bool col_ok = 16 * s < N;
+  rr_u32x4_a4 w[STEPR_PASSES];
+  int act[STEPR_PASSES];
+#pragma unroll
+  for (int i = 0; i < STEPR_PASSES; ++i) {
+    const long r = rbase + 8 * i + rl;
+    const long rc = r < R ? r : 0;                       // rows past the end read row 0 and store nothing
+    w[i] = *reinterpret_cast<const rr_u32x4_a4*>(mask_in + rc * N + ws);
+    act[i] = (int)action[rc];
+  }
+#pragma unroll
+  for (int i = 0; i < STEPR_PASSES; ++i) {
+    const long r = rbase + 8 * i + rl;
+    const bool ok = r < R && col_ok;
+    const int c = act[i] - ws;                           // the action's byte inside this lane's window, if 0 <= c < 16
+    const uint32_t clr = ~(0xffu << (8 * (c & 3)));
+    w[i].x &= (c >> 2) == 0 ? clr : 0xffffffffu; w[i].y &= (c >> 2) == 1 ? clr : 0xffffffffu;
+    w[i].z &= (c >> 2) == 2 ? clr : 0xffffffffu; w[i].w &= (c >> 2) == 3 ? clr : 0xffffffffu;
+    if (ok) *reinterpret_cast<rr_u32x4_a4*>(mask_out + r * N + ws) = w[i];
+    const unsigned long long left = __ballot(ok && (w[i].x | w[i].y | w[i].z | w[i].w) != 0);
+    if (s == 0 && r < R) done[r] = ((left >> (8 * rl)) & 0xffull) == 0;
+  }
+}
+
 extern "C" int rr_atsp_step(const int64_t* action, const uint8_t* mask_in, uint8_t* mask_out, uint8_t* done,
                             int R, int N, hipStream_t st) {
   if (R <= 0 || N <= 0) return RR_EINVAL;
   const bool aligned = ((reinterpret_cast<uintptr_t>(mask_in) | reinterpret_cast<uintptr_t>(mask_out)) & 15) == 0;
-  if (N % 2 == 0 && 8 * N <= 1024 && N >= 16 && aligned)
-    hipLaunchKernelGGL(k_atsp_step_v, dim3((R + 31) / 32), dim3(256), 0, st, action, mask_in, mask_out, done, R, N);
+  static const int variant = [] { const char* e = getenv("RR_STEP_VARIANT"); return e ? atoi(e) : 1; }();
+  if (variant == 1 && N % 4 == 0 && N >= 16 && N <= 128 && ((reinterpret_cast<uintptr_t>(mask_in) | reinterpret_cast<uintptr_t>(mask_out)) & 3) == 0)
+    hipLaunchKernelGGL(k_atsp_step_r, dim3((R + 32 * STEPR_PASSES - 1) / (32 * STEPR_PASSES)), dim3(256), 0, st, action, mask_in, mask_out, done, R, N);
+  else if (N % 2 == 0 && N <= 128 && N >= 16 && aligned) {          // N >= 16: a 16-byte chunk spans at most two rows
+    if (variant == 0) hipLaunchKernelGGL(k_atsp_step_v0, dim3((R + 31) / 32), dim3(256), 0, st, action, mask_in, mask_out, done, R, N);
+    else if (variant == 3) hipLaunchKernelGGL(k_atsp_step_v<2>, dim3((R + 63) / 64), dim3(256), 0, st, action, mask_in, mask_out, done, R, N);
+    else hipLaunchKernelGGL(k_atsp_step_v<1>, dim3((R + 31) / 32), dim3(256), 0, st, action, mask_in, mask_out, done, R, N);
+  }
   else
     hipLaunchKernelGGL(k_atsp_step, dim3((R + 3) / 4), dim3(256), 0, st, action, mask_in, mask_out, done, R, N);
   return rr_check(hipGetLastError());
@@ -366,11 +485,142 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
                     seed, step, top_k, top_p);
 }
 
+// Second generation for the plain strategies (no top-k / top-p): 16 lanes per row, 4 rows per wave pass, SEL16_PASSES
+// passes per wave with every load issued up front.  A lane owns two groups of four consecutive keys (16-byte logits load,
+// 4-byte mask load when N % 4 == 0), so a row's reductions are 7 in-lane steps + 4 DPP steps inside the 16-lane row
+// (quad_perm xor 1 / xor 2, row_half_mirror, row_mirror: every lane ends with the row's result) instead of 6 ds_bpermute
+// round trips per reduction; elementwise formulas are those of rr_select_row.
+#define SEL16_PASSES 4
+template <int CTRL> __device__ __forceinline__ float rr_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL> __device__ __forceinline__ int rr_dppi(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ float rr_row16_max(float v) {
+  v = fmaxf(v, rr_dpp<0xB1>(v)); v = fmaxf(v, rr_dpp<0x4E>(v)); v = fmaxf(v, rr_dpp<0x141>(v)); return fmaxf(v, rr_dpp<0x140>(v));
+}
+__device__ __forceinline__ float rr_row16_sum(float v) {
+  v += rr_dpp<0xB1>(v); v += rr_dpp<0x4E>(v); v += rr_dpp<0x141>(v); return v + rr_dpp<0x140>(v);
+}
+// (value, key, logp) candidates: larger value wins, then the lower key — symmetric, so both lanes of a pair agree
+template <int CTRL> __device__ __forceinline__ void rr_row16_best(float& bv, int& bi, float& blp) {
+  const float ov = rr_dpp<CTRL>(bv), ol = rr_dpp<CTRL>(blp);
+  const int oi = rr_dppi<CTRL>(bi);
+  const bool take = ov > bv || (ov == bv && oi < bi);
+  bv = take ? ov : bv; bi = take ? oi : bi; blp = take ? ol : blp;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_select16(const float* __restrict__ logits, const uint8_t* __restrict__ mask,
+                                                  const int64_t* __restrict__ action_in, int64_t* __restrict__ action_out,
+                                                  float* __restrict__ logp_out, float* __restrict__ logp_all,
+                                                  int R, int N, float tanh_clip, float temperature, int mode,
+                                                  uint64_t seed, uint32_t step) {
+  const int lane = threadIdx.x & 63, p = lane & 15, rw = lane >> 4;
+  const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (4 * SEL16_PASSES) + rw;
+  float raw[SEL16_PASSES][8];
+  uint32_t keep[SEL16_PASSES][2];
+#pragma unroll
+  for (int i = 0; i < SEL16_PASSES; ++i) {
+    const int r = r0 + 4 * i;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int c = 4 * (p + 16 * q);
+      const size_t off = (size_t)r * N + c;
+      keep[i][q] = 0x01010101u;
+      if (VEC) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < R && c < N) {
+          v = *reinterpret_cast<const float4*>(logits + off);
+          if (mask != nullptr) keep[i][q] = *reinterpret_cast<const uint32_t*>(mask + off);
+        }
+        raw[i][4 * q] = v.x; raw[i][4 * q + 1] = v.y; raw[i][4 * q + 2] = v.z; raw[i][4 * q + 3] = v.w;
+      } else {
+        uint32_t kw = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const bool ok = r < R && c + k < N;
+          raw[i][4 * q + k] = ok ? logits[off + k] : 0.f;
+          kw |= (uint32_t)((ok && mask != nullptr) ? (mask[off + k] != 0) : 1) << (8 * k);
+        }
+        keep[i][q] = kw;
+      }
+    }
+  }
+  const float inv_temp = 1.0f / temperature;
+#pragma unroll
+  for (int i = 0; i < SEL16_PASSES; ++i) {
+    const int r = r0 + 4 * i;            // rows >= R run on zeros and store nothing: the DPP steps need the whole wave
+    float x[8];
+    float m = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int j = 4 * (p + 16 * (e >> 2)) + (e & 3);
+      float v = raw[i][e];
+      // tanh through one plain v_exp_f32: |error| <= 4e-8 on tanh (4e-7 after the x10 clip), largest near |v| = 0.75
+      if (tanh_clip > 0.f) v = fmaf(__builtin_amdgcn_rcpf(rr_exp_fast(2.0f * v) + 1.0f), -2.0f * tanh_clip, tanh_clip);
+      if (((keep[i][e >> 2] >> (8 * (e & 3))) & 0xffu) == 0) v = -INFINITY;
+      v = v * inv_temp;
+      x[e] = j < N ? v : -INFINITY;
+      m = fmaxf(m, x[e]);
+    }
+    m = rr_row16_max(m);
+    float ssum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int j = 4 * (p + 16 * (e >> 2)) + (e & 3);
+      ssum += j < N ? rr_exp_fast(x[e] - m) : 0.f;       // arguments in [-2 clip / T, 0]; same form as the fused rollout
+    }
+    const float lse = rr_log(rr_row16_sum(ssum));
+    const int want = (mode == 2 && r < R) ? (int)action_in[r] : -1;
+    float bv = -INFINITY, blp = 0.f;
+    int bi = 0x7fffffff;
+    float lp[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int j = 4 * (p + 16 * (e >> 2)) + (e & 3);
+      lp[e] = x[e] - m - lse;
+      float sv;
+      if (mode == 2) sv = j == want ? 1.f : -INFINITY;
+      else if (mode == 1) sv = (j < N && lp[e] > -INFINITY) ? lp[e] + rr_gumbel(seed, (uint32_t)r, step, (uint32_t)j) : -INFINITY;
+      else sv = j < N ? lp[e] : -INFINITY;
+      const bool better = sv > bv || (bi == 0x7fffffff && j < N && mode == 0);   // ascending keys in the lane: first maximum kept
+      bv = better ? sv : bv; bi = better ? j : bi; blp = better ? lp[e] : blp;
+    }
+    if (logp_all != nullptr && r < R) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int c = 4 * (p + 16 * q);
+        float* dst = logp_all + (size_t)r * N + c;
+        if (VEC) { if (c < N) *reinterpret_cast<float4*>(dst) = make_float4(lp[4 * q], lp[4 * q + 1], lp[4 * q + 2], lp[4 * q + 3]); }
+        else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) if (c + k < N) dst[k] = lp[4 * q + k];
+        }
+      }
+    }
+    rr_row16_best<0xB1>(bv, bi, blp); rr_row16_best<0x4E>(bv, bi, blp);
+    rr_row16_best<0x141>(bv, bi, blp); rr_row16_best<0x140>(bv, bi, blp);
+    if (p == 0 && r < R) { action_out[r] = bi; logp_out[r] = blp; }
+  }
+}
+
 extern "C" int rr_select(const float* logits, const uint8_t* mask, const int64_t* action_in, int64_t* action_out,
                          float* logp_out, float* logp_all, int R, int N, float tanh_clip, float temperature,
                          int mode, uint64_t seed, uint32_t step, int top_k, float top_p, hipStream_t st) {
   if (R <= 0 || N <= 0 || N > 128 || temperature <= 0.f || top_k < 0 || top_p < 0.f || top_p > 1.f) return RR_EINVAL;
   if (mode == 2 && action_in == nullptr) return RR_EINVAL;
+  static const int gen = [] { const char* e = getenv("RR_SELECT_VARIANT"); return e ? atoi(e) : 1; }();
+  const bool filters = (top_k > 0 && top_k < N) || (top_p > 0.f && top_p < 1.f);
+  if (gen == 1 && !filters) {
+    const uintptr_t al = reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(logp_all);
+    const bool vec = N % 4 == 0 && (al & 15) == 0 && (reinterpret_cast<uintptr_t>(mask) & 3) == 0;
+    const dim3 grid((R + 16 * SEL16_PASSES - 1) / (16 * SEL16_PASSES));
+    if (vec) hipLaunchKernelGGL(k_select16<true>, grid, dim3(256), 0, st, logits, mask, action_in, action_out, logp_out, logp_all, R, N,
+                                tanh_clip, temperature, mode, seed, step);
+    else hipLaunchKernelGGL(k_select16<false>, grid, dim3(256), 0, st, logits, mask, action_in, action_out, logp_out, logp_all, R, N,
+                            tanh_clip, temperature, mode, seed, step);
+    return rr_check(hipGetLastError());
+  }
   hipLaunchKernelGGL(k_select, dim3((R + 4 * SEL_ROWS - 1) / (4 * SEL_ROWS)), dim3(256), 0, st, logits, mask, action_in, action_out, logp_out,
                      logp_all, R, N, tanh_clip, temperature, mode, seed, step, top_k, top_p);
   return rr_check(hipGetLastError());
