@@ -127,7 +127,10 @@ typedef struct {
   const float* dist_limit;      /* [Bp], +inf = none */
   const int32_t* bclass;        /* [Bp] backhaul class 1 or 2 */
 } MtvrpExtra;
-int rr_rmtvrp_step(const int64_t* action, const float* D, const float* T, const float* demand_l, const float* tw,
+int rr_rmtvrp_step(const int64_t* action, const float* D, const float* T,
+                   const float* to_depot_D /* [Bp][N] = D[:, :, 0] contiguous, or NULL (read strided from D) */,
+                   const float* to_depot_T /* [Bp][N] = T[:, :, 0], NULL together with to_depot_D */,
+                   const float* demand_l, const float* tw,
                    const float* service, const float* vcap, int64_t* cur, float* ctime, float* rlen, float* used_l,
                    uint8_t* visited, uint8_t* mask, uint8_t* done, int R, int Bp, int N, const MtvrpExtra* extra,
                    hipStream_t stream);

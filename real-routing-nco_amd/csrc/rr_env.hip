@@ -705,7 +705,136 @@ __global__ __launch_bounds__(256) void k_rmtvrp_step(const int64_t* __restrict__
   }
 }
 
-extern "C" int rr_rmtvrp_step(const int64_t* action, const float* D, const float* T, const float* demand_l,
+// Second form (4 <= N <= 128): 32 lanes per rollout, lane l owns the four nodes of the window starting at min(4 l, N - 4)
+// (the last window is pulled back to end at N - 1 and overlaps its neighbour, which computes and stores the same bytes),
+// so every per-node operand is one 16-byte load: the rows D[a,:], T[a,:], the depot columns as contiguous vectors
+// (to_depot_D / to_depot_T, [Bp][N], prepared once per instance by the caller: read through D[k*N] they were 2 x N
+// separate cache lines per rollout, 80 % of the kernel's L2 traffic), time windows, service times, demands.  The counts of
+// the first form (visited == N, linehauls missing, any free customer) are existence tests: three ballots, no shuffle
+// reduction, and `visited` is updated by one byte store instead of being rewritten.  Same fp32 expressions as
+// k_rmtvrp_step: masks are bit-identical.  MTV_PASSES x 2 rollouts per wave.
+typedef float rr_f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t rr_u32_a1 __attribute__((aligned(1)));
+#define MTV_PASSES 2
+__global__ __launch_bounds__(256) void k_rmtvrp_step_v(const int64_t* __restrict__ action, const float* __restrict__ D,
+                                                       const float* __restrict__ T, const float* __restrict__ D0,
+                                                       const float* __restrict__ T0, const float* __restrict__ dem_l,
+                                                       const float* __restrict__ tw, const float* __restrict__ service,
+                                                       const float* __restrict__ vcap, int64_t* __restrict__ cur_io,
+                                                       float* __restrict__ ctime, float* __restrict__ rlen,
+                                                       float* __restrict__ used_l, uint8_t* __restrict__ visited,
+                                                       uint8_t* __restrict__ mask, uint8_t* __restrict__ done,
+                                                       int R, int Bp, int N, MtvrpExtra ex, int has_ex) {
+  const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
+  const long rbase = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (2 * MTV_PASSES);
+  const int ws = min(4 * hl, N - 4);
+  const bool col_ok = 4 * hl < N;
+  int a[MTV_PASSES], prev[MTV_PASSES], b[MTV_PASSES];
+  float ct[MTV_PASSES], rl[MTV_PASSES], ul[MTV_PASSES], ub[MTV_PASSES], cap[MTV_PASSES];
+#pragma unroll
+  for (int i = 0; i < MTV_PASSES; ++i) {
+    const long r = rbase + 2 * i + half;
+    const long rc = r < R ? r : R - 1;                    // rows past the end recompute the last row and store nothing
+    b[i] = (int)(rc % Bp);
+    a[i] = (int)action[rc]; prev[i] = (int)cur_io[rc];
+    ct[i] = ctime[rc]; rl[i] = rlen[rc]; ul[i] = used_l[rc]; cap[i] = vcap[rc];
+    ub[i] = has_ex ? ex.used_b[rc] : 0.f;
+  }
+  float Tpa[MTV_PASSES], Dpa[MTV_PASSES], twa[MTV_PASSES], sva[MTV_PASSES], dla[MTV_PASSES], dba[MTV_PASSES], late0[MTV_PASSES];
+  float closed[MTV_PASSES], limit[MTV_PASSES];
+  int bclass[MTV_PASSES];
+  uint32_t visw[MTV_PASSES];
+  rr_f32x4_a4 Trow[MTV_PASSES], Drow[MTV_PASSES], T0v[MTV_PASSES], D0v[MTV_PASSES], twlo[MTV_PASSES], twhi[MTV_PASSES];
+  rr_f32x4_a4 svv[MTV_PASSES], dlv[MTV_PASSES], dbv[MTV_PASSES];
+#pragma unroll
+  for (int i = 0; i < MTV_PASSES; ++i) {
+    const long r = rbase + 2 * i + half;
+    const long rc = r < R ? r : R - 1;
+    const size_t bo = (size_t)b[i] * N;
+    const float* Db = D + bo * N;
+    const float* Tb = T + bo * N;
+    const float* twb = tw + bo * 2;
+    Tpa[i] = Tb[prev[i] * N + a[i]]; Dpa[i] = Db[prev[i] * N + a[i]];
+    twa[i] = twb[a[i] * 2]; sva[i] = service[bo + a[i]]; dla[i] = dem_l[bo + a[i]]; late0[i] = twb[1];
+    dba[i] = has_ex ? ex.demand_b[bo + a[i]] : 0.f;
+    closed[i] = (has_ex && ex.open_route[b[i]]) ? 0.f : 1.f;
+    limit[i] = has_ex ? ex.dist_limit[b[i]] : INFINITY;
+    bclass[i] = has_ex ? ex.bclass[b[i]] : 1;
+    visw[i] = *reinterpret_cast<const rr_u32_a1*>(visited + rc * N + ws);
+    Trow[i] = *reinterpret_cast<const rr_f32x4_a4*>(Tb + a[i] * N + ws);
+    Drow[i] = *reinterpret_cast<const rr_f32x4_a4*>(Db + a[i] * N + ws);
+    if (T0 != nullptr) {
+      T0v[i] = *reinterpret_cast<const rr_f32x4_a4*>(T0 + bo + ws);
+      D0v[i] = *reinterpret_cast<const rr_f32x4_a4*>(D0 + bo + ws);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { T0v[i][q] = Tb[(ws + q) * N]; D0v[i][q] = Db[(ws + q) * N]; }
+    }
+    twlo[i] = *reinterpret_cast<const rr_f32x4_a4*>(twb + 2 * ws);
+    twhi[i] = *reinterpret_cast<const rr_f32x4_a4*>(twb + 2 * ws + 4);
+    svv[i] = *reinterpret_cast<const rr_f32x4_a4*>(service + bo + ws);
+    dlv[i] = *reinterpret_cast<const rr_f32x4_a4*>(dem_l + bo + ws);
+    if (has_ex) dbv[i] = *reinterpret_cast<const rr_f32x4_a4*>(ex.demand_b + bo + ws);
+    else dbv[i] = rr_f32x4_a4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int i = 0; i < MTV_PASSES; ++i) {
+    const long r = rbase + 2 * i + half;
+    const bool row_ok = r < R;
+    const int av = a[i];
+    const float nz = av != 0 ? 1.0f : 0.0f;
+    const float t1 = nz * (fmaxf(ct[i] + Tpa[i], twa[i]) + sva[i]);                     // env.py:170-172
+    const float len1 = nz * (rl[i] + Dpa[i]);                                          // :175-177
+    const float u1 = nz * (ul[i] + dla[i]);                                            // :189-191
+    const float ub1 = has_ex ? nz * (ub[i] + dba[i]) : 0.f;                            // :192-194
+    const bool carrying_b = has_ex && dba[i] > 0.f;                                    // :388-396
+    bool vq[4];
+    bool unvis = false, miss = false;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      vq[q] = ((visw[i] >> (8 * q)) & 0xffu) != 0 || ws + q == av;
+      unvis |= !vq[q];
+      miss |= !vq[q] && dlv[i][q] > 0.f;                                               // linehauls_missing :384-386
+    }
+    const int sh = 32 * half;
+    const bool missing = (uint32_t)(__ballot(col_ok && miss) >> sh) != 0;
+    const bool all_visited = (uint32_t)(__ballot(col_ok && unvis) >> sh) == 0;
+    bool can[4];
+    bool free_here = false;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float early = q < 2 ? twlo[i][2 * q] : twhi[i][2 * q - 4], late = q < 2 ? twlo[i][2 * q + 1] : twhi[i][2 * q - 3];
+      const float arrival = t1 + Trow[i][q];
+      const bool reach = arrival < late;                                               // :361
+      const bool back = ((fmaxf(arrival, early) + svv[i][q] + T0v[i][q]) * closed[i]) < late0[i];      // :364-366
+      const bool far = (len1 + Drow[i][q] + D0v[i][q] * closed[i]) > limit[i];         // :369-372
+      const float dlk = dlv[i][q], dbk = dbv[i][q];
+      const bool ex_l = dlk + u1 > cap[i], ex_b = dbk + ub1 > cap[i];                  // :375-380
+      const bool ok1 = (missing && !ex_l && !carrying_b && dlk > 0.f) || (!ex_b && dbk > 0.f);       // :397-402
+      const bool ok2 = !ex_l && !ex_b && !(dlk > cap[i] - ub1);                        // :407-412
+      const bool ok = bclass[i] == 1 ? ok1 : (bclass[i] == 2 ? ok2 : false);           // :415-417
+      can[q] = reach && back && ok && !far && !vq[q];                                  // :420-426
+      free_here |= can[q] && ws + q >= 1;
+    }
+    const bool anyfree = (uint32_t)(__ballot(col_ok && free_here) >> sh) != 0;
+    uint32_t mw = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool bit = ws + q == 0 ? !(av == 0 && anyfree) : can[q];                   // depot rule :429
+      mw |= (bit ? 1u : 0u) << (8 * q);
+    }
+    if (row_ok && col_ok) *reinterpret_cast<rr_u32_a1*>(mask + r * N + ws) = mw;
+    if (row_ok && hl == 0) {
+      visited[r * N + av] = 1;
+      cur_io[r] = av; ctime[r] = t1; rlen[r] = len1; used_l[r] = u1;
+      if (has_ex) ex.used_b[r] = ub1;
+      done[r] = all_visited;
+    }
+  }
+}
+
+extern "C" int rr_rmtvrp_step(const int64_t* action, const float* D, const float* T, const float* to_depot_D,
+                              const float* to_depot_T, const float* demand_l,
                               const float* tw, const float* service, const float* vcap, int64_t* cur, float* ctime,
                               float* rlen, float* used_l, uint8_t* visited, uint8_t* mask, uint8_t* done,
                               int R, int Bp, int N, const MtvrpExtra* extra, hipStream_t st) {
@@ -715,8 +844,15 @@ extern "C" int rr_rmtvrp_step(const int64_t* action, const float* D, const float
     ex = *extra;
     if (!ex.demand_b || !ex.used_b || !ex.open_route || !ex.dist_limit || !ex.bclass) return RR_EINVAL;
   }
-  hipLaunchKernelGGL(k_rmtvrp_step, dim3((R + 3) / 4), dim3(256), 0, st, action, D, T, demand_l, tw, service, vcap, cur,
-                     ctime, rlen, used_l, visited, mask, done, R, Bp, N, ex, extra != nullptr ? 1 : 0);
+  if ((to_depot_D == nullptr) != (to_depot_T == nullptr)) return RR_EINVAL;
+  static const int variant = [] { const char* e = getenv("RR_STEP_VARIANT"); return e ? atoi(e) : 1; }();
+  if (variant != 0 && N >= 4 && N <= 128)
+    hipLaunchKernelGGL(k_rmtvrp_step_v, dim3((R + 8 * MTV_PASSES - 1) / (8 * MTV_PASSES)), dim3(256), 0, st, action, D, T, to_depot_D,
+                       to_depot_T, demand_l, tw, service, vcap, cur, ctime, rlen, used_l, visited, mask, done, R, Bp, N, ex,
+                       extra != nullptr ? 1 : 0);
+  else
+    hipLaunchKernelGGL(k_rmtvrp_step, dim3((R + 3) / 4), dim3(256), 0, st, action, D, T, demand_l, tw, service, vcap, cur,
+                       ctime, rlen, used_l, visited, mask, done, R, Bp, N, ex, extra != nullptr ? 1 : 0);
   return rr_check(hipGetLastError());
 }
 

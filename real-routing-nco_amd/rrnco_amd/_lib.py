@@ -69,7 +69,7 @@ _SIGS = {
     "rr_edge_angles": [vp, vp, i32, i32, vp],
     "rr_nab_dur": [C.POINTER(NabDurW), C.POINTER(NabDurW), vp, vp, vp, vp, i32, i32, vp],
     "rr_nab_simple": [C.POINTER(NabSimpleW), C.POINTER(NabSimpleW), i32, vp, vp, vp, vp, i32, i32, vp],
-    "rr_rmtvrp_step": [vp] * 14 + [i32, i32, i32, C.POINTER(MtvrpExtra), vp],
+    "rr_rmtvrp_step": [vp] * 16 + [i32, i32, i32, C.POINTER(MtvrpExtra), vp],
     "rr_reinforce_loss": [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "rr_init_embed": [C.POINTER(InitW), i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "rr_dec_cache": [C.POINTER(CacheW), vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],

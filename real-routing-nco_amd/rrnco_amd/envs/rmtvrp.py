@@ -166,7 +166,11 @@ class RMTVRPEnv(EnvBase):
             extra = L.MtvrpExtra()
             extra.demand_b, extra.used_b = L.ptr(keep[0]), L.ptr(used_b)
             extra.open_route, extra.dist_limit, extra.bclass = L.ptr(keep[1]), L.ptr(keep[2]), L.ptr(keep[3])
-        L.check(L.lib().rr_rmtvrp_step(L.ptr(action), L.ptr(D), L.ptr(T), L.ptr(dl), L.ptr(tw), L.ptr(sv), L.ptr(vcap),
+        col = td.meta.get("_to_depot")          # D[:, :, 0], T[:, :, 0] as contiguous [Bp, N] vectors, once per instance batch
+        if col is None or col[0] != (D.data_ptr(), T.data_ptr()):
+            col = ((D.data_ptr(), T.data_ptr()), D[:, :, 0].contiguous(), T[:, :, 0].contiguous())
+            td.meta["_to_depot"] = col
+        L.check(L.lib().rr_rmtvrp_step(L.ptr(action), L.ptr(D), L.ptr(T), L.ptr(col[1]), L.ptr(col[2]), L.ptr(dl), L.ptr(tw), L.ptr(sv), L.ptr(vcap),
                                        L.ptr(cur), L.ptr(ctime), L.ptr(rlen), L.ptr(used), L.ptr(vis), L.ptr(mask),
                                        L.ptr(done), R, D.shape[0], D.shape[-1], extra, L.stream()), "rr_rmtvrp_step")
         td.update({"current_node": cur, "current_route_length": rlen, "current_time": ctime, "done": done,

@@ -12,6 +12,7 @@ from rrnco_amd.models import rollout as R
 from rrnco_amd import TensorDict
 
 dev = torch.device("cuda")
+FUSED = os.environ.get("FUSED", "1") != "0"      # FUSED=0: the reference-shaped per-step loop on the step kernels
 
 
 def policy(env_name):
@@ -33,7 +34,7 @@ def run(name, env, pol, B, S, aug, decode, steps=2):
         if aug:
             td = StateAugmentation(augment_fn="dihedral8", no_aug_coords=False)(td)
         td["sample_idx"] = sidx
-        return pol(env.reset(td), env, phase="val", decode_type=decode, num_starts=S, seed=1)
+        return pol(env.reset(td), env, phase="val", decode_type=decode, num_starts=S, seed=1, fused=FUSED)
     out = step(); torch.cuda.synchronize()
     R.TIMING = []
     t0 = time.perf_counter()
@@ -41,7 +42,7 @@ def run(name, env, pol, B, S, aug, decode, steps=2):
         out = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    k = [a.elapsed_time(b) for a, b in R.TIMING]; R.TIMING = None
+    k = [a.elapsed_time(b) for a, b in R.TIMING] or [0.0]; R.TIMING = None
     print(json.dumps({"config": name, "instances_per_s": B / dt, "ms_per_step": dt * 1e3, "rollout_kernel_ms": sum(k) / len(k),
                       "decode_steps": int(out["actions"].shape[1]), "rollouts": int(out["actions"].shape[0]),
                       "mean_best_cost": float(-out["reward"].view(S, -1).max(0).values.mean())}))
