@@ -10,6 +10,7 @@
  */
 #ifndef RRNCO_HIP_H
 #define RRNCO_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -168,6 +169,30 @@ int rr_nab_train_bwd(const float* tab, const float* xd, const float* xa, const f
  * grad_ll are [S*B] with r = s*B + b; bl and partial are [B] workspaces; loss is one float. */
 int rr_reinforce_loss(const float* reward, const float* ll, float* adv, float* grad_ll, float* bl, float* partial,
                       float* loss, int B, int S, hipStream_t stream);
+
+/* ---- MatNet baseline encoder ------------------------------------------------------------------------
+ * One MatNetLayer (rrnco/baselines/MatNet/encoder.py:148-172): mixed-score cross attention (MixedScoresSDPA :14-92 inside
+ * rl4co's MultiHeadCrossAttention: Wq, Wkv = K | V, out_proj, no biases) of the row block on the column embeddings with
+ * dmat = D and of the column block on the row embeddings with dmat = D^T (:133-145), each followed by TransformerFFN
+ * (norm1(x_old + x), norm2(x + W2 relu(W1 x + b1) + b2), InstanceNorm1d affine).  Head dim 16 (E = 16 heads), E and ff
+ * multiples of 256 (configs/experiment/matnet.yaml: 256 / 16 / 512), N <= 112.  Weight matrices are packed A operands
+ * (rrnco_amd/packing.pack_a); mix [heads][68] = W1 score row / sqrt(16) | W1 distance row | b1 | W2 | b2, 0, 0, 0. */
+typedef struct {
+  const void *wq, *wkv, *wo, *w1, *w2;
+  const float *b1, *b2;
+  const float *n1g, *n1b, *n2g, *n2b;
+  const float* mix;
+} MatNetSideW;
+size_t rr_matnet_workspace_bytes(int Bp, int N, int E, int ff);
+int rr_matnet_layer(const MatNetSideW* row_side, const MatNetSideW* col_side, const float* row_in, const float* col_in,
+                    float* row_out, float* col_out, const float* D, float* workspace, size_t workspace_bytes,
+                    int Bp, int N, int E, int heads, int ff, hipStream_t stream);
+/* MatNet init embeddings (env_embeddings/atsp.py:21-34; rcvrp.py:37-81 with use_coords=False) in host-folded form:
+ * row[n] = rowv[kind] + rowv[2] * demand, col[n] = slot_t[rand_idx[n]] + colv[kind] + colv[2] * demand (kind 0 depot,
+ * 1 customer; rowv / colv [3][E], slot_t [E][E] = col_combine_embed.weight[:, :E]^T, demand [Bp][N-1]); with rowv = colv =
+ * NULL: row = 0, col = one-hot at rand_idx (ATSP).  rand_idx [Bp][N] int64 = the reference's rand.argsort(dim=1). */
+int rr_matnet_init(const int64_t* rand_idx, const float* demand, const float* rowv, const float* colv, const float* slot_t,
+                   float* row, float* col, int Bp, int N, int E, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -301,6 +301,49 @@ def gen_rcvrptw(tag, B, N, S, sample_size, seed, layers=6, keep_trace=True, nab_
     print(f"wrote {path}  ({os.path.getsize(path)/1e3:.0f} kB) T={out['actions'].shape[1]} reward[:3]={out['reward'][:3].tolist()}")
 
 
+def gen_matnet(tag, env_name, B, N, seed, layers, embed_dim=256, heads=16):
+    """MatNet baseline encoder (rrnco/baselines/MatNet/encoder.py), the reference module run as is.  Its init embedding
+    draws the one-hot slots from torch.rand inside forward(); the same draw is reproduced here from the same seed and stored."""
+    from rrnco.baselines.MatNet.encoder import MatNetEncoder
+
+    kw = dict(use_coords=False, use_polar_feats=False) if env_name == "rcvrp" else {}
+    enc = MatNetEncoder(embed_dim=embed_dim, num_heads=heads, num_layers=layers, normalization="instance", env_name=env_name,
+                        init_embedding_kwargs=kw).eval()
+    tmpl = {k: tuple(v.shape) for k, v in enc.state_dict().items()}
+    assert tmpl == restate.matnet_weight_template(embed_dim, heads, layers, 512, env_name), \
+        set(tmpl) ^ set(restate.matnet_weight_template(embed_dim, heads, layers, 512, env_name))
+    w = restate.make_weights(tmpl, seed)
+    enc.load_state_dict(w, strict=True)
+    if env_name == "atsp":
+        st = restate.atsp_reset(restate.atsp_synthetic(B, N, seed))
+        nodes = N
+    else:
+        st = restate.rcvrp_reset(restate.rcvrp_synthetic(B, N, seed, 30.0 if N <= 20 else 50.0))
+        nodes = N + 1
+    td = TensorDict({k: v.clone() for k, v in st.items() if isinstance(v, torch.Tensor)}, batch_size=[B])
+    torch.manual_seed(seed)
+    rand_idx = torch.rand(B, nodes).argsort(dim=1)             # env_embeddings/atsp.py:29-30 draw, replayed
+    torch.manual_seed(seed)
+    l1 = []
+    hook = enc.layers[0].register_forward_hook(lambda m, a, o: l1.append(o))
+    with torch.inference_mode():
+        (row, col), _ = enc(td)
+    hook.remove()
+    tr = {}
+    with torch.inference_mode():
+        mrow, mcol = restate.matnet_encoder(dict(enc.state_dict()), st, rand_idx, layers, heads, env_name, embed_dim, trace=tr)
+    assert torch.equal(mrow, row) and torch.equal(mcol, col), ((mrow - row).abs().max(), (mcol - col).abs().max())
+    assert torch.equal(tr["row1"], l1[0][0]) and torch.equal(tr["col1"], l1[0][1])
+    fx = {"env_name": env_name, "B": B, "N": N, "seed": seed, "layers": layers, "embed_dim": embed_dim, "heads": heads,
+          "distance_matrix": st["distance_matrix"], "rand_idx": rand_idx, "row_emb": row, "col_emb": col,
+          "row_l1": l1[0][0], "col_l1": l1[0][1]}
+    if env_name == "rcvrp":
+        fx["demand"] = st["demand"]
+    path = os.path.join(GOLD, tag + ".npz")
+    np.savez_compressed(path, **_np(fx))
+    print(f"wrote {path}  ({os.path.getsize(path)/1e3:.0f} kB) |row|={float(row.abs().mean()):.4f} |col|={float(col.abs().mean()):.4f}")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     which = sys.argv[1:] or ["atsp"]
@@ -330,3 +373,8 @@ if __name__ == "__main__":
         gen_rcvrptw("rmtvrp_n20_b8_pomo_variants", B=8, N=20, S=20, sample_size=15, seed=51, variant=True)
         # (at N=50 the reference and its restatement already part ways on 11 % of the rollouts, each at a decision gap
         #  < 1e-3: no stable golden tours there; tests/test_gpu_shapes.py covers that size against the oracle run live)
+    if "matnet" in which:        # the MatNet baseline's mixed-score attention encoder (configs/experiment/matnet.yaml sizes)
+        gen_matnet("matnet_atsp_n20_b4", "atsp", B=4, N=20, seed=81, layers=5)
+        gen_matnet("matnet_rcvrp_n20_b4", "rcvrp", B=4, N=20, seed=82, layers=5)
+        gen_matnet("matnet_atsp_n100_b2", "atsp", B=2, N=100, seed=83, layers=2)
+        gen_matnet("matnet_rcvrp_n100_b2", "rcvrp", B=2, N=100, seed=84, layers=2)

@@ -381,6 +381,44 @@ class REINFORCE(nn.Module):  # placeholder; rrnco/models/rl.py is imported but n
 
 
 # --------------------------------------------------------------------------------------
+class MultiHeadCrossAttention(nn.Module):  # [recalled] rl4co.models.nn.attention (0.6.0); MatNet's MatNetCrossMHA derives from it
+    def __init__(self, embed_dim, num_heads, bias=False, attention_dropout=0.0, device=None, dtype=None, sdpa_fn=None):
+        super().__init__()
+        assert embed_dim % num_heads == 0
+        self.embed_dim, self.num_heads, self.attention_dropout = embed_dim, num_heads, attention_dropout
+        self.head_dim = embed_dim // num_heads
+        self.sdpa_fn = sdpa_fn
+        self.Wq = nn.Linear(embed_dim, embed_dim, bias=bias)
+        self.Wkv = nn.Linear(embed_dim, 2 * embed_dim, bias=bias)
+        self.out_proj = nn.Linear(embed_dim, embed_dim, bias=bias)
+
+    def forward(self, q_input, kv_input, cross_attn_mask=None, dmat=None):
+        b, m, _ = q_input.shape
+        n = kv_input.shape[1]
+        h, d = self.num_heads, self.head_dim
+        q = self.Wq(q_input).view(b, m, h, d).permute(0, 2, 1, 3)                      # "b m (h d) -> b h m d"
+        kv = self.Wkv(kv_input).view(b, n, 2, h, d).permute(2, 0, 3, 1, 4)             # "b n (two h d) -> two b h n d"
+        k, v = kv[0], kv[1]
+        if cross_attn_mask is not None:
+            cross_attn_mask = cross_attn_mask.unsqueeze(1)
+        out = self.sdpa_fn(q, k, v, attn_mask=cross_attn_mask, dmat=dmat, dropout_p=self.attention_dropout)
+        return self.out_proj(out.permute(0, 2, 1, 3).reshape(b, m, h * d))             # "b h s d -> b s (h d)"
+
+
+class _TransformerFFNProxy:
+    """rl4co.models.nn.ops.TransformerFFN: the reference carries its own copy (rrnco/models/nn/attn_freenet.py:330-357),
+    which is what this name resolves to — no recalled arithmetic."""
+
+    def __new__(cls, *a, **k):
+        from rrnco.models.nn.attn_freenet import TransformerFFN
+        return TransformerFFN(*a, **k)
+
+
+class _Inert(nn.Module):  # names the MatNet package imports at module level but the encoder path never instantiates
+    def __init__(self, *a, **k):
+        raise NotImplementedError("inert stand-in")
+
+
 def _mod(name, **attrs):
     m = types.ModuleType(name)
     m.__path__ = []
@@ -432,6 +470,14 @@ def install():
     _mod("rl4co.models.nn.env_embeddings.context", TSPContext=TSPContext, VRPContext=VRPContext,
          VRPTWContext=VRPTWContext, EnvContext=EnvContext)
     _mod("rl4co.models.nn.env_embeddings.dynamic", StaticEmbedding=StaticEmbedding)
+    _mod("rl4co.models.nn.attention", MultiHeadCrossAttention=MultiHeadCrossAttention, PointerAttention=_Inert, PointerAttnMoE=_Inert)
+    _mod("rl4co.models.nn.ops", TransformerFFN=_TransformerFFNProxy)
+    sys.modules["rl4co.models.common.constructive.autoregressive"].AutoregressivePolicy = AutoregressivePolicy
+    _mod("rl4co.models.zoo")
+    _mod("rl4co.models.zoo.am")
+    _mod("rl4co.models.zoo.am.decoder", AttentionModelDecoder=_Inert)
+    _mod("rl4co.models.zoo.pomo", POMO=_Inert)
+    _mod("rl4co.data.transforms", StateAugmentation=_Inert)
     _mod("rl4co.models.rl")
     _mod("rl4co.models.rl.reinforce")
     _mod("rl4co.models.rl.reinforce.reinforce", REINFORCE=REINFORCE)

@@ -1039,3 +1039,96 @@ def rcvrptw_weight_template(embed_dim: int = 128, num_layers: int = 6, ff: int =
             t[f + ".gate_temperature"] = ()
     t["decoder.beta"] = (1,)
     return t
+
+
+# ----------------------------------------------------------------------------------------------
+# MatNet baseline encoder (rrnco/baselines/MatNet/encoder.py).  Mixed-score attention = softmax attention
+# whose per-head logit is a 2 -> 16 -> 1 MLP of (scaled dot product, distance-matrix entry).
+# ----------------------------------------------------------------------------------------------
+def matnet_weight_template(embed_dim: int = 256, heads: int = 16, layers: int = 5, ff: int = 512, env_name: str = "atsp",
+                           mixer_hidden: int = 16) -> Dict[str, tuple]:
+    """state_dict names / shapes of MatNetEncoder (encoder.py:175-215; configs/experiment/matnet.yaml: 256 / 16 / 5)."""
+    E = embed_dim
+    t = {}
+    for l in range(layers):
+        for side in ("row", "col"):
+            p = f"layers.{l}.MHA.{side}_encoding_block"
+            t[p + ".sdpa_fn.mix_W1"] = (heads, 2, mixer_hidden); t[p + ".sdpa_fn.mix_b1"] = (heads, mixer_hidden)
+            t[p + ".sdpa_fn.mix_W2"] = (heads, mixer_hidden, 1); t[p + ".sdpa_fn.mix_b2"] = (heads, 1)
+            t[p + ".Wq.weight"] = (E, E); t[p + ".Wkv.weight"] = (2 * E, E); t[p + ".out_proj.weight"] = (E, E)
+        for f in ("F_a", "F_b"):
+            p = f"layers.{l}.{f}.ops"
+            t[p + ".norm1.normalizer.weight"] = (E,); t[p + ".norm1.normalizer.bias"] = (E,)
+            t[p + ".ffn.W1.weight"] = (ff, E); t[p + ".ffn.W1.bias"] = (ff,)
+            t[p + ".ffn.W2.weight"] = (E, ff); t[p + ".ffn.W2.bias"] = (E,)
+            t[p + ".norm2.normalizer.weight"] = (E,); t[p + ".norm2.normalizer.bias"] = (E,)
+    if env_name == "rcvrp":      # env_embeddings/rcvrp.py:22-33 with use_coords=False (configs/experiment/matnet.yaml:27-29)
+        t["init_embedding.depot_client_emb.weight"] = (2, E)
+        t["init_embedding.init_embed.weight"] = (E, 1); t["init_embedding.init_embed.bias"] = (E,)
+        t["init_embedding.row_combine_embed.weight"] = (E, 2 * E); t["init_embedding.row_combine_embed.bias"] = (E,)
+        t["init_embedding.col_combine_embed.weight"] = (E, 2 * E); t["init_embedding.col_combine_embed.bias"] = (E,)
+    return t
+
+
+def matnet_init_embedding(w: W, env_name: str, td: dict, rand_idx: Tensor, embed_dim: int):
+    """env_embeddings/atsp.py:21-34 (zero rows, one-hot columns at a random permutation of feature slots) and
+    env_embeddings/rcvrp.py:37-81 with use_coords=False.  `rand_idx` [B, N] is the reference's `rand.argsort(dim=1)`."""
+    D = td["distance_matrix"]
+    b, r, c = D.shape
+    row = torch.zeros(b, r, embed_dim)
+    col = torch.zeros(b, c, embed_dim)
+    col[torch.arange(b)[:, None].expand(b, c), torch.arange(c)[None, :].expand(b, c), rand_idx] = 1.0
+    if env_name == "atsp":
+        return row, col, D
+    p = "init_embedding"
+    emb = w[p + ".depot_client_emb.weight"]                                          # rcvrp.py:70-76
+    depot = emb[0:1].unsqueeze(1).expand(b, -1, -1)
+    nodes = emb[1:2] + F.linear(td["demand"][..., None], w[p + ".init_embed.weight"], w[p + ".init_embed.bias"])
+    out = torch.cat((depot, nodes), -2)                                              # :78
+    row = F.linear(torch.cat([row, out], -1), w[p + ".row_combine_embed.weight"], w[p + ".row_combine_embed.bias"])
+    col = F.linear(torch.cat([col, out], -1), w[p + ".col_combine_embed.weight"], w[p + ".col_combine_embed.bias"])
+    return row, col, D
+
+
+def matnet_cross_mha(w: W, p: str, q_in: Tensor, kv_in: Tensor, dmat: Tensor, heads: int) -> Tensor:
+    """MatNetCrossMHA = rl4co MultiHeadCrossAttention [recalled: Wq, Wkv = (K | V) chunks, out_proj, no bias] around
+    MixedScoresSDPA.forward (encoder.py:45-92)."""
+    b, m, E = q_in.shape
+    n = kv_in.shape[1]
+    d = E // heads
+    q = F.linear(q_in, w[p + ".Wq.weight"]).view(b, m, heads, d).permute(0, 2, 1, 3)
+    kv = F.linear(kv_in, w[p + ".Wkv.weight"]).view(b, n, 2, heads, d).permute(2, 0, 3, 1, 4)
+    k, v = kv[0], kv[1]
+    s = torch.matmul(q, k.transpose(-2, -1)) / (d ** 0.5)                            # :52
+    mix = torch.cat([s.unsqueeze(-1), dmat[:, None, :, :, None].expand(b, heads, m, n, 1)], -1)     # :54-60
+    W1, b1 = w[p + ".sdpa_fn.mix_W1"], w[p + ".sdpa_fn.mix_b1"]
+    W2, b2 = w[p + ".sdpa_fn.mix_W2"], w[p + ".sdpa_fn.mix_b2"]
+    hid = F.relu(torch.matmul(mix.transpose(1, 2), W1) + b1[None, None, :, None, :])                # :63-69
+    s = (torch.matmul(hid, W2) + b2[None, None, :, None, :]).transpose(1, 2).squeeze(-1)            # :70-75
+    a = F.softmax(s, dim=-1)                                                         # :86
+    o = torch.matmul(a, v)                                                           # :92
+    return F.linear(o.permute(0, 2, 1, 3).reshape(b, m, E), w[p + ".out_proj.weight"])
+
+
+def matnet_ffn(w: W, p: str, x: Tensor, x_old: Tensor) -> Tensor:
+    """TransformerFFN.forward (in-tree copy attn_freenet.py:352-356) with FeedForward (:534-536)."""
+    x = instance_norm(w, p + ".norm1", x_old + x)
+    y = F.linear(F.relu(F.linear(x, w[p + ".ffn.W1.weight"], w[p + ".ffn.W1.bias"])), w[p + ".ffn.W2.weight"], w[p + ".ffn.W2.bias"])
+    return instance_norm(w, p + ".norm2", x + y)
+
+
+def matnet_encoder(w: W, td: dict, rand_idx: Tensor, layers: int, heads: int, env_name: str = "atsp", embed_dim: int = 256,
+                   trace: Optional[dict] = None):
+    """MatNetEncoder.forward (encoder.py:217-231), MatNetLayer (:168-172), MatNetMHA (:133-145); no attention mask
+    (mask_non_neighbors=False)."""
+    row, col, D = matnet_init_embedding(w, env_name, td, rand_idx, embed_dim)
+    if trace is not None:
+        trace["row0"], trace["col0"] = row, col
+    for l in range(layers):
+        p = f"layers.{l}"
+        r_att = matnet_cross_mha(w, p + ".MHA.row_encoding_block", row, col, D, heads)
+        c_att = matnet_cross_mha(w, p + ".MHA.col_encoding_block", col, row, D.transpose(-2, -1), heads)
+        row, col = matnet_ffn(w, p + ".F_a.ops", r_att, row), matnet_ffn(w, p + ".F_b.ops", c_att, col)
+        if trace is not None and l == 0:
+            trace["row1"], trace["col1"] = row, col
+    return row, col

@@ -46,6 +46,10 @@ class NabSimpleW(C.Structure):
     _fields_ = [(n, vp) for n in ("w0", "b0", "w2")] + [(n, f32) for n in ("b2", "alpha", "dw", "tw")]
 
 
+class MatNetSideW(C.Structure):
+    _fields_ = [(n, vp) for n in ("wq", "wkv", "wo", "w1", "w2", "b1", "b2", "n1g", "n1b", "n2g", "n2b", "mix")]
+
+
 class RolloutIO(C.Structure):
     _fields_ = [(n, vp) for n in (
         "K", "Vt", "L", "ctxA", "ctxB", "D", "Dur", "demand", "tw", "service", "cur", "first", "mask", "visited", "used",
@@ -75,6 +79,8 @@ _SIGS = {
     "rr_dec_cache": [C.POINTER(CacheW), vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "rr_rollout": [C.POINTER(DecW), C.POINTER(RolloutIO), i32, vp],
     "rr_submatrix_gather": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "rr_matnet_layer": [C.POINTER(MatNetSideW), C.POINTER(MatNetSideW), vp, vp, vp, vp, vp, vp, C.c_size_t] + [i32] * 5 + [vp],
+    "rr_matnet_init": [vp] * 7 + [i32, i32, i32, vp],
     "rr_nab_train_fwd": [vp, vp, vp, vp, C.c_long, vp],
     "rr_nab_train_bwd": [vp, vp, vp, vp, vp, C.c_long, vp],
 }
@@ -95,6 +101,8 @@ def lib():
             fn = getattr(_lib, name)
             fn.argtypes = args
             fn.restype = i32
+        _lib.rr_matnet_workspace_bytes.argtypes = [i32] * 4
+        _lib.rr_matnet_workspace_bytes.restype = C.c_size_t
     return _lib
 
 

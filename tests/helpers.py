@@ -82,3 +82,7 @@ def rcvrptw_instance(fx):
     keys = ("locs", "distance_matrix", "duration_matrix", "demand_linehaul", "time_windows", "service_time")
     opt = ("demand_backhaul", "backhaul_class", "open_route", "distance_limit")            # multi-task variants
     return {k: fx[k] for k in keys + tuple(o for o in opt if o in fx)}
+
+
+def matnet_weights(fx):
+    return restate.make_weights(restate.matnet_weight_template(fx["embed_dim"], fx["heads"], fx["layers"], 512, fx["env_name"]), fx["seed"])

@@ -387,3 +387,27 @@ def test_oracle_beam_search_reproduces_reference_golden(name):
         out = restate.atsp_beam_search(w, restate.atsp_reset(H.fixture_state(fx)), fx["sample_idx"], fx["S"], select_best=False)
     assert torch.equal(out["actions"], fx["actions"]) and torch.allclose(out["reward"], fx["reward"], atol=1e-5)
     assert torch.allclose(out["log_likelihood"], fx["log_likelihood"], atol=1e-4)
+
+
+# ---------------------------------------------------------------- MatNet baseline encoder
+@pytest.mark.parametrize("name", ["matnet_atsp_n20_b4", "matnet_rcvrp_n20_b4", "matnet_atsp_n100_b2", "matnet_rcvrp_n100_b2"])
+def test_oracle_matnet_encoder_reproduces_reference_golden(name):
+    """oracle/restate.matnet_encoder against the outputs of the reference's own MatNetEncoder (oracle/gen_golden.py matnet)."""
+    fx = H.load_fixture(name)
+    w = H.matnet_weights(fx)
+    td = {"distance_matrix": fx["distance_matrix"]}
+    if fx["env_name"] == "rcvrp":
+        td["demand"] = fx["demand"]
+    tr = {}
+    with torch.inference_mode():
+        row, col = restate.matnet_encoder(w, td, fx["rand_idx"], fx["layers"], fx["heads"], fx["env_name"], fx["embed_dim"], trace=tr)
+    assert torch.allclose(tr["row1"], fx["row_l1"], atol=1e-5) and torch.allclose(tr["col1"], fx["col_l1"], atol=1e-5)
+    assert torch.allclose(row, fx["row_emb"], atol=2e-5) and torch.allclose(col, fx["col_emb"], atol=2e-5)
+
+
+def test_matnet_encoder_state_dict_names_match_reference_template():
+    from rrnco_amd.baselines import MatNetEncoder
+    for env_name in ("atsp", "rcvrp"):
+        enc = MatNetEncoder(embed_dim=256, num_heads=16, num_layers=2, env_name=env_name)
+        mine = {k: tuple(v.shape) for k, v in enc.state_dict().items()}
+        assert mine == restate.matnet_weight_template(256, 16, 2, 512, env_name)
