@@ -57,11 +57,14 @@ typedef struct {                /* arguments of the persistent rollout: see csrc
   int64_t *actions; float *logp, *logits_out; const int64_t *actions_in; int *steps_out;
   int Bp, N, S, T, t0, nsteps, mode, use_placeholder, set_first, write_state, logits_only, stagger;
   float tanh_clip, temperature; unsigned long long seed;
-  /* MTVRP variants, decoder context only (env_embeddings/context.py:51-70); NULL = vrptw preset.  The fused env.step of the
-   * rollout covers the vrptw preset; with these set the caller runs one decoder.forward per launch (logits_only). */
-  const float *used_b;          /* [R] used_capacity_backhaul */
+  /* MTVRP variants (backhauls, open routes, distance limits; rmtvrp/env.py:343-428, env_embeddings/context.py:51-70);
+   * all NULL = vrptw preset.  used_b / open_route / dist_limit feed the decoder context; the in-kernel env.step of a
+   * multi-step launch also needs demand_b and bclass (a logits_only launch does not). */
+  float *used_b;                /* [R] used_capacity_backhaul (state, written back with write_state) */
   const uint8_t *open_route;    /* [Bp] */
-  const float *dist_limit;      /* [Bp] */
+  const float *dist_limit;      /* [Bp] (+inf = none) */
+  const float *demand_b;        /* [Bp][N] demand_backhaul incl. the depot zero */
+  const int32_t *bclass;        /* [Bp] backhaul class 1 / 2 */
 } RolloutIO;
 
 /* ATSPEnv._reset / RCVRPEnv._reset / RMTVRPEnv._reset min-max normalisation

@@ -55,10 +55,13 @@ struct RolloutIO {
   int stagger;                           // k_rollout_w: initial delay of waves 4-7, in units of ~8k cycles
   float tanh_clip, temperature;
   unsigned long long seed;
-  // MTVRP variants (decoder context only; NULL = vrptw preset): used_capacity_backhaul [R], open_route [Bp], distance_limit [Bp]
-  const float* used_b;
+  // MTVRP variants (NULL = vrptw preset): used_capacity_backhaul [R] (state), open_route [Bp], distance_limit [Bp];
+  // demand_backhaul [Bp][N] and backhaul_class [Bp] are needed by the in-kernel env.step (not by a logits_only launch)
+  float* used_b;
   const uint8_t* open_route;
   const float* dist_limit;
+  const float* demand_b;
+  const int32_t* bclass;
 };
 
 template <int NT, int PROB>  // PROB 0 = ATSP, 1 = RCVRP
@@ -382,8 +385,13 @@ extern "C" int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStrea
   const int N = io->N, S = io->S;
   if (io->Bp <= 0 || N < 2 || N > RR_MAXN || S < 1 || io->T < 1 || prob < 0 || prob > 2) return RR_EINVAL;
   if (prob == 2 && (io->Dur == nullptr || io->tw == nullptr || io->service == nullptr || io->ctime == nullptr)) return RR_EINVAL;
-  // backhauls / open routes / distance limits: the fused env.step evaluates the vrptw preset only
-  if ((io->used_b != nullptr || io->open_route != nullptr || io->dist_limit != nullptr) && !(prob == 2 && io->logits_only)) return RR_EINVAL;
+  // backhauls / open routes / distance limits (rmtvrp/env.py:343-428): RCVRPTW launches only, all variant inputs together
+  {
+    const bool any_var = io->used_b || io->open_route || io->dist_limit || io->demand_b || io->bclass;
+    const bool ctx_var = io->used_b && io->open_route && io->dist_limit;
+    if (any_var && (prob != 2 || !ctx_var)) return RR_EINVAL;
+    if (any_var && !io->logits_only && !(io->demand_b && io->bclass)) return RR_EINVAL;
+  }
   if (io->mode == 2 && io->actions_in == nullptr) return RR_EINVAL;
   static const int variant = getenv("RR_ROLLOUT_VARIANT") ? atoi(getenv("RR_ROLLOUT_VARIANT")) : 1;
   if (variant == 0 && prob < 2) {   // workgroup-per-instance variant (kept for A/B measurements; ATSP / RCVRP only)
@@ -428,7 +436,8 @@ extern "C" int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStrea
   do {                                                                                       \
     if (prob == 0) RR_LAUNCHW2(NTV, 0);                                                      \
     else if (prob == 1) RR_LAUNCHW2(NTV, 1);                                                 \
-    else RR_LAUNCHW2(NTV, 2);                                                                \
+    else if (io->used_b == nullptr) RR_LAUNCHW2(NTV, 2);                                     \
+    else RR_LAUNCHW2(NTV, 3);                                                                \
   } while (0)
   if (N <= 32) RR_LAUNCHW(2);
   else if (N <= 64) RR_LAUNCHW(4);

@@ -56,7 +56,7 @@ class RolloutIO(C.Structure):
         "vcap", "ctime", "rlen", "done", "actions", "logp", "logits_out", "actions_in", "steps_out")] + \
         [(n, i32) for n in ("Bp", "N", "S", "T", "t0", "nsteps", "mode", "use_placeholder", "set_first",
                             "write_state", "logits_only", "stagger")] + \
-        [("tanh_clip", f32), ("temperature", f32), ("seed", u64)] + [(n, vp) for n in ("used_b", "open_route", "dist_limit")]
+        [("tanh_clip", f32), ("temperature", f32), ("seed", u64)] + [(n, vp) for n in ("used_b", "open_route", "dist_limit", "demand_b", "bclass")]
 
 
 class MtvrpExtra(C.Structure):

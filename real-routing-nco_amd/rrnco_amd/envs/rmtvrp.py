@@ -1,9 +1,9 @@
 """RCVRPTW environment — drop-in for rrnco.envs.rmtvrp.RMTVRPEnv (rrnco/envs/rmtvrp/env.py, configs/env/rcvrptw.yaml).
 
-The vrptw preset (linehaul demands, time windows, closed routes: BASELINE configs[3]) runs on the fused rollout kernel.
-Instances that carry the other multi-task features — backhauls (classes 1 / 2), open routes, distance limits — are
-evaluated by the general step kernel (rr_rmtvrp_step with MtvrpExtra) in the step-wise decode loop; `td.meta["mtvrp_variant"]`
-tells the policy which path applies."""
+The vrptw preset (linehaul demands, time windows, closed routes: BASELINE configs[3]) and instances that carry the other
+multi-task features — backhauls (classes 1 / 2), open routes, distance limits — both run on the fused rollout kernel (two
+instantiations; `td.meta["mtvrp_variant"]` selects) and, with `fused=False`, on the general step kernel
+(rr_rmtvrp_step with MtvrpExtra) in the step-wise decode loop."""
 from __future__ import annotations
 
 import torch

@@ -69,7 +69,6 @@ class RRNetPolicy(nn.Module):
         td, env, cache = self.decoder.pre_decoder_hook(td, env, (row_emb, col_emb), num_starts, packed=packed)
 
         if (fused and self.env_name in PROB_ID and strategy.mask_logits and strategy.top_k == 0 and not (0.0 < strategy.top_p < 1.0)
-                and not td.meta.get("mtvrp_variant", False)        # MTVRP variants: general step kernel, step-wise loop
                 and not getattr(strategy, "is_beam_search", False)):
             logprobs, actions_out, td = self._fused_rollout(td, env, cache, packed, strategy, actions)
         else:

@@ -56,14 +56,17 @@ def launch_rollout(env_name, packed, cache, td, num_starts, *, actions=None, log
         io.Dur, io.demand, io.tw, io.service = L.ptr(T_), L.ptr(dem), L.ptr(tw), L.ptr(sv)
         io.visited, io.used, io.vcap, io.ctime, io.rlen = L.ptr(vis), L.ptr(used), L.ptr(vcap), L.ptr(ctime), L.ptr(rlen)
         keep += [T_, dem, vis, tw, sv, used, vcap, ctime, rlen]
-        if td.meta.get("mtvrp_variant", False):        # context inputs of the multi-task variants (logits_only launches)
-            if not logits_only:
-                raise NotImplementedError("the fused rollout evaluates the vrptw preset; use fused=False for MTVRP variants")
+        if td.meta.get("mtvrp_variant", False):        # multi-task variants: context inputs + what the in-kernel env.step needs
             ub = td["used_capacity_backhaul"].reshape(-1).float().contiguous()
             opn = td["open_route"].reshape(-1).to(torch.uint8).contiguous()
             lim = td["distance_limit"].reshape(-1).float().contiguous()
+            dmb = td["demand_backhaul"].float().contiguous()
+            bcl = td["backhaul_class"].reshape(-1).to(torch.int32).contiguous()
+            if ub.shape[0] != R:
+                ub = ub.repeat(R // ub.shape[0])
             io.used_b, io.open_route, io.dist_limit = L.ptr(ub), L.ptr(opn), L.ptr(lim)
-            keep += [ub, opn, lim]
+            io.demand_b, io.bclass = L.ptr(dmb), L.ptr(bcl)
+            keep += [ub, opn, lim, dmb, bcl]
     done = td["done"].reshape(-1).contiguous() if "done" in td and td["done"].numel() == R else None
     io.done = L.ptr(done)
     io.actions, io.logp = L.ptr(actions), L.ptr(logp)

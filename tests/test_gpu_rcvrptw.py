@@ -77,12 +77,14 @@ def test_rmtvrp_variant_env_step_and_masks_bit_exact_vs_oracle():
     assert torch.allclose(real.cpu(), fx["reward"], atol=COST_ATOL) and torch.allclose(nd.cpu(), fx["normalized_reward"], atol=COST_ATOL)
 
 
-def test_rmtvrp_variant_policy_routes_match_reference():
-    """Greedy multistart decode on the mixed-variant batch: the policy leaves the fused rollout by itself (general step
-    kernel, MTVRP context with open-route flag / remaining distance / backhaul load) and reproduces the reference's tours."""
+@pytest.mark.parametrize("fused", [True, False])
+def test_rmtvrp_variant_policy_routes_match_reference(fused):
+    """Greedy multistart decode on the mixed-variant batch (backhaul classes 1 / 2, open routes, distance limits), on the
+    fused rollout (general mask inside the kernel) and on the step-wise loop (rr_rmtvrp_step with MtvrpExtra): MTVRP context
+    with open-route flag / remaining distance / backhaul load; both reproduce the reference's tours."""
     fx, w, pol, inst, env, td_in = _setup(VARIANTS)
     S = fx["S"]
-    out = pol(env.reset(td_in), env, phase="val", decode_type="multistart_greedy", num_starts=S, return_actions=True)
+    out = pol(env.reset(td_in), env, phase="val", decode_type="multistart_greedy", num_starts=S, return_actions=True, fused=fused)
     acts = out["actions"].cpu()
     T = min(acts.shape[1], fx["actions"].shape[1])
     frac, first = H.tour_agreement(acts[:, :T], fx["actions"][:, :T])
@@ -99,9 +101,34 @@ def test_rmtvrp_variant_policy_routes_match_reference():
     same = first < 0
     assert torch.allclose(out["reward"].cpu()[same], fx["reward"][same], atol=COST_ATOL)
     assert torch.allclose(out["log_likelihood"].cpu()[same], fx["log_likelihood"][same], rtol=LL_RTOL, atol=LL_ATOL)
-    # asking for the fused rollout changes nothing: variants are routed to the step-wise loop
-    out_f = pol(env.reset(td_in), env, phase="val", decode_type="multistart_greedy", num_starts=S, return_actions=True, fused=True)
-    assert torch.equal(out_f["actions"], out["actions"])
+
+
+@pytest.mark.parametrize("n_nodes", [21, 51, 101])
+def test_rmtvrp_variant_fused_rollout_agrees_with_stepwise_loop(n_nodes):
+    """Sampling decode of random multi-task instances: the in-kernel general env.step and the step kernel see the same
+    masks, so both paths draw the same tours (same counter-based noise) up to near-tie decisions."""
+    from rrnco_amd import TensorDict
+    from rrnco_amd.envs import RMTVRPEnv
+    fx, w, pol, _, _, _ = _setup(VARIANTS)
+    n = n_nodes - 1
+    env = RMTVRPEnv(generator_params=dict(num_loc=n))
+    inst = restate.rmtvrp_variant_synthetic(6, n, 500 + n)
+    sidx = restate.sample_neighbor_indices(restate.rmtvrp_reset(inst)["distance_matrix"], fx["sample_size"],
+                                           generator=torch.Generator().manual_seed(n))
+    outs = []
+    for fused in (True, False):
+        td = TensorDict({k: v.cuda() for k, v in inst.items()}, batch_size=[6])
+        td["sample_idx"] = sidx.cuda()
+        td = env.reset(td)
+        assert td.meta.get("mtvrp_variant", False)
+        outs.append(pol(td, env, phase="val", decode_type="multistart_sampling", num_starts=n, return_actions=True, fused=fused, seed=5))
+    a, b = outs[0]["actions"], outs[1]["actions"]
+    T = min(a.shape[1], b.shape[1])
+    same = (a[:, :T] == b[:, :T]).all(1)
+    assert same.float().mean() >= 0.95
+    assert torch.allclose(outs[0]["reward"][same], outs[1]["reward"][same], atol=COST_ATOL)
+    cust = a.sort(1).values[:, -n:]
+    assert (cust == torch.arange(1, n + 1, device=a.device)).all()
 
 
 @pytest.mark.parametrize("name", FIXTURES)
