@@ -28,9 +28,9 @@ N_NODES, BATCH, STARTS, AUG = 100, 512, 100, 8
 FLOP_PER_ROLLOUT_STEP = 404_480          # pointer step K6-K7, per rollout per decode step
 PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: fp32 matrix peak
 # HBM-side traffic of ONE rollout launch at the default workload, from rocprofv3 PMC (separate FETCH_SIZE / WRITE_SIZE
-# passes, profiles/r01/bench_v7_pmc_hbm_traffic.txt): (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B — FETCH_SIZE doubled for
+# passes, profiles/r01/bench_v8_pmc_hbm_traffic.txt): (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B — FETCH_SIZE doubled for
 # gfx950's 16-B/lane reads as MI355X_MICROARCH.md §HBM prescribes; Infinity-Cache hits are included in the counter.
-ROLLOUT_TRAFFIC_BYTES_DEFAULT = (2 * 1.9684e8 + 4.0053e6) * 1024
+ROLLOUT_TRAFFIC_BYTES_DEFAULT = (2 * 1.9670e8 + 4.0033e6) * 1024
 
 
 def make_policy(device, seed=1234):
@@ -126,6 +126,8 @@ def main():
             td_.barrier()
             torch.cuda.synchronize()
 
+    # the headline number is always the fp32-MFMA rollout; the opt-in bf16-pipe MLP is measured separately below
+    split_env = os.environ.pop("RR_MLP_SPLIT", None)
     for _ in range(args.warmup):
         hot_path_step(pol, env, inst, sample_idx)
     R.TIMING = []
@@ -158,6 +160,25 @@ def main():
                          "algorithmic_flop_per_launch": rollout_steps * FLOP_PER_ROLLOUT_STEP},
             "mean_best_cost": float(-best.mean().item()),
         }
+        if world == 1:
+            # Opt-in variant, NOT part of `value`: the rollout's pointer MLP on the bf16 matrix pipe with 3-way split fp32
+            # operands (six partial products, fp32 accumulate; same tours and tolerances, tests/test_gpu_atsp.py)
+            os.environ["RR_MLP_SPLIT"] = "1"
+            hot_path_step(pol, env, inst, sample_idx)
+            R.TIMING = []
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                best_s, _ = hot_path_step(pol, env, inst, sample_idx)
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - t1
+            ks = [a.elapsed_time(b) for a, b in R.TIMING]
+            R.TIMING = None
+            os.environ.pop("RR_MLP_SPLIT")
+            line["variants"] = {"rollout_mlp_3xbf16_split (RR_MLP_SPLIT=1, off by default)": {
+                "value": args.batch * args.steps / dts, "unit": "instances/s", "ms_per_step": dts / args.steps * 1e3,
+                "kernel_ms": sum(ks) / max(len(ks), 1), "mean_best_cost": float(-best_s.mean().item()),
+                "best_costs_identical_to_fp32_rollout": bool(torch.equal(best_s, best))}}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(line))

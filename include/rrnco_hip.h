@@ -49,6 +49,7 @@ typedef struct { const void *wk, *wv, *wl, *wca, *wcb; } CacheW;   /* rrnco/mode
 
 typedef struct {                /* pointer MLP + inductive-bias scalars: rrnco/models/decoder.py:186-198, 272-277 */
   const void *w1, *w2; const float *b1, *b2, *q0, *wstate; float alpha, beta;
+  const void *w1s, *w2s;        /* optional 3-way bf16 splits of w1 / w2 (packing.pack_a_bf16x3) for the opt-in RR_MLP_SPLIT=1 rollout */
 } DecW;
 
 typedef struct {                /* arguments of the persistent rollout: see csrc/rr_decode.hip */

@@ -95,6 +95,30 @@ __device__ __forceinline__ float4 rr_bld4(__amdgpu_buffer_rsrc_t r, unsigned vof
 __device__ __forceinline__ float rr_bld1(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff_bytes, soff_bytes, 0));   // out of range -> 0
 }
+// ---- bf16 matrix pipe with 3-way split fp32 operands (opt-in pointer MLP of the rollout, RR_MLP_SPLIT=1)
+typedef __bf16 rr_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 rr_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float rr_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 rr_mfma_bf16(rr_bf16x8 a, rr_bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ rr_bf16x8 rr_bldh(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
+  rr_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, soff_bytes, 0);
+  return __builtin_bit_cast(rr_bf16x8, v);
+}
+// x[0..7] -> hi + mid + lo, each bf16 with round-to-nearest (v_cvt_pk_bf16_f32): x - hi and (x - hi) - mid are exact in fp32
+__device__ __forceinline__ void rr_split8(const float (&x)[8], rr_bf16x8& hi, rr_bf16x8& mid, rr_bf16x8& lo) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const rr_f32x2 v = {x[2 * q], x[2 * q + 1]};
+    const rr_bf16x2 h = __builtin_convertvector(v, rr_bf16x2);
+    const rr_f32x2 r1 = v - __builtin_convertvector(h, rr_f32x2);
+    const rr_bf16x2 m = __builtin_convertvector(r1, rr_bf16x2);
+    const rr_f32x2 r2 = r1 - __builtin_convertvector(m, rr_f32x2);
+    const rr_bf16x2 l = __builtin_convertvector(r2, rr_bf16x2);
+    hi[2 * q] = h[0]; hi[2 * q + 1] = h[1]; mid[2 * q] = m[0]; mid[2 * q + 1] = m[1]; lo[2 * q] = l[0]; lo[2 * q + 1] = l[1];
+  }
+}
 // exp without the low-order correction of rr_exp: |rel err| <= 6e-8 * |x| * log2(e); used where x is O(10)
 __device__ __forceinline__ float rr_exp_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 

@@ -25,6 +25,7 @@ struct DecW {
   const float* q0;             // project_context(W_placeholder) [E] (ATSP first step without multistart)
   const float* wstate;         // VRP: step-context state columns of project_context [nstate][E]
   float alpha, beta;
+  const void *w1s, *w2s;       // optional: the same two matrices as 3-way bf16 splits (packing.pack_a_bf16x3), RR_MLP_SPLIT=1
 };
 
 struct RolloutIO {
@@ -394,6 +395,8 @@ extern "C" int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStrea
   }
   if (io->mode == 2 && io->actions_in == nullptr) return RR_EINVAL;
   static const int variant = getenv("RR_ROLLOUT_VARIANT") ? atoi(getenv("RR_ROLLOUT_VARIANT")) : 1;
+  const char* es = getenv("RR_MLP_SPLIT");
+  const bool mlp_split = es != nullptr && atoi(es) != 0 && w->w1s != nullptr && w->w2s != nullptr;
   if (variant == 0 && prob < 2) {   // workgroup-per-instance variant (kept for A/B measurements; ATSP / RCVRP only)
     dim3 grid(io->Bp, (S + ROWS - 1) / ROWS), blk(DEC_THREADS);
     const int need = N > (S < ROWS ? S : ROWS) ? N : (S < ROWS ? S : ROWS);
@@ -419,11 +422,22 @@ extern "C" int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStrea
   const size_t per_wg = (size_t)(160 * 1024) / (512 / WTHREADS) - 512;
   const int lds_inst = 2 * tile <= per_wg ? 2 : (tile <= per_wg ? 1 : 0);
   const size_t shmem = (size_t)lds_inst * tile;
+  // split-MLP variant: two 24 KB weight stage buffers behind the distance tiles
+  const int lds_inst_s = 2 * tile + 2 * 24576 + 16 <= per_wg ? 2 : (tile + 2 * 24576 + 16 <= per_wg ? 1 : 0);
+  const dim3 grid_s = grid, blk_s = blk;
   const int mode = io->logits_only ? 3 : io->mode;
-#define RR_LAUNCHW3(NTV, P, M)                                                                                \
+#define RR_LAUNCHW4(NTV, P, M, SP)                                                                            \
   do {                                                                                                       \
-    (void)hipFuncSetAttribute((const void*)k_rollout_w<NTV, P, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
-    hipLaunchKernelGGL((k_rollout_w<NTV, P, M>), grid, blk, shmem, st, *w, *io, tail_g, lds_inst);            \
+    const size_t shm = (SP) ? (((size_t)lds_inst_s * tile + 15) / 16) * 16 + 2 * 24576 : shmem;              \
+    (void)hipFuncSetAttribute((const void*)k_rollout_w<NTV, P, M, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+    hipLaunchKernelGGL((k_rollout_w<NTV, P, M, SP>), (SP) ? grid_s : grid, (SP) ? blk_s : blk, shm, st, *w, *io, tail_g, \
+                       (SP) ? lds_inst_s : lds_inst);                                                        \
+  } while (0)
+  // the split-bf16 pointer MLP is opt-in (RR_MLP_SPLIT=1) and instantiated for the ATSP greedy / sampling rollouts only
+#define RR_LAUNCHW3(NTV, P, M)                                                                               \
+  do {                                                                                                       \
+    if ((P) == 0 && (M) <= 1 && mlp_split && io->nsteps > 0) RR_LAUNCHW4(NTV, 0, ((M) <= 1 ? (M) : 0), true); \
+    else RR_LAUNCHW4(NTV, P, M, false);                                                                      \
   } while (0)
 #define RR_LAUNCHW2(NTV, P)                                                                                  \
   do {                                                                                                       \
@@ -444,6 +458,7 @@ extern "C" int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStrea
   else RR_LAUNCHW(7);
 #undef RR_LAUNCHW2
 #undef RR_LAUNCHW3
+#undef RR_LAUNCHW4
 #undef RR_LAUNCHW
   return rr_check(hipGetLastError());
 }

@@ -33,7 +33,8 @@ class CacheW(C.Structure):
 
 
 class DecW(C.Structure):
-    _fields_ = [(n, vp) for n in ("w1", "w2", "b1", "b2", "q0", "wstate")] + [("alpha", f32), ("beta", f32)]
+    _fields_ = [(n, vp) for n in ("w1", "w2", "b1", "b2", "q0", "wstate")] + [("alpha", f32), ("beta", f32)] + \
+        [("w1s", vp), ("w2s", vp)]
 
 
 class NabDurW(C.Structure):

@@ -24,6 +24,25 @@ def pack_a(Wm: torch.Tensor) -> torch.Tensor:
     return x.view(Mp // 16, Kp // 16, 64, 4)
 
 
+def pack_a_bf16x3(Wm: torch.Tensor) -> torch.Tensor:
+    """[M,K] fp32 -> [M/16, K/32, 3, 64, 8] bf16: A operands of v_mfma_f32_16x16x32_bf16 for the three pieces
+    W = hi + mid + lo (each rounded to nearest bf16 of what is left; the sum is exactly W).  Lane (i = l&15, g = l>>4) of
+    tile t, k-slice s holds, for e = 0..7, W[16t+i][32s + 4g + e] (e < 4) and W[16t+i][32s + 16 + 4g + e - 4] (e >= 4): the
+    order in which a lane owns the values of two consecutive C-layout tiles (csrc/rr_rollout_w.inc, SPLIT)."""
+    M, K = Wm.shape
+    assert M % 16 == 0 and K % 32 == 0
+    W = Wm.detach().float().cpu()
+    hi = W.to(torch.bfloat16)
+    r1 = W - hi.float()
+    mid = r1.to(torch.bfloat16)
+    lo = (r1 - mid.float()).to(torch.bfloat16)
+    out = []
+    for piece in (hi, mid, lo):
+        x = piece.view(M // 16, 16, K // 32, 2, 4, 4)            # t, i, s, half, g, e4
+        out.append(x.permute(0, 2, 4, 1, 3, 5).reshape(M // 16, K // 32, 64, 8))     # t, s, (g, i), (half, e4)
+    return torch.stack(out, dim=2).contiguous()                  # [t][s][piece][lane][8]
+
+
 def fold_nab(sd, p: str, alpha: torch.Tensor) -> torch.Tensor:
     """DistAngleFusion without duration (attn_freenet.py:242-289) -> [8*E + 8] coefficients.
     wo.(W2 h + b2) = (W2^T wo).h + wo.b2, same for the two gate halves; folded in float64."""
@@ -233,6 +252,11 @@ class _Arena:
         self.keep.append(t)
         return t.data_ptr()
 
+    def put_raw(self, t: torch.Tensor):
+        t = t.detach().to(device=self.device).contiguous()
+        self.keep.append(t)
+        return t.data_ptr()
+
 
 def pack_policy(sd: dict, env_name: str, device) -> dict:
     """state_dict (reference names) -> ctypes structs for the kernels."""
@@ -340,6 +364,9 @@ def pack_policy(sd: dict, env_name: str, device) -> dict:
         dw.wstate = ar.put(wctx[:, E:].t().contiguous())   # [nstate][E]
     dw.w1 = ar.put(pack_a(sd["decoder.pointer.ffn.lins.0.weight"].detach().float()))
     dw.w2 = ar.put(pack_a(sd["decoder.pointer.ffn.lins.1.weight"].detach().float()))
+    # the same matrices as 3-way bf16 splits for the opt-in bf16-pipe MLP (RR_MLP_SPLIT=1); kept as raw 16-bit words
+    dw.w1s = ar.put_raw(pack_a_bf16x3(sd["decoder.pointer.ffn.lins.0.weight"]))
+    dw.w2s = ar.put_raw(pack_a_bf16x3(sd["decoder.pointer.ffn.lins.1.weight"]))
     dw.b1, dw.b2 = ar.put(sd["decoder.pointer.ffn.lins.0.bias"]), ar.put(sd["decoder.pointer.ffn.lins.1.bias"])
     dw.alpha = float(sd["decoder.alpha"].reshape(-1)[0])
     dw.beta = float(sd["decoder.beta"].reshape(-1)[0]) if "decoder.beta" in sd else 0.0

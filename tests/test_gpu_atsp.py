@@ -145,6 +145,40 @@ def test_policy_greedy_tours_match_reference(name, fused):
     assert torch.allclose(out["log_likelihood"].cpu()[same], fx["log_likelihood"][same], rtol=LL_RTOL, atol=LL_ATOL)
 
 
+@pytest.mark.parametrize("name", ["atsp_n20_b4_pomo", "atsp_n20_b2_pomo_aug8", "atsp_n100_b2_pomo"])
+def test_split_bf16_mlp_rollout_meets_the_fp32_contract(name, monkeypatch, capsys):
+    """RR_MLP_SPLIT=1 runs the pointer MLP of the fused rollout on the bf16 matrix pipe with 3-way split fp32 operands
+    (six partial products, fp32 accumulate; dropped terms <= 2^-23 of a product).  It has to meet the same contract as the
+    fp32-MFMA rollout: tours identical to the reference except at decision gaps < GAP_TOL, costs and log-likelihoods within
+    the fp32 tolerances — and it must not be further from the reference than the fp32 rollout is by more than LOGIT_ATOL per step."""
+    fx, w, pol, st, env, td_in = _setup(name)
+    S = fx["S"]
+    kw = dict(phase="val", decode_type="multistart_greedy", num_starts=S, return_actions=True, fused=True)
+    ref32 = pol(env.reset(td_in), env, **kw)
+    monkeypatch.setenv("RR_MLP_SPLIT", "1")
+    out = pol(env.reset(td_in), env, **kw)
+    monkeypatch.delenv("RR_MLP_SPLIT")
+    acts = out["actions"].cpu()
+    assert restate.atsp_check(acts)
+    frac, first = H.tour_agreement(acts, fx["actions"])
+    if frac < 1.0:
+        gaps = _decision_gaps(fx, w, st)
+        for r in torch.nonzero(first >= 0).flatten().tolist():
+            assert gaps[r, int(first[r]) - 1] < GAP_TOL
+    assert frac >= 0.98
+    same = first < 0
+    assert torch.allclose(out["reward"].cpu()[same], fx["reward"][same], atol=COST_ATOL)
+    assert torch.allclose(out["log_likelihood"].cpu()[same], fx["log_likelihood"][same], rtol=LL_RTOL, atol=LL_ATOL)
+    both = same & (H.tour_agreement(ref32["actions"].cpu(), fx["actions"])[1] < 0)
+    e_split = (out["log_likelihood"].cpu() - fx["log_likelihood"])[both].abs().max()
+    e_fp32 = (ref32["log_likelihood"].cpu() - fx["log_likelihood"])[both].abs().max()
+    d = (out["log_likelihood"] - ref32["log_likelihood"]).cpu()[both].abs().max()
+    with capsys.disabled():
+        print(f"\n[{name}] |LL - reference|: split {float(e_split):.2e}, fp32 MFMA {float(e_fp32):.2e}; |split - fp32| {float(d):.2e}; "
+              f"tours equal to the fp32 rollout: {float((out['actions'] == ref32['actions']).all(1).float().mean()):.4f}")
+    assert d <= LOGIT_ATOL * fx["N"]
+
+
 @pytest.mark.parametrize("fused", [True, False])
 def test_policy_evaluate_mode_reproduces_reference_loglik(fused):
     fx, w, pol, st, env, td_in = _setup("atsp_n20_b4_pomo")
