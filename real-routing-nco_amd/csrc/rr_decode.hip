@@ -433,10 +433,10 @@ extern "C" int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStrea
     hipLaunchKernelGGL((k_rollout_w<NTV, P, M, SP>), (SP) ? grid_s : grid, (SP) ? blk_s : blk, shm, st, *w, *io, tail_g, \
                        (SP) ? lds_inst_s : lds_inst);                                                        \
   } while (0)
-  // the split-bf16 pointer MLP is opt-in (RR_MLP_SPLIT=1) and instantiated for the ATSP greedy / sampling rollouts only
+  // the split-bf16 pointer MLP is opt-in (RR_MLP_SPLIT=1), for the greedy / sampling rollouts of every problem
 #define RR_LAUNCHW3(NTV, P, M)                                                                               \
   do {                                                                                                       \
-    if ((P) == 0 && (M) <= 1 && mlp_split && io->nsteps > 0) RR_LAUNCHW4(NTV, 0, ((M) <= 1 ? (M) : 0), true); \
+    if ((M) <= 1 && mlp_split) RR_LAUNCHW4(NTV, P, ((M) <= 1 ? (M) : 0), true);                               \
     else RR_LAUNCHW4(NTV, P, M, false);                                                                      \
   } while (0)
 #define RR_LAUNCHW2(NTV, P)                                                                                  \
