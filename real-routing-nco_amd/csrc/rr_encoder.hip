@@ -30,6 +30,7 @@ struct EncBlockW {
   const float4 *wq, *wk, *wv, *wp, *wc, *w1, *w2;                             // packed A operands; wp = Wc Wp (folded), wc unused
   const float *bq, *bk, *bv, *bp, *bc, *b1, *b2;
   const float* nab;  // folded NAB: rows a_d,b_d,co_d,cg_d,a_a,b_a,co_a,cg_a [8][E] + 8 scalars
+  const void *w1s, *w2s;  // optional 3-way bf16 splits of w1 / w2 (packing.pack_a_bf16x3): FFN on the bf16 pipe, RR_MLP_SPLIT=1
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -409,9 +410,13 @@ extern "C" int rr_enc_layer(const EncBlockW* wrow, const EncBlockW* wcol, const 
   static const int variant = [] { const char* e = getenv("RR_ENC_VARIANT"); return e ? atoi(e) : 1; }();
   if ((variant == 1 || norm_affine_only) && dbg == nullptr && (theta != nullptr || bias_pre != nullptr)) {
     EncBlockW2 ws; ws.blk[0] = *wrow; ws.blk[1] = *wcol;   // wave = node tile, register-resident (rr_enc_w.inc); stage dumps use the LDS-staged kernel
-    if (N <= 32) hipLaunchKernelGGL(k_enc_block_w<2>, grid, dim3(128), 0, st, ws, row_in, col_in, row_out, col_out, D, theta, bias_pre, N, norm_affine_only);
-    else if (N <= 64) hipLaunchKernelGGL(k_enc_block_w<4>, grid, dim3(256), 0, st, ws, row_in, col_in, row_out, col_out, D, theta, bias_pre, N, norm_affine_only);
-    else hipLaunchKernelGGL(k_enc_block_w<7>, grid, dim3(448), 0, st, ws, row_in, col_in, row_out, col_out, D, theta, bias_pre, N, norm_affine_only);
+    const char* es = getenv("RR_MLP_SPLIT");
+    const bool split = es != nullptr && atoi(es) != 0 && wrow->w1s && wrow->w2s && wcol->w1s && wcol->w2s;
+#define RR_ENCW(NTV, SP) hipLaunchKernelGGL((k_enc_block_w<NTV, SP>), grid, dim3(64 * NTV), 0, st, ws, row_in, col_in, row_out, col_out, D, theta, bias_pre, N, norm_affine_only)
+    if (N <= 32) { if (split) RR_ENCW(2, true); else RR_ENCW(2, false); }
+    else if (N <= 64) { if (split) RR_ENCW(4, true); else RR_ENCW(4, false); }
+    else { if (split) RR_ENCW(7, true); else RR_ENCW(7, false); }
+#undef RR_ENCW
     return rr_check(hipGetLastError());
   }
   if (N <= 32) hipLaunchKernelGGL(k_enc_block<2>, grid, blk, 0, st, *wrow, *wcol, row_in, col_in, row_out, col_out, D, locs, bias_pre, N, dbg);

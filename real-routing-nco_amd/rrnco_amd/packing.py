@@ -289,6 +289,9 @@ def pack_policy(sd: dict, env_name: str, device) -> dict:
             Wc, bc = sd[f"{b}.multi_head_combine.weight"].detach().double(), sd[f"{b}.multi_head_combine.bias"].detach().double()
             w.wp, w.bp = ar.put(pack_a((Wc @ Wp).float())), ar.put((Wc @ bp + bc).float())
             w.wc, w.bc = None, None
+            # FFN weights again as 3-way bf16 splits for the opt-in bf16-pipe FFN (RR_MLP_SPLIT=1)
+            w.w1s = ar.put_raw(pack_a_bf16x3(sd[f"{b}.feed_forward.ops.ffn.W1.weight"]))
+            w.w2s = ar.put_raw(pack_a_bf16x3(sd[f"{b}.feed_forward.ops.ffn.W2.weight"]))
             if nab_kind != "gating":          # ablation modules: bias computed by rr_nab_simple, fed as bias_pre
                 w.nab = None
                 q, sw = f"{b}.neural_adaptive_bias", L.NabSimpleW()
