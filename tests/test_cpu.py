@@ -411,3 +411,25 @@ def test_matnet_encoder_state_dict_names_match_reference_template():
         enc = MatNetEncoder(embed_dim=256, num_heads=16, num_layers=2, env_name=env_name)
         mine = {k: tuple(v.shape) for k, v in enc.state_dict().items()}
         assert mine == restate.matnet_weight_template(256, 16, 2, 512, env_name)
+
+
+def test_pack_a_bf16x3_is_an_exact_three_way_split_in_kernel_order():
+    """packing.pack_a_bf16x3 (A operands of the opt-in bf16-pipe MLP / FFN): the three bf16 pieces sum back to the fp32 weight
+    exactly, each piece is at most 2^-8 of the previous one, and lane (i, g) of tile t / k-slice s holds the eight k values a
+    lane owns in two consecutive C-layout tiles (k = 32 s + 4 g + e, then 32 s + 16 + 4 g + e)."""
+    from rrnco_amd.packing import pack_a_bf16x3
+    g = torch.Generator().manual_seed(5)
+    W = torch.randn(48, 96, generator=g) * torch.logspace(-3, 2, 96)[None, :]
+    P = pack_a_bf16x3(W)
+    assert P.shape == (3, 3, 3, 64, 8) and P.dtype == torch.bfloat16
+    pieces = P.float()
+    rec = pieces.sum(2)
+    for t in range(3):
+        for s_ in range(3):
+            for lane in (0, 17, 37, 63):
+                i, gg = lane & 15, lane >> 4
+                for e in range(8):
+                    k = 32 * s_ + (4 * gg + e if e < 4 else 16 + 4 * gg + e - 4)
+                    assert rec[t, s_, lane, e].item() == W[16 * t + i, k].item()
+    hi, mid, lo = pieces[:, :, 0], pieces[:, :, 1], pieces[:, :, 2]
+    assert (mid.abs() <= hi.abs() * 2.0 ** -8 + 1e-45).all() and (lo.abs() <= hi.abs() * 2.0 ** -16 + 1e-45).all()
