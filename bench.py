@@ -164,7 +164,7 @@ def main():
             # Opt-in variant, NOT part of `value`: the rollout's pointer MLP and the encoder's FFN on the bf16 matrix pipe with
             # 3-way split fp32 operands (six partial products, fp32 accumulate; same tolerances, tests/test_gpu_atsp.py)
             os.environ["RR_MLP_SPLIT"] = "1"
-            hot_path_step(pol, env, inst, sample_idx)
+            hot_path_step(pol, env, inst, sample_idx)              # (warm-up of the variant's kernels)
             R.TIMING = []
             torch.cuda.synchronize()
             t1 = time.perf_counter()

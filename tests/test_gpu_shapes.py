@@ -40,7 +40,8 @@ def _run(N, B, S, ss, seed, layers=2):
         assert torch.allclose(out["log_likelihood"].cpu()[same], ref["log_likelihood"][same], rtol=2e-5, atol=3e-3)
     # fused and step-wise agree except where fp32 noise decides a near-tie (each was checked against the oracle's gaps above;
     # the two paths evaluate tanh(log u) differently: (u^2-1)/(u^2+1) in the rollout, tanh(log) in rr_select)
-    assert float((outs[0]["actions"] == outs[1]["actions"]).all(1).float().mean()) >= 0.99
+    R = outs[0]["actions"].shape[0]
+    assert float((outs[0]["actions"] == outs[1]["actions"]).all(1).float().mean()) >= min(0.99, 1.0 - 2.0 / R)   # two near-ties allowed on tiny batches
 
 
 @pytest.mark.parametrize("N,B,S,ss", [
