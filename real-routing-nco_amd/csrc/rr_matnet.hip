@@ -109,7 +109,16 @@ __global__ __launch_bounds__(64 * MN_ATTN_WAVES) void k_mn_attn(MnAttnArgs a, in
   const float* Q = a.q[side] + (size_t)b * N * E;
   const float* KV = a.kv[side] + (size_t)b * N * 2 * E;
   float* O = a.o[side] + (size_t)b * N * E;
-  const float* Db = a.D + (size_t)b * N * N;
+  // the instance's distance matrix, as this side reads it (side 1: transposed), staged once: every head re-reads all of it
+  extern __shared__ __attribute__((aligned(16))) float mn_d[];
+  {
+    const float* Dg = a.D + (size_t)b * N * N;
+    for (int i = threadIdx.x; i < N * N; i += 64 * MN_ATTN_WAVES) {
+      const int q = i / N, k = i - q * N;
+      mn_d[i] = side == 0 ? Dg[i] : Dg[(size_t)k * N + q];
+    }
+    __syncthreads();
+  }
   for (int h = wave + blockIdx.y * MN_ATTN_WAVES; h < a.heads; h += MN_ATTN_WAVES * gridDim.y) {
     const float* mx = a.mix[side] + h * 68;
     // K_h as A operand of S^T (keys x dk), V_h^T as A operand of O^T (dk x keys, permuted k = 16 kt + 4 g + m)
@@ -146,7 +155,7 @@ __global__ __launch_bounds__(64 * MN_ATTN_WAVES) void k_mn_attn(MnAttnArgs a, in
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           int key = kt * 16 + 4 * g + r; key = key < N ? key : N - 1;
-          d[r] = side == 0 ? Db[(size_t)qn * N + key] : Db[(size_t)key * N + qn];
+          d[r] = mn_d[qn * N + key];
         }
 #pragma unroll
         for (int rp = 0; rp < 4; rp += 2) {
@@ -263,7 +272,9 @@ static int mn_layer(const MatNetSideW* ws, const float* row_in, const float* col
   MnAttnArgs aa;
   for (int s = 0; s < 2; ++s) { aa.q[s] = Qb[s]; aa.kv[s] = KVb[s]; aa.o[s] = Ob[s]; aa.mix[s] = ws[s].mix; }
   aa.D = D; aa.E = E; aa.heads = heads;
-  hipLaunchKernelGGL(k_mn_attn<NT>, dim3(Bp, (heads + 4 * MN_ATTN_WAVES - 1) / (4 * MN_ATTN_WAVES), 2), dim3(64 * MN_ATTN_WAVES), 0, st, aa, N);
+  const int lds_d = N * N * (int)sizeof(float);
+  (void)hipFuncSetAttribute((const void*)k_mn_attn<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_d);
+  hipLaunchKernelGGL(k_mn_attn<NT>, dim3(Bp, (heads + 4 * MN_ATTN_WAVES - 1) / (4 * MN_ATTN_WAVES), 2), dim3(64 * MN_ATTN_WAVES), lds_d, st, aa, N);
   // x1 = norm1(x_old + O Wo^T)
   for (int s = 0; s < 2; ++s) { la.wp[s] = ws[s].wo; la.bias[s] = nullptr; la.x[s] = Ob[s]; la.y[s] = X1b[s]; la.resid[s] = xin[s]; la.gamma[s] = ws[s].n1g; la.beta[s] = ws[s].n1b; }
   la.K = E; la.Nout = E; launch(2, E);
