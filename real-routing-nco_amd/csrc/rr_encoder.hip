@@ -774,7 +774,7 @@ __global__ __launch_bounds__(NABL_THREADS) void k_nab_dur_lds(NabDurW wr, NabDur
 
 extern "C" int rr_nab_dur(const NabDurW* wrow, const NabDurW* wcol, const float* D, const float* T, const float* locs,
                           float* bias_out, int Bp, int N, hipStream_t st) {
-  if (Bp <= 0 || N < 2 || wrow == nullptr || wcol == nullptr) return RR_EINVAL;
+  if (Bp <= 0 || N < 2 || wrow == nullptr || wcol == nullptr || !D || !T || !locs || !bias_out) return RR_EINVAL;
   const int per_wg = 4 * 16 * NAB_ET;
   dim3 grid((N * N + per_wg - 1) / per_wg, Bp, 2), blk(256);
   const char* ev = getenv("RR_NABDUR_VARIANT");           // 1 (default) LDS-resident rows, 2 rows gathered from L2, 0 MFMA contraction

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void k_minmax_normalize(const float* __restric
 }
 
 extern "C" int rr_minmax_normalize(const float* in, float* out, float* mn, float* mx, int B, int M, hipStream_t st) {
-  if (B <= 0 || M <= 0) return RR_EINVAL;
+  if (B <= 0 || M <= 0 || in == nullptr || out == nullptr || mn == nullptr || mx == nullptr) return RR_EINVAL;
   hipLaunchKernelGGL(k_minmax_normalize, dim3(B), dim3(256), 0, st, in, out, mn, mx, M);
   return rr_check(hipGetLastError());
 }
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void k_atsp_step_r(const int64_t* __restrict__
 
 extern "C" int rr_atsp_step(const int64_t* action, const uint8_t* mask_in, uint8_t* mask_out, uint8_t* done,
                             int R, int N, hipStream_t st) {
-  if (R <= 0 || N <= 0) return RR_EINVAL;
+  if (R <= 0 || N <= 0 || action == nullptr || mask_in == nullptr || mask_out == nullptr || done == nullptr) return RR_EINVAL;
   const bool aligned = ((reinterpret_cast<uintptr_t>(mask_in) | reinterpret_cast<uintptr_t>(mask_out)) & 15) == 0;
   static const int variant = [] { const char* e = getenv("RR_STEP_VARIANT"); return e ? atoi(e) : 1; }();
   if (variant == 1 && N % 4 == 0 && N >= 16 && N <= 128 && ((reinterpret_cast<uintptr_t>(mask_in) | reinterpret_cast<uintptr_t>(mask_out)) & 3) == 0)
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void k_rcvrp_step(const int64_t* __restrict__ 
 extern "C" int rr_rcvrp_step(const int64_t* action, const float* demand, const float* vcap, float* used,
                              uint8_t* visited, uint8_t* mask, int64_t* cur_out, uint8_t* done,
                              int R, int Bp, int N, hipStream_t st) {
-  if (R <= 0 || N <= 0 || Bp <= 0) return RR_EINVAL;
+  if (R <= 0 || N <= 0 || Bp <= 0 || !action || !demand || !vcap || !used || !visited || !mask || !cur_out || !done) return RR_EINVAL;
   hipLaunchKernelGGL(k_rcvrp_step, dim3((R + 3) / 4), dim3(256), 0, st, action, demand, vcap, used, visited, mask,
                      cur_out, done, R, Bp, N);
   return rr_check(hipGetLastError());
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void k_tour_cost(const float* __restrict__ D, 
 extern "C" int rr_tour_cost(const float* D, const int64_t* actions, const float* mn, const float* mx,
                             float* norm_out, float* real_out, int R, int Bp, int N, int T, int mode,
                             const uint8_t* open_route, hipStream_t st) {
-  if (R <= 0 || N <= 0 || T <= 0 || Bp <= 0) return RR_EINVAL;
+  if (R <= 0 || N <= 0 || T <= 0 || Bp <= 0 || !D || !actions || !norm_out || !real_out || ((mn == nullptr) != (mx == nullptr))) return RR_EINVAL;
   hipLaunchKernelGGL(k_tour_cost, dim3((R + 3) / 4), dim3(256), 0, st, D, actions, mn, mx, norm_out, real_out, R, Bp, N, T, mode,
                      open_route);
   return rr_check(hipGetLastError());
@@ -609,6 +609,7 @@ extern "C" int rr_select(const float* logits, const uint8_t* mask, const int64_t
                          int mode, uint64_t seed, uint32_t step, int top_k, float top_p, hipStream_t st) {
   if (R <= 0 || N <= 0 || N > 128 || temperature <= 0.f || top_k < 0 || top_p < 0.f || top_p > 1.f) return RR_EINVAL;
   if (mode == 2 && action_in == nullptr) return RR_EINVAL;
+  if (logits == nullptr || action_out == nullptr || logp_out == nullptr || mode < 0 || mode > 2) return RR_EINVAL;
   static const int gen = [] { const char* e = getenv("RR_SELECT_VARIANT"); return e ? atoi(e) : 1; }();
   const bool filters = (top_k > 0 && top_k < N) || (top_p > 0.f && top_p < 1.f);
   if (gen == 1 && !filters) {
@@ -839,6 +840,7 @@ extern "C" int rr_rmtvrp_step(const int64_t* action, const float* D, const float
                               float* rlen, float* used_l, uint8_t* visited, uint8_t* mask, uint8_t* done,
                               int R, int Bp, int N, const MtvrpExtra* extra, hipStream_t st) {
   if (R <= 0 || N < 2 || Bp <= 0) return RR_EINVAL;
+  if (!action || !D || !T || !demand_l || !tw || !service || !vcap || !cur || !ctime || !rlen || !used_l || !visited || !mask || !done) return RR_EINVAL;
   MtvrpExtra ex = {nullptr, nullptr, nullptr, nullptr, nullptr};
   if (extra != nullptr) {
     ex = *extra;

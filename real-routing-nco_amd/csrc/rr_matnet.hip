@@ -294,6 +294,7 @@ extern "C" int rr_matnet_layer(const MatNetSideW* row_side, const MatNetSideW* c
   if (E % 256 != 0 || heads * 16 != E || ff % 256 != 0) return RR_EINVAL;       // head dim 16; tiles of 256 output features
   if (workspace_bytes < rr_matnet_workspace_bytes(Bp, N, E, ff)) return RR_EINVAL;
   if (row_in == row_out || col_in == col_out) return RR_EINVAL;
+  if (!row_in || !col_in || !row_out || !col_out || !D) return RR_EINVAL;
   const MatNetSideW ws[2] = {*row_side, *col_side};
   if (N <= 32) return mn_layer<2>(ws, row_in, col_in, row_out, col_out, D, workspace, Bp, N, E, heads, ff, st);
   if (N <= 64) return mn_layer<4>(ws, row_in, col_in, row_out, col_out, D, workspace, Bp, N, E, heads, ff, st);
