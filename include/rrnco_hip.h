@@ -100,8 +100,9 @@ int rr_select(const float* logits, const uint8_t* mask, const int64_t* action_in
  * bias_pre [Bp][2][N*N] = rr_nab_dur output when the encoder uses the duration matrix, else NULL. */
 int rr_enc_layer(const EncBlockW* wrow, const EncBlockW* wcol, const float* row_in, const float* col_in,
                  float* row_out, float* col_out, const float* D, const float* locs, const float* theta,
-                 const float* bias_pre, int Bp, int N, int norm_affine_only /* 1: the five norms are per-feature affine
-                 maps (BatchNorm1d in eval mode, running statistics folded into n*g / n*b by the caller) */,
+                 const float* bias_pre, int Bp, int N, int norm_affine_only /* Normalization (attn_freenet.py:78-116) of the five norms:
+                 0 InstanceNorm1d; 1 per-feature affine maps (BatchNorm1d in eval mode, running statistics folded into n*g / n*b
+                 by the caller); 2 "layer" (one mean / unbiased variance per instance, no affine); 3 RMSNorm (n*g = weight) */,
                  float* dbg, hipStream_t stream);
 
 /* theta[b][i][j] = atan2(y_i - y_j, x_i - x_j): the angle input of the Neural Adaptive Bias

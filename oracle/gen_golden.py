@@ -72,6 +72,8 @@ def gen_atsp(tag, B, N, S, sample_size, seed, layers=6, aug=False, keep_trace=Tr
         mine_t = restate.ablation_template(mine_t, nab_type, use_duration=False)
     if normalization == "batch":
         mine_t = restate.batchnorm_template(mine_t)
+    elif normalization in ("rms", "layer"):
+        mine_t = restate.norm_template(mine_t, normalization)
     assert tmpl == mine_t, "state_dict template drift"
     w = restate.make_weights(tmpl, seed)
     pol.load_state_dict(w, strict=True)
@@ -369,6 +371,9 @@ if __name__ == "__main__":
         gen_atsp_beam("atsp_n20_b3_beam20", B=3, N=20, W=20, sample_size=15, seed=72, layers=2)
     if "batchnorm" in which:     # normalization="batch" (the constructor default of RRNetPolicy), eval mode, 3 layers (default too)
         gen_atsp("atsp_n20_b4_pomo_batchnorm", B=4, N=20, S=20, sample_size=15, seed=61, layers=3, keep_trace=False, normalization="batch")
+    if "norms" in which:         # the other two Normalization kinds (attn_freenet.py:85, 92-93): RMSNorm and the parameter-free "layer"
+        gen_atsp("atsp_n20_b4_pomo_rmsnorm", B=4, N=20, S=20, sample_size=15, seed=62, layers=3, keep_trace=False, normalization="rms")
+        gen_atsp("atsp_n20_b4_pomo_layernorm", B=4, N=20, S=20, sample_size=15, seed=63, layers=3, keep_trace=False, normalization="layer")
     if "variant" in which:       # RMTVRPEnv beyond the vrptw preset: backhauls (classes 1, 2), open routes, distance limits
         gen_rcvrptw("rmtvrp_n20_b8_pomo_variants", B=8, N=20, S=20, sample_size=15, seed=51, variant=True)
         # (at N=50 the reference and its restatement already part ways on 11 % of the rollouts, each at a decision gap

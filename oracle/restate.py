@@ -195,8 +195,21 @@ def instance_norm(w: W, p: str, x: Tensor) -> Tensor:
         return F.batch_norm(x.reshape(-1, x.size(-1)), w[p + ".normalizer.running_mean"], w[p + ".normalizer.running_var"],
                             weight=w[p + ".normalizer.weight"], bias=w[p + ".normalizer.bias"], training=False,
                             eps=1e-5).view(*x.size())
+    if (p + ".normalizer.weight") not in w:          # normalization='layer' (:106-109): no parameters, torch.var is unbiased
+        return (x - x.mean((1, 2)).view(-1, 1, 1)) / torch.sqrt(x.var((1, 2)).view(-1, 1, 1) + 1e-05)
+    if (p + ".normalizer.bias") not in w:            # normalization='rms': RMSNorm (:13-26, 110-111), weight only
+        return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5) * w[p + ".normalizer.weight"]
     return F.instance_norm(x.permute(0, 2, 1), weight=w[p + ".normalizer.weight"],
                            bias=w[p + ".normalizer.bias"], eps=1e-5).permute(0, 2, 1)
+
+
+def norm_template(template: Dict[str, tuple], normalization: str) -> Dict[str, tuple]:
+    """state_dict template of the same policy built with normalization='rms' (weight only) or 'layer' (no parameters)."""
+    if normalization == "rms":
+        return {k: v for k, v in template.items() if not k.endswith(".normalizer.bias")}
+    if normalization == "layer":
+        return {k: v for k, v in template.items() if ".normalizer." not in k}
+    return template
 
 
 def batchnorm_template(template: Dict[str, tuple]) -> Dict[str, tuple]:

@@ -405,6 +405,7 @@ extern "C" int rr_enc_layer(const EncBlockW* wrow, const EncBlockW* wcol, const 
                             const float* bias_pre, int Bp, int N, int norm_affine_only, float* dbg, hipStream_t st) {
   if (Bp <= 0 || N < 2 || N > RR_MAXN || wrow == nullptr || wcol == nullptr) return RR_EINVAL;
   // BatchNorm (eval) as a per-feature affine map is implemented in the register-resident block only
+  if (norm_affine_only < 0 || norm_affine_only > 3) return RR_EINVAL;           // 0 instance, 1 batch (eval), 2 layer, 3 rms
   if (norm_affine_only && (dbg != nullptr || (theta == nullptr && bias_pre == nullptr))) return RR_EINVAL;
   dim3 grid(Bp, 2), blk(ENC_THREADS);
   static const int variant = [] { const char* e = getenv("RR_ENC_VARIANT"); return e ? atoi(e) : 1; }();

@@ -11,10 +11,21 @@ import torch.nn as nn
 from .. import _lib as L
 
 
+class _RMSWeight(nn.Module):     # RMSNorm attn_freenet.py:13-26 -> `.normalizer.weight`
+    def __init__(self, E):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(E))
+
+
 class _Norm(nn.Module):          # Normalization attn_freenet.py:78-116 -> `.normalizer.{weight,bias}` (+ running stats for "batch")
     def __init__(self, E, normalization="instance"):
         super().__init__()
-        self.normalizer = nn.BatchNorm1d(E, affine=True) if normalization == "batch" else nn.InstanceNorm1d(E, affine=True)
+        if normalization == "layer":            # attn_freenet.py:92-93, 106-109: no parameters (the reference stores the string)
+            self.normalizer = None
+        elif normalization == "rms":            # :13-26: weight only
+            self.normalizer = _RMSWeight(E)
+        else:
+            self.normalizer = nn.BatchNorm1d(E, affine=True) if normalization == "batch" else nn.InstanceNorm1d(E, affine=True)
 
 
 class _MLP1(nn.Sequential):      # nn.Sequential(Linear(1,E), ReLU, Linear(E,E))  attn_freenet.py:216-225
@@ -143,8 +154,8 @@ class RRNetEncoder(nn.Module):
         super().__init__()
         if embed_dim != 128 or feedforward_hidden != 512:
             raise NotImplementedError("rrnco_amd kernels are specialised for embed_dim=128, feedforward_hidden=512")
-        if normalization not in ("instance", "batch"):
-            raise NotImplementedError("rrnco_amd implements normalization='instance' (configs/experiment/rrnet.yaml) and 'batch'")
+        if normalization not in ("instance", "batch", "layer", "rms"):
+            raise NotImplementedError(f"Normalization type {normalization} not found")      # attn_freenet.py:94-99 logs and skips
         self.normalization = normalization
         self.env_name = getattr(env_name, "name", env_name)
         kw = dict(init_embedding_kwargs or {})
@@ -162,6 +173,7 @@ class RRNetEncoder(nn.Module):
         """-> (row_emb, col_emb) [B,N,E].  `packed` = packing.pack_policy(...) (the policy caches it)."""
         assert packed is not None, "RRNetEncoder.forward needs packed weights (call through RRNetPolicy or pass packed=)"
         bn = self.normalization == "batch"
+        norm_mode = {"instance": 0, "batch": 1, "layer": 2, "rms": 3}[self.normalization]        # rr_enc_layer norm_affine_only
         if bn and self.training:
             raise NotImplementedError("normalization='batch' is evaluated with running statistics (module.eval()); batch "
                                       "statistics across instances (train mode) are not implemented")
@@ -211,7 +223,7 @@ class RRNetEncoder(nn.Module):
                 L.check(lib.rr_nab_dur(nr, nc, L.ptr(D), L.ptr(T), L.ptr(locs), L.ptr(bias), Bp, N, L.stream()), "rr_nab_dur")
             L.check(lib.rr_enc_layer(wr, wc, L.ptr(row), L.ptr(col), L.ptr(row2), L.ptr(col2), L.ptr(D), L.ptr(locs),
                                      L.ptr(theta) if theta is not None else None, L.ptr(bias) if use_dur else None,
-                                     Bp, N, int(bn), L.ptr(dbg) if (dbg is not None and l == 0) else None, L.stream()),
+                                     Bp, N, norm_mode, L.ptr(dbg) if (dbg is not None and l == 0) else None, L.stream()),
                     "rr_enc_layer")
             if l == 0 and dbg is not None:
                 row, col, row2, col2 = row2, col2, torch.empty_like(row), torch.empty_like(col)

@@ -34,7 +34,12 @@ def _lin(P, name, x):
 
 
 def _inorm(P, p, x):
-    """Normalization('instance') attn_freenet.py:104-105."""
+    """Normalization attn_freenet.py:101-111: 'instance' (:104-105); 'layer' (no parameters, unbiased variance over nodes x
+    features); 'rms' (RMSNorm :13-26, weight only) — told apart by which parameters the module has."""
+    if (p + ".normalizer.weight") not in P:
+        return (x - x.mean((1, 2)).view(-1, 1, 1)) / torch.sqrt(x.var((1, 2)).view(-1, 1, 1) + 1e-05)
+    if (p + ".normalizer.bias") not in P:
+        return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5) * P[p + ".normalizer.weight"]
     return F.instance_norm(x.transpose(1, 2), weight=P[p + ".normalizer.weight"], bias=P[p + ".normalizer.bias"],
                            eps=1e-5).transpose(1, 2)
 

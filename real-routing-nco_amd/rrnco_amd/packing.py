@@ -273,7 +273,9 @@ def pack_policy(sd: dict, env_name: str, device) -> dict:
             w = L.EncBlockW()
             for f, k in (("n1", "norm1"), ("n2", "norm2"), ("n3", "norm3"),
                          ("f1", "feed_forward.ops.norm1"), ("f2", "feed_forward.ops.norm2")):
-                gam, bet = sd[f"{b}.{k}.normalizer.weight"].detach().double(), sd[f"{b}.{k}.normalizer.bias"].detach().double()
+                # "layer" has no parameters, RMSNorm a weight only (attn_freenet.py:13-26, 92-93): identity where absent
+                gam = sd[f"{b}.{k}.normalizer.weight"].detach().double() if f"{b}.{k}.normalizer.weight" in sd else torch.ones(E, dtype=torch.float64)
+                bet = sd[f"{b}.{k}.normalizer.bias"].detach().double() if f"{b}.{k}.normalizer.bias" in sd else torch.zeros(E, dtype=torch.float64)
                 if f"{b}.{k}.normalizer.running_mean" in sd:      # BatchNorm1d (eval): fold the running statistics
                     rm, rv = sd[f"{b}.{k}.normalizer.running_mean"].double(), sd[f"{b}.{k}.normalizer.running_var"].double()
                     gam = gam / torch.sqrt(rv + 1e-5)

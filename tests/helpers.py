@@ -30,6 +30,8 @@ def atsp_weights(fx_or_ss, layers=6, seed=None):
         t = restate.ablation_template(t, fx_or_ss["nab_type"], use_duration=False)
     if isinstance(fx_or_ss, dict) and fx_or_ss.get("normalization", "instance") == "batch":
         t = restate.batchnorm_template(t)
+    if isinstance(fx_or_ss, dict) and fx_or_ss.get("normalization", "instance") in ("rms", "layer"):
+        t = restate.norm_template(t, fx_or_ss["normalization"])
     return restate.make_weights(t, seed)
 
 
@@ -39,7 +41,9 @@ def make_policy(w, env_name="atsp", device="cuda"):
     ss = [v for k, v in w.items() if k.endswith(".row_embed.weight")][0].shape[1]
     q0 = "encoder.net.layers.0.row_encoding_block.neural_adaptive_bias"
     nab_type = "naive" if (q0 + ".mlp.0.weight") in w else "heuristic" if (q0 + ".alpha") in w else "gating"
-    norm = "batch" if any(k.endswith(".normalizer.running_mean") for k in w) else "instance"
+    n1 = "encoder.net.layers.0.row_encoding_block.norm1.normalizer"
+    norm = ("batch" if (n1 + ".running_mean") in w else "layer" if (n1 + ".weight") not in w
+            else "rms" if (n1 + ".bias") not in w else "instance")
     pol = RRNetPolicy(env_name=env_name, embed_dim=128, num_heads=8, num_encoder_layers=layers,
                       normalization=norm, use_graph_context=False, nab_type=nab_type,
                       init_embedding_kwargs=dict(use_coords=True, use_polar_feats=True, use_dist=True,

@@ -72,3 +72,20 @@ def test_batchnorm_eval_policy_matches_reference_and_train_mode_is_rejected():
     pol.train()
     with pytest.raises(NotImplementedError, match="running statistics"):
         pol(env.reset(td_in), env, phase="train", num_starts=fx["S"])
+
+
+@pytest.mark.parametrize("name,kind", [("atsp_n20_b4_pomo_rmsnorm", "rms"), ("atsp_n20_b4_pomo_layernorm", "layer")])
+def test_rms_and_layer_normalization_policies_match_reference(name, kind):
+    """The other two kinds of Normalization (attn_freenet.py:85, 92-93, 106-111): RMSNorm (per node over the features, weight
+    only) and the parameter-free 'layer' (one mean / unbiased variance per instance); golden vectors from the reference built
+    with those options."""
+    fx, w, pol, inst, env, td_in = _run_plain(name)
+    assert pol.encoder.normalization == kind
+    row, col = pol.encoder(env.reset(td_in), packed=pol.packed(torch.device("cuda")))
+    assert torch.allclose(row.cpu(), fx["row_emb"], atol=ENC_ATOL) and torch.allclose(col.cpu(), fx["col_emb"], atol=ENC_ATOL)
+    out = pol(env.reset(td_in), env, phase="val", decode_type="multistart_greedy", num_starts=fx["S"], return_actions=True)
+    frac, first = H.tour_agreement(out["actions"].cpu(), fx["actions"])
+    assert frac >= 0.98
+    same = first < 0
+    assert torch.allclose(out["reward"].cpu()[same], fx["reward"][same], atol=COST_ATOL)
+
