@@ -433,3 +433,39 @@ def test_pack_a_bf16x3_is_an_exact_three_way_split_in_kernel_order():
                     assert rec[t, s_, lane, e].item() == W[16 * t + i, k].item()
     hi, mid, lo = pieces[:, :, 0], pieces[:, :, 1], pieces[:, :, 2]
     assert (mid.abs() <= hi.abs() * 2.0 ** -8 + 1e-45).all() and (lo.abs() <= hi.abs() * 2.0 ** -16 + 1e-45).all()
+
+
+def test_state_augmentation_matches_reference_functions():
+    """models/transforms.py against the reference's formulas (transforms.py:15-154): dihedral-8 blocks, the random 'symmetric'
+    transform (an isometry about (0.5, 0.5), identity on the first block, reproducible from torch's RNG like the reference's
+    own torch.rand draw), num_augment other than 8, custom callables, normalize."""
+    import math
+    from rrnco_amd import TensorDict
+    from rrnco_amd.models.transforms import StateAugmentation
+    g = torch.Generator().manual_seed(3)
+    locs = torch.rand(5, 12, 2, generator=g)
+    D = torch.rand(5, 12, 12, generator=g)
+    td = TensorDict({"locs": locs, "distance_matrix": D}, batch_size=[5])
+    out = StateAugmentation(augment_fn="dihedral8", no_aug_coords=False)(td)
+    x, y = locs[..., 0], locs[..., 1]
+    assert out["locs"].shape == (40, 12, 2) and torch.equal(out["locs"][:5], locs)
+    assert torch.equal(out["locs"][5:10, :, 0], 1 - x) and torch.equal(out["locs"][20:25, :, 0], y)
+    assert torch.equal(out["distance_matrix"][35:], D)
+    torch.manual_seed(11)
+    sym = StateAugmentation(num_augment=4, augment_fn="symmetric", no_aug_coords=False)(td)
+    torch.manual_seed(11)
+    phi = torch.rand(20) * 4 * math.pi
+    phi[:5] = 0.0
+    xs, ys = locs.repeat(4, 1, 1)[..., [0]] - 0.5, locs.repeat(4, 1, 1)[..., [1]] - 0.5
+    p3 = phi[:, None, None]
+    ref = torch.cat((torch.cos(p3) * xs - torch.sin(p3) * ys, torch.sin(p3) * xs + torch.cos(p3) * ys), -1)
+    ref = torch.where(p3 > 2 * math.pi, ref.flip(-1), ref) + 0.5
+    assert torch.equal(sym["locs"], ref) and torch.allclose(sym["locs"][:5], locs, atol=1e-7)
+    d0 = torch.cdist(locs.repeat(4, 1, 1), locs.repeat(4, 1, 1))
+    assert torch.allclose(torch.cdist(sym["locs"], sym["locs"]), d0, atol=1e-5)          # isometry
+    same = StateAugmentation(num_augment=8)(td)                                             # defaults: no_aug_coords=True
+    assert torch.equal(same["locs"], locs.repeat(8, 1, 1))
+    twice = StateAugmentation(num_augment=2, augment_fn=lambda xy, n: xy * 2, no_aug_coords=False, normalize=True)(td)
+    assert float(twice["locs"].min()) == 0.0 and float(twice["locs"].max()) == 1.0
+    with pytest.raises(ValueError):
+        StateAugmentation(augment_fn="nope")
