@@ -5,7 +5,7 @@ import torch
 import torch.nn as nn
 
 from .. import packing
-from ..ops import get_log_likelihood
+from ..ops import calculate_entropy, get_log_likelihood
 from .decoder import RRNetDecoder
 from .decoding import get_decoding_strategy
 from .encoder import RRNetEncoder
@@ -49,8 +49,6 @@ class RRNetPolicy(nn.Module):
                 max_steps=1_000_000, fused=True, **decoding_kwargs) -> dict:
         if env is None or isinstance(env, str):
             raise ValueError("pass an instantiated rrnco_amd env")
-        if return_entropy:
-            raise NotImplementedError("return_entropy (store_all_logp) is available through fused=False only")
         packed = self.packed(td.device)
         row_emb, col_emb = self.encoder(td, phase=phase, packed=packed)
 
@@ -68,7 +66,8 @@ class RRNetPolicy(nn.Module):
         td, env, num_starts = strategy.pre_decoder_hook(td, env)
         td, env, cache = self.decoder.pre_decoder_hook(td, env, (row_emb, col_emb), num_starts, packed=packed)
 
-        if (fused and self.env_name in PROB_ID and strategy.mask_logits and strategy.top_k == 0 and not (0.0 < strategy.top_p < 1.0)
+        # the fused rollout keeps one log-probability per step; full rows (store_all_logp / return_entropy) come from the step-wise loop
+        if (fused and not strategy.store_all_logp and self.env_name in PROB_ID and strategy.mask_logits and strategy.top_k == 0 and not (0.0 < strategy.top_p < 1.0)
                 and not getattr(strategy, "is_beam_search", False)):
             logprobs, actions_out, td = self._fused_rollout(td, env, cache, packed, strategy, actions)
         else:
@@ -94,8 +93,10 @@ class RRNetPolicy(nn.Module):
             out["normalized_reward"] = normd
         if return_actions:
             out["actions"] = actions_out
+        if return_entropy:
+            out["entropy"] = calculate_entropy(logprobs)                            # policy.py:248-249
         if return_hidden:
-            out["hidden"] = cache
+            out["hidden"] = (row_emb, col_emb)                                      # policy.py:250-251: the encoder output
         return out
 
     def _fused_rollout(self, td, env, cache, packed, strategy, actions_in):

@@ -54,3 +54,10 @@ def get_log_likelihood(logprobs, actions=None, mask=None, return_sum=True):
     if logprobs.dim() == 3:
         logprobs = logprobs.gather(-1, actions.unsqueeze(-1)).squeeze(-1)
     return logprobs.sum(1) if return_sum else logprobs
+
+
+def calculate_entropy(logprobs):
+    """rl4co.utils.ops.calculate_entropy (call site rrnco/models/policy.py:248-249): logprobs [R, T, N] -> [R]."""
+    logprobs = torch.nan_to_num(logprobs, nan=0.0)
+    return -(logprobs.exp() * logprobs).sum(dim=-1).sum(dim=1)
+

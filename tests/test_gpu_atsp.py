@@ -350,3 +350,22 @@ def test_beam_search_matches_reference_beams(name):
     assert best["actions"].shape == (B, fx["N"])
     ref_best = out["reward"].view(W, B).max(0).values
     assert torch.allclose(best["reward"], ref_best, atol=COST_ATOL)
+
+
+def test_return_entropy_and_hidden_follow_the_reference_out_dict():
+    """policy.py:248-251: `entropy` = rl4co calculate_entropy of the full per-step log-probability rows (the policy leaves the
+    fused rollout by itself for it), `hidden` = the encoder output."""
+    fx, w, pol, st, env, td_in = _setup("atsp_n20_b4_pomo")
+    S = fx["S"]
+    out = pol(env.reset(td_in), env, phase="val", decode_type="multistart_greedy", num_starts=S, return_actions=True,
+              return_entropy=True, return_hidden=True)
+    assert torch.equal(out["actions"].cpu(), fx["actions"])
+    tr = {}
+    with torch.inference_mode():
+        restate.atsp_policy(w, restate.atsp_reset(st), fx["sample_idx"], S, "greedy", trace=tr)
+    lp = torch.nan_to_num(torch.stack(tr["logp"], 1), nan=0.0)                     # [R, T-1, N] (the multistart step has zero rows)
+    ent = -(lp.exp() * lp).sum(-1).sum(1)
+    assert torch.allclose(out["entropy"].cpu(), ent, rtol=1e-4, atol=1e-3)
+    row, col = out["hidden"]
+    assert torch.allclose(row.cpu(), fx["row_emb"], atol=ENC_ATOL) and torch.allclose(col.cpu(), fx["col_emb"], atol=ENC_ATOL)
+
