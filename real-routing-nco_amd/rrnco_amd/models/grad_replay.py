@@ -277,52 +277,80 @@ def decode_log_likelihood_rcvrp(P, row_emb, col_emb, D, demand, actions, tanh_cl
 
 
 @torch.no_grad()
-def rcvrptw_replay_states(D, Dur, demand_l, tw, service, actions, cap=1.0):
-    """RMTVRPEnv._step / get_action_mask under the vrptw preset (rmtvrp/env.py:155-215, 343-428), replayed along given
-    routes in the env's operation order.  demand_l / service [b,N+1] (depot first), tw [b,N+1,2], actions [b,S,T] ->
-    (remaining load, current time) [b,S,T-1] and masks [b,S,T-1,N+1] seen when actions[..., 1:] were chosen."""
+def rcvrptw_replay_states(D, Dur, demand_l, tw, service, actions, cap=1.0, variant=None):
+    """RMTVRPEnv._step / get_action_mask (rmtvrp/env.py:155-215, 343-428), replayed along given routes in the env's operation
+    order.  demand_l / service [b,N+1] (depot first), tw [b,N+1,2], actions [b,S,T]; `variant` = None (vrptw preset) or a dict
+    with demand_backhaul [b,N+1], open_route [b] bool, distance_limit [b], backhaul_class [b] (the multi-task terms: backhaul
+    loads, open routes, distance limits, class 1 / 2).  -> per decision (when actions[..., 1:] were chosen): available load,
+    current time, open-route flag, remaining distance (the four MTVRP context scalars, context.py:51-70) [b,S,T-1] each, and
+    the masks [b,S,T-1,N+1]."""
     b, S, T = actions.shape
     N1 = D.shape[-1]
     dev = D.device
     bi = torch.arange(b, device=dev)[:, None].expand(b, S)
     ex = lambda v: v[:, None].expand(b, S, *v.shape[1:])                                             # noqa: E731
     dl, sv, early, late = ex(demand_l), ex(service), ex(tw[..., 0]), ex(tw[..., 1])
-    dur_j0 = ex(Dur[:, :, 0])
-    t = torch.zeros(b, S, device=dev); used = torch.zeros(b, S, device=dev)
+    dur_j0, dist_j0 = ex(Dur[:, :, 0]), ex(D[:, :, 0])
+    if variant is not None:
+        db = ex(variant["demand_backhaul"].float())
+        closed = ex((~variant["open_route"].reshape(b).bool()).float())               # [b,S]
+        limit = ex(variant["distance_limit"].reshape(b).float())
+        bclass = ex(variant["backhaul_class"].reshape(b).long())
+    else:
+        db = torch.zeros_like(dl)
+        closed = torch.ones(b, S, device=dev)
+        limit = torch.full((b, S), float("inf"), device=dev)
+        bclass = torch.ones(b, S, dtype=torch.long, device=dev)
+    t = torch.zeros(b, S, device=dev); used = torch.zeros(b, S, device=dev); ub = torch.zeros(b, S, device=dev)
+    rlen = torch.zeros(b, S, device=dev)
     prev = torch.zeros(b, S, dtype=torch.long, device=dev)
     visited = torch.zeros(b, S, N1, dtype=torch.bool, device=dev)
-    rems, times, masks = [], [], []
+    rems, times, rds, masks = [], [], [], []
     for k in range(T - 1):
         a = actions[..., k]
         nz = (a != 0).float()
-        t = nz * (torch.maximum(t + Dur[bi, prev, a], early.gather(2, a[..., None])[..., 0]) + sv.gather(2, a[..., None])[..., 0])
-        used = nz * (used + dl.gather(2, a[..., None])[..., 0])
+        pick = lambda v: v.gather(2, a[..., None])[..., 0]                                            # noqa: E731
+        t = nz * (torch.maximum(t + Dur[bi, prev, a], pick(early)) + pick(sv))                        # :170-172
+        rlen = nz * (rlen + D[bi, prev, a])                                                          # :175-177
+        used = nz * (used + pick(dl))                                                                # :189-191
+        dba = pick(db)
+        ub = nz * (ub + dba)                                                                         # :192-194
         visited = visited.scatter(2, a[..., None], True)
-        arrival = t[..., None] + Dur[bi, a]                                  # [b,S,N1]
-        reach = arrival < late
-        back = (torch.maximum(arrival, early) + sv + dur_j0) < late[..., 0:1]
+        arrival = t[..., None] + Dur[bi, a]                                                           # [b,S,N1]
+        reach = arrival < late                                                                       # :361
+        back = ((torch.maximum(arrival, early) + sv + dur_j0) * closed[..., None]) < late[..., 0:1]   # :364-366
+        far = (rlen[..., None] + D[bi, a] + dist_j0 * closed[..., None]) > limit[..., None]           # :369-372
         ex_l = dl + used[..., None] > cap
-        missing = ((dl * ~visited).sum(-1) > 0)[..., None]
-        can = reach & back & (missing & ~ex_l & (dl > 0)) & ~visited
-        can[..., 0] = ~((a == 0) & (can[..., 1:].sum(-1) > 0))
-        masks.append(can); rems.append(cap - used); times.append(t)
+        ex_b = db + ub[..., None] > cap                                                              # :375-380
+        missing = ((dl * ~visited).sum(-1) > 0)[..., None]                                           # :384-386
+        carrying = (dba > 0)[..., None]                                                              # :388-396
+        ok1 = (missing & ~ex_l & ~carrying & (dl > 0)) | (~ex_b & (db > 0))                           # :397-402
+        ok2 = ~ex_l & ~ex_b & ~(dl > cap - ub[..., None])                                            # :407-412
+        ok = torch.where((bclass == 1)[..., None], ok1, torch.where((bclass == 2)[..., None], ok2, torch.zeros_like(ok1)))
+        can = reach & back & ok & ~far & ~visited                                                    # :420-426
+        can[..., 0] = ~((a == 0) & (can[..., 1:].sum(-1) > 0))                                        # :429
+        masks.append(can); rems.append(cap - torch.where(ub == 0, used, ub)); times.append(t)        # context.py:55-60
+        rds.append(torch.where(torch.isfinite(limit), limit - rlen, torch.full_like(rlen, 10.0)))     # nan_to_num(posinf=10)
         prev = a
-    return torch.stack(rems, 2), torch.stack(times, 2), torch.stack(masks, 2)
+    opn = (1.0 - closed)[..., None].expand(b, S, T - 1)
+    return torch.stack(rems, 2), torch.stack(times, 2), opn, torch.stack(rds, 2), torch.stack(masks, 2)
 
 
-def decode_log_likelihood_rcvrptw(P, row_emb, col_emb, D, Dur, demand_l, tw, service, actions, tanh_clipping=10.0, temperature=1.0):
-    """Teacher-forced decoder for RCVRPTW: MTVRPContextEmbedding (context.py:34-70: [emb[cur]; available load, current time,
-    open route = 0, remaining distance = 10 without a limit]), bias alpha*D[cur] + beta*Dur[cur] (decoder.py:187-190)."""
+def decode_log_likelihood_rcvrptw(P, row_emb, col_emb, D, Dur, demand_l, tw, service, actions, tanh_clipping=10.0, temperature=1.0,
+                                  variant=None):
+    """Teacher-forced decoder for RCVRPTW / RMTVRP: MTVRPContextEmbedding (context.py:34-70: [emb[cur]; available load, current
+    time, open route, remaining distance (10 without a limit)]), bias alpha*D[cur] + beta*Dur[cur] (decoder.py:187-190)."""
     b, S, T = actions.shape
     N1 = row_emb.shape[1]
     Td = T - 1
-    rem, tm, mask = rcvrptw_replay_states(D, Dur, demand_l, tw, service, actions)
+    rem, tm, opn, rd, mask = rcvrptw_replay_states(D, Dur, demand_l, tw, service, actions, variant=variant)
     k, v, lk = F.linear(col_emb, P["decoder.project_node_embeddings.weight"]).chunk(3, dim=-1)
     Wc = P["decoder.context_embedding.project_context.weight"]                  # [E, E+4]
     ctx_cur = F.linear(row_emb, Wc[:, :E])
     prev, target = actions[..., :Td], actions[..., 1:]
     idx = lambda t, i: t.gather(1, i.reshape(b, -1, 1).expand(-1, -1, t.size(-1)))                    # noqa: E731
-    q = idx(ctx_cur, prev).view(b, S, Td, E) + rem[..., None] * Wc[:, E] + tm[..., None] * Wc[:, E + 1] + 10.0 * Wc[:, E + 3]
+    q = (idx(ctx_cur, prev).view(b, S, Td, E) + rem[..., None] * Wc[:, E] + tm[..., None] * Wc[:, E + 1]
+         + opn[..., None] * Wc[:, E + 2] + rd[..., None] * Wc[:, E + 3])
     q = q.reshape(b, S * Td, E)
     heads = lambda t: t.unflatten(-1, (HEADS, -1)).transpose(1, 2)                                    # noqa: E731
     h = F.scaled_dot_product_attention(heads(q), heads(k), heads(v), attn_mask=mask.reshape(b, 1, S * Td, N1))
@@ -348,8 +376,6 @@ def replay_backward(policy, td, actions, num_starts, grad_ll, sample_idx, enc_ch
     if policy.env_name not in ("atsp", "rcvrp", "rcvrptw"):
         raise NotImplementedError(f"gradient replay for env '{policy.env_name}'")
     vrp, vtw = policy.env_name == "rcvrp", policy.env_name == "rcvrptw"
-    if vtw and getattr(td, "meta", {}).get("mtvrp_variant", False):
-        raise NotImplementedError("gradient replay covers the vrptw preset of RMTVRPEnv")
     P = dict(policy.named_parameters())
     nl = 1 + max(int(n.split(".")[3]) for n in P if n.startswith("encoder.net.layers."))
     D, locs = td["distance_matrix"].float(), td["locs"].float()
@@ -359,6 +385,13 @@ def replay_backward(policy, td, actions, num_starts, grad_ll, sample_idx, enc_ch
         tw, service = td["time_windows"].float(), td["service_time"].float()
         demand = dl_full[:, 1:]
         extra = torch.cat([tw, service[..., None]], -1)
+        # multi-task terms, when the instances carry any (same test as RMTVRPEnv._reset): backhauls, open routes, limits
+        variant = None
+        if "demand_backhaul" in td.keys():
+            v = {k: td[k] for k in ("demand_backhaul", "open_route", "distance_limit", "backhaul_class")}
+            if bool((v["demand_backhaul"] != 0).any() or v["open_route"].any() or torch.isfinite(v["distance_limit"]).any()
+                    or (v["backhaul_class"] != 1).any()):
+                variant = v
     B, N = D.shape[0], D.shape[-1]
     S = num_starts
     acts = actions.view(S, B, actions.shape[-1]).transpose(0, 1)  # [B,S,T]
@@ -374,7 +407,8 @@ def replay_backward(policy, td, actions, num_starts, grad_ll, sample_idx, enc_ch
                 z = min(hi, a + dec_chunk)
                 if vtw:
                     ll = decode_log_likelihood_rcvrptw(P, row_d[a - lo:z - lo], col_d[a - lo:z - lo], D[a:z], Dur[a:z], dl_full[a:z],
-                                                       tw[a:z], service[a:z], acts[a:z], policy.tanh_clipping, policy.temperature)
+                                                       tw[a:z], service[a:z], acts[a:z], policy.tanh_clipping, policy.temperature,
+                                                       variant=None if variant is None else {k: u[a:z] for k, u in variant.items()})
                 elif vrp:
                     ll = decode_log_likelihood_rcvrp(P, row_d[a - lo:z - lo], col_d[a - lo:z - lo], D[a:z], demand[a:z], acts[a:z],
                                                      policy.tanh_clipping, policy.temperature)

@@ -62,9 +62,9 @@ class RRNet:
         if self.env_name == "rcvrp":
             state["demand"] = td["demand"]
         elif self.env_name == "rcvrptw":
-            if td.meta.get("mtvrp_variant", False):
-                raise NotImplementedError("training_step covers the vrptw preset of RMTVRPEnv")
             state.update({k: td[k] for k in ("duration_matrix", "demand_linehaul", "time_windows", "service_time")})
+            if td.meta.get("mtvrp_variant", False):      # backhauls / open routes / distance limits: replayed with their terms
+                state.update({k: td[k] for k in ("demand_backhaul", "open_route", "distance_limit", "backhaul_class")})
         sidx = td["sample_idx"]
         n_start = self.env.get_num_starts(td) if self.num_starts is None else self.num_starts
         out = self.policy(td, self.env, phase="train", num_starts=n_start, **policy_kw)

@@ -379,6 +379,37 @@ def test_gradient_replay_rcvrptw_matches_oracle_autograd():
     assert checked > 200 and num ** 0.5 / gnorm < 5e-3, num ** 0.5 / gnorm
 
 
+def test_gradient_replay_rmtvrp_variants_matches_oracle_autograd():
+    """The multi-task RMTVRP instances (backhaul classes 1 / 2, open routes, distance limits): masks, loads, route lengths and
+    the four MTVRP context scalars replayed in the env's operation order; gradients against autograd through the oracle."""
+    from rrnco_amd.models.grad_replay import replay_backward
+    fx = H.load_fixture("rmtvrp_n20_b8_pomo_variants")
+    w = H.rcvrptw_weights(fx)
+    S = fx["S"]
+    st0 = restate.rmtvrp_reset(H.rcvrptw_instance(fx))
+    gll = torch.from_numpy(np.random.default_rng(8).standard_normal(fx["actions"].shape[0]).astype(np.float32))
+    wg = {k: v.clone().requires_grad_() for k, v in w.items()}
+    out = restate.rcvrptw_policy(wg, st0, fx["sample_idx"], S, decode="evaluate", actions=fx["actions"][:, 1:])
+    assert torch.equal(out["actions"], fx["actions"])
+    (out["log_likelihood"] * gll).sum().backward()
+    pol = H.make_policy(w, env_name="rcvrptw", device="cpu")
+    pol.zero_grad()
+    state = {k: st0[k] for k in ("distance_matrix", "locs", "duration_matrix", "demand_linehaul", "time_windows", "service_time",
+                                 "demand_backhaul", "open_route", "distance_limit", "backhaul_class")}
+    ll = replay_backward(pol, state, fx["actions"], S, gll, fx["sample_idx"], enc_chunk=5, dec_chunk=3)
+    assert torch.allclose(ll, out["log_likelihood"].detach(), rtol=2e-5, atol=3e-4), (ll - out["log_likelihood"]).abs().max()
+    refs = {n: wg[n].grad for n, _ in pol.named_parameters()}
+    gnorm = sum(float((g ** 2).sum()) for g in refs.values() if g is not None) ** 0.5
+    num = 0.0
+    for name, p in pol.named_parameters():
+        if refs[name] is None:
+            continue
+        err = float(((p.grad - refs[name]) ** 2).sum()) ** 0.5
+        assert err <= 5e-2 * float((refs[name] ** 2).sum()) ** 0.5 + 2e-5 * gnorm, (name, err)
+        num += err ** 2
+    assert num ** 0.5 / gnorm < 5e-3, num ** 0.5 / gnorm
+
+
 @pytest.mark.parametrize("name", ["atsp_n20_b4_beam5", "atsp_n20_b3_beam20"])
 def test_oracle_beam_search_reproduces_reference_golden(name):
     fx = H.load_fixture(name)

@@ -150,12 +150,14 @@ def test_rcvrp_training_step_gradients_match_oracle_autograd():
     assert num ** 0.5 / gnorm < 5e-3
 
 
-def test_rcvrptw_training_step_gradients_match_oracle_autograd():
-    """... and for RCVRPTW (vrptw preset): duration NAB, time-window masks, MTVRP context."""
+@pytest.mark.parametrize("fixture", ["rcvrptw_n20_b4_pomo", "rmtvrp_n20_b8_pomo_variants"])
+def test_rcvrptw_training_step_gradients_match_oracle_autograd(fixture):
+    """... and for RCVRPTW (vrptw preset) and the multi-task RMTVRP instances (backhauls, open routes, distance limits):
+    duration NAB, time-window masks, MTVRP context; sampling rollout on the fused kernel, gradients by the replay."""
     from rrnco_amd import TensorDict
     from rrnco_amd.envs import RMTVRPEnv
     from rrnco_amd.models.rl import RRNet
-    fx = H.load_fixture("rcvrptw_n20_b4_pomo")
+    fx = H.load_fixture(fixture)
     w = H.rcvrptw_weights(fx)
     pol = H.make_policy(w, env_name="rcvrptw").train()
     env = RMTVRPEnv(generator_params=dict(num_loc=fx["N"]))
