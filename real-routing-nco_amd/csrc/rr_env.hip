@@ -273,12 +273,82 @@ __global__ __launch_bounds__(256) void k_rcvrp_step(const int64_t* __restrict__ 
   }
 }
 
+// Second form (4 <= N + 1 <= 128): 32 lanes per rollout, lane l owns the four nodes of the window starting at
+// min(4 l, N + 1 - 4) (the last window is pulled back and overlaps its neighbour, which computes and stores the same bytes):
+// 16-byte demand loads, one 4-byte visited load and mask store per lane, `done` / "any free customer" by ballot, `visited`
+// updated by one byte store.  Same fp32 expressions as k_rcvrp_step: bit-identical masks.  RCV_PASSES x 2 rollouts per wave.
+#define RCV_PASSES 2
+__global__ __launch_bounds__(256) void k_rcvrp_step_v(const int64_t* __restrict__ action, const float* __restrict__ demand,
+                                                      const float* __restrict__ vcap, float* __restrict__ used,
+                                                      uint8_t* __restrict__ visited, uint8_t* __restrict__ mask,
+                                                      int64_t* __restrict__ cur_out, uint8_t* __restrict__ done,
+                                                      int R, int Bp, int N /*customers*/) {
+  typedef uint32_t u32_a1 __attribute__((aligned(1)));
+  const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
+  const long rbase = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (2 * RCV_PASSES);
+  const int N1 = N + 1;
+  const int ws = min(4 * hl, N1 - 4);
+  const bool col_ok = 4 * hl < N1;
+  int a[RCV_PASSES];
+  float u0[RCV_PASSES], cap[RCV_PASSES], sel[RCV_PASSES], dem[RCV_PASSES][4];
+  uint32_t visw[RCV_PASSES];
+#pragma unroll
+  for (int i = 0; i < RCV_PASSES; ++i) {
+    const long r = rbase + 2 * i + half;
+    const long rc = r < R ? r : R - 1;
+    a[i] = (int)action[rc]; u0[i] = used[rc]; cap[i] = vcap[rc];
+    visw[i] = *reinterpret_cast<const u32_a1*>(visited + rc * N1 + ws);
+    const float* db = demand + (size_t)(rc % Bp) * N;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int k = ws + q; dem[i][q] = db[k >= 1 ? k - 1 : 0]; }   // node k <-> demand[k-1]
+    int ci = a[i] - 1; ci = ci < 0 ? 0 : (ci > N - 1 ? N - 1 : ci);
+    sel[i] = db[ci];
+  }
+#pragma unroll
+  for (int i = 0; i < RCV_PASSES; ++i) {
+    const long r = rbase + 2 * i + half;
+    const bool row_ok = r < R;
+    const int av = a[i];
+    const float u = (u0[i] + sel[i]) * (av != 0 ? 1.0f : 0.0f);                        // rcvrp/env.py:96-101
+    bool unvis = false, free_here = false;
+    bool ml[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = ws + q;
+      const bool v = ((visw[i] >> (8 * q)) & 0xffu) != 0 || k == av;
+      unvis |= !v;
+      const bool exceeds = dem[i][q] + u > cap[i];                                     // :185-187
+      ml[q] = v || exceeds;
+      free_here |= k >= 1 && !ml[q];
+    }
+    const int sh = 32 * half;
+    const bool anyfree = (uint32_t)(__ballot(col_ok && free_here) >> sh) != 0;
+    const bool all_visited = (uint32_t)(__ballot(col_ok && unvis) >> sh) == 0;
+    uint32_t mw = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool bit = ws + q == 0 ? !(av == 0 && anyfree) : !ml[q];                   // :189-195
+      mw |= (bit ? 1u : 0u) << (8 * q);
+    }
+    if (row_ok && col_ok) *reinterpret_cast<u32_a1*>(mask + r * N1 + ws) = mw;
+    if (row_ok && hl == 0) {
+      visited[r * N1 + av] = 1;
+      used[r] = u; cur_out[r] = av; done[r] = all_visited;
+    }
+  }
+}
+
 extern "C" int rr_rcvrp_step(const int64_t* action, const float* demand, const float* vcap, float* used,
                              uint8_t* visited, uint8_t* mask, int64_t* cur_out, uint8_t* done,
                              int R, int Bp, int N, hipStream_t st) {
   if (R <= 0 || N <= 0 || Bp <= 0 || !action || !demand || !vcap || !used || !visited || !mask || !cur_out || !done) return RR_EINVAL;
-  hipLaunchKernelGGL(k_rcvrp_step, dim3((R + 3) / 4), dim3(256), 0, st, action, demand, vcap, used, visited, mask,
-                     cur_out, done, R, Bp, N);
+  static const int variant = [] { const char* e = getenv("RR_STEP_VARIANT"); return e ? atoi(e) : 1; }();
+  if (variant != 0 && N + 1 >= 4 && N + 1 <= 128)
+    hipLaunchKernelGGL(k_rcvrp_step_v, dim3((R + 8 * RCV_PASSES - 1) / (8 * RCV_PASSES)), dim3(256), 0, st, action, demand, vcap, used,
+                       visited, mask, cur_out, done, R, Bp, N);
+  else
+    hipLaunchKernelGGL(k_rcvrp_step, dim3((R + 3) / 4), dim3(256), 0, st, action, demand, vcap, used, visited, mask,
+                       cur_out, done, R, Bp, N);
   return rr_check(hipGetLastError());
 }
 
