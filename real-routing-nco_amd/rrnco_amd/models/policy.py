@@ -38,7 +38,8 @@ class RRNetPolicy(nn.Module):
 
     # ---- packed (MFMA-ordered / folded) weights, rebuilt when any parameter changes
     def packed(self, device):
-        key = (str(device), tuple(p._version for p in self.parameters()), tuple(p.data_ptr() for p in self.parameters()))
+        key = (str(device), packing.mlp_split_enabled(), tuple(p._version for p in self.parameters()),
+               tuple(p.data_ptr() for p in self.parameters()))
         if self._pack_cache is None or self._pack_cache[0] != key:
             self._pack_cache = (key, packing.pack_policy(self.state_dict(), self.env_name, device))
         return self._pack_cache[1]

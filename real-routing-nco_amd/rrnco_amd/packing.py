@@ -24,6 +24,13 @@ def pack_a(Wm: torch.Tensor) -> torch.Tensor:
     return x.view(Mp // 16, Kp // 16, 64, 4)
 
 
+def mlp_split_enabled() -> bool:
+    """RR_MLP_SPLIT=1: pointer MLP / encoder FFN on the bf16 matrix pipe with 3-way split operands (opt-in)."""
+    import os
+    v = os.environ.get("RR_MLP_SPLIT", "")
+    return v not in ("", "0")
+
+
 def pack_a_bf16x3(Wm: torch.Tensor) -> torch.Tensor:
     """[M,K] fp32 -> [M/16, K/32, 3, 64, 8] bf16: A operands of v_mfma_f32_16x16x32_bf16 for the three pieces
     W = hi + mid + lo (each rounded to nearest bf16 of what is left; the sum is exactly W).  Lane (i = l&15, g = l>>4) of
@@ -31,7 +38,7 @@ def pack_a_bf16x3(Wm: torch.Tensor) -> torch.Tensor:
     order in which a lane owns the values of two consecutive C-layout tiles (csrc/rr_rollout_w.inc, SPLIT)."""
     M, K = Wm.shape
     assert M % 16 == 0 and K % 32 == 0
-    W = Wm.detach().float().cpu()
+    W = Wm.detach().float()                                  # stays on the weights' device: this runs on every repack
     hi = W.to(torch.bfloat16)
     r1 = W - hi.float()
     mid = r1.to(torch.bfloat16)
@@ -261,6 +268,7 @@ class _Arena:
 def pack_policy(sd: dict, env_name: str, device) -> dict:
     """state_dict (reference names) -> ctypes structs for the kernels."""
     ar = _Arena(device)
+    split = mlp_split_enabled()          # the bf16 split copies are only built when the opt-in switch is on at pack time
     nl = 1 + max(int(k.split(".")[3]) for k in sd if k.startswith("encoder.net.layers."))
     blocks, nabdur, nabsimple = [], {}, {}
     nabname = "angle_distance_fusion" if env_name in ("atsp", "rcvrp") else "neural_adaptive_bias"
@@ -292,8 +300,9 @@ def pack_policy(sd: dict, env_name: str, device) -> dict:
             w.wp, w.bp = ar.put(pack_a((Wc @ Wp).float())), ar.put((Wc @ bp + bc).float())
             w.wc, w.bc = None, None
             # FFN weights again as 3-way bf16 splits for the opt-in bf16-pipe FFN (RR_MLP_SPLIT=1)
-            w.w1s = ar.put_raw(pack_a_bf16x3(sd[f"{b}.feed_forward.ops.ffn.W1.weight"]))
-            w.w2s = ar.put_raw(pack_a_bf16x3(sd[f"{b}.feed_forward.ops.ffn.W2.weight"]))
+            if split:
+                w.w1s = ar.put_raw(pack_a_bf16x3(sd[f"{b}.feed_forward.ops.ffn.W1.weight"]))
+                w.w2s = ar.put_raw(pack_a_bf16x3(sd[f"{b}.feed_forward.ops.ffn.W2.weight"]))
             if nab_kind != "gating":          # ablation modules: bias computed by rr_nab_simple, fed as bias_pre
                 w.nab = None
                 q, sw = f"{b}.neural_adaptive_bias", L.NabSimpleW()
@@ -370,8 +379,9 @@ def pack_policy(sd: dict, env_name: str, device) -> dict:
     dw.w1 = ar.put(pack_a(sd["decoder.pointer.ffn.lins.0.weight"].detach().float()))
     dw.w2 = ar.put(pack_a(sd["decoder.pointer.ffn.lins.1.weight"].detach().float()))
     # the same matrices as 3-way bf16 splits for the opt-in bf16-pipe MLP (RR_MLP_SPLIT=1); kept as raw 16-bit words
-    dw.w1s = ar.put_raw(pack_a_bf16x3(sd["decoder.pointer.ffn.lins.0.weight"]))
-    dw.w2s = ar.put_raw(pack_a_bf16x3(sd["decoder.pointer.ffn.lins.1.weight"]))
+    if split:
+        dw.w1s = ar.put_raw(pack_a_bf16x3(sd["decoder.pointer.ffn.lins.0.weight"]))
+        dw.w2s = ar.put_raw(pack_a_bf16x3(sd["decoder.pointer.ffn.lins.1.weight"]))
     dw.b1, dw.b2 = ar.put(sd["decoder.pointer.ffn.lins.0.bias"]), ar.put(sd["decoder.pointer.ffn.lins.1.bias"])
     dw.alpha = float(sd["decoder.alpha"].reshape(-1)[0])
     dw.beta = float(sd["decoder.beta"].reshape(-1)[0]) if "decoder.beta" in sd else 0.0
