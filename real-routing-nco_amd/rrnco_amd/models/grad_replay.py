@@ -400,7 +400,10 @@ def replay_backward(policy, td, actions, num_starts, grad_ll, sample_idx, enc_ch
     with torch.enable_grad():
         for lo in range(0, B, enc_chunk):
             hi = min(B, lo + enc_chunk)
-            row, col = encode(P, locs[lo:hi], D[lo:hi], sample_idx[lo:hi], nl, demand=demand[lo:hi] if (vrp or vtw) else None,
+            # activation checkpointing only where the block is memory-heavy: the duration NAB's [b,N,N,E] tensors (RCVRPTW);
+            # the ATSP / RCVRP blocks keep ~10 GB of activations per 512 instances, which a 288 GB device does not notice
+            row, col = encode(P, locs[lo:hi], D[lo:hi], sample_idx[lo:hi], nl, use_checkpoint=vtw,
+                              demand=demand[lo:hi] if (vrp or vtw) else None,
                               extra=extra[lo:hi] if vtw else None, dur=Dur[lo:hi] if vtw else None)
             row_d, col_d = row.detach().requires_grad_(), col.detach().requires_grad_()
             for a in range(lo, hi, dec_chunk):
