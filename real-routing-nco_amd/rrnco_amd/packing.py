@@ -85,21 +85,20 @@ def fold_nab_pwl(sd, p: str, alpha: torch.Tensor) -> torch.Tensor:
         nz = a != 0
         t = np.sort(-b[nz] / a[nz])
         M = len(t)
-
-        def f(x, c, k0):
-            return float(np.sum(c * np.maximum(a * x + b, 0.0)) + k0)
+        # all M + 1 segments at once (this runs after every optimizer step): probe point inside the segment -> active units ->
+        # slope; anchor breakpoint -> function value.  Same float64 sums as a per-segment loop.
         seg = np.zeros((129, 4))
-        for m in range(M + 1):
-            if M == 0:
-                xm, anchor = 0.0, 0.0
-            elif m == 0:
-                xm, anchor = t[0] - 1.0, t[0]
-            elif m == M:
-                xm, anchor = t[M - 1] + 1.0, t[M - 1]
-            else:
-                xm, anchor = 0.5 * (t[m - 1] + t[m]), t[m - 1]
-            act = (a * xm + b) > 0
-            seg[m] = (np.sum((co * a)[act]), f(anchor, co, ko), np.sum((cg * a)[act]), f(anchor, cg, kg))
+        if M == 0:
+            xm, anchor = np.zeros(1), np.zeros(1)
+        else:
+            xm = np.concatenate(([t[0] - 1.0], 0.5 * (t[:-1] + t[1:]), [t[M - 1] + 1.0]))
+            anchor = np.concatenate(([t[0]], t))                                   # segment m > 0 is anchored at t[m-1]
+        act = (a[None, :] * xm[:, None] + b[None, :]) > 0                          # [M+1, 128]
+        h = np.maximum(a[None, :] * anchor[:, None] + b[None, :], 0.0)
+        seg[:M + 1, 0] = (act * (co * a)[None, :]).sum(1)
+        seg[:M + 1, 1] = (h * co[None, :]).sum(1) + ko
+        seg[:M + 1, 2] = (act * (cg * a)[None, :]).sum(1)
+        seg[:M + 1, 3] = (h * cg[None, :]).sum(1) + kg
         seg[M + 1:] = seg[M]
         tt = np.full(128, np.inf)
         tt[:M] = t
