@@ -367,7 +367,7 @@ def decode_log_likelihood_rcvrptw(P, row_emb, col_emb, D, Dur, demand_l, tw, ser
     return logp.sum(-1)
 
 
-def replay_backward(policy, td, actions, num_starts, grad_ll, sample_idx, enc_chunk=512, dec_chunk=64):
+def replay_backward(policy, td, actions, num_starts, grad_ll, sample_idx, enc_chunk=512, dec_chunk=None):
     """Accumulate d loss / d theta into policy parameters' .grad, given d loss / d log-likelihood.
 
     td: the reset state the rollout started from (`locs`, normalised `distance_matrix`); actions [S*B, N] and grad_ll [S*B]
@@ -376,6 +376,8 @@ def replay_backward(policy, td, actions, num_starts, grad_ll, sample_idx, enc_ch
     if policy.env_name not in ("atsp", "rcvrp", "rcvrptw"):
         raise NotImplementedError(f"gradient replay for env '{policy.env_name}'")
     vrp, vtw = policy.env_name == "rcvrp", policy.env_name == "rcvrptw"
+    if dec_chunk is None:      # instances per teacher-forced decoder evaluation: measured optimum (tools/bench_train.py --dec-chunk);
+        dec_chunk = 32 if vtw else 256      # RCVRPTW routes are ~1.8 N steps long and its masked attention scales worse
     P = dict(policy.named_parameters())
     nl = 1 + max(int(n.split(".")[3]) for n in P if n.startswith("encoder.net.layers."))
     D, locs = td["distance_matrix"].float(), td["locs"].float()

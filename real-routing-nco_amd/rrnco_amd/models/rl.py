@@ -47,7 +47,7 @@ class RRNet:
             if "multistart" not in getattr(self.policy, attr):
                 setattr(self.policy, attr, "multistart_" + getattr(self.policy, attr))
 
-    def training_step(self, batch, optimizer=None, world: int = 1, enc_chunk: int = 512, dec_chunk: int = 64, **policy_kw) -> dict:
+    def training_step(self, batch, optimizer=None, world: int = 1, enc_chunk: int = 512, dec_chunk: int = None, **policy_kw) -> dict:
         """One REINFORCE step on this rank's shard of instances (rl.py:96-128 + Lightning's DDP mean-reduction):
         sampling rollout, reward, shared-baseline loss and d loss / d ll on the HIP kernels; parameter gradients by the
         teacher-forced replay; one flat all-reduce (mean over ranks); optimizer step.  Returns the shared_step dict plus

@@ -17,7 +17,7 @@ ap.add_argument("--problem", default="atsp", choices=["atsp", "rcvrp", "rcvrptw"
 ap.add_argument("--batch", type=int, default=512)
 ap.add_argument("--steps", type=int, default=2)
 ap.add_argument("--enc-chunk", type=int, default=512)
-ap.add_argument("--dec-chunk", type=int, default=64)
+ap.add_argument("--dec-chunk", type=int, default=None)
 args = ap.parse_args()
 world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
 backend = os.environ.get("RR_DIST_BACKEND", "nccl")      # gloo: ranks may share a GPU (single-GPU boxes)
