@@ -200,6 +200,21 @@ int rr_matnet_layer(const MatNetSideW* row_side, const MatNetSideW* col_side, co
 int rr_matnet_init(const int64_t* rand_idx, const float* demand, const float* rowv, const float* colv, const float* slot_t,
                    float* row, float* col, int Bp, int N, int E, hipStream_t stream);
 
+/* MatNet baseline decoder (rrnco/baselines/MatNet/decoder.py = rl4co AttentionModelDecoder + PointerAttention, 256 wide / 16
+ * heads, no graph context): rr_matnet_linear = y[b] = x[b] W^T per instance (cache K | V | L = col_emb W_node^T [Bp][N][3E];
+ * context tables ctxA / ctxB = row_emb W_ctx[:, :E]^T / W_ctx[:, E:]^T), w_packed = packing.pack_a(W);
+ * rr_matnet_dec_step = one decoder.forward for all R = S * Bp rollouts (r = s * Bp + b): logits [R][N], before process_logits;
+ * first == NULL: the placeholder context q0 = W_ctx W_placeholder (nothing visited yet).
+ * rr_select_matnet = the baseline's own process_logits (MatNet/decoding.py:316-372: shift by the row maximum, clamp to
+ * [-50, -1e-4], log-softmax) + greedy / sampling / evaluate selection; arguments as rr_select. */
+int rr_matnet_linear(const void* w_packed, const float* x, float* y, int Bp, int N, int K, int Nout, hipStream_t stream);
+int rr_matnet_dec_step(const void* wo_packed, const float* kvl, const float* ctxA, const float* ctxB, const float* q0,
+                       const int64_t* first, const int64_t* cur, const uint8_t* mask, float* logits,
+                       int Bp, int N, int S, int E, int heads, hipStream_t stream);
+int rr_select_matnet(const float* logits, const uint8_t* mask, const int64_t* action_in, int64_t* action_out,
+                     float* logp_out, float* logp_all, int R, int N, float tanh_clipping, float temperature,
+                     int mode, uint64_t seed, uint32_t step, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

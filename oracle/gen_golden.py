@@ -346,6 +346,39 @@ def gen_matnet(tag, env_name, B, N, seed, layers, embed_dim=256, heads=16):
     print(f"wrote {path}  ({os.path.getsize(path)/1e3:.0f} kB) |row|={float(row.abs().mean()):.4f} |col|={float(col.abs().mean()):.4f}")
 
 
+def gen_matnet_policy(tag, B, N, S, seed, layers, embed_dim=256, heads=16):
+    """MatNetPolicy.forward of the reference (rrnco/baselines/MatNet/policy.py, decoder.py, decoding.py — in-tree code) on ATSP;
+    rl4co's AttentionModelDecoder / PointerAttention base classes are the recalled stand-ins of oracle/ref_shim.py."""
+    from rrnco.baselines.MatNet.policy import MatNetPolicy
+    from rrnco.envs.atsp.env import ATSPEnv
+
+    pol = MatNetPolicy(env_name="atsp", embed_dim=embed_dim, num_heads=heads, num_encoder_layers=layers, normalization="instance",
+                       use_graph_context=False, tanh_clipping=10.0).eval()
+    tmpl = {k: tuple(v.shape) for k, v in pol.state_dict().items()}
+    assert tmpl == restate.matnet_policy_template(embed_dim, heads, layers, 512, "atsp"), \
+        set(tmpl) ^ set(restate.matnet_policy_template(embed_dim, heads, layers, 512, "atsp"))
+    w = restate.make_weights(tmpl, seed)
+    pol.load_state_dict(w, strict=True)
+    inst = restate.atsp_synthetic(B, N, seed)
+    st0 = restate.atsp_reset(inst)
+    env = ATSPEnv(generator=_Gen(N), check_solution=True)
+    td = env.reset(TensorDict({k: v.clone() for k, v in inst.items()}, batch_size=[B]))
+    torch.manual_seed(seed)
+    rand_idx = torch.rand(B, N).argsort(dim=1)
+    torch.manual_seed(seed)
+    with torch.inference_mode():
+        out = pol(td.clone(), env, phase="val", decode_type="multistart_greedy", num_starts=S, return_actions=True)
+        mine = restate.matnet_policy_atsp(dict(pol.state_dict()), st0, rand_idx, S, layers, heads, embed_dim)
+    assert torch.equal(mine["actions"], out["actions"])
+    assert torch.allclose(mine["reward"], out["reward"], atol=1e-6) and torch.allclose(mine["log_likelihood"], out["log_likelihood"], atol=1e-4)
+    fx = {"B": B, "N": N, "S": S, "seed": seed, "layers": layers, "embed_dim": embed_dim, "heads": heads,
+          "locs": inst["locs"], "distance_matrix": inst["distance_matrix"], "rand_idx": rand_idx, "actions": out["actions"],
+          "reward": out["reward"], "log_likelihood": out["log_likelihood"]}
+    path = os.path.join(GOLD, tag + ".npz")
+    np.savez_compressed(path, **_np(fx))
+    print(f"wrote {path}  ({os.path.getsize(path)/1e3:.0f} kB) reward[:3]={out['reward'][:3].tolist()}")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     which = sys.argv[1:] or ["atsp"]
@@ -383,3 +416,7 @@ if __name__ == "__main__":
         gen_matnet("matnet_rcvrp_n20_b4", "rcvrp", B=4, N=20, seed=82, layers=5)
         gen_matnet("matnet_atsp_n100_b2", "atsp", B=2, N=100, seed=83, layers=2)
         gen_matnet("matnet_rcvrp_n100_b2", "rcvrp", B=2, N=100, seed=84, layers=2)
+    if "matnet_policy" in which:     # the whole MatNet baseline policy on ATSP (encoder + AM decoder + in-tree decoding loop)
+        gen_matnet_policy("matnet_policy_atsp_n20_b4", B=4, N=20, S=20, seed=91, layers=3)
+        gen_matnet_policy("matnet_policy_atsp_n50_b2", B=2, N=50, S=50, seed=92, layers=2)
+

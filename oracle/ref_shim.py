@@ -414,6 +414,67 @@ class _TransformerFFNProxy:
         return TransformerFFN(*a, **k)
 
 
+class PointerAttention(nn.Module):
+    """[recalled] rl4co.models.nn.attention.PointerAttention (0.6.0).  The reference's own RRNet_PointerAttention
+    (rrnco/models/decoder.py:235-329) is this class with the `project_out` step replaced by a residual MLP (the original line
+    is still there, commented out, :295): heads = masked MHA without projections, glimpse = project_out(heads),
+    logits = glimpse . logit_key^T / sqrt(E)."""
+
+    def __init__(self, embed_dim, num_heads, mask_inner=True, out_bias=False, check_nan=True, sdpa_fn=None, **kwargs):
+        super().__init__()
+        self.num_heads, self.mask_inner, self.check_nan = num_heads, mask_inner, check_nan
+        self.project_out = nn.Linear(embed_dim, embed_dim, bias=out_bias)
+
+    def _make_heads(self, v):                      # "... g (h s) -> ... h g s"
+        return v.unflatten(-1, (self.num_heads, -1)).transpose(-2, -3)
+
+    def forward(self, query, key, value, logit_key, attn_mask=None):
+        q, k, v = self._make_heads(query), self._make_heads(key), self._make_heads(value)
+        m = None
+        if self.mask_inner:
+            m = attn_mask.unsqueeze(1) if attn_mask.ndim == 3 else attn_mask.unsqueeze(1).unsqueeze(2)
+        heads = torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=m)
+        heads = heads.transpose(-2, -3).flatten(-2)                                   # "... h n g -> ... n (h g)"
+        glimpse = self.project_out(heads)
+        logits = (torch.bmm(glimpse, logit_key.squeeze(-2).transpose(-2, -1)) / (glimpse.size(-1) ** 0.5)).squeeze(-2)
+        if self.check_nan:
+            assert not torch.isnan(logits).any(), "Logits contain NaNs"
+        return logits
+
+
+class AttentionModelDecoder(AutoregressiveDecoder):
+    """[recalled] rl4co.models.zoo.am.decoder.AttentionModelDecoder (0.6.0): forward / _compute_q / _compute_kvl /
+    pre_decoder_hook.  The reference's RRNetDecoder (rrnco/models/decoder.py:123-212) is a copy of these methods plus the
+    inductive-bias lines (:183-198); this is that code without them.  MatNetDecoder (in-tree) supplies __init__ and
+    _precompute_cache."""
+
+    def _compute_q(self, cached, td):
+        graph_context_cache = cached.graph_context
+        if td.dim() == 2 and isinstance(graph_context_cache, torch.Tensor):
+            graph_context_cache = graph_context_cache.unsqueeze(1)
+        glimpse_q = self.context_embedding(cached.node_embeddings, td) + graph_context_cache
+        return glimpse_q.unsqueeze(1) if glimpse_q.ndim == 2 else glimpse_q
+
+    def _compute_kvl(self, cached, td):
+        dk, dv, dl = self.dynamic_embedding(td)
+        return cached.glimpse_key + dk, cached.glimpse_val + dv, cached.logit_key + dl
+
+    def forward(self, td, cached, num_starts=0):
+        if num_starts > 1:
+            td = unbatchify(td, num_starts)
+        glimpse_q = self._compute_q(cached, td)
+        glimpse_k, glimpse_v, logit_k = self._compute_kvl(cached, td)
+        mask = td["action_mask"]
+        logits = self.pointer(glimpse_q, glimpse_k, glimpse_v, logit_k, mask)
+        if num_starts > 1:                                                            # "b s l -> (s b) l"
+            logits = logits.transpose(0, 1).reshape(-1, logits.shape[-1])
+            mask = mask.transpose(0, 1).reshape(-1, mask.shape[-1])
+        return logits, mask
+
+    def pre_decoder_hook(self, td, env, embeddings, num_starts=0):
+        return td, env, self._precompute_cache(embeddings, num_starts=num_starts)
+
+
 class _Inert(nn.Module):  # names the MatNet package imports at module level but the encoder path never instantiates
     def __init__(self, *a, **k):
         raise NotImplementedError("inert stand-in")
@@ -470,12 +531,12 @@ def install():
     _mod("rl4co.models.nn.env_embeddings.context", TSPContext=TSPContext, VRPContext=VRPContext,
          VRPTWContext=VRPTWContext, EnvContext=EnvContext)
     _mod("rl4co.models.nn.env_embeddings.dynamic", StaticEmbedding=StaticEmbedding)
-    _mod("rl4co.models.nn.attention", MultiHeadCrossAttention=MultiHeadCrossAttention, PointerAttention=_Inert, PointerAttnMoE=_Inert)
+    _mod("rl4co.models.nn.attention", MultiHeadCrossAttention=MultiHeadCrossAttention, PointerAttention=PointerAttention, PointerAttnMoE=_Inert)
     _mod("rl4co.models.nn.ops", TransformerFFN=_TransformerFFNProxy)
     sys.modules["rl4co.models.common.constructive.autoregressive"].AutoregressivePolicy = AutoregressivePolicy
     _mod("rl4co.models.zoo")
     _mod("rl4co.models.zoo.am")
-    _mod("rl4co.models.zoo.am.decoder", AttentionModelDecoder=_Inert)
+    _mod("rl4co.models.zoo.am.decoder", AttentionModelDecoder=AttentionModelDecoder)
     _mod("rl4co.models.zoo.pomo", POMO=_Inert)
     _mod("rl4co.data.transforms", StateAugmentation=_Inert)
     _mod("rl4co.models.rl")

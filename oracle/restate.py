@@ -1145,3 +1145,94 @@ def matnet_encoder(w: W, td: dict, rand_idx: Tensor, layers: int, heads: int, en
         if trace is not None and l == 0:
             trace["row1"], trace["col1"] = row, col
     return row, col
+
+
+def matnet_policy_template(embed_dim: int = 256, heads: int = 16, layers: int = 5, ff: int = 512, env_name: str = "atsp") -> Dict[str, tuple]:
+    """state_dict of MatNetPolicy (rrnco/baselines/MatNet/policy.py:19-92): `encoder.*` + MatNetDecoder (decoder.py:24-87)."""
+    E = embed_dim
+    t = {"encoder." + k: v for k, v in matnet_weight_template(E, heads, layers, ff, env_name).items()}
+    if env_name == "atsp":
+        t["decoder.context_embedding.W_placeholder"] = (2 * E,)
+        t["decoder.context_embedding.project_context.weight"] = (E, 2 * E)
+    else:
+        t["decoder.context_embedding.project_context.weight"] = (E, E + 1)
+    t["decoder.pointer.project_out.weight"] = (E, E)
+    t["decoder.project_node_embeddings.weight"] = (3 * E, E)
+    t["decoder.project_fixed_context.weight"] = (E, E)
+    return t
+
+
+def matnet_pointer(w: W, q: Tensor, k: Tensor, v: Tensor, lk: Tensor, mask: Tensor, num_heads: int) -> Tensor:
+    """rl4co PointerAttention [recalled; the in-tree RRNet_PointerAttention, rrnco/models/decoder.py:281-323, is this with the
+    `project_out` step (still there, commented out, :295) replaced by a residual MLP]."""
+    def heads(t):
+        return t.unflatten(-1, (num_heads, -1)).transpose(-2, -3)
+    am = mask.unsqueeze(1) if mask.ndim == 3 else mask.unsqueeze(1).unsqueeze(2)
+    h = F.scaled_dot_product_attention(heads(q), heads(k), heads(v), attn_mask=am)
+    g = F.linear(h.transpose(-2, -3).flatten(-2), w["decoder.pointer.project_out.weight"])
+    return torch.bmm(g, lk.squeeze(-2).transpose(-2, -1)).squeeze(-2) / math.sqrt(g.size(-1))
+
+
+def matnet_process_logits(logits: Tensor, mask: Tensor, temperature: float = 1.0, tanh_clipping: float = 10.0) -> Tensor:
+    """process_logits of the MatNet baseline's own decoding module (rrnco/baselines/MatNet/decoding.py:316-372).  Unlike
+    rrnco/models/decoding.py it shifts the row by its maximum and clamps to [-50, -1e-4] before the log-softmax (:357-359): every
+    action within 1e-4 of the best one ties with it (argmax then takes the lowest index), and masked actions keep the finite
+    logit -50 instead of -inf."""
+    if tanh_clipping > 0:
+        logits = torch.tanh(logits) * tanh_clipping
+    logits = logits.clone()
+    logits[~mask] = float("-inf")
+    logits = logits.float() / temperature
+    logits = logits - logits.max(dim=-1, keepdim=True).values
+    logits = torch.clamp(logits, min=-50.0, max=-1e-4)
+    return F.log_softmax(logits, dim=-1)
+
+
+def matnet_policy_atsp(w: W, td0: dict, rand_idx: Tensor, num_starts: int, layers: int, heads: int, embed_dim: int = 256,
+                       decode: str = "greedy", actions: Optional[Tensor] = None, trace: Optional[dict] = None) -> dict:
+    """MatNetPolicy.forward (rrnco/baselines/MatNet/policy.py:94-212) for ATSP, use_graph_context=False, multistart greedy /
+    evaluate: MatNetEncoder, MatNetDecoder._precompute_cache (decoder.py:89-113: glimpse key / value / logit key from the
+    COLUMN embeddings, step context from the ROW embeddings), rl4co AttentionModelDecoder.forward [recalled; in-tree copy with
+    an inductive bias: rrnco/models/decoder.py:151-206], the in-tree DecodingStrategy (MatNet/decoding.py), ATSPEnv."""
+    we = {k[len("encoder."):]: v for k, v in w.items() if k.startswith("encoder.")}
+    row, col = matnet_encoder(we, td0, rand_idx, layers, heads, "atsp", embed_dim)
+    if trace is not None:
+        trace["row_emb"], trace["col_emb"] = row, col
+    B, N = td0["action_mask"].shape
+    S = num_starts if num_starts > 1 else 0
+    gk, gv, lk = F.linear(col, w["decoder.project_node_embeddings.weight"]).chunk(3, dim=-1)
+    acts, lps = [], []
+    if S >= 1:
+        a0 = torch.arange(S).repeat_interleave(B) % N
+        td = batchify_state({k: v for k, v in td0.items() if k not in ("locs",)}, S)
+        td["action"] = a0
+        td = atsp_step(td)
+        lps.append(torch.zeros_like(a0, dtype=torch.float32)); acts.append(a0)
+    else:
+        td = dict(td0)
+    k = 0
+    while not td["done"].all():
+        if S > 1:
+            tv = {kk: unbatchify(td[kk], S) for kk in ("first_node", "current_node", "i", "action_mask")}
+            tv["_two_d"] = True
+        else:
+            tv = {kk: td[kk] for kk in ("first_node", "current_node", "i", "action_mask")}
+            tv["_two_d"] = False
+        q = atsp_context(w, row, tv)                              # TSPContext on the row embeddings (+ graph context 0)
+        q = q.unsqueeze(1) if q.ndim == 2 else q
+        mask = tv["action_mask"]
+        logits = matnet_pointer(w, q, gk, gv, lk, mask, heads)
+        if S > 1:
+            logits = logits.permute(1, 0, 2).reshape(-1, logits.shape[-1])
+            mask = mask.permute(1, 0, 2).reshape(-1, mask.shape[-1])
+        logp = matnet_process_logits(logits, mask)
+        sel = logp.argmax(dim=-1) if decode == "greedy" else actions[:, k]
+        if trace is not None:
+            trace.setdefault("logits", []).append(logits); trace.setdefault("logp", []).append(logp)
+        lps.append(gather_by_index(logp, sel, dim=1)); acts.append(sel)
+        td["action"] = sel
+        td = atsp_step(td)
+        k += 1
+    logprobs, actions_out = torch.stack(lps, 1), torch.stack(acts, 1)
+    real, nd = atsp_reward(dict(td), actions_out, True)
+    return {"reward": real, "normalized_reward": nd, "log_likelihood": logprobs.sum(1), "actions": actions_out, "logprobs": logprobs}

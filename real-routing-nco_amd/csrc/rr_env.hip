@@ -584,7 +584,7 @@ __global__ __launch_bounds__(256) void k_select16(const float* __restrict__ logi
                                                   const int64_t* __restrict__ action_in, int64_t* __restrict__ action_out,
                                                   float* __restrict__ logp_out, float* __restrict__ logp_all,
                                                   int R, int N, float tanh_clip, float temperature, int mode,
-                                                  uint64_t seed, uint32_t step) {
+                                                  uint64_t seed, uint32_t step, int shift_clamp) {
   const int lane = threadIdx.x & 63, p = lane & 15, rw = lane >> 4;
   const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (4 * SEL16_PASSES) + rw;
   float raw[SEL16_PASSES][8];
@@ -634,6 +634,16 @@ __global__ __launch_bounds__(256) void k_select16(const float* __restrict__ logi
       m = fmaxf(m, x[e]);
     }
     m = rr_row16_max(m);
+    if (shift_clamp) {     // MatNet's process_logits (rrnco/baselines/MatNet/decoding.py:357-359): x - max, clamped to [-50, -1e-4]:
+      const float m0 = m;  // actions within 1e-4 of the best tie with it, masked ones keep the finite logit -50
+      m = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int j = 4 * (p + 16 * (e >> 2)) + (e & 3);
+        if (j < N) { x[e] = fminf(fmaxf(x[e] - m0, -50.0f), -1e-4f); m = fmaxf(m, x[e]); }
+      }
+      m = rr_row16_max(m);
+    }
     float ssum = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -687,13 +697,26 @@ extern "C" int rr_select(const float* logits, const uint8_t* mask, const int64_t
     const bool vec = N % 4 == 0 && (al & 15) == 0 && (reinterpret_cast<uintptr_t>(mask) & 3) == 0;
     const dim3 grid((R + 16 * SEL16_PASSES - 1) / (16 * SEL16_PASSES));
     if (vec) hipLaunchKernelGGL(k_select16<true>, grid, dim3(256), 0, st, logits, mask, action_in, action_out, logp_out, logp_all, R, N,
-                                tanh_clip, temperature, mode, seed, step);
+                                tanh_clip, temperature, mode, seed, step, 0);
     else hipLaunchKernelGGL(k_select16<false>, grid, dim3(256), 0, st, logits, mask, action_in, action_out, logp_out, logp_all, R, N,
-                            tanh_clip, temperature, mode, seed, step);
+                            tanh_clip, temperature, mode, seed, step, 0);
     return rr_check(hipGetLastError());
   }
   hipLaunchKernelGGL(k_select, dim3((R + 4 * SEL_ROWS - 1) / (4 * SEL_ROWS)), dim3(256), 0, st, logits, mask, action_in, action_out, logp_out,
                      logp_all, R, N, tanh_clip, temperature, mode, seed, step, top_k, top_p);
+  return rr_check(hipGetLastError());
+}
+
+// MatNet's own process_logits + selection (rrnco/baselines/MatNet/decoding.py:316-372, 219-298): as rr_select without the
+// top-k / top-p filters, with the row shifted by its maximum and clamped to [-50, -1e-4] before the log-softmax.
+extern "C" int rr_select_matnet(const float* logits, const uint8_t* mask, const int64_t* action_in, int64_t* action_out,
+                                float* logp_out, float* logp_all, int R, int N, float tanh_clip, float temperature,
+                                int mode, uint64_t seed, uint32_t step, hipStream_t st) {
+  if (R <= 0 || N <= 0 || N > 128 || temperature <= 0.f || mode < 0 || mode > 2) return RR_EINVAL;
+  if (logits == nullptr || mask == nullptr || action_out == nullptr || logp_out == nullptr || (mode == 2 && action_in == nullptr)) return RR_EINVAL;
+  const dim3 grid((R + 16 * SEL16_PASSES - 1) / (16 * SEL16_PASSES));
+  hipLaunchKernelGGL(k_select16<false>, grid, dim3(256), 0, st, logits, mask, action_in, action_out, logp_out, logp_all, R, N,
+                     tanh_clip, temperature, mode, seed, step, 1);
   return rr_check(hipGetLastError());
 }
 

@@ -300,3 +300,167 @@ extern "C" int rr_matnet_layer(const MatNetSideW* row_side, const MatNetSideW* c
   if (N <= 64) return mn_layer<4>(ws, row_in, col_in, row_out, col_out, D, workspace, Bp, N, E, heads, ff, st);
   return mn_layer<RR_NT>(ws, row_in, col_in, row_out, col_out, D, workspace, Bp, N, E, heads, ff, st);
 }
+
+// ------------------------------------------------------------------------------------------------
+// MatNet baseline decoder (rrnco/baselines/MatNet/decoder.py; rl4co AttentionModelDecoder + PointerAttention at 256 / 16
+// heads): one decoder.forward for every rollout = step context -> masked multi-head glimpse -> project_out -> pointer logits.
+//   rr_matnet_linear    y = x W^T per instance (the cache: K | V | L = col_emb W_node^T; context tables row_emb W_ctx^T)
+//   rr_matnet_dec_step  wave = 16 rollouts of one instance (r = s * Bp + b): q^T gathered from the context tables straight into
+//                       B-operand registers, per head S^T = K_h q_h on MFMA, mask, softmax, heads^T = V_h^T P^T; glimpse^T =
+//                       W_out heads^T and logits^T = L glimpse^T / sqrt(E) chain in registers (C layout = next B operand)
+// The selection (MatNet's own process_logits: shift by the row maximum, clamp to [-50, -1e-4]) is rr_select's job.
+// ------------------------------------------------------------------------------------------------
+extern "C" int rr_matnet_linear(const void* w_packed, const float* x, float* y, int Bp, int N, int K, int Nout, hipStream_t st) {
+  if (w_packed == nullptr || x == nullptr || y == nullptr || Bp <= 0 || N < 1 || N > 16 * RR_NT) return RR_EINVAL;
+  if (K % 256 != 0 || Nout % 256 != 0) return RR_EINVAL;
+  MnLinArgs la;
+  for (int s = 0; s < 2; ++s) { la.wp[s] = static_cast<const float4*>(w_packed); la.bias[s] = nullptr; la.x[s] = x; la.y[s] = y; la.resid[s] = nullptr; la.gamma[s] = la.beta[s] = nullptr; }
+  la.K = K; la.Nout = Nout;
+  const int lds = N * MN_LDX * (int)sizeof(float);
+  const int tpw = Nout % 512 == 0 ? 4 : 2;
+  const dim3 grid(Bp, Nout / (MN_WAVES * tpw * 16), 1), blk(MN_THREADS);
+#define MN_LIN1(NTV, TPWV)                                                                                            \
+  do {                                                                                                                 \
+    (void)hipFuncSetAttribute((const void*)k_mn_lin<NTV, TPWV, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);        \
+    hipLaunchKernelGGL((k_mn_lin<NTV, TPWV, 0>), grid, blk, lds, st, la, N);                                           \
+  } while (0)
+  if (N <= 32) { if (tpw == 4) MN_LIN1(2, 4); else MN_LIN1(2, 2); }
+  else if (N <= 64) { if (tpw == 4) MN_LIN1(4, 4); else MN_LIN1(4, 2); }
+  else { if (tpw == 4) MN_LIN1(RR_NT, 4); else MN_LIN1(RR_NT, 2); }
+#undef MN_LIN1
+  return rr_check(hipGetLastError());
+}
+
+struct MnDecArgs {
+  const float4* wo;            // pointer.project_out.weight, packed A operand [E/16][E/16][64]
+  const float* kvl;            // [Bp][N][3E]: glimpse key | glimpse value | logit key
+  const float *ctxA, *ctxB;    // [Bp][N][E]: W_ctx[:, :E] row_emb (first node), W_ctx[:, E:] row_emb (current node)
+  const float* q0;             // [E] project_context(W_placeholder), used when first == nullptr (no node visited yet)
+  const int64_t *first, *cur;  // [R]
+  const uint8_t* mask;         // [R][N] action mask
+  float* logits;               // [R][N]
+  int Bp, N, S, E, heads;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_mn_dec_step(MnDecArgs a) {
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int N = a.N, E = a.E, S = a.S, Bp = a.Bp;
+  const int TPI = (S + 15) >> 4;
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile >= Bp * TPI) return;
+  const int b = tile / TPI, s = (tile - b * TPI) * 16 + j;
+  const bool valid = s < S;
+  const size_t r = (size_t)(valid ? s : 0) * Bp + b;
+  const float* KVL = a.kvl + (size_t)b * N * 3 * E;
+  // ---- step context: q^T [E x 16 rollouts] in B-operand form (rl4co TSPContext: W_ctx [emb_first; emb_cur])
+  f32x4 q[16];
+  if (a.first != nullptr) {
+    const float* pa = a.ctxA + ((size_t)b * N + (int)a.first[r]) * E + 4 * g;
+    const float* pb = a.ctxB + ((size_t)b * N + (int)a.cur[r]) * E + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const float4 u = rr_ld4(pa + 16 * t), v = rr_ld4(pb + 16 * t);
+      q[t][0] = u.x + v.x; q[t][1] = u.y + v.y; q[t][2] = u.z + v.z; q[t][3] = u.w + v.w;
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { const float4 u = rr_ld4(a.q0 + 16 * t + 4 * g); q[t][0] = u.x; q[t][1] = u.y; q[t][2] = u.z; q[t][3] = u.w; }
+  }
+  const uint8_t* mk = a.mask + r * N;
+  // ---- masked multi-head glimpse, one head at a time; heads^T stays in registers (B operand of project_out)
+  f32x4 H[16];
+#pragma unroll
+  for (int h = 0; h < 16; ++h) {      // unrolled: q[h] / H[h] must be register-indexed
+    f32x4 sc[NT];
+    float mxv = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      int key = kt * 16 + j; key = key < N ? key : N - 1;
+      const float4 kf = rr_ld4(KVL + (size_t)key * 3 * E + 16 * h + 4 * g);
+      f32x4 c = rr_zero4();
+      c = rr_mfma(kf.x, q[h][0], c); c = rr_mfma(kf.y, q[h][1], c); c = rr_mfma(kf.z, q[h][2], c); c = rr_mfma(kf.w, q[h][3], c);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int k2 = kt * 16 + 4 * g + rr;
+        const bool ok = k2 < N && mk[k2 < N ? k2 : 0] != 0;
+        c[rr] = ok ? c[rr] * 0.25f : -INFINITY;
+        mxv = fmaxf(mxv, c[rr]);
+      }
+      sc[kt] = c;
+    }
+    mxv = rr_max_g(mxv);
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) { sc[kt][rr] = rr_exp(sc[kt][rr] - mxv); sum += sc[kt][rr]; }
+    const float inv = 1.0f / rr_sum_g(sum);
+    f32x4 o = rr_zero4();
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        int kv = kt * 16 + 4 * g + m; kv = kv < N ? kv : N - 1;
+        o = rr_mfma(KVL[(size_t)kv * 3 * E + E + 16 * h + j], sc[kt][m], o);
+      }
+    H[h][0] = o[0] * inv; H[h][1] = o[1] * inv; H[h][2] = o[2] * inv; H[h][3] = o[3] * inv;
+  }
+  // ---- glimpse^T = W_out heads^T (project_out, no bias)
+  f32x4 G[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    f32x4 c0 = rr_zero4(), c1 = rr_zero4();
+#pragma unroll
+    for (int kk = 0; kk < 16; kk += 2) {
+      const float4 w0 = a.wo[(size_t)(t * 16 + kk) * 64 + lane], w1 = a.wo[(size_t)(t * 16 + kk + 1) * 64 + lane];
+      c0 = rr_mfma(w0.x, H[kk][0], c0); c1 = rr_mfma(w1.x, H[kk + 1][0], c1);
+      c0 = rr_mfma(w0.y, H[kk][1], c0); c1 = rr_mfma(w1.y, H[kk + 1][1], c1);
+      c0 = rr_mfma(w0.z, H[kk][2], c0); c1 = rr_mfma(w1.z, H[kk + 1][2], c1);
+      c0 = rr_mfma(w0.w, H[kk][3], c0); c1 = rr_mfma(w1.w, H[kk + 1][3], c1);
+    }
+    G[t] = c0 + c1;
+  }
+  // ---- logits^T = L glimpse^T / sqrt(E)
+  const float isq = 1.0f / sqrtf((float)E);
+#pragma unroll 1
+  for (int kt = 0; kt < NT; ++kt) {
+    int key = kt * 16 + j; key = key < N ? key : N - 1;
+    const float* pl = KVL + (size_t)key * 3 * E + 2 * E + 4 * g;
+    f32x4 c0 = rr_zero4(), c1 = rr_zero4();
+#pragma unroll
+    for (int kk = 0; kk < 16; kk += 2) {
+      const float4 l0 = rr_ld4(pl + 16 * kk), l1 = rr_ld4(pl + 16 * (kk + 1));
+      c0 = rr_mfma(l0.x, G[kk][0], c0); c1 = rr_mfma(l1.x, G[kk + 1][0], c1);
+      c0 = rr_mfma(l0.y, G[kk][1], c0); c1 = rr_mfma(l1.y, G[kk + 1][1], c1);
+      c0 = rr_mfma(l0.z, G[kk][2], c0); c1 = rr_mfma(l1.z, G[kk + 1][2], c1);
+      c0 = rr_mfma(l0.w, G[kk][3], c0); c1 = rr_mfma(l1.w, G[kk + 1][3], c1);
+    }
+    if (valid) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int k2 = kt * 16 + 4 * g + rr;
+        if (k2 < N) a.logits[r * N + k2] = (c0[rr] + c1[rr]) * isq;
+      }
+    }
+  }
+}
+
+extern "C" int rr_matnet_dec_step(const void* wo_packed, const float* kvl, const float* ctxA, const float* ctxB, const float* q0,
+                                  const int64_t* first, const int64_t* cur, const uint8_t* mask, float* logits,
+                                  int Bp, int N, int S, int E, int heads, hipStream_t st) {
+  if (!wo_packed || !kvl || !mask || !logits || Bp <= 0 || S < 1 || N < 2 || N > 16 * RR_NT) return RR_EINVAL;
+  if (E != 256 || heads != 16) return RR_EINVAL;                       // registers are sized for the matnet.yaml configuration
+  if (first != nullptr ? (cur == nullptr || ctxA == nullptr || ctxB == nullptr) : q0 == nullptr) return RR_EINVAL;
+  MnDecArgs a;
+  a.wo = static_cast<const float4*>(wo_packed); a.kvl = kvl; a.ctxA = ctxA; a.ctxB = ctxB; a.q0 = q0; a.first = first; a.cur = cur;
+  a.mask = mask; a.logits = logits; a.Bp = Bp; a.N = N; a.S = S; a.E = E; a.heads = heads;
+  const int tiles = Bp * ((S + 15) / 16);
+  const dim3 grid((tiles + 3) / 4), blk(256);
+  if (N <= 32) hipLaunchKernelGGL(k_mn_dec_step<2>, grid, blk, 0, st, a);
+  else if (N <= 64) hipLaunchKernelGGL(k_mn_dec_step<4>, grid, blk, 0, st, a);
+  else hipLaunchKernelGGL(k_mn_dec_step<RR_NT>, grid, blk, 0, st, a);
+  return rr_check(hipGetLastError());
+}
+

@@ -1,4 +1,5 @@
-"""Baselines of the reference that run on the MI355X engine (rrnco/baselines): the MatNet mixed-score attention encoder."""
-from .matnet import MatNetEncoder
+"""Baselines of the reference that run on the MI355X engine (rrnco/baselines): the MatNet baseline (mixed-score attention
+encoder, attention-model decoder, the baseline's own decoding rules)."""
+from .matnet import MatNetDecoder, MatNetEncoder, MatNetPolicy
 
-__all__ = ["MatNetEncoder"]
+__all__ = ["MatNetEncoder", "MatNetDecoder", "MatNetPolicy"]

@@ -191,3 +191,143 @@ class MatNetEncoder(nn.Module):
                                         L.ptr(ws), nbytes, Bp, N, E, self.num_heads, self.ff, L.stream()), "rr_matnet_layer")
             row, col, row2, col2 = row2, col2, row, col
         return (row, col), None
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Decoder and policy: rrnco/baselines/MatNet/decoder.py (rl4co AttentionModelDecoder + PointerAttention) and policy.py
+# ----------------------------------------------------------------------------------------------------------------------
+class _ProjectContext(nn.Module):
+    """rl4co TSPContext: `project_context` Linear(2E, E, bias=False) on [emb_first; emb_cur], `W_placeholder` before the first move."""
+
+    def __init__(self, embed_dim):
+        super().__init__()
+        self.W_placeholder = nn.Parameter(torch.empty(2 * embed_dim).uniform_(-1, 1))
+        self.project_context = nn.Linear(2 * embed_dim, embed_dim, bias=False)
+
+
+class _Pointer(nn.Module):
+    def __init__(self, embed_dim):
+        super().__init__()
+        self.project_out = nn.Linear(embed_dim, embed_dim, bias=False)
+
+
+class MatNetDecoder(nn.Module):
+    """decoder.py:24-113 for ATSP: cache (glimpse key / value / logit key from the COLUMN embeddings, step context from the ROW
+    embeddings, no graph context) by rr_matnet_linear, one forward per decode step by rr_matnet_dec_step."""
+
+    def __init__(self, embed_dim: int = 256, num_heads: int = 16, env_name: str = "atsp", use_graph_context: bool = False, **unused):
+        super().__init__()
+        if env_name != "atsp" or use_graph_context or embed_dim != 256 or num_heads != 16:
+            raise NotImplementedError("MatNetDecoder on HIP: ATSP, embed_dim=256, num_heads=16, use_graph_context=False "
+                                      "(configs/experiment/matnet.yaml)")
+        self.embed_dim, self.num_heads = embed_dim, num_heads
+        self.context_embedding = _ProjectContext(embed_dim)
+        self.pointer = _Pointer(embed_dim)
+        self.project_node_embeddings = nn.Linear(embed_dim, 3 * embed_dim, bias=False)
+        self.project_fixed_context = nn.Linear(embed_dim, embed_dim, bias=False)      # unused without the graph context (as in the reference)
+        self._pack_cache = None
+
+    def packed(self, device):
+        key = (str(device), tuple(p._version for p in self.parameters()), tuple(p.data_ptr() for p in self.parameters()))
+        if self._pack_cache is None or self._pack_cache[0] != key:
+            E = self.embed_dim
+            f = lambda t: pack_a(t.detach().float()).to(device).contiguous()          # noqa: E731
+            Wc = self.context_embedding.project_context.weight
+            q0 = (Wc.detach().double() @ self.context_embedding.W_placeholder.detach().double()).float().to(device).contiguous()
+            self._pack_cache = (key, {"wnode": f(self.project_node_embeddings.weight), "wca": f(Wc[:, :E]), "wcb": f(Wc[:, E:]),
+                                      "wo": f(self.pointer.project_out.weight), "q0": q0})
+        return self._pack_cache[1]
+
+    @torch.no_grad()
+    def pre_decoder_hook(self, td, env, embeddings, num_starts: int = 0):
+        """-> td, env, cache (decoder.py:89-113 `_precompute_cache`)."""
+        row, col = embeddings
+        Bp, N, E = row.shape
+        pk, lib = self.packed(row.device), L.lib()
+        kvl = torch.empty(Bp, N, 3 * E, device=row.device)
+        ctxa, ctxb = torch.empty(Bp, N, E, device=row.device), torch.empty(Bp, N, E, device=row.device)
+        row, col = row.contiguous(), col.contiguous()
+        L.check(lib.rr_matnet_linear(L.ptr(pk["wnode"]), L.ptr(col), L.ptr(kvl), Bp, N, E, 3 * E, L.stream()), "rr_matnet_linear")
+        L.check(lib.rr_matnet_linear(L.ptr(pk["wca"]), L.ptr(row), L.ptr(ctxa), Bp, N, E, E, L.stream()), "rr_matnet_linear")
+        L.check(lib.rr_matnet_linear(L.ptr(pk["wcb"]), L.ptr(row), L.ptr(ctxb), Bp, N, E, E, L.stream()), "rr_matnet_linear")
+        return td, env, {"kvl": kvl, "ctxA": ctxa, "ctxB": ctxb, "Bp": Bp, "N": N}
+
+    @torch.no_grad()
+    def forward(self, td, cached, num_starts: int = 0):
+        """-> logits [R, N], mask [R, N] (AttentionModelDecoder.forward; r = s * B + b)."""
+        mask = td["action_mask"].contiguous()
+        R, N = mask.shape
+        Bp = cached["Bp"]
+        S = R // Bp
+        pk = self.packed(mask.device)
+        logits = torch.empty(R, N, device=mask.device)
+        placeholder = td.meta.get("i", 1) == 0                    # nothing visited yet (plain greedy / sampling, first step)
+        first = None if placeholder else td["first_node"].reshape(-1).contiguous()
+        cur = None if placeholder else td["current_node"].reshape(-1).contiguous()
+        L.check(L.lib().rr_matnet_dec_step(L.ptr(pk["wo"]), L.ptr(cached["kvl"]), L.ptr(cached["ctxA"]), L.ptr(cached["ctxB"]),
+                                           L.ptr(pk["q0"]), L.ptr(first), L.ptr(cur), L.ptr(mask.view(torch.uint8)), L.ptr(logits),
+                                           Bp, N, S, self.embed_dim, self.num_heads, L.stream()), "rr_matnet_dec_step")
+        return logits, mask
+
+
+class MatNetPolicy(nn.Module):
+    """rrnco.baselines.MatNet.policy.MatNetPolicy (policy.py:19-212) for ATSP: MatNetEncoder -> MatNetDecoder, decoded with the
+    baseline's own process_logits (MatNet/decoding.py: row shifted by its maximum and clamped to [-50, -1e-4], rr_select_matnet)
+    in the reference's step loop (decoder.forward -> strategy.step -> env.step)."""
+
+    def __init__(self, env_name: str = "atsp", embed_dim: int = 256, num_encoder_layers: int = 5, num_heads: int = 16,
+                 normalization: str = "instance", use_graph_context: bool = False, temperature: float = 1.0,
+                 tanh_clipping: float = 10.0, mask_logits: bool = True, bias: bool = False, init_embedding_kwargs: dict = {},
+                 train_decode_type: str = "sampling", val_decode_type: str = "greedy", test_decode_type: str = "greedy", **unused):
+        super().__init__()
+        self.env_name = getattr(env_name, "name", env_name)
+        self.encoder = MatNetEncoder(embed_dim=embed_dim, num_heads=num_heads, num_layers=num_encoder_layers, normalization=normalization,
+                                     env_name=self.env_name, init_embedding_kwargs=init_embedding_kwargs, bias=bias)
+        self.decoder = MatNetDecoder(embed_dim=embed_dim, num_heads=num_heads, env_name=self.env_name, use_graph_context=use_graph_context)
+        self.temperature, self.tanh_clipping, self.mask_logits = temperature, tanh_clipping, mask_logits
+        self.train_decode_type, self.val_decode_type, self.test_decode_type = train_decode_type, val_decode_type, test_decode_type
+
+    @torch.no_grad()
+    def forward(self, td, env=None, phase: str = "train", calc_reward: bool = True, return_actions: bool = True,
+                return_hidden: bool = False, return_sum_log_likelihood: bool = True, actions=None, max_steps: int = 1_000_000,
+                rand_idx=None, **decoding_kwargs) -> dict:
+        from ..models.decoding import get_decoding_strategy
+        from ..ops import get_log_likelihood
+        if env is None or isinstance(env, str):
+            raise ValueError("pass an instantiated rrnco_amd env")
+        hidden, _ = self.encoder(td, rand_idx=rand_idx)
+        decode_type = decoding_kwargs.pop("decode_type", None)
+        if actions is not None:
+            decode_type = "evaluate"
+        elif decode_type is None:
+            decode_type = getattr(self, f"{phase}_decode_type")
+        strategy = get_decoding_strategy(decode_type, temperature=decoding_kwargs.pop("temperature", self.temperature),
+                                         tanh_clipping=decoding_kwargs.pop("tanh_clipping", self.tanh_clipping),
+                                         mask_logits=decoding_kwargs.pop("mask_logits", self.mask_logits), **decoding_kwargs)
+        if strategy.top_k or strategy.top_p or getattr(strategy, "is_beam_search", False) or strategy.store_all_logp:
+            raise NotImplementedError("MatNetPolicy on HIP: greedy / sampling / evaluate without top-k / top-p filters")
+        strategy.matnet_clamp = True                              # MatNet/decoding.py:357-359 inside rr_select_matnet
+        td, env, num_starts = strategy.pre_decoder_hook(td, env)
+        td, env, cache = self.decoder.pre_decoder_hook(td, env, hidden, num_starts)
+        step = 0
+        while not td["done"].all():
+            logits, mask = self.decoder(td, cache, num_starts)
+            td = strategy.step(logits, mask, td, action=actions[..., step] if actions is not None else None)
+            td = env.step(td)["next"]
+            step += 1
+            if step > max_steps:
+                break
+        logprobs, actions_out, td, env = strategy.post_decoder_hook(td, env)
+        out = {}
+        if calc_reward:
+            if env.normalize:
+                real, normd = env.get_reward(td, actions_out)
+                out["reward"], out["normalized_reward"] = real, normd
+            else:
+                out["reward"] = env.get_reward(td, actions_out)
+        out["log_likelihood"] = get_log_likelihood(logprobs, actions_out, td.get("mask", None), return_sum_log_likelihood)
+        if return_actions:
+            out["actions"] = actions_out
+        if return_hidden:
+            out["hidden"] = hidden
+        return out

@@ -80,9 +80,14 @@ class DecodingStrategy:
         lp_all = torch.empty(R, N, dtype=torch.float32, device=logits.device) if self.store_all_logp else None
         mode = {"greedy": 0, "sampling": 1, "evaluate": 2}[self.mode]
         act_in = action.contiguous() if action is not None else None
-        L.check(L.lib().rr_select(L.ptr(logits), L.ptr(m), L.ptr(act_in), L.ptr(sel), L.ptr(lp), L.ptr(lp_all), R, N,
-                                  float(self.tanh_clipping), float(self.temperature), mode, int(self.seed),
-                                  len(self.actions), self.top_k, self.top_p, L.stream()), "rr_select")
+        if getattr(self, "matnet_clamp", False):       # the MatNet baseline's own process_logits (MatNet/decoding.py:316-372)
+            L.check(L.lib().rr_select_matnet(L.ptr(logits), L.ptr(m), L.ptr(act_in), L.ptr(sel), L.ptr(lp), L.ptr(lp_all), R, N,
+                                             float(self.tanh_clipping), float(self.temperature), mode, int(self.seed),
+                                             len(self.actions), L.stream()), "rr_select_matnet")
+        else:
+            L.check(L.lib().rr_select(L.ptr(logits), L.ptr(m), L.ptr(act_in), L.ptr(sel), L.ptr(lp), L.ptr(lp_all), R, N,
+                                      float(self.tanh_clipping), float(self.temperature), mode, int(self.seed),
+                                      len(self.actions), self.top_k, self.top_p, L.stream()), "rr_select")
         td.set("action", sel)
         self.actions.append(sel)
         self.logprobs.append(lp_all if self.store_all_logp else lp)

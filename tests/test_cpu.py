@@ -500,3 +500,20 @@ def test_state_augmentation_matches_reference_functions():
     assert float(twice["locs"].min()) == 0.0 and float(twice["locs"].max()) == 1.0
     with pytest.raises(ValueError):
         StateAugmentation(augment_fn="nope")
+
+
+@pytest.mark.parametrize("name", ["matnet_policy_atsp_n20_b4", "matnet_policy_atsp_n50_b2"])
+def test_oracle_matnet_policy_reproduces_reference_golden(name):
+    """The whole MatNet baseline policy on ATSP (oracle/restate.matnet_policy_atsp) against the reference's MatNetPolicy.forward
+    (in-tree policy / decoder / decoding code over the recalled rl4co AttentionModelDecoder base): tours bit-exact, including the
+    ties its process_logits creates by clamping to [-50, -1e-4]."""
+    fx = H.load_fixture(name)
+    w = restate.make_weights(restate.matnet_policy_template(fx["embed_dim"], fx["heads"], fx["layers"], 512, "atsp"), fx["seed"])
+    st0 = restate.atsp_reset({"locs": fx["locs"], "distance_matrix": fx["distance_matrix"]})
+    with torch.inference_mode():
+        out = restate.matnet_policy_atsp(w, st0, fx["rand_idx"], fx["S"], fx["layers"], fx["heads"], fx["embed_dim"])
+    assert torch.equal(out["actions"], fx["actions"])
+    assert torch.allclose(out["reward"], fx["reward"], atol=1e-5) and torch.allclose(out["log_likelihood"], fx["log_likelihood"], atol=1e-3)
+    from rrnco_amd.baselines import MatNetPolicy
+    pol = MatNetPolicy(env_name="atsp", num_encoder_layers=fx["layers"])
+    assert {k: tuple(v.shape) for k, v in pol.state_dict().items()} == restate.matnet_policy_template(256, 16, fx["layers"], 512, "atsp")
