@@ -208,7 +208,8 @@ int rr_matnet_init(const int64_t* rand_idx, const float* demand, const float* ro
  * rr_select_matnet = the baseline's own process_logits (MatNet/decoding.py:316-372: shift by the row maximum, clamp to
  * [-50, -1e-4], log-softmax) + greedy / sampling / evaluate selection; arguments as rr_select. */
 int rr_matnet_linear(const void* w_packed, const float* x, float* y, int Bp, int N, int K, int Nout, hipStream_t stream);
-int rr_matnet_dec_step(const void* wo_packed, const float* kvl, const float* ctxA, const float* ctxB, const float* q0,
+int rr_matnet_dec_step(const void* wo_packed, const float* kvl, const float* vt /* [Bp][E][112] = V^T, zero-padded */,
+                       const float* ctxA, const float* ctxB, const float* q0,
                        const int64_t* first, const int64_t* cur, const uint8_t* mask, float* logits,
                        int Bp, int N, int S, int E, int heads, hipStream_t stream);
 int rr_select_matnet(const float* logits, const uint8_t* mask, const int64_t* action_in, int64_t* action_out,

@@ -334,6 +334,7 @@ extern "C" int rr_matnet_linear(const void* w_packed, const float* x, float* y, 
 struct MnDecArgs {
   const float4* wo;            // pointer.project_out.weight, packed A operand [E/16][E/16][64]
   const float* kvl;            // [Bp][N][3E]: glimpse key | glimpse value | logit key
+  const float* vt;             // [Bp][E][112]: the glimpse values transposed (keys along the row, zero-padded)
   const float *ctxA, *ctxB;    // [Bp][N][E]: W_ctx[:, :E] row_emb (first node), W_ctx[:, E:] row_emb (current node)
   const float* q0;             // [E] project_context(W_placeholder), used when first == nullptr (no node visited yet)
   const int64_t *first, *cur;  // [R]
@@ -398,13 +399,12 @@ __global__ __launch_bounds__(256) void k_mn_dec_step(MnDecArgs a) {
       for (int rr = 0; rr < 4; ++rr) { sc[kt][rr] = rr_exp(sc[kt][rr] - mxv); sum += sc[kt][rr]; }
     const float inv = 1.0f / rr_sum_g(sum);
     f32x4 o = rr_zero4();
+    const float* pv = a.vt + ((size_t)b * E + 16 * h + j) * 112 + 4 * g;       // V^T [E][112]: four keys per 16-byte load
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        int kv = kt * 16 + 4 * g + m; kv = kv < N ? kv : N - 1;
-        o = rr_mfma(KVL[(size_t)kv * 3 * E + E + 16 * h + j], sc[kt][m], o);
-      }
+    for (int kt = 0; kt < NT; ++kt) {
+      const float4 vv = rr_ld4(pv + 16 * kt);                                     // keys >= N carry zero probability
+      o = rr_mfma(vv.x, sc[kt][0], o); o = rr_mfma(vv.y, sc[kt][1], o); o = rr_mfma(vv.z, sc[kt][2], o); o = rr_mfma(vv.w, sc[kt][3], o);
+    }
     H[h][0] = o[0] * inv; H[h][1] = o[1] * inv; H[h][2] = o[2] * inv; H[h][3] = o[3] * inv;
   }
   // ---- glimpse^T = W_out heads^T (project_out, no bias)
@@ -447,14 +447,14 @@ __global__ __launch_bounds__(256) void k_mn_dec_step(MnDecArgs a) {
   }
 }
 
-extern "C" int rr_matnet_dec_step(const void* wo_packed, const float* kvl, const float* ctxA, const float* ctxB, const float* q0,
+extern "C" int rr_matnet_dec_step(const void* wo_packed, const float* kvl, const float* vt, const float* ctxA, const float* ctxB, const float* q0,
                                   const int64_t* first, const int64_t* cur, const uint8_t* mask, float* logits,
                                   int Bp, int N, int S, int E, int heads, hipStream_t st) {
-  if (!wo_packed || !kvl || !mask || !logits || Bp <= 0 || S < 1 || N < 2 || N > 16 * RR_NT) return RR_EINVAL;
+  if (!wo_packed || !kvl || !vt || !mask || !logits || Bp <= 0 || S < 1 || N < 2 || N > 16 * RR_NT) return RR_EINVAL;
   if (E != 256 || heads != 16) return RR_EINVAL;                       // registers are sized for the matnet.yaml configuration
   if (first != nullptr ? (cur == nullptr || ctxA == nullptr || ctxB == nullptr) : q0 == nullptr) return RR_EINVAL;
   MnDecArgs a;
-  a.wo = static_cast<const float4*>(wo_packed); a.kvl = kvl; a.ctxA = ctxA; a.ctxB = ctxB; a.q0 = q0; a.first = first; a.cur = cur;
+  a.wo = static_cast<const float4*>(wo_packed); a.kvl = kvl; a.vt = vt; a.ctxA = ctxA; a.ctxB = ctxB; a.q0 = q0; a.first = first; a.cur = cur;
   a.mask = mask; a.logits = logits; a.Bp = Bp; a.N = N; a.S = S; a.E = E; a.heads = heads;
   const int tiles = Bp * ((S + 15) / 16);
   const dim3 grid((tiles + 3) / 4), blk(256);

@@ -250,7 +250,9 @@ class MatNetDecoder(nn.Module):
         L.check(lib.rr_matnet_linear(L.ptr(pk["wnode"]), L.ptr(col), L.ptr(kvl), Bp, N, E, 3 * E, L.stream()), "rr_matnet_linear")
         L.check(lib.rr_matnet_linear(L.ptr(pk["wca"]), L.ptr(row), L.ptr(ctxa), Bp, N, E, E, L.stream()), "rr_matnet_linear")
         L.check(lib.rr_matnet_linear(L.ptr(pk["wcb"]), L.ptr(row), L.ptr(ctxb), Bp, N, E, E, L.stream()), "rr_matnet_linear")
-        return td, env, {"kvl": kvl, "ctxA": ctxa, "ctxB": ctxb, "Bp": Bp, "N": N}
+        vt = torch.zeros(Bp, E, 112, device=row.device)                           # V^T, keys along the row (16-byte operand loads)
+        vt[:, :, :N] = kvl[:, :, E:2 * E].transpose(1, 2)
+        return td, env, {"kvl": kvl, "vt": vt, "ctxA": ctxa, "ctxB": ctxb, "Bp": Bp, "N": N}
 
     @torch.no_grad()
     def forward(self, td, cached, num_starts: int = 0):
@@ -264,7 +266,7 @@ class MatNetDecoder(nn.Module):
         placeholder = td.meta.get("i", 1) == 0                    # nothing visited yet (plain greedy / sampling, first step)
         first = None if placeholder else td["first_node"].reshape(-1).contiguous()
         cur = None if placeholder else td["current_node"].reshape(-1).contiguous()
-        L.check(L.lib().rr_matnet_dec_step(L.ptr(pk["wo"]), L.ptr(cached["kvl"]), L.ptr(cached["ctxA"]), L.ptr(cached["ctxB"]),
+        L.check(L.lib().rr_matnet_dec_step(L.ptr(pk["wo"]), L.ptr(cached["kvl"]), L.ptr(cached["vt"]), L.ptr(cached["ctxA"]), L.ptr(cached["ctxB"]),
                                            L.ptr(pk["q0"]), L.ptr(first), L.ptr(cur), L.ptr(mask.view(torch.uint8)), L.ptr(logits),
                                            Bp, N, S, self.embed_dim, self.num_heads, L.stream()), "rr_matnet_dec_step")
         return logits, mask
