@@ -210,6 +210,7 @@ int rr_matnet_init(const int64_t* rand_idx, const float* demand, const float* ro
 int rr_matnet_linear(const void* w_packed, const float* x, float* y, int Bp, int N, int K, int Nout, hipStream_t stream);
 int rr_matnet_dec_step(const void* wo_packed, const float* kvl, const float* vt /* [Bp][E][112] = V^T, zero-padded */,
                        const float* ctxA, const float* ctxB, const float* q0,
+                       const float* state /* VRP: [R] vehicle_capacity - used_capacity, or NULL */, const float* wstate /* [E] */,
                        const int64_t* first, const int64_t* cur, const uint8_t* mask, float* logits,
                        int Bp, int N, int S, int E, int heads, hipStream_t stream);
 int rr_select_matnet(const float* logits, const uint8_t* mask, const int64_t* action_in, int64_t* action_out,

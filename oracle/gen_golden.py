@@ -346,6 +346,39 @@ def gen_matnet(tag, env_name, B, N, seed, layers, embed_dim=256, heads=16):
     print(f"wrote {path}  ({os.path.getsize(path)/1e3:.0f} kB) |row|={float(row.abs().mean()):.4f} |col|={float(col.abs().mean()):.4f}")
 
 
+def gen_matnet_policy_rcvrp(tag, B, N, S, seed, layers, embed_dim=256, heads=16):
+    """MatNetPolicy.forward on RCVRP, the environment of configs/experiment/matnet.yaml (init_embedding_kwargs as there)."""
+    from rrnco.baselines.MatNet.policy import MatNetPolicy
+    from rrnco.envs.rcvrp.env import RCVRPEnv
+
+    pol = MatNetPolicy(env_name="rcvrp", embed_dim=embed_dim, num_heads=heads, num_encoder_layers=layers, normalization="instance",
+                       use_graph_context=False, tanh_clipping=10.0, init_embedding_kwargs=dict(use_coords=False, use_polar_feats=False)).eval()
+    tmpl = {k: tuple(v.shape) for k, v in pol.state_dict().items()}
+    assert tmpl == restate.matnet_policy_template(embed_dim, heads, layers, 512, "rcvrp"), \
+        set(tmpl) ^ set(restate.matnet_policy_template(embed_dim, heads, layers, 512, "rcvrp"))
+    w = restate.make_weights(tmpl, seed)
+    pol.load_state_dict(w, strict=True)
+    inst = restate.rcvrp_synthetic(B, N, seed, 30.0 if N <= 20 else 40.0)
+    st0 = restate.rcvrp_reset(inst)
+    env = RCVRPEnv(generator=_Gen(N), check_solution=True)
+    td = env.reset(TensorDict({k: v.clone() for k, v in inst.items()}, batch_size=[B]))
+    torch.manual_seed(seed)
+    rand_idx = torch.rand(B, N + 1).argsort(dim=1)
+    torch.manual_seed(seed)
+    with torch.inference_mode():
+        out = pol(td.clone(), env, phase="val", decode_type="multistart_greedy", num_starts=S, return_actions=True)
+        mine = restate.matnet_policy_rcvrp(dict(pol.state_dict()), st0, rand_idx, S, layers, heads, embed_dim)
+    T = min(mine["actions"].shape[1], out["actions"].shape[1])
+    assert torch.equal(mine["actions"][:, :T], out["actions"][:, :T])
+    assert torch.allclose(mine["reward"], out["reward"], atol=1e-5) and torch.allclose(mine["log_likelihood"], out["log_likelihood"], atol=1e-3)
+    fx = {"B": B, "N": N, "S": S, "seed": seed, "layers": layers, "embed_dim": embed_dim, "heads": heads,
+          "locs": inst["locs"], "depot": inst["depot"], "distance_matrix": inst["distance_matrix"], "demand": inst["demand"],
+          "rand_idx": rand_idx, "actions": out["actions"], "reward": out["reward"], "log_likelihood": out["log_likelihood"]}
+    path = os.path.join(GOLD, tag + ".npz")
+    np.savez_compressed(path, **_np(fx))
+    print(f"wrote {path}  ({os.path.getsize(path)/1e3:.0f} kB) T={out['actions'].shape[1]} reward[:3]={out['reward'][:3].tolist()}")
+
+
 def gen_matnet_policy(tag, B, N, S, seed, layers, embed_dim=256, heads=16):
     """MatNetPolicy.forward of the reference (rrnco/baselines/MatNet/policy.py, decoder.py, decoding.py — in-tree code) on ATSP;
     rl4co's AttentionModelDecoder / PointerAttention base classes are the recalled stand-ins of oracle/ref_shim.py."""
@@ -419,4 +452,7 @@ if __name__ == "__main__":
     if "matnet_policy" in which:     # the whole MatNet baseline policy on ATSP (encoder + AM decoder + in-tree decoding loop)
         gen_matnet_policy("matnet_policy_atsp_n20_b4", B=4, N=20, S=20, seed=91, layers=3)
         gen_matnet_policy("matnet_policy_atsp_n50_b2", B=2, N=50, S=50, seed=92, layers=2)
+    if "matnet_policy_rcvrp" in which:
+        gen_matnet_policy_rcvrp("matnet_policy_rcvrp_n20_b4", B=4, N=20, S=20, seed=93, layers=3)
+        gen_matnet_policy_rcvrp("matnet_policy_rcvrp_n50_b2", B=2, N=50, S=50, seed=94, layers=2)
 

@@ -1236,3 +1236,51 @@ def matnet_policy_atsp(w: W, td0: dict, rand_idx: Tensor, num_starts: int, layer
     logprobs, actions_out = torch.stack(lps, 1), torch.stack(acts, 1)
     real, nd = atsp_reward(dict(td), actions_out, True)
     return {"reward": real, "normalized_reward": nd, "log_likelihood": logprobs.sum(1), "actions": actions_out, "logprobs": logprobs}
+
+
+def matnet_policy_rcvrp(w: W, td0: dict, rand_idx: Tensor, num_starts: int, layers: int, heads: int, embed_dim: int = 256,
+                        decode: str = "greedy", actions: Optional[Tensor] = None, trace: Optional[dict] = None) -> dict:
+    """MatNetPolicy.forward for RCVRP — the environment configs/experiment/matnet.yaml trains on (RVRPInitEmbedding with
+    use_coords=False, rl4co VRPContext: Linear(E+1, E) on [emb_cur; vehicle_capacity - used_capacity]); td0 = rcvrp_reset(...)."""
+    we = {k[len("encoder."):]: v for k, v in w.items() if k.startswith("encoder.")}
+    row, col = matnet_encoder(we, td0, rand_idx, layers, heads, "rcvrp", embed_dim)
+    B, N1 = td0["action_mask"].shape
+    n_loc = N1 - 1
+    S = num_starts if num_starts > 1 else 0
+    gk, gv, lk = F.linear(col, w["decoder.project_node_embeddings.weight"]).chunk(3, dim=-1)
+    static = ("locs", "distance_matrix", "min_distance", "max_distance")
+    acts, lps = [], []
+    if S >= 1:
+        a0 = torch.arange(S).repeat_interleave(B) % n_loc + 1
+        td = batchify_state({k: v for k, v in td0.items() if k not in static}, S)
+        td["action"] = a0
+        td = rcvrp_step(td)
+        lps.append(torch.zeros_like(a0, dtype=torch.float32)); acts.append(a0)
+    else:
+        td = {k: v for k, v in td0.items() if k not in static}
+    k = 0
+    while not td["done"].all():
+        keys = ("current_node", "used_capacity", "vehicle_capacity", "action_mask")
+        tv = {kk: (unbatchify(td[kk], S) if S > 1 else td[kk]) for kk in keys}
+        cur = gather_by_index(row, tv["current_node"])
+        q = F.linear(torch.cat([cur, tv["vehicle_capacity"] - tv["used_capacity"]], -1), w["decoder.context_embedding.project_context.weight"])
+        q = q.unsqueeze(1) if q.ndim == 2 else q
+        mask = tv["action_mask"]
+        logits = matnet_pointer(w, q, gk, gv, lk, mask, heads)
+        if S > 1:
+            logits = logits.permute(1, 0, 2).reshape(-1, logits.shape[-1])
+            mask = mask.permute(1, 0, 2).reshape(-1, mask.shape[-1])
+        logp = matnet_process_logits(logits, mask)
+        sel = logp.argmax(dim=-1) if decode == "greedy" else actions[:, k]
+        if trace is not None:
+            trace.setdefault("logits", []).append(logits); trace.setdefault("logp", []).append(logp)
+        lps.append(gather_by_index(logp, sel, dim=1)); acts.append(sel)
+        td["action"] = sel
+        td = rcvrp_step(td)
+        k += 1
+    logprobs, actions_out = torch.stack(lps, 1), torch.stack(acts, 1)
+    R = actions_out.shape[0]
+    rtd = {"distance_matrix": td0["distance_matrix"][torch.arange(R) % B],
+           "min_distance": td0["min_distance"][torch.arange(R) % B], "max_distance": td0["max_distance"][torch.arange(R) % B]}
+    real, nd = vrp_reward(rtd, actions_out, True)
+    return {"reward": real, "normalized_reward": nd, "log_likelihood": logprobs.sum(1), "actions": actions_out, "logprobs": logprobs}

@@ -337,6 +337,7 @@ struct MnDecArgs {
   const float* vt;             // [Bp][E][112]: the glimpse values transposed (keys along the row, zero-padded)
   const float *ctxA, *ctxB;    // [Bp][N][E]: W_ctx[:, :E] row_emb (first node), W_ctx[:, E:] row_emb (current node)
   const float* q0;             // [E] project_context(W_placeholder), used when first == nullptr (no node visited yet)
+  const float *state, *wstate; // VRP: [R] vehicle_capacity - used_capacity and the state column of W_ctx [E] (then ctxA / first unused)
   const int64_t *first, *cur;  // [R]
   const uint8_t* mask;         // [R][N] action mask
   float* logits;               // [R][N]
@@ -357,7 +358,15 @@ __global__ __launch_bounds__(256) void k_mn_dec_step(MnDecArgs a) {
   const float* KVL = a.kvl + (size_t)b * N * 3 * E;
   // ---- step context: q^T [E x 16 rollouts] in B-operand form (rl4co TSPContext: W_ctx [emb_first; emb_cur])
   f32x4 q[16];
-  if (a.first != nullptr) {
+  if (a.state != nullptr) {      // rl4co VRPContext: W_ctx [emb_cur; vehicle_capacity - used_capacity]
+    const float* pb = a.ctxB + ((size_t)b * N + (int)a.cur[r]) * E + 4 * g;
+    const float st = a.state[r];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const float4 v = rr_ld4(pb + 16 * t), ws = rr_ld4(a.wstate + 16 * t + 4 * g);
+      q[t][0] = fmaf(ws.x, st, v.x); q[t][1] = fmaf(ws.y, st, v.y); q[t][2] = fmaf(ws.z, st, v.z); q[t][3] = fmaf(ws.w, st, v.w);
+    }
+  } else if (a.first != nullptr) {
     const float* pa = a.ctxA + ((size_t)b * N + (int)a.first[r]) * E + 4 * g;
     const float* pb = a.ctxB + ((size_t)b * N + (int)a.cur[r]) * E + 4 * g;
 #pragma unroll
@@ -448,13 +457,15 @@ __global__ __launch_bounds__(256) void k_mn_dec_step(MnDecArgs a) {
 }
 
 extern "C" int rr_matnet_dec_step(const void* wo_packed, const float* kvl, const float* vt, const float* ctxA, const float* ctxB, const float* q0,
+                                  const float* state, const float* wstate,
                                   const int64_t* first, const int64_t* cur, const uint8_t* mask, float* logits,
                                   int Bp, int N, int S, int E, int heads, hipStream_t st) {
   if (!wo_packed || !kvl || !vt || !mask || !logits || Bp <= 0 || S < 1 || N < 2 || N > 16 * RR_NT) return RR_EINVAL;
   if (E != 256 || heads != 16) return RR_EINVAL;                       // registers are sized for the matnet.yaml configuration
-  if (first != nullptr ? (cur == nullptr || ctxA == nullptr || ctxB == nullptr) : q0 == nullptr) return RR_EINVAL;
+  if (state != nullptr) { if (wstate == nullptr || cur == nullptr || ctxB == nullptr) return RR_EINVAL; }
+  else if (first != nullptr ? (cur == nullptr || ctxA == nullptr || ctxB == nullptr) : q0 == nullptr) return RR_EINVAL;
   MnDecArgs a;
-  a.wo = static_cast<const float4*>(wo_packed); a.kvl = kvl; a.vt = vt; a.ctxA = ctxA; a.ctxB = ctxB; a.q0 = q0; a.first = first; a.cur = cur;
+  a.wo = static_cast<const float4*>(wo_packed); a.kvl = kvl; a.vt = vt; a.ctxA = ctxA; a.ctxB = ctxB; a.q0 = q0; a.state = state; a.wstate = wstate; a.first = first; a.cur = cur;
   a.mask = mask; a.logits = logits; a.Bp = Bp; a.N = N; a.S = S; a.E = E; a.heads = heads;
   const int tiles = Bp * ((S + 15) / 16);
   const dim3 grid((tiles + 3) / 4), blk(256);

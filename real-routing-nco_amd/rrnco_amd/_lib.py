@@ -83,7 +83,7 @@ _SIGS = {
     "rr_matnet_layer": [C.POINTER(MatNetSideW), C.POINTER(MatNetSideW), vp, vp, vp, vp, vp, vp, C.c_size_t] + [i32] * 5 + [vp],
     "rr_matnet_init": [vp] * 7 + [i32, i32, i32, vp],
     "rr_matnet_linear": [vp, vp, vp, i32, i32, i32, i32, vp],
-    "rr_matnet_dec_step": [vp] * 10 + [i32] * 5 + [vp],
+    "rr_matnet_dec_step": [vp] * 12 + [i32] * 5 + [vp],
     "rr_select_matnet": [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, u64, u32, vp],
     "rr_nab_train_fwd": [vp, vp, vp, vp, C.c_long, vp],
     "rr_nab_train_bwd": [vp, vp, vp, vp, vp, C.c_long, vp],

@@ -205,6 +205,14 @@ class _ProjectContext(nn.Module):
         self.project_context = nn.Linear(2 * embed_dim, embed_dim, bias=False)
 
 
+class _ProjectContextVRP(nn.Module):
+    """rl4co VRPContext: `project_context` Linear(E + 1, E, bias=False) on [emb_cur; vehicle_capacity - used_capacity]."""
+
+    def __init__(self, embed_dim):
+        super().__init__()
+        self.project_context = nn.Linear(embed_dim + 1, embed_dim, bias=False)
+
+
 class _Pointer(nn.Module):
     def __init__(self, embed_dim):
         super().__init__()
@@ -217,11 +225,11 @@ class MatNetDecoder(nn.Module):
 
     def __init__(self, embed_dim: int = 256, num_heads: int = 16, env_name: str = "atsp", use_graph_context: bool = False, **unused):
         super().__init__()
-        if env_name != "atsp" or use_graph_context or embed_dim != 256 or num_heads != 16:
-            raise NotImplementedError("MatNetDecoder on HIP: ATSP, embed_dim=256, num_heads=16, use_graph_context=False "
+        if env_name not in ("atsp", "rcvrp") or use_graph_context or embed_dim != 256 or num_heads != 16:
+            raise NotImplementedError("MatNetDecoder on HIP: ATSP / RCVRP, embed_dim=256, num_heads=16, use_graph_context=False "
                                       "(configs/experiment/matnet.yaml)")
-        self.embed_dim, self.num_heads = embed_dim, num_heads
-        self.context_embedding = _ProjectContext(embed_dim)
+        self.embed_dim, self.num_heads, self.env_name = embed_dim, num_heads, env_name
+        self.context_embedding = _ProjectContext(embed_dim) if env_name == "atsp" else _ProjectContextVRP(embed_dim)
         self.pointer = _Pointer(embed_dim)
         self.project_node_embeddings = nn.Linear(embed_dim, 3 * embed_dim, bias=False)
         self.project_fixed_context = nn.Linear(embed_dim, embed_dim, bias=False)      # unused without the graph context (as in the reference)
@@ -233,9 +241,13 @@ class MatNetDecoder(nn.Module):
             E = self.embed_dim
             f = lambda t: pack_a(t.detach().float()).to(device).contiguous()          # noqa: E731
             Wc = self.context_embedding.project_context.weight
-            q0 = (Wc.detach().double() @ self.context_embedding.W_placeholder.detach().double()).float().to(device).contiguous()
-            self._pack_cache = (key, {"wnode": f(self.project_node_embeddings.weight), "wca": f(Wc[:, :E]), "wcb": f(Wc[:, E:]),
-                                      "wo": f(self.pointer.project_out.weight), "q0": q0})
+            pk = {"wnode": f(self.project_node_embeddings.weight), "wo": f(self.pointer.project_out.weight)}
+            if self.env_name == "atsp":
+                pk["wca"], pk["wcb"] = f(Wc[:, :E]), f(Wc[:, E:])
+                pk["q0"] = (Wc.detach().double() @ self.context_embedding.W_placeholder.detach().double()).float().to(device).contiguous()
+            else:
+                pk["wcb"], pk["wstate"] = f(Wc[:, :E]), Wc[:, E].detach().float().to(device).contiguous()
+            self._pack_cache = (key, pk)
         return self._pack_cache[1]
 
     @torch.no_grad()
@@ -245,10 +257,12 @@ class MatNetDecoder(nn.Module):
         Bp, N, E = row.shape
         pk, lib = self.packed(row.device), L.lib()
         kvl = torch.empty(Bp, N, 3 * E, device=row.device)
-        ctxa, ctxb = torch.empty(Bp, N, E, device=row.device), torch.empty(Bp, N, E, device=row.device)
+        ctxa, ctxb = None, torch.empty(Bp, N, E, device=row.device)
         row, col = row.contiguous(), col.contiguous()
         L.check(lib.rr_matnet_linear(L.ptr(pk["wnode"]), L.ptr(col), L.ptr(kvl), Bp, N, E, 3 * E, L.stream()), "rr_matnet_linear")
-        L.check(lib.rr_matnet_linear(L.ptr(pk["wca"]), L.ptr(row), L.ptr(ctxa), Bp, N, E, E, L.stream()), "rr_matnet_linear")
+        if self.env_name == "atsp":
+            ctxa = torch.empty(Bp, N, E, device=row.device)
+            L.check(lib.rr_matnet_linear(L.ptr(pk["wca"]), L.ptr(row), L.ptr(ctxa), Bp, N, E, E, L.stream()), "rr_matnet_linear")
         L.check(lib.rr_matnet_linear(L.ptr(pk["wcb"]), L.ptr(row), L.ptr(ctxb), Bp, N, E, E, L.stream()), "rr_matnet_linear")
         vt = torch.zeros(Bp, E, 112, device=row.device)                           # V^T, keys along the row (16-byte operand loads)
         vt[:, :, :N] = kvl[:, :, E:2 * E].transpose(1, 2)
@@ -263,17 +277,25 @@ class MatNetDecoder(nn.Module):
         S = R // Bp
         pk = self.packed(mask.device)
         logits = torch.empty(R, N, device=mask.device)
-        placeholder = td.meta.get("i", 1) == 0                    # nothing visited yet (plain greedy / sampling, first step)
-        first = None if placeholder else td["first_node"].reshape(-1).contiguous()
-        cur = None if placeholder else td["current_node"].reshape(-1).contiguous()
+        state = wstate = q0 = first = None
+        if self.env_name == "atsp":
+            placeholder = td.meta.get("i", 1) == 0                # nothing visited yet (plain greedy / sampling, first step)
+            q0 = pk["q0"]
+            first = None if placeholder else td["first_node"].reshape(-1).contiguous()
+            cur = None if placeholder else td["current_node"].reshape(-1).contiguous()
+        else:                                                     # VRPContext: [emb_cur; vehicle_capacity - used_capacity]
+            cur = td["current_node"].reshape(-1).contiguous()
+            vcap = td["vehicle_capacity"].reshape(-1)
+            state = ((vcap if vcap.shape[0] == R else vcap.repeat(R // vcap.shape[0])) - td["used_capacity"].reshape(-1)).float().contiguous()
+            wstate = pk["wstate"]
         L.check(L.lib().rr_matnet_dec_step(L.ptr(pk["wo"]), L.ptr(cached["kvl"]), L.ptr(cached["vt"]), L.ptr(cached["ctxA"]), L.ptr(cached["ctxB"]),
-                                           L.ptr(pk["q0"]), L.ptr(first), L.ptr(cur), L.ptr(mask.view(torch.uint8)), L.ptr(logits),
-                                           Bp, N, S, self.embed_dim, self.num_heads, L.stream()), "rr_matnet_dec_step")
+                                           L.ptr(q0), L.ptr(state), L.ptr(wstate), L.ptr(first), L.ptr(cur), L.ptr(mask.view(torch.uint8)),
+                                           L.ptr(logits), Bp, N, S, self.embed_dim, self.num_heads, L.stream()), "rr_matnet_dec_step")
         return logits, mask
 
 
 class MatNetPolicy(nn.Module):
-    """rrnco.baselines.MatNet.policy.MatNetPolicy (policy.py:19-212) for ATSP: MatNetEncoder -> MatNetDecoder, decoded with the
+    """rrnco.baselines.MatNet.policy.MatNetPolicy (policy.py:19-212) for ATSP and RCVRP (the environment matnet.yaml trains on): MatNetEncoder -> MatNetDecoder, decoded with the
     baseline's own process_logits (MatNet/decoding.py: row shifted by its maximum and clamped to [-50, -1e-4], rr_select_matnet)
     in the reference's step loop (decoder.forward -> strategy.step -> env.step)."""
 

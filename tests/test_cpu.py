@@ -517,3 +517,16 @@ def test_oracle_matnet_policy_reproduces_reference_golden(name):
     from rrnco_amd.baselines import MatNetPolicy
     pol = MatNetPolicy(env_name="atsp", num_encoder_layers=fx["layers"])
     assert {k: tuple(v.shape) for k, v in pol.state_dict().items()} == restate.matnet_policy_template(256, 16, fx["layers"], 512, "atsp")
+
+
+@pytest.mark.parametrize("name", ["matnet_policy_rcvrp_n20_b4", "matnet_policy_rcvrp_n50_b2"])
+def test_oracle_matnet_policy_rcvrp_reproduces_reference_golden(name):
+    fx = H.load_fixture(name)
+    w = restate.make_weights(restate.matnet_policy_template(fx["embed_dim"], fx["heads"], fx["layers"], 512, "rcvrp"), fx["seed"])
+    st0 = restate.rcvrp_reset({k: fx[k] for k in ("locs", "depot", "distance_matrix", "demand")})
+    with torch.inference_mode():
+        out = restate.matnet_policy_rcvrp(w, st0, fx["rand_idx"], fx["S"], fx["layers"], fx["heads"], fx["embed_dim"])
+    T = min(out["actions"].shape[1], fx["actions"].shape[1])
+    assert torch.equal(out["actions"][:, :T], fx["actions"][:, :T])
+    assert torch.allclose(out["reward"], fx["reward"], atol=1e-4) and torch.allclose(out["log_likelihood"], fx["log_likelihood"], atol=1e-3)
+

@@ -96,3 +96,31 @@ def test_matnet_policy_tours_match_reference(name):
             lg = torch.tanh(tr["logits"][int(first[r]) - 1][r]) * 10.0
             top = lg.masked_fill(tr["logp"][int(first[r]) - 1][r] < -40, float("-inf")).topk(2).values
             assert float(top[0] - top[1]) < 1.2e-3
+
+
+@pytest.mark.parametrize("name", ["matnet_policy_rcvrp_n20_b4", "matnet_policy_rcvrp_n50_b2"])
+def test_matnet_policy_rcvrp_routes_match_reference(name):
+    """MatNetPolicy on RCVRP, the environment configs/experiment/matnet.yaml trains on (RVRPInitEmbedding without coordinates,
+    rl4co VRPContext, RCVRPEnv masks), against the reference's MatNetPolicy.forward."""
+    from rrnco_amd import TensorDict
+    from rrnco_amd.baselines import MatNetPolicy
+    from rrnco_amd.envs import RCVRPEnv
+    fx = H.load_fixture(name)
+    w = restate.make_weights(restate.matnet_policy_template(fx["embed_dim"], fx["heads"], fx["layers"], 512, "rcvrp"), fx["seed"])
+    pol = MatNetPolicy(env_name="rcvrp", num_encoder_layers=fx["layers"])
+    pol.load_state_dict(w, strict=True)
+    pol = pol.cuda().eval()
+    env = RCVRPEnv(generator_params=dict(num_loc=fx["N"]), check_solution=True)
+    td = TensorDict({k: fx[k].cuda() for k in ("locs", "depot", "distance_matrix", "demand")}, batch_size=[fx["B"]])
+    out = pol(env.reset(td), env, phase="val", decode_type="multistart_greedy", num_starts=fx["S"], return_actions=True,
+              rand_idx=fx["rand_idx"].cuda())
+    acts = out["actions"].cpu()
+    n = fx["N"]
+    assert (acts.sort(1).values[:, -n:] == torch.arange(1, n + 1)).all()
+    T = min(acts.shape[1], fx["actions"].shape[1])
+    frac, first = H.tour_agreement(acts[:, :T], fx["actions"][:, :T])
+    assert frac >= 0.95
+    same = first < 0
+    assert torch.allclose(out["reward"].cpu()[same], fx["reward"][same], atol=1e-4)
+    assert torch.allclose(out["log_likelihood"].cpu()[same], fx["log_likelihood"][same], rtol=2e-5, atol=4e-3)
+
