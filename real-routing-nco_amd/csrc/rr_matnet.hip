@@ -356,46 +356,71 @@ __global__ __launch_bounds__(256) void k_mn_dec_step(MnDecArgs a) {
   const bool valid = s < S;
   const size_t r = (size_t)(valid ? s : 0) * Bp + b;
   const float* KVL = a.kvl + (size_t)b * N * 3 * E;
-  // ---- step context: q^T [E x 16 rollouts] in B-operand form (rl4co TSPContext: W_ctx [emb_first; emb_cur])
-  f32x4 q[16];
-  if (a.state != nullptr) {      // rl4co VRPContext: W_ctx [emb_cur; vehicle_capacity - used_capacity]
-    const float* pb = a.ctxB + ((size_t)b * N + (int)a.cur[r]) * E + 4 * g;
-    const float st = a.state[r];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const float4 v = rr_ld4(pb + 16 * t), ws = rr_ld4(a.wstate + 16 * t + 4 * g);
-      q[t][0] = fmaf(ws.x, st, v.x); q[t][1] = fmaf(ws.y, st, v.y); q[t][2] = fmaf(ws.z, st, v.z); q[t][3] = fmaf(ws.w, st, v.w);
-    }
-  } else if (a.first != nullptr) {
-    const float* pa = a.ctxA + ((size_t)b * N + (int)a.first[r]) * E + 4 * g;
-    const float* pb = a.ctxB + ((size_t)b * N + (int)a.cur[r]) * E + 4 * g;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const float4 u = rr_ld4(pa + 16 * t), v = rr_ld4(pb + 16 * t);
-      q[t][0] = u.x + v.x; q[t][1] = u.y + v.y; q[t][2] = u.z + v.z; q[t][3] = u.w + v.w;
-    }
-  } else {
-#pragma unroll
-    for (int t = 0; t < 16; ++t) { const float4 u = rr_ld4(a.q0 + 16 * t + 4 * g); q[t][0] = u.x; q[t][1] = u.y; q[t][2] = u.z; q[t][3] = u.w; }
+  // ---- step context q^T [E x 16 rollouts] (rl4co TSPContext: W_ctx [emb_first; emb_cur]; VRPContext: W_ctx [emb_cur; free
+  // capacity]), gathered one head (16 features = one B-operand register quad) at a time, one head ahead of its use
+  const float* pa = nullptr;
+  const float* pb = nullptr;
+  float st = 0.f;
+  if (a.state != nullptr) { pb = a.ctxB + ((size_t)b * N + (int)a.cur[r]) * E + 4 * g; st = a.state[r]; }
+  else if (a.first != nullptr) {
+    pa = a.ctxA + ((size_t)b * N + (int)a.first[r]) * E + 4 * g;
+    pb = a.ctxB + ((size_t)b * N + (int)a.cur[r]) * E + 4 * g;
   }
+  auto load_q = [&](int h) -> f32x4 {
+    f32x4 qh;
+    if (pb == nullptr) { const float4 u = rr_ld4(a.q0 + 16 * h + 4 * g); qh[0] = u.x; qh[1] = u.y; qh[2] = u.z; qh[3] = u.w; return qh; }
+    const float4 v = rr_ld4(pb + 16 * h);
+    if (pa != nullptr) {
+      const float4 u = rr_ld4(pa + 16 * h);
+      qh[0] = u.x + v.x; qh[1] = u.y + v.y; qh[2] = u.z + v.z; qh[3] = u.w + v.w;
+    } else {
+      const float4 ws = rr_ld4(a.wstate + 16 * h + 4 * g);
+      qh[0] = fmaf(ws.x, st, v.x); qh[1] = fmaf(ws.y, st, v.y); qh[2] = fmaf(ws.z, st, v.z); qh[3] = fmaf(ws.w, st, v.w);
+    }
+    return qh;
+  };
+  // action mask of this lane's keys (4 per key tile), once
   const uint8_t* mk = a.mask + r * N;
-  // ---- masked multi-head glimpse, one head at a time; heads^T stays in registers (B operand of project_out)
-  f32x4 H[16];
+  uint32_t okbits = 0;
 #pragma unroll
-  for (int h = 0; h < 16; ++h) {      // unrolled: q[h] / H[h] must be register-indexed
+  for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int k2 = kt * 16 + 4 * g + rr;
+      if (k2 < N && mk[k2 < N ? k2 : 0] != 0) okbits |= 1u << (4 * kt + rr);
+    }
+  int keyoff[NT];
+#pragma unroll
+  for (int kt = 0; kt < NT; ++kt) { int key = kt * 16 + j; key = key < N ? key : N - 1; keyoff[kt] = key * 3 * E + 4 * g; }
+  const float* pv0 = a.vt + (size_t)b * E * 112 + (size_t)j * 112 + 4 * g;       // V^T [E][112]: four keys per 16-byte load
+  // ---- masked multi-head glimpse, one head at a time, the next head's operands (q, K fragments, V^T fragments) in flight;
+  // heads^T stays in registers (B operand of project_out)
+  f32x4 H[16];
+  f32x4 qn = load_q(0);
+  float4 kn[NT], vn[NT];
+#pragma unroll
+  for (int kt = 0; kt < NT; ++kt) { kn[kt] = rr_ld4(KVL + keyoff[kt]); vn[kt] = rr_ld4(pv0 + 16 * kt); }
+#pragma unroll
+  for (int h = 0; h < 16; ++h) {      // unrolled: H[h] must be register-indexed
+    const f32x4 qh = qn;
+    float4 kf[NT], vv[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) { kf[kt] = kn[kt]; vv[kt] = vn[kt]; }
+    if (h + 1 < 16) {
+      qn = load_q(h + 1);
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) { kn[kt] = rr_ld4(KVL + keyoff[kt] + 16 * (h + 1)); vn[kt] = rr_ld4(pv0 + (size_t)(16 * (h + 1)) * 112 + 16 * kt); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     f32x4 sc[NT];
     float mxv = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
-      int key = kt * 16 + j; key = key < N ? key : N - 1;
-      const float4 kf = rr_ld4(KVL + (size_t)key * 3 * E + 16 * h + 4 * g);
       f32x4 c = rr_zero4();
-      c = rr_mfma(kf.x, q[h][0], c); c = rr_mfma(kf.y, q[h][1], c); c = rr_mfma(kf.z, q[h][2], c); c = rr_mfma(kf.w, q[h][3], c);
+      c = rr_mfma(kf[kt].x, qh[0], c); c = rr_mfma(kf[kt].y, qh[1], c); c = rr_mfma(kf[kt].z, qh[2], c); c = rr_mfma(kf[kt].w, qh[3], c);
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
-        const int k2 = kt * 16 + 4 * g + rr;
-        const bool ok = k2 < N && mk[k2 < N ? k2 : 0] != 0;
-        c[rr] = ok ? c[rr] * 0.25f : -INFINITY;
+        c[rr] = ((okbits >> (4 * kt + rr)) & 1u) ? c[rr] * 0.25f : -INFINITY;
         mxv = fmaxf(mxv, c[rr]);
       }
       sc[kt] = c;
@@ -408,13 +433,12 @@ __global__ __launch_bounds__(256) void k_mn_dec_step(MnDecArgs a) {
       for (int rr = 0; rr < 4; ++rr) { sc[kt][rr] = rr_exp(sc[kt][rr] - mxv); sum += sc[kt][rr]; }
     const float inv = 1.0f / rr_sum_g(sum);
     f32x4 o = rr_zero4();
-    const float* pv = a.vt + ((size_t)b * E + 16 * h + j) * 112 + 4 * g;       // V^T [E][112]: four keys per 16-byte load
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt) {
-      const float4 vv = rr_ld4(pv + 16 * kt);                                     // keys >= N carry zero probability
-      o = rr_mfma(vv.x, sc[kt][0], o); o = rr_mfma(vv.y, sc[kt][1], o); o = rr_mfma(vv.z, sc[kt][2], o); o = rr_mfma(vv.w, sc[kt][3], o);
+    for (int kt = 0; kt < NT; ++kt) {                                              // keys >= N carry zero probability
+      o = rr_mfma(vv[kt].x, sc[kt][0], o); o = rr_mfma(vv[kt].y, sc[kt][1], o); o = rr_mfma(vv[kt].z, sc[kt][2], o); o = rr_mfma(vv[kt].w, sc[kt][3], o);
     }
     H[h][0] = o[0] * inv; H[h][1] = o[1] * inv; H[h][2] = o[2] * inv; H[h][3] = o[3] * inv;
+    __builtin_amdgcn_sched_barrier(0);
   }
   // ---- glimpse^T = W_out heads^T (project_out, no bias)
   f32x4 G[16];
