@@ -24,6 +24,8 @@ import math
 
 import torch
 import torch.nn.functional as F
+
+from .. import _lib as L
 from torch.utils.checkpoint import checkpoint
 
 E, HEADS = 128, 8
@@ -102,17 +104,78 @@ def _nab_folded(P, p, cost, theta, alpha):
     return (g * od + (1 - g) * oa + bo) * alpha
 
 
+class _NabDurationFolded(torch.autograd.Function):
+    """DistAngleFusion with the duration matrix in its folded form (the arithmetic of csrc/rr_encoder.hip:k_nab_dur), with a
+    hand-written backward that recomputes instead of storing: per edge, h_f = relu(a_f x_f + b_f) (3 x 128), z = Mcat h + cg,
+    gate = softmax((Wg2 silu(z) + bg2) / tau), bias = sum_f gate_f (co_f . h_f + ko_f) + bo, out = alpha * bias.  Through the
+    unfolded module autograd kept a dozen [edges, 128..384] tensors per block alive and ran ~60 elementwise kernels over them;
+    here the three contractions are single GEMMs over all edges ([M,384] x [384,128] and its two transposes) and nothing but
+    the three input scalars per edge is saved.  The folded parameters are built with torch ops from the module's, so autograd
+    carries their gradients back (tiny tensors)."""
+
+    @staticmethod
+    def _forward_parts(x3, a, b, Mcat, cg, co, ko, Wg2, bg2, inv_tau):
+        xr = x3.repeat_interleave(E, dim=1)                                      # [M, 3E]: the family's scalar under each hidden unit
+        H = torch.relu(xr * a + b)
+        Z = torch.addmm(cg, H, Mcat.t())
+        sg = torch.sigmoid(Z)
+        zs = Z * sg
+        lraw = torch.addmm(bg2, zs, Wg2.t())
+        g = torch.softmax(lraw * inv_tau, dim=-1)
+        po = (H * co).view(-1, 3, E).sum(-1) + ko
+        return xr, H, Z, sg, zs, lraw, g, po
+
+    @staticmethod
+    def forward(ctx, x3, a, b, Mcat, cg, co, ko, Wg2, bg2, inv_tau, bo, alpha):
+        _, _, _, _, _, _, g, po = _NabDurationFolded._forward_parts(x3, a, b, Mcat, cg, co, ko, Wg2, bg2, inv_tau)
+        ctx.save_for_backward(x3, a, b, Mcat, cg, co, ko, Wg2, bg2, inv_tau, bo, alpha)
+        return ((g * po).sum(-1) + bo) * alpha
+
+    @staticmethod
+    def backward(ctx, gout):
+        x3, a, b, Mcat, cg, co, ko, Wg2, bg2, inv_tau, bo, alpha = ctx.saved_tensors
+        xr, H, Z, sg, zs, lraw, g, po = _NabDurationFolded._forward_parts(x3, a, b, Mcat, cg, co, ko, Wg2, bg2, inv_tau)
+        bias = (g * po).sum(-1) + bo
+        dalpha = (bias * gout).sum().reshape(alpha.shape)
+        dbias = gout * alpha
+        dbo = dbias.sum().reshape(bo.shape)
+        dpo = dbias[:, None] * g
+        dg = dbias[:, None] * po
+        dl = g * (dg - (g * dg).sum(-1, keepdim=True))                           # softmax backward, w.r.t. lraw * inv_tau
+        dinv_tau = (dl * lraw).sum().reshape(inv_tau.shape)
+        dlraw = dl * inv_tau
+        dWg2 = dlraw.t() @ zs
+        dbg2 = dlraw.sum(0)
+        dZ = (dlraw @ Wg2) * (sg * (1 + Z * (1 - sg)))                           # silu'(z) = s (1 + z (1 - s))
+        dcg = dZ.sum(0)
+        dMcat = dZ.t() @ H
+        dpor = dpo.repeat_interleave(E, dim=1)
+        dko = dpo.sum(0)
+        dco = (H * dpor).sum(0)
+        dpre = (dZ @ Mcat + dpor * co) * (H > 0)
+        da = (dpre * xr).sum(0)
+        db = dpre.sum(0)
+        return None, da, db, dMcat, dcg, dco, dko, dWg2, dbg2, dinv_tau, dbo, dalpha
+
+
 def _nab_duration(P, p, cost, theta, dur, alpha):
-    """alpha * DistAngleFusion(use_duration_matrix=True) attn_freenet.py:226-237, 265-286, in the module's own (unfolded)
-    form: its Linear(E,E) / Linear(3E,E) layers are proper GEMMs over the b*N*N edges, which hipBLAS handles well — unlike
-    the gating variant's matrix-vector products, which is why that one has its own kernels."""
-    def mlp(q, x):
-        return _lin(P, q + ".2", F.relu(_lin(P, q + ".0", x.unsqueeze(-1))))
-    de, ae, du = mlp(p + ".dist_emb", cost), mlp(p + ".angle_emb", theta), mlp(p + ".dur_emb", dur)
-    logits = _lin(P, p + ".gate.2", F.silu(_lin(P, p + ".gate.0", torch.cat([de, ae, du], dim=-1))))
-    g = F.softmax(logits / P[p + ".gate_temperature"].exp(), dim=-1)
-    fused = g[..., [0]] * de + g[..., [1]] * ae + g[..., [2]] * du
-    return _lin(P, p + ".out_lin", fused).squeeze(-1) * alpha
+    """alpha * DistAngleFusion(use_duration_matrix=True) attn_freenet.py:226-237, 265-286 through _NabDurationFolded; the fold
+    (M_f = Wg0_f W2_f, cg = sum_f Wg0_f b2_f + bg0, co_f = W2_f^T wo, ko_f = wo . b2_f) is packing.py's, in torch ops."""
+    Wg0, bg0 = P[p + ".gate.0.weight"], P[p + ".gate.0.bias"]
+    wo, bo = P[p + ".out_lin.weight"][0], P[p + ".out_lin.bias"][0]
+    a_, b_, Ms, cos, kos = [], [], [], [], []
+    cg = bg0
+    for f, nm in enumerate(("dist_emb", "angle_emb", "dur_emb")):
+        W2, b2 = P[f"{p}.{nm}.2.weight"], P[f"{p}.{nm}.2.bias"]
+        Wg0f = Wg0[:, f * E:(f + 1) * E]
+        a_.append(P[f"{p}.{nm}.0.weight"][:, 0]); b_.append(P[f"{p}.{nm}.0.bias"])
+        Ms.append(Wg0f @ W2); cg = cg + Wg0f @ b2
+        cos.append(W2.t() @ wo); kos.append(wo @ b2)
+    x3 = torch.stack([cost.reshape(-1), theta.reshape(-1), dur.reshape(-1)], dim=1)
+    out = _NabDurationFolded.apply(x3, torch.cat(a_), torch.cat(b_), torch.cat(Ms, dim=1), cg, torch.cat(cos), torch.stack(kos),
+                                   P[p + ".gate.2.weight"], P[p + ".gate.2.bias"], torch.exp(-P[p + ".gate_temperature"]), bo,
+                                   alpha.reshape(()))
+    return out.view(cost.shape)
 
 
 def _block(P, p, x, y, cost, theta, dur=None):
@@ -340,14 +403,62 @@ def rcvrptw_replay_states(D, Dur, demand_l, tw, service, actions, cap=1.0, varia
     return torch.stack(rems, 2), torch.stack(times, 2), opn, torch.stack(rds, 2), torch.stack(masks, 2)
 
 
+def rcvrptw_replay_states_hip(D, Dur, demand_l, tw, service, actions, cap=1.0, variant=None):
+    """The same replay on the env's own step kernel (rr_rmtvrp_step, the product's masks bit for bit): one launch per decode
+    step for all b * S routes instead of ~45 small torch launches — the training step of RCVRPTW was launch-bound on them."""
+    b, S, T = actions.shape
+    N1 = D.shape[-1]
+    dev = D.device
+    R = b * S
+    lib = L.lib()
+    Dc, Tc = D.contiguous(), Dur.contiguous()
+    d0, t0 = Dc[:, :, 0].contiguous(), Tc[:, :, 0].contiguous()
+    dl, twc, sv = demand_l.contiguous(), tw.contiguous(), service.contiguous()
+    acts = actions.permute(2, 1, 0).reshape(T, R).contiguous()                    # step-major, r = s * b + instance
+    vcap = torch.full((R,), float(cap), device=dev)
+    cur = torch.zeros(R, dtype=torch.int64, device=dev)
+    ctime, rlen, used = torch.zeros(R, device=dev), torch.zeros(R, device=dev), torch.zeros(R, device=dev)
+    vis = torch.zeros(R, N1, dtype=torch.uint8, device=dev)
+    done = torch.empty(R, dtype=torch.uint8, device=dev)
+    masks = torch.empty(T - 1, R, N1, dtype=torch.uint8, device=dev)
+    rems, times, rds = torch.empty(T - 1, R, device=dev), torch.empty(T - 1, R, device=dev), torch.empty(T - 1, R, device=dev)
+    extra, ub, lim, keep = None, None, None, None
+    if variant is not None:
+        ub = torch.zeros(R, device=dev)
+        lim = variant["distance_limit"].reshape(b).float().contiguous()
+        keep = (variant["demand_backhaul"].float().contiguous(), variant["open_route"].reshape(b).to(torch.uint8).contiguous(), lim,
+                variant["backhaul_class"].reshape(b).to(torch.int32).contiguous())
+        extra = L.MtvrpExtra()
+        extra.demand_b, extra.used_b = L.ptr(keep[0]), L.ptr(ub)
+        extra.open_route, extra.dist_limit, extra.bclass = L.ptr(keep[1]), L.ptr(keep[2]), L.ptr(keep[3])
+    for k in range(T - 1):
+        L.check(lib.rr_rmtvrp_step(L.ptr(acts[k]), L.ptr(Dc), L.ptr(Tc), L.ptr(d0), L.ptr(t0), L.ptr(dl), L.ptr(twc), L.ptr(sv),
+                                   L.ptr(vcap), L.ptr(cur), L.ptr(ctime), L.ptr(rlen), L.ptr(used), L.ptr(vis), L.ptr(masks[k]),
+                                   L.ptr(done), R, b, N1, extra, L.stream()), "rr_rmtvrp_step")
+        times[k] = ctime
+        if variant is None:
+            rems[k] = cap - used
+        else:
+            rems[k] = cap - torch.where(ub == 0, used, ub)
+            rds[k] = rlen
+    view = lambda t: t.view(T - 1, S, b).permute(2, 1, 0)                          # noqa: E731  -> [b, S, T-1]
+    if variant is None:
+        opn, rd = torch.zeros(b, S, T - 1, device=dev), torch.full((b, S, T - 1), 10.0, device=dev)
+    else:
+        limr = lim.repeat(S)[None, :]                                              # [1, R]: r = s * b + instance
+        rd = view(torch.where(torch.isfinite(limr), limr - rds, torch.full_like(rds, 10.0)))
+        opn = keep[1].float()[:, None, None].expand(b, S, T - 1)
+    return view(rems), view(times), opn, rd, masks.view(T - 1, S, b, N1).permute(2, 1, 0, 3).bool()
+
+
 def decode_log_likelihood_rcvrptw(P, row_emb, col_emb, D, Dur, demand_l, tw, service, actions, tanh_clipping=10.0, temperature=1.0,
-                                  variant=None):
+                                  variant=None, states=None):
     """Teacher-forced decoder for RCVRPTW / RMTVRP: MTVRPContextEmbedding (context.py:34-70: [emb[cur]; available load, current
     time, open route, remaining distance (10 without a limit)]), bias alpha*D[cur] + beta*Dur[cur] (decoder.py:187-190)."""
     b, S, T = actions.shape
     N1 = row_emb.shape[1]
     Td = T - 1
-    rem, tm, opn, rd, mask = rcvrptw_replay_states(D, Dur, demand_l, tw, service, actions, variant=variant)
+    rem, tm, opn, rd, mask = states if states is not None else rcvrptw_replay_states(D, Dur, demand_l, tw, service, actions, variant=variant)
     k, v, lk = F.linear(col_emb, P["decoder.project_node_embeddings.weight"]).chunk(3, dim=-1)
     Wc = P["decoder.context_embedding.project_context.weight"]                  # [E, E+4]
     ctx_cur = F.linear(row_emb, Wc[:, :E])
@@ -381,7 +492,7 @@ def replay_backward(policy, td, actions, num_starts, grad_ll, sample_idx, enc_ch
         raise NotImplementedError(f"gradient replay for env '{policy.env_name}'")
     vrp, vtw = policy.env_name == "rcvrp", policy.env_name == "rcvrptw"
     if dec_chunk is None:      # instances per teacher-forced decoder evaluation: measured optimum (tools/bench_train.py --dec-chunk);
-        dec_chunk = 32 if vtw else 256      # RCVRPTW routes are ~1.8 N steps long and its masked attention scales worse
+        dec_chunk = 64 if vtw else 256      # RCVRPTW routes are ~1.8 N steps long: 4x the rows per instance
     P = dict(policy.named_parameters())
     nl = 1 + max(int(n.split(".")[3]) for n in P if n.startswith("encoder.net.layers."))
     D, locs = td["distance_matrix"].float(), td["locs"].float()
@@ -403,12 +514,17 @@ def replay_backward(policy, td, actions, num_starts, grad_ll, sample_idx, enc_ch
     acts = actions.view(S, B, actions.shape[-1]).transpose(0, 1)  # [B,S,T]
     gll = grad_ll.view(S, B).transpose(0, 1)
     ll_out = torch.empty(B, S, device=D.device)
+    vstates = None
+    if vtw:      # the env replay is data (no gradient) and ~40 tiny launches per decode step: once for the whole shard, not per chunk
+        with torch.no_grad():
+            replay = rcvrptw_replay_states_hip if D.is_cuda else rcvrptw_replay_states      # (CPU: the oracle-side unit tests)
+            vstates = replay(D, Dur, dl_full, tw, service, acts, variant=variant)
     with torch.enable_grad():
         for lo in range(0, B, enc_chunk):
             hi = min(B, lo + enc_chunk)
             # activation checkpointing only where the block is memory-heavy: the duration NAB's [b,N,N,E] tensors (RCVRPTW);
             # the ATSP / RCVRP blocks keep ~10 GB of activations per 512 instances, which a 288 GB device does not notice
-            row, col = encode(P, locs[lo:hi], D[lo:hi], sample_idx[lo:hi], nl, use_checkpoint=vtw,
+            row, col = encode(P, locs[lo:hi], D[lo:hi], sample_idx[lo:hi], nl, use_checkpoint=False,
                               demand=demand[lo:hi] if (vrp or vtw) else None,
                               extra=extra[lo:hi] if vtw else None, dur=Dur[lo:hi] if vtw else None)
             row_d, col_d = row.detach().requires_grad_(), col.detach().requires_grad_()
@@ -417,7 +533,7 @@ def replay_backward(policy, td, actions, num_starts, grad_ll, sample_idx, enc_ch
                 if vtw:
                     ll = decode_log_likelihood_rcvrptw(P, row_d[a - lo:z - lo], col_d[a - lo:z - lo], D[a:z], Dur[a:z], dl_full[a:z],
                                                        tw[a:z], service[a:z], acts[a:z], policy.tanh_clipping, policy.temperature,
-                                                       variant=None if variant is None else {k: u[a:z] for k, u in variant.items()})
+                                                       states=tuple(u[a:z] for u in vstates))
                 elif vrp:
                     ll = decode_log_likelihood_rcvrp(P, row_d[a - lo:z - lo], col_d[a - lo:z - lo], D[a:z], demand[a:z], acts[a:z],
                                                      policy.tanh_clipping, policy.temperature)
