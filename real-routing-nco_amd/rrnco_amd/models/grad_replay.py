@@ -315,13 +315,36 @@ def rcvrp_replay_states(demand, actions, cap=1.0):
     return torch.stack(rem, 2), torch.stack(masks, 2)
 
 
-def decode_log_likelihood_rcvrp(P, row_emb, col_emb, D, demand, actions, tanh_clipping=10.0, temperature=1.0):
+def rcvrp_replay_states_hip(demand, actions, cap=1.0):
+    """The same replay on the env's own step kernel (rr_rcvrp_step): one launch per decode step for all b * S routes."""
+    b, S, T = actions.shape
+    N = demand.shape[1]
+    dev = demand.device
+    R = b * S
+    lib = L.lib()
+    dem = demand.contiguous()
+    acts = actions.permute(2, 1, 0).reshape(T, R).contiguous()                    # step-major, r = s * b + instance
+    vcap = torch.full((R,), float(cap), device=dev)
+    used = torch.zeros(R, device=dev)
+    vis = torch.zeros(R, N + 1, dtype=torch.uint8, device=dev)
+    cur = torch.empty(R, dtype=torch.int64, device=dev)
+    done = torch.empty(R, dtype=torch.uint8, device=dev)
+    masks = torch.empty(T - 1, R, N + 1, dtype=torch.uint8, device=dev)
+    rems = torch.empty(T - 1, R, device=dev)
+    for k in range(T - 1):
+        L.check(lib.rr_rcvrp_step(L.ptr(acts[k]), L.ptr(dem), L.ptr(vcap), L.ptr(used), L.ptr(vis), L.ptr(masks[k]), L.ptr(cur),
+                                  L.ptr(done), R, b, N, L.stream()), "rr_rcvrp_step")
+        rems[k] = cap - used
+    return rems.view(T - 1, S, b).permute(2, 1, 0), masks.view(T - 1, S, b, N + 1).permute(2, 1, 0, 3).bool()
+
+
+def decode_log_likelihood_rcvrp(P, row_emb, col_emb, D, demand, actions, tanh_clipping=10.0, temperature=1.0, states=None):
     """Teacher-forced decoder for RCVRP (rl4co VRPContext: Linear(E+1,E)([emb[cur]; capacity - used]); routes of different
     lengths are padded with depot visits, whose log-probability is 0 once everything is served).  actions [b,S,T]."""
     b, S, T = actions.shape
     N1 = row_emb.shape[1]
     Td = T - 1
-    rem, mask = rcvrp_replay_states(demand, actions)
+    rem, mask = states if states is not None else rcvrp_replay_states(demand, actions)
     k, v, lk = F.linear(col_emb, P["decoder.project_node_embeddings.weight"]).chunk(3, dim=-1)
     Wc = P["decoder.context_embedding.project_context.weight"]                  # [E, E+1]
     ctx_cur = F.linear(row_emb, Wc[:, :E])
@@ -519,6 +542,9 @@ def replay_backward(policy, td, actions, num_starts, grad_ll, sample_idx, enc_ch
         with torch.no_grad():
             replay = rcvrptw_replay_states_hip if D.is_cuda else rcvrptw_replay_states      # (CPU: the oracle-side unit tests)
             vstates = replay(D, Dur, dl_full, tw, service, acts, variant=variant)
+    elif vrp:
+        with torch.no_grad():
+            vstates = (rcvrp_replay_states_hip if D.is_cuda else rcvrp_replay_states)(demand, acts)
     with torch.enable_grad():
         for lo in range(0, B, enc_chunk):
             hi = min(B, lo + enc_chunk)
@@ -536,7 +562,7 @@ def replay_backward(policy, td, actions, num_starts, grad_ll, sample_idx, enc_ch
                                                        states=tuple(u[a:z] for u in vstates))
                 elif vrp:
                     ll = decode_log_likelihood_rcvrp(P, row_d[a - lo:z - lo], col_d[a - lo:z - lo], D[a:z], demand[a:z], acts[a:z],
-                                                     policy.tanh_clipping, policy.temperature)
+                                                     policy.tanh_clipping, policy.temperature, states=tuple(u[a:z] for u in vstates))
                 else:
                     ll = decode_log_likelihood(P, row_d[a - lo:z - lo], col_d[a - lo:z - lo], D[a:z], acts[a:z],
                                                policy.tanh_clipping, policy.temperature)
