@@ -452,7 +452,9 @@ if __name__ == "__main__":
     if "matnet_policy" in which:     # the whole MatNet baseline policy on ATSP (encoder + AM decoder + in-tree decoding loop)
         gen_matnet_policy("matnet_policy_atsp_n20_b4", B=4, N=20, S=20, seed=91, layers=3)
         gen_matnet_policy("matnet_policy_atsp_n50_b2", B=2, N=50, S=50, seed=92, layers=2)
+        gen_matnet_policy("matnet_policy_atsp_n100_b2", B=2, N=100, S=100, seed=95, layers=2)
     if "matnet_policy_rcvrp" in which:
         gen_matnet_policy_rcvrp("matnet_policy_rcvrp_n20_b4", B=4, N=20, S=20, seed=93, layers=3)
         gen_matnet_policy_rcvrp("matnet_policy_rcvrp_n50_b2", B=2, N=50, S=50, seed=94, layers=2)
+        gen_matnet_policy_rcvrp("matnet_policy_rcvrp_n100_b2", B=2, N=100, S=101, seed=96, layers=2)
 

@@ -502,7 +502,7 @@ def test_state_augmentation_matches_reference_functions():
         StateAugmentation(augment_fn="nope")
 
 
-@pytest.mark.parametrize("name", ["matnet_policy_atsp_n20_b4", "matnet_policy_atsp_n50_b2"])
+@pytest.mark.parametrize("name", ["matnet_policy_atsp_n20_b4", "matnet_policy_atsp_n50_b2", "matnet_policy_atsp_n100_b2"])
 def test_oracle_matnet_policy_reproduces_reference_golden(name):
     """The whole MatNet baseline policy on ATSP (oracle/restate.matnet_policy_atsp) against the reference's MatNetPolicy.forward
     (in-tree policy / decoder / decoding code over the recalled rl4co AttentionModelDecoder base): tours bit-exact, including the
@@ -519,7 +519,7 @@ def test_oracle_matnet_policy_reproduces_reference_golden(name):
     assert {k: tuple(v.shape) for k, v in pol.state_dict().items()} == restate.matnet_policy_template(256, 16, fx["layers"], 512, "atsp")
 
 
-@pytest.mark.parametrize("name", ["matnet_policy_rcvrp_n20_b4", "matnet_policy_rcvrp_n50_b2"])
+@pytest.mark.parametrize("name", ["matnet_policy_rcvrp_n20_b4", "matnet_policy_rcvrp_n50_b2", "matnet_policy_rcvrp_n100_b2"])
 def test_oracle_matnet_policy_rcvrp_reproduces_reference_golden(name):
     fx = H.load_fixture(name)
     w = restate.make_weights(restate.matnet_policy_template(fx["embed_dim"], fx["heads"], fx["layers"], 512, "rcvrp"), fx["seed"])

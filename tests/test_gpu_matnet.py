@@ -62,7 +62,7 @@ def test_matnet_encoder_rejects_what_it_does_not_implement():
         enc({"distance_matrix": torch.rand(2, 10, 10)})          # CPU tensors: there is no CPU path
 
 
-@pytest.mark.parametrize("name", ["matnet_policy_atsp_n20_b4", "matnet_policy_atsp_n50_b2"])
+@pytest.mark.parametrize("name", ["matnet_policy_atsp_n20_b4", "matnet_policy_atsp_n50_b2", "matnet_policy_atsp_n100_b2"])
 def test_matnet_policy_tours_match_reference(name):
     """MatNetPolicy end to end on ATSP (HIP encoder, rr_matnet_linear / rr_matnet_dec_step decoder, rr_select_matnet with the
     baseline's clamped process_logits, rr_atsp_step) against the reference's MatNetPolicy.forward.  The clamp makes every action
@@ -98,7 +98,7 @@ def test_matnet_policy_tours_match_reference(name):
             assert float(top[0] - top[1]) < 1.2e-3
 
 
-@pytest.mark.parametrize("name", ["matnet_policy_rcvrp_n20_b4", "matnet_policy_rcvrp_n50_b2"])
+@pytest.mark.parametrize("name", ["matnet_policy_rcvrp_n20_b4", "matnet_policy_rcvrp_n50_b2", "matnet_policy_rcvrp_n100_b2"])
 def test_matnet_policy_rcvrp_routes_match_reference(name):
     """MatNetPolicy on RCVRP, the environment configs/experiment/matnet.yaml trains on (RVRPInitEmbedding without coordinates,
     rl4co VRPContext, RCVRPEnv masks), against the reference's MatNetPolicy.forward."""
