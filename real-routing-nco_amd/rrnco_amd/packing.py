@@ -4,6 +4,7 @@ Nothing here touches per-instance data; it runs once per set of weights (cached 
 """
 from __future__ import annotations
 
+import contextlib
 import math
 
 import torch
@@ -48,6 +49,26 @@ def pack_a_bf16x3(Wm: torch.Tensor) -> torch.Tensor:
         x = piece.view(M // 16, 16, K // 32, 2, 4, 4)            # t, i, s, half, g, e4
         out.append(x.permute(0, 2, 4, 1, 3, 5).reshape(M // 16, K // 32, 64, 8))     # t, s, (g, i), (half, e4)
     return torch.stack(out, dim=2).contiguous()                  # [t][s][piece][lane][8]
+
+
+
+@contextlib.contextmanager
+def _few_threads():
+    """The folds are a few hundred small float64 host ops.  On a many-core host (128 intra-op threads on the MI355X boxes)
+    the per-op fork/join of the BLAS / intra-op pools costs 15x the arithmetic (397 -> 26 ms per repack of the RCVRPTW
+    policy), and the repack runs after every optimizer step: run them single-threaded."""
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        try:
+            from threadpoolctl import threadpool_limits
+        except ImportError:          # optional: only numpy's BLAS pool is left unlimited without it
+            yield
+        else:
+            with threadpool_limits(limits=1):
+                yield
+    finally:
+        torch.set_num_threads(n)
 
 
 def fold_nab(sd, p: str, alpha: torch.Tensor) -> torch.Tensor:
@@ -151,7 +172,17 @@ def eval_nab_pwl(tab: torch.Tensor, dmat: torch.Tensor, theta: torch.Tensor) -> 
 def fold_nab_dur(sd, p: str, alpha: torch.Tensor, ar) -> "L.NabDurW":
     """DistAngleFusion with duration (attn_freenet.py:226-237, 265-286): fold every second MLP layer into the gate's
     first Linear (M_x = Wg0_x W2_x) and into out_lin (co_x = W2_x^T wo), in float64; see csrc/rr_encoder.hip:k_nab_dur."""
-    d = lambda k: sd[p + k].detach().double().cpu()  # noqa: E731
+    names = [".out_lin.weight", ".out_lin.bias", ".gate.0.weight", ".gate.0.bias", ".gate.2.weight", ".gate.2.bias",
+             ".gate_temperature"] + [f".{nm}.{l}.{wb}" for nm in ("dist_emb", "angle_emb", "dur_emb") for l in (0, 2)
+                                     for wb in ("weight", "bias")]
+    # ONE device-to-host copy for the module (this runs after every optimizer step; per-tensor .cpu() calls each synchronise)
+    flat = torch.cat([sd[p + k].detach().reshape(-1).double() for k in names]).cpu()
+    host, off = {}, 0
+    for k in names:
+        n = sd[p + k].numel()
+        host[k] = flat[off:off + n].view(sd[p + k].shape)
+        off += n
+    d = host.__getitem__
     wo, bo = d(".out_lin.weight")[0], d(".out_lin.bias")[0]
     Wg0, bg0 = d(".gate.0.weight"), d(".gate.0.bias")
     Ms, cos, kos, a_, b_ = [], [], [], [], []
@@ -215,22 +246,24 @@ def fold_nab_dur_pwl(Ms, cg, cos, kos, a_, b_) -> torch.Tensor:
         t = np.sort(-b[nz] / a[nz])
         nb = len(t)
         ts[f, :nb] = t
-        for m in range(NABD_SEG):
-            mm = min(m, nb)
-            if nb == 0:
-                xm, an = 0.0, 0.0
-            elif mm == 0:
-                xm, an = t[0] - 1.0, t[0]
-            elif mm == nb:
-                xm, an = t[nb - 1] + 1.0, t[nb - 1]
-            else:
-                xm, an = 0.5 * (t[mm - 1] + t[mm]), t[mm - 1]
-            act = (a * xm + b) > 0
-            h = np.maximum(a * an + b, 0.0)
-            rows[f, m, 0] = M @ h + (cg if f == 0 else 0.0)
-            rows[f, m, 1] = M[:, act] @ a[act]
-            osc[(f * NABD_SEG + m) * 2] = co @ h + kos[f]; osc[(f * NABD_SEG + m) * 2 + 1] = np.sum(co[act] * a[act])
-            anc[f, m] = an
+        # all 129 segments at once (this runs after every optimizer step).  Segment m: probe point inside it -> active units ->
+        # slope; anchor breakpoint -> value.  Segments beyond the family's nb breakpoints repeat the last one.
+        mm = np.minimum(np.arange(NABD_SEG), nb)
+        if nb == 0:
+            xm, an = np.zeros(NABD_SEG), np.zeros(NABD_SEG)
+        else:
+            lo_ = t[np.clip(mm - 1, 0, nb - 1)]
+            hi_ = t[np.clip(mm, 0, nb - 1)]
+            xm = np.where(mm == 0, t[0] - 1.0, np.where(mm == nb, t[nb - 1] + 1.0, 0.5 * (lo_ + hi_)))
+            an = np.where(mm == 0, t[0], lo_)
+        act = (a[None, :] * xm[:, None] + b[None, :]) > 0                          # [129, 128]
+        h = np.maximum(a[None, :] * an[:, None] + b[None, :], 0.0)
+        rows[f, :, 0] = h @ M.T + (cg if f == 0 else 0.0)
+        rows[f, :, 1] = (act * a[None, :]) @ M.T
+        oscv = osc[:3 * NABD_SEG * 2].reshape(3, NABD_SEG, 2)                      # a view: (F_o, S_o) pairs
+        oscv[f, :, 0] = h @ co + kos[f]
+        oscv[f, :, 1] = (act * (co * a)[None, :]).sum(1)
+        anc[f, :NABD_SEG] = an
         # grid start bounds, same construction as nab_grid_cells (float32 breakpoints as the kernel sees them)
         t32 = ts[f, :128].astype(np.float32).astype(np.float64)
         t32 = t32[np.isfinite(t32)]
@@ -265,6 +298,11 @@ class _Arena:
 
 
 def pack_policy(sd: dict, env_name: str, device) -> dict:
+    with _few_threads():
+        return _pack_policy(sd, env_name, device)
+
+
+def _pack_policy(sd: dict, env_name: str, device) -> dict:
     """state_dict (reference names) -> ctypes structs for the kernels."""
     ar = _Arena(device)
     split = mlp_split_enabled()          # the bf16 split copies are only built when the opt-in switch is on at pack time
