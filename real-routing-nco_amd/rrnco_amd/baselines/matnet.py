@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib as L
-from ..packing import pack_a
+from ..packing import pack_a, weights_fingerprint
 
 
 class _MixedScoresSDPA(nn.Module):
@@ -108,7 +108,8 @@ class MatNetEncoder(nn.Module):
 
     # ---- MFMA-ordered weights, rebuilt when any parameter changes
     def packed(self, device):
-        key = (str(device), tuple(p._version for p in self.parameters()), tuple(p.data_ptr() for p in self.parameters()))
+        key = (str(device), tuple(p._version for p in self.parameters()), tuple(p.data_ptr() for p in self.parameters()),
+               weights_fingerprint(self))
         if self._pack_cache is None or self._pack_cache[0] != key:
             self._pack_cache = (key, self._pack(device))
         return self._pack_cache[1]
@@ -236,7 +237,8 @@ class MatNetDecoder(nn.Module):
         self._pack_cache = None
 
     def packed(self, device):
-        key = (str(device), tuple(p._version for p in self.parameters()), tuple(p.data_ptr() for p in self.parameters()))
+        key = (str(device), tuple(p._version for p in self.parameters()), tuple(p.data_ptr() for p in self.parameters()),
+               weights_fingerprint(self))
         if self._pack_cache is None or self._pack_cache[0] != key:
             E = self.embed_dim
             f = lambda t: pack_a(t.detach().float()).to(device).contiguous()          # noqa: E731

@@ -36,10 +36,13 @@ class RRNetPolicy(nn.Module):
             train_decode_type, val_decode_type, test_decode_type
         self._pack_cache = None
 
-    # ---- packed (MFMA-ordered / folded) weights, rebuilt when any parameter changes
+    # ---- packed (MFMA-ordered / folded) weights, rebuilt when any parameter changes (versions + packing.weights_fingerprint)
+    def invalidate_pack(self) -> None:
+        self._pack_cache = None
+
     def packed(self, device):
         key = (str(device), packing.mlp_split_enabled(), tuple(p._version for p in self.parameters()),
-               tuple(p.data_ptr() for p in self.parameters()))
+               tuple(p.data_ptr() for p in self.parameters()), packing.weights_fingerprint(self))
         if self._pack_cache is None or self._pack_cache[0] != key:
             self._pack_cache = (key, packing.pack_policy(self.state_dict(), self.env_name, device))
         return self._pack_cache[1]

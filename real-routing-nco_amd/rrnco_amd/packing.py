@@ -14,6 +14,15 @@ from . import _lib as L
 E = 128
 
 
+@torch.no_grad()
+def weights_fingerprint(module) -> tuple:
+    """Per-parameter L2 norms (one multi-tensor launch, one host read) for the pack caches.  Version counters alone are not
+    enough: fused optimizers (torch.optim.Adam(fused=True)) update the parameters in place WITHOUT bumping `_version`, and a
+    stale pack would silently roll out with the previous weights."""
+    ps = [q for q in module.parameters() if q.is_floating_point()]
+    return tuple(torch.stack(torch._foreach_norm(ps)).tolist()) if ps else ()
+
+
 def pack_a(Wm: torch.Tensor) -> torch.Tensor:
     """[M,K] -> [M/16, K/16, 64, 4] float32: lane (i = l&15, g = l>>4) of tile t, k-group kk holds
     W[16t+i][16kk+4g+m], m = 0..3 (csrc/rr_common.h).  M, K zero-padded to multiples of 16."""

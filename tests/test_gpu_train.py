@@ -83,6 +83,30 @@ def test_optimizer_steps_change_the_policy_and_repack():
     assert pol.packed(torch.device("cuda")) is not packed0
 
 
+def test_fused_optimizer_updates_are_seen_by_the_pack_cache():
+    """torch.optim.Adam(fused=True) updates parameters in place without bumping their version counters; the pack cache must
+    still notice (packing.weights_fingerprint), or the next rollout would silently use the previous weights."""
+    fx = H.load_fixture("atsp_n20_b4_pomo")
+    w, pol, model, st, td_in = _model(fx)
+    opt = torch.optim.Adam(pol.parameters(), lr=1e-3, fused=True)
+    dev = torch.device("cuda")
+    packed0 = pol.packed(dev)
+    model.training_step(td_in, optimizer=opt, seed=7)
+    assert pol.packed(dev) is not packed0
+    assert pol.packed(dev) is pol.packed(dev)              # and it is stable again afterwards
+    # the two optimizers agree, so a rollout after the fused step equals one after the plain step
+    w2, pol2, model2, st2, td2 = _model(fx)
+    opt2 = torch.optim.Adam(pol2.parameters(), lr=1e-3)
+    model2.training_step(td2, optimizer=opt2, seed=7)
+    pol.eval(); pol2.eval()
+    env = model.env
+    with torch.no_grad():
+        a = pol(env.reset(td_in), env, phase="test", decode_type="multistart_greedy", num_starts=20)
+        b = pol2(env.reset(td2), env, phase="test", decode_type="multistart_greedy", num_starts=20)
+    same = (a["reward"] - b["reward"]).abs() < 1e-4          # greedy tours may flip at near-ties between the two optimizers
+    assert float(same.float().mean()) > 0.9
+
+
 def test_nab_training_kernels_match_the_torch_formula():
     """csrc/rr_train.hip: forward value and d loss / d (folded table) of the gating NAB against the same formula in torch ops."""
     from rrnco_amd import _lib as L

@@ -44,7 +44,7 @@ else:
     env = RCVRPEnv(generator_params=gp, check_solution=False, device=dev) if args.problem == "rcvrp" else RMTVRPEnv(generator_params=gp, device=dev)
 pol.train()
 model = RRNet(env, policy=pol)
-opt = torch.optim.Adam(pol.parameters(), lr=1e-4)
+opt = torch.optim.Adam(pol.parameters(), lr=1e-4, fused=True)
 gen = torch.Generator(device=dev).manual_seed(1234 + rank)
 batches = [env.generator(args.batch, generator=gen) for _ in range(args.steps + 1)]
 out = model.training_step(batches[0], optimizer=opt, world=world, enc_chunk=args.enc_chunk, dec_chunk=args.dec_chunk, seed=1)

@@ -10,7 +10,7 @@ dev = torch.device("cuda")
 pol, w = bench.make_policy(dev); pol.train()
 env = ATSPEnv(generator_params=dict(num_loc=100, device=dev), check_solution=False, device=dev)
 model = RRNet(env, policy=pol)
-opt = torch.optim.Adam(pol.parameters(), lr=1e-4)
+opt = torch.optim.Adam(pol.parameters(), lr=1e-4, fused=True)
 gen = torch.Generator(device=dev).manual_seed(1)
 B = int(os.environ.get("PB", "512"))
 for i in range(2):

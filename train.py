@@ -61,7 +61,7 @@ def main(argv=None):
            "rcvrp": lambda: RCVRPEnv(check_solution=False, generator_params=gp, device=dev),
            "rcvrptw": lambda: RMTVRPEnv(generator_params=gp, device=dev)}[o.problem]()
     model = RRNet(env, policy=policy)
-    opt = torch.optim.Adam(policy.parameters(), lr=o.lr, weight_decay=o.weight_decay)
+    opt = torch.optim.Adam(policy.parameters(), lr=o.lr, weight_decay=o.weight_decay, fused=True)   # one launch per step, same update
     sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=o.milestones, gamma=o.gamma)
     start_epoch = 0
     if o.resume:
