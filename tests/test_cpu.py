@@ -530,3 +530,22 @@ def test_oracle_matnet_policy_rcvrp_reproduces_reference_golden(name):
     assert torch.equal(out["actions"][:, :T], fx["actions"][:, :T])
     assert torch.allclose(out["reward"], fx["reward"], atol=1e-4) and torch.allclose(out["log_likelihood"], fx["log_likelihood"], atol=1e-3)
 
+
+
+def test_pack_cache_fingerprint_sees_in_place_updates_without_version_bumps():
+    """Fused optimizers write parameters in place without bumping `_version` (the first key of the pack cache); the second key,
+    packing.weights_fingerprint, must change with them and must be stable when nothing changed."""
+    from rrnco_amd import packing
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Linear(8, 4))
+    f0 = packing.weights_fingerprint(m)
+    assert f0 == packing.weights_fingerprint(m) and len(f0) == 4
+    v0 = [p._version for p in m.parameters()]
+    with torch.no_grad():
+        torch._foreach_mul_([p.data for p in m.parameters()], 1.01)      # in place through .data: versions stay
+    assert [p._version for p in m.parameters()] == v0
+    assert packing.weights_fingerprint(m) != f0
+    n = torch.get_num_threads()
+    with packing._few_threads():
+        assert torch.get_num_threads() == 1
+    assert torch.get_num_threads() == n
