@@ -20,7 +20,12 @@ def weights_fingerprint(module) -> tuple:
     enough: fused optimizers (torch.optim.Adam(fused=True)) update the parameters in place WITHOUT bumping `_version`, and a
     stale pack would silently roll out with the previous weights."""
     ps = [q for q in module.parameters() if q.is_floating_point()]
-    return tuple(torch.stack(torch._foreach_norm(ps)).tolist()) if ps else ()
+    if not ps:
+        return ()
+    norms = torch._foreach_norm(ps)
+    if len({(n.dtype, n.device) for n in norms}) > 1:      # mixed precision / devices: bring the scalars together first
+        norms = [n.to(device=norms[0].device, dtype=torch.float64) for n in norms]
+    return tuple(torch.stack(norms).tolist())
 
 
 def pack_a(Wm: torch.Tensor) -> torch.Tensor:
