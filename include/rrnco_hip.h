@@ -67,6 +67,10 @@ typedef struct {                /* arguments of the persistent rollout: see csrc
   const float *dist_limit;      /* [Bp] (+inf = none) */
   const float *demand_b;        /* [Bp][N] demand_backhaul incl. the depot zero */
   const int32_t *bclass;        /* [Bp] backhaul class 1 / 2 */
+  /* training dump (NULL / 0 otherwise), row m = (b*dumpT + step)*S + s per decoder evaluation: pointer-MLP input g0 and
+   * output g [m][128], meta [m][8] = 4 action-mask words seen, node decided at, node chosen, live flag, 0; VRP state
+   * scalars scal [m][4] (context.py:51-70).  Consumed by rr_dec_* below (the REINFORCE backward of decoder.py:151-329). */
+  float *dump_g0, *dump_g; uint32_t *dump_meta; float *dump_scal; int dumpT;
 } RolloutIO;
 
 /* ATSPEnv._reset / RCVRPEnv._reset / RMTVRPEnv._reset min-max normalisation
@@ -169,6 +173,47 @@ int rr_submatrix_gather(const float* dist, const float* dur, const int64_t* idx,
 int rr_nab_train_fwd(const float* tab, const float* xd, const float* xa, float* out, long M, hipStream_t stream);
 int rr_nab_train_bwd(const float* tab, const float* xd, const float* xa, const float* gout, float* grad_tab, long M,
                      hipStream_t stream);
+
+/* ---- hand-written backward of the REINFORCE step's decoder (csrc/rr_train_dec.hip) ------------------------------------
+ * Replaces what Lightning autograd does for rrnco/models/rl.py:118-128 through rrnco/models/decoder.py:151-329
+ * (RRNetDecoder.forward, RRNet_PointerAttention) and rrnco/models/decoding.py:311-361 (process_logits).  Rows are the
+ * decoder evaluations the sampling rollout dumped (RolloutIO::dump_*): instance b owns rows b*seg_stride + t*S + s. */
+typedef struct {
+  const float *g; const uint32_t *meta; const float *L, *Lt, *D, *Dur, *gll;   /* Lt: [Bp][128][112] zero padded; gll [S*Bp] */
+  float *dlg, *dg, *logp, *dscal;     /* dlg [rows][112], dg [rows][128], logp [rows], dscal[2] += d alpha, d beta */
+  int Bp, N, S, T; long long seg_stride;
+  float alpha, beta, tanh_clip, temperature;
+} DecLogitIO;
+/* logits = g L^T / sqrt(E), inductive bias, log(exp + 1e-6), 10 tanh, mask, log-softmax (decoder.py:186-198, 300-302;
+ * decoding.py:341-361): the chosen node's log-probability per row, d logits and d g. */
+int rr_dec_logit_bwd(const DecLogitIO* io, hipStream_t stream);
+
+/* C[b][p][q] (+)= sum_m A[b][m][p] B[b][m][q], q < 128: d logit keys (dlg^T g per instance) and the weight gradient of a
+ * Linear layer (dY^T X).  msplit > 1 or accumulate != 0: float atomics into C (caller zeroes it). */
+int rr_gemm_tn(const float* A, const float* B, float* C, int batch, int Mb, int P, int lda, int ldb, int ldc,
+               long long strideA, long long strideB, long long strideC, int msplit, int accumulate, hipStream_t stream);
+
+typedef struct { const void *wa1, *wa2, *wb; const float *b1, *b2; } MlpRowsW;   /* packing.pack_mlp_train */
+typedef struct { const void *w1n, *w2tn; const float *b1; } MlpWgradW;
+/* The 128 -> 512 -> 128 ReLU MLP with residual on rows (pointer MLP decoder.py:272-277, 296; TransformerFFN
+ * attn_freenet.py:330-357) on the bf16 matrix pipe with two-piece split fp32 operands:
+ * mode 0: out = x + W2 relu(W1 x + b1) + b2;  mode 1: out = dy + W1^T[(W2^T dy) . 1(W1 x + b1 > 0)].
+ * Rows: nseg segments of seg_rows rows, seg_stride rows apart. */
+int rr_mlp_rows(const MlpRowsW* w, int mode, const float* X, const float* dY, float* out, int nseg, int seg_rows,
+                long long seg_stride, hipStream_t stream);
+/* dW1 [512][128], db1 [512], dW2 [128][512], db2 [128] of that MLP from (x, dy); ADDED to (caller zeroes). */
+int rr_mlp_wgrad(const MlpWgradW* w, const float* X, const float* dY, float* dW1, float* db1, float* dW2, float* db2,
+                 int nseg, int seg_rows, long long seg_stride, hipStream_t stream);
+
+typedef struct {
+  const float *dg0; const uint32_t *meta; const float *scal; const int64_t *first;
+  const float *K, *V, *Kt, *ctxA, *ctxB, *wstate;     /* Kt [Bp][128][112] zero padded; wstate [nscal][128] */
+  float *dK, *dV, *dctxA, *dctxB, *dwstate;           /* [Bp][N][128] written; dwstate [nscal][128] added to */
+  int Bp, N, S, T, nscal; long long seg_stride;
+} DecAttnIO;
+/* Masked multi-head attention of the pointer (decoder.py:281-323) backward: d keys, d values, and d query scattered into
+ * the step-context tables (rl4co TSPContext / VRPContext, env_embeddings/context.py:34-70). */
+int rr_dec_attn_bwd(const DecAttnIO* io, hipStream_t stream);
 
 /* POMO shared-baseline REINFORCE loss, forward half + d loss / d log-likelihood
  * (rrnco/models/rl.py:112-128; in-tree formula rrnco/baselines/routefinder/model.py:182-202). reward / ll / adv /

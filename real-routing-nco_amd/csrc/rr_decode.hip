@@ -63,6 +63,13 @@ struct RolloutIO {
   const float* dist_limit;
   const float* demand_b;
   const int32_t* bclass;
+  // Training dump (all NULL / 0 outside a training step): per decoder evaluation (instance b, step, start s), row
+  // m = (b*dumpT + step)*S + s, what the hand-written backward (csrc/rr_train_dec.hip) needs and the rollout has in registers
+  // anyway: the glimpse input of the pointer MLP g0 [m][128], its output g [m][128], and meta [m][8] = the 4 action-mask
+  // words the decision saw, the node it was taken at, the chosen node, 1 if the row is live (not a finished / padding
+  // rollout), 0; VRP: the step-context state scalars scal [m][4] (available load, current time, open route, remaining distance).
+  float* dump_g0; float* dump_g; uint32_t* dump_meta; float* dump_scal;
+  int dumpT;
 };
 
 template <int NT, int PROB>  // PROB 0 = ATSP, 1 = RCVRP

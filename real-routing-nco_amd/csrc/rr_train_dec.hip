@@ -1,0 +1,893 @@
+// Hand-written backward of the REINFORCE step's decoder (BASELINE configs[4]): everything
+// rrnco/models/rl.py:118-128 differentiates through rrnco/models/decoder.py:151-329 (RRNetDecoder.forward,
+// RRNet_PointerAttention) and rrnco/models/decoding.py:311-361 (process_logits) for the sampled tours.
+//
+// The sampling rollout (csrc/rr_rollout_w.inc) leaves, per decoder evaluation m = (instance b, step t, start s), what it
+// had in registers anyway: the pointer-MLP input g0[m][128] (glimpse + query, decoder.py:294), its output g[m][128]
+// (:296), the action-mask words the decision saw, the node it was taken at, the node chosen (RolloutIO::dump_*).  With those
+// the backward is five row-parallel kernels, none of which replays the environment and none of which is problem specific:
+//
+//   k_dec_logit_bwd   per 16-row tile: logits = g L^T / sqrt(E) (fp32 MFMA), inductive bias, log / 10 tanh / mask /
+//                     log-softmax exactly as the rollout computed them, the row's log-probability (the replayed
+//                     log-likelihood), d logits (-> dlg[m][112]) and dg = dlg L (fp32 MFMA); d alpha / d beta.
+//   k_gemm_tn         dL[b] = dlg_b^T g_b: batched "TN" GEMM with the row index as the MFMA k dimension (also the weight
+//                     gradient of every Linear layer: dW = dY^T X).
+//   k_mlp_rows<1>     dg0 = dg + W1^T [ (W2^T dg) . 1(W1 g0 + b1 > 0) ]: the pointer MLP's input gradient, on the bf16 matrix
+//                     pipe with every fp32 operand split in two bf16 pieces (hi + lo, three partial products, error 2^-16 of
+//                     a product; the fp32 MFMA is 1/16 of that rate), weights shared by the workgroup through LDS-DMA stages.
+//   k_mlp_wgrad       dW1, db1, dW2, db2 from (g0, dg): recomputes the hidden tile it owns, products with the ROW index on the
+//                     MFMA k axis from transposed LDS images.
+//   k_dec_attn_bwd    masked multi-head attention backward, one (instance, head) per workgroup so that K_h, V_h, K_h^T and
+//                     the dK_h / dV_h accumulators stay in registers over all rows of the instance; d query scattered to the
+//                     step-context tables (ctxA[first], ctxB[current]) through LDS float atomics.
+#include "rr_common.h"
+
+#define TD_NT 7
+#define TD_LDK 112          // padded key count: dlg rows, K^T / L^T rows
+
+// rows of one launch: nseg segments (instances) of seg_rows live rows each, seg_stride rows apart
+struct RowSegs { int nseg; int seg_rows; long long seg_stride; };
+__device__ __forceinline__ long long td_row(const RowSegs& rs, long long i) {
+  const long long sg = i / rs.seg_rows;
+  return sg * rs.seg_stride + (i - sg * rs.seg_rows);
+}
+
+// ------------------------------------------------------------------------------------------------ logits backward
+struct DecLogitIO {
+  const float* g;             // [rows][128] pointer-MLP output (decoder.py:296)
+  const uint32_t* meta;       // [rows][8]
+  const float *L, *Lt;        // logit keys [Bp][N][128] and transposed, zero padded [Bp][128][112]
+  const float *D, *Dur;       // [Bp][N][N] (Dur NULL unless rcvrptw)
+  const float* gll;           // [S*Bp] d loss / d log-likelihood, r = s*Bp + b
+  float *dlg;                 // [rows][112] d loss / d (L g) (before the 1/sqrt(E))
+  float *dg;                  // [rows][128]
+  float *logp;                // [rows] log-probability of the chosen node (0 for dead rows)
+  float *dscal;               // [2] += d alpha, d beta (decoder.py:187-190)
+  int Bp, N, S, T;            // T = decode steps that ran; rows of instance b: b*seg_stride + t*S + s
+  long long seg_stride;
+  float alpha, beta, tanh_clip, temperature;
+};
+
+__global__ __launch_bounds__(256, 2) void k_dec_logit_bwd(DecLogitIO io, int tiles_per_inst, int wgs_per_inst) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / wgs_per_inst;
+  const int tile = (blockIdx.x - b * wgs_per_inst) * 4 + wave;
+  if (tile >= tiles_per_inst) return;
+  const int N = io.N, S = io.S, rows_b = io.T * S;
+  int q = tile * 16 + j;
+  const bool vrow = q < rows_b;
+  q = vrow ? q : rows_b - 1;
+  const size_t m = (size_t)b * (size_t)io.seg_stride + (size_t)q;
+  const int t = q / S, s = q - t * S;
+  const uint4 m0 = *reinterpret_cast<const uint4*>(io.meta + m * 8);
+  const uint4 m1 = *reinterpret_cast<const uint4*>(io.meta + m * 8 + 4);
+  const int prev = min((int)m1.x, N - 1), target = (int)m1.y;
+  const bool live = vrow && m1.z != 0u;
+  const float gl = live ? io.gll[(size_t)s * io.Bp + b] : 0.f;
+  const uint32_t mw[4] = {m0.x, m0.y, m0.z, m0.w};
+
+  f32x4 F[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {
+    const float4 v = rr_ld4(io.g + m * RR_E + 16 * kk + 4 * g);
+    F[kk][0] = live ? v.x : 0.f; F[kk][1] = live ? v.y : 0.f; F[kk][2] = live ? v.z : 0.f; F[kk][3] = live ? v.w : 0.f;
+  }
+  // ---- logits^T[key][row] = L F^T (decoder.py:300-302)
+  const size_t nE4 = (size_t)N * RR_E * 4;
+  const __amdgpu_buffer_rsrc_t rL = rr_make_buf((const char*)io.L + (size_t)b * nE4, (unsigned)nE4);
+  unsigned koff[TD_NT];
+#pragma unroll
+  for (int kt = 0; kt < TD_NT; ++kt) {
+    int key = kt * 16 + j; key = key < N ? key : N - 1;
+    koff[kt] = (unsigned)(key * RR_E + 4 * g) * 4u;
+  }
+  f32x4 la[TD_NT];
+#pragma unroll
+  for (int kt = 0; kt < TD_NT; ++kt) la[kt] = rr_zero4();
+  {
+    float4 fa[TD_NT], fb[TD_NT];
+#pragma unroll
+    for (int kt = 0; kt < TD_NT; ++kt) fa[kt] = rr_bld4(rL, koff[kt], 0);
+#pragma unroll
+    for (int kk = 0; kk < 8; kk += 2) {
+#pragma unroll
+      for (int kt = 0; kt < TD_NT; ++kt) fb[kt] = rr_bld4(rL, koff[kt], 64u * (kk + 1));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kt = 0; kt < TD_NT; ++kt) {
+        la[kt] = rr_mfma(fa[kt].x, F[kk][0], la[kt]); la[kt] = rr_mfma(fa[kt].y, F[kk][1], la[kt]);
+        la[kt] = rr_mfma(fa[kt].z, F[kk][2], la[kt]); la[kt] = rr_mfma(fa[kt].w, F[kk][3], la[kt]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (kk + 2 < 8) {
+#pragma unroll
+        for (int kt = 0; kt < TD_NT; ++kt) fa[kt] = rr_bld4(rL, koff[kt], 64u * (kk + 2));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kt = 0; kt < TD_NT; ++kt) {
+        la[kt] = rr_mfma(fb[kt].x, F[kk + 1][0], la[kt]); la[kt] = rr_mfma(fb[kt].y, F[kk + 1][1], la[kt]);
+        la[kt] = rr_mfma(fb[kt].z, F[kk + 1][2], la[kt]); la[kt] = rr_mfma(fb[kt].w, F[kk + 1][3], la[kt]);
+      }
+    }
+  }
+  // ---- bias, log(exp(.) + 1e-6) (decoder.py:187-198), 10 tanh, mask, temperature, log-softmax (decoding.py:341-361)
+  const float inv_sqe = 1.0f / sqrtf((float)RR_E), inv_temp = 1.0f / io.temperature;
+  const bool clip = io.tanh_clip > 0.f;
+  const float* Drow = io.D + ((size_t)b * N + prev) * N;
+  const float* Trow = io.Dur ? io.Dur + ((size_t)b * N + prev) * N : nullptr;
+  float uu[TD_NT][4], vv[TD_NT][4], dd[TD_NT][4], tt[TD_NT][4];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < TD_NT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = kt * 16 + 4 * g + r;
+      const int kc = key < N ? key : N - 1;
+      dd[kt][r] = Drow[kc];
+      tt[kt][r] = Trow ? Trow[kc] : 0.f;
+      const float x = la[kt][r] * inv_sqe - (io.alpha * dd[kt][r] + io.beta * tt[kt][r]);
+      const float u = rr_exp(x) + 1e-6f;
+      uu[kt][r] = u;
+      float v;
+      if (clip) v = (1.0f - 2.0f / fmaf(u, u, 1.0f)) * io.tanh_clip * inv_temp;      // tanh(log u) = (u^2-1)/(u^2+1)
+      else v = rr_log(u) * inv_temp;
+      const bool ok = key < N && ((mw[kt >> 1] >> (16 * (kt & 1) + 4 * g + r)) & 1u);
+      v = ok ? v : -INFINITY;
+      vv[kt][r] = v;
+      mx = fmaxf(mx, v);
+    }
+  mx = rr_max_g(mx);
+  if (mx == -INFINITY) mx = 0.f;
+  float sum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < TD_NT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sum += rr_exp(vv[kt][r] - mx);
+  sum = rr_sum_g(sum);
+  const float lse = rr_log(sum);
+  float lpt = 0.f, da = 0.f, db = 0.f;
+  f32x4 dla[TD_NT];
+#pragma unroll
+  for (int kt = 0; kt < TD_NT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = kt * 16 + 4 * g + r;
+      const float v = vv[kt][r];
+      const bool ok = v > -INFINITY;
+      const float lp = v - mx - lse;
+      if (key == target) lpt += ok ? lp : 0.f;
+      const float p = ok ? rr_exp(lp) : 0.f;
+      float dv = gl * ((key == target ? 1.0f : 0.f) - p);          // d loss / d v (log-softmax picked at the target)
+      dv = (ok && live) ? dv : 0.f;
+      const float u = uu[kt][r];
+      float dx;                                                    // through v(u), u = exp(x) + 1e-6
+      if (clip) { const float w = fmaf(u, u, 1.0f); dx = dv * io.tanh_clip * inv_temp * (4.0f * u / (w * w)) * (u - 1e-6f); }
+      else dx = dv * inv_temp * (u - 1e-6f) / u;
+      dla[kt][r] = dx * inv_sqe;
+      da -= dx * dd[kt][r];
+      db -= dx * tt[kt][r];
+    }
+  lpt = rr_sum_g(lpt);
+  if (vrow && g == 0) io.logp[m] = live ? lpt : 0.f;
+  if (vrow) {
+#pragma unroll
+    for (int kt = 0; kt < TD_NT; ++kt)
+      rr_st4(io.dlg + m * TD_LDK + 16 * kt + 4 * g, make_float4(dla[kt][0], dla[kt][1], dla[kt][2], dla[kt][3]));
+  }
+  da = rr_wave_sum(vrow ? da : 0.f); db = rr_wave_sum(vrow ? db : 0.f);
+  if (lane == 0) { atomicAdd(io.dscal, da); if (io.Dur) atomicAdd(io.dscal + 1, db); }
+  // ---- dg^T[feat][row] = L^T dla  (A operand: L^T rows = features, k = key)
+  const __amdgpu_buffer_rsrc_t rT = rr_make_buf((const char*)io.Lt + (size_t)b * (RR_E * TD_LDK * 4), RR_E * TD_LDK * 4);
+  const unsigned voff = (unsigned)(j * TD_LDK + 4 * g) * 4u;
+  float4 lf[TD_NT], ln[TD_NT];
+#pragma unroll
+  for (int kt = 0; kt < TD_NT; ++kt) lf[kt] = rr_bld4(rT, voff, 64u * kt);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    if (u + 1 < 8) {
+#pragma unroll
+      for (int kt = 0; kt < TD_NT; ++kt) ln[kt] = rr_bld4(rT, voff, (unsigned)((u + 1) * 16 * TD_LDK * 4) + 64u * kt);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 c0 = rr_zero4(), c1 = rr_zero4();
+#pragma unroll
+    for (int kt = 0; kt < TD_NT; ++kt) {
+      c0 = rr_mfma(lf[kt].x, dla[kt][0], c0); c1 = rr_mfma(lf[kt].y, dla[kt][1], c1);
+      c0 = rr_mfma(lf[kt].z, dla[kt][2], c0); c1 = rr_mfma(lf[kt].w, dla[kt][3], c1);
+    }
+    if (vrow) rr_st4(io.dg + m * RR_E + 16 * u + 4 * g, make_float4(c0[0] + c1[0], c0[1] + c1[1], c0[2] + c1[2], c0[3] + c1[3]));
+    if (u + 1 < 8) {
+#pragma unroll
+      for (int kt = 0; kt < TD_NT; ++kt) lf[kt] = ln[kt];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+extern "C" int rr_dec_logit_bwd(const DecLogitIO* io, hipStream_t st) {
+  if (io == nullptr || io->g == nullptr || io->meta == nullptr || io->L == nullptr || io->Lt == nullptr || io->D == nullptr ||
+      io->gll == nullptr || io->dlg == nullptr || io->dg == nullptr || io->logp == nullptr || io->dscal == nullptr)
+    return RR_EINVAL;
+  if (io->Bp <= 0 || io->N < 2 || io->N > TD_LDK || io->S < 1 || io->T < 1) return RR_EINVAL;
+  const int tiles = (io->T * io->S + 15) / 16, wgs = (tiles + 3) / 4;
+  hipLaunchKernelGGL(k_dec_logit_bwd, dim3((unsigned)io->Bp * wgs), dim3(256), 0, st, *io, tiles, wgs);
+  return rr_check(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------ C = A^T B (k = rows)
+// C[b][p][q] (+)= sum_m A[b][m][p] B[b][m][q],  p < P (<= PT*16 per p-block), q < 128.
+// A workgroup (4 waves) owns a PT*16 x 128 block of one batch element and one M split; wave w owns q tiles 2w, 2w+1.
+// Rows go through LDS in chunks of 32 (row-major, leading dimensions = 16 mod 32 words so that the four k rows a
+// v_mfma_f32_16x16x4_f32 operand takes from one ds_read_b32 fall on distinct banks).
+template <int PT>
+__global__ __launch_bounds__(256, 2) void k_gemm_tn(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                                    int Mb, int lda, int ldb, int ldc, int P, long long sA, long long sB, long long sC,
+                                                    int msplit, int accumulate) {
+  constexpr int LA = PT * 16 + ((PT * 16) % 32 == 16 ? 0 : 16), LB = 144;
+  __shared__ __attribute__((aligned(16))) float As[32 * LA];
+  __shared__ __attribute__((aligned(16))) float Bs[32 * LB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int pb = blockIdx.x, ms = blockIdx.y, b = blockIdx.z;
+  const int p0 = pb * PT * 16;
+  const int chunks = (Mb + 31) / 32;
+  const int cper = (chunks + msplit - 1) / msplit;
+  const int c_lo = ms * cper, c_hi = min(chunks, c_lo + cper);
+  const float* Ab = A + (size_t)b * sA;
+  const float* Bb = B + (size_t)b * sB;
+  constexpr int NA4 = 32 * PT * 4, NB4 = 32 * 32;          // float4 units per chunk
+  constexpr int IA = (NA4 + 255) / 256, IB = NB4 / 256;
+  float4 ra[IA], rb[IB];
+  auto g_load = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+      const int e = tid + 256 * i;
+      const int row = e / (PT * 4), c4 = e - row * (PT * 4);
+      const int mrow = c * 32 + row;
+      const bool ok = e < NA4 && mrow < Mb && p0 + 4 * c4 < lda;
+      ra[i] = ok ? rr_ld4(Ab + (size_t)mrow * lda + p0 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+      const int e = tid + 256 * i;
+      const int row = e >> 5, c4 = e & 31;
+      const int mrow = c * 32 + row;
+      rb[i] = mrow < Mb ? rr_ld4(Bb + (size_t)mrow * ldb + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto s_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+      const int e = tid + 256 * i;
+      const int row = e / (PT * 4), c4 = e - row * (PT * 4);
+      if (e < NA4) rr_st4(As + row * LA + 4 * c4, ra[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+      const int e = tid + 256 * i;
+      rr_st4(Bs + (e >> 5) * LB + 4 * (e & 31), rb[i]);
+    }
+  };
+  f32x4 acc[PT][2];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) { acc[pt][0] = rr_zero4(); acc[pt][1] = rr_zero4(); }
+  if (c_lo < c_hi) g_load(c_lo);
+  for (int c = c_lo; c < c_hi; ++c) {
+    __syncthreads();                 // previous chunk fully consumed
+    s_store();
+    __syncthreads();
+    if (c + 1 < c_hi) g_load(c + 1);
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+      const float* ar = As + (4 * kb + g) * LA + j;
+      const float* br = Bs + (4 * kb + g) * LB + 32 * wave + j;
+      const float b0 = br[0], b1 = br[16];
+      float a[PT];
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) a[pt] = ar[16 * pt];
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) { acc[pt][0] = rr_mfma(a[pt], b0, acc[pt][0]); acc[pt][1] = rr_mfma(a[pt], b1, acc[pt][1]); }
+    }
+  }
+  float* Cb = C + (size_t)b * sC;
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int p = p0 + 16 * pt + 4 * g + r, qq = 32 * wave + 16 * qt + j;
+        if (p < P) {
+          float* dst = Cb + (size_t)p * ldc + qq;
+          if (msplit > 1 || accumulate) atomicAdd(dst, acc[pt][qt][r]);
+          else *dst = acc[pt][qt][r];
+        }
+      }
+}
+
+// C[b] = A[b]^T B[b] with B 128 columns wide.  msplit > 1 (or accumulate) adds into C with float atomics: the caller zeroes C.
+extern "C" int rr_gemm_tn(const float* A, const float* B, float* C, int batch, int Mb, int P, int lda, int ldb, int ldc,
+                          long long strideA, long long strideB, long long strideC, int msplit, int accumulate, hipStream_t st) {
+  if (A == nullptr || B == nullptr || C == nullptr || batch <= 0 || Mb <= 0 || P <= 0 || msplit < 1) return RR_EINVAL;
+  if ((lda & 3) || (ldb & 3) || ldb < 128 || lda < P) return RR_EINVAL;
+  if (P <= 112 || (P % 128) != 0) {
+    if (P > 112 && (P % 112) != 0) return RR_EINVAL;
+    hipLaunchKernelGGL((k_gemm_tn<7>), dim3((P + 111) / 112, msplit, batch), dim3(256), 0, st, A, B, C, Mb, lda, ldb, ldc, P,
+                       strideA, strideB, strideC, msplit, accumulate);
+  } else {
+    hipLaunchKernelGGL((k_gemm_tn<8>), dim3(P / 128, msplit, batch), dim3(256), 0, st, A, B, C, Mb, lda, ldb, ldc, P,
+                       strideA, strideB, strideC, msplit, accumulate);
+  }
+  return rr_check(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------ pointer MLP on rows
+// bf16 matrix pipe, two-piece split operands.  x = hi + lo with hi = bf16(x), lo = bf16(x - hi): x - (hi + lo) <= 2^-17 |x|;
+// a product keeps hi*hi + hi*lo + lo*hi (fp32 accumulate), dropping lo*lo <= 2^-16 |x w|.
+typedef rr_bf16x8 bfrag;
+__device__ __forceinline__ void td_split8(const float (&x)[8], bfrag& hi, bfrag& lo) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const rr_f32x2 v = {x[2 * q], x[2 * q + 1]};
+    const rr_bf16x2 h = __builtin_convertvector(v, rr_bf16x2);
+    const rr_f32x2 r1 = v - __builtin_convertvector(h, rr_f32x2);
+    const rr_bf16x2 l = __builtin_convertvector(r1, rr_bf16x2);
+    hi[2 * q] = h[0]; hi[2 * q + 1] = h[1]; lo[2 * q] = l[0]; lo[2 * q + 1] = l[1];
+  }
+}
+__device__ __forceinline__ f32x4 td_mfma3(bfrag ah, bfrag al, bfrag bh, bfrag bl, f32x4 c) {
+  c = rr_mfma_bf16(ah, bl, c);
+  c = rr_mfma_bf16(al, bh, c);
+  return rr_mfma_bf16(ah, bh, c);
+}
+__device__ __forceinline__ void td_glds16(const void* gsrc, void* ldst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
+}
+
+struct MlpRowsW {
+  const void* wa1;   // W1   [512][128] as A operands, tile-major  [32][4][2][64][8] bf16 (packing.pack_bf16x2)
+  const void* wa2;   // MODE 1: W2^T [512][128] likewise
+  const void* wb;    // MODE 0: W2 [128][512], MODE 1: W1^T [128][512]; k-major [16][8][2][64][8]
+  const float *b1, *b2;
+};
+
+// MODE 0: out = x + W2 relu(W1 x + b1) + b2        (TransformerFFN / pointer MLP forward, decoder.py:296)
+// MODE 1: out = dy + W1^T [ (W2^T dy) . 1(W1 x + b1 > 0) ]   (its input gradient)
+// A workgroup = 4 waves x 32 rows; the weight fragments of one hidden pair (32 units) are one LDS stage, filled by LDS-DMA
+// one stage ahead, one barrier per stage.
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void k_mlp_rows(MlpRowsW w, const float* __restrict__ X, const float* __restrict__ dY,
+                                                     float* __restrict__ out, RowSegs rs) {
+  constexpr int NF = MODE == 1 ? 48 : 32;                 // fragments (1 KB each) per stage
+  extern __shared__ __attribute__((aligned(16))) char td_lds[];
+  char* stage = td_lds;                                   // [2][NF * 1024]
+  float* b1s = reinterpret_cast<float*>(td_lds + 2 * NF * 1024);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  for (int i = tid; i < RR_FF; i += 256) b1s[i] = w.b1[i];
+  const long long total = (long long)rs.nseg * rs.seg_rows;
+  const long long nblk = (total + 127) / 128;
+  auto issue = [&](int p, int buf) {
+#pragma unroll
+    for (int q = 0; q < NF / 4; ++q) {
+      const int f = wave * (NF / 4) + q;
+      const char* src;
+      if (f < 16) src = (const char*)w.wa1 + ((size_t)p * 16 + f) * 1024;
+      else if (MODE == 1 && f < 32) src = (const char*)w.wa2 + ((size_t)p * 16 + (f - 16)) * 1024;
+      else src = (const char*)w.wb + ((size_t)p * 16 + (f - (MODE == 1 ? 32 : 16))) * 1024;
+      td_glds16(src + lane * 16, stage + buf * (NF * 1024) + f * 1024);
+    }
+  };
+  auto frag = [&](int buf, int f) { return *reinterpret_cast<const bfrag*>(stage + buf * (NF * 1024) + f * 1024 + lane * 16); };
+  for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    long long mrow[2]; bool vr[2];
+    bfrag Xh[2][4], Xl[2][4], Yh[2][4], Yl[2][4];
+    f32x4 acc[2][8];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      long long i = blk * 128 + wave * 32 + rt * 16 + j;
+      vr[rt] = i < total;
+      i = vr[rt] ? i : total - 1;
+      mrow[rt] = td_row(rs, i);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float4 xa = rr_ld4(X + mrow[rt] * RR_E + 32 * s + 4 * g), xb = rr_ld4(X + mrow[rt] * RR_E + 32 * s + 16 + 4 * g);
+        const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+        td_split8(xv, Xh[rt][s], Xl[rt][s]);
+        if (MODE == 1) {
+          const float4 ya = rr_ld4(dY + mrow[rt] * RR_E + 32 * s + 4 * g), yb = rr_ld4(dY + mrow[rt] * RR_E + 32 * s + 16 + 4 * g);
+          const float yv[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
+          td_split8(yv, Yh[rt][s], Yl[rt][s]);
+          acc[rt][2 * s] = f32x4{ya.x, ya.y, ya.z, ya.w}; acc[rt][2 * s + 1] = f32x4{yb.x, yb.y, yb.z, yb.w};
+        } else {
+          const float4 ba = rr_ld4(w.b2 + 32 * s + 4 * g), bb = rr_ld4(w.b2 + 32 * s + 16 + 4 * g);
+          acc[rt][2 * s] = f32x4{xa.x + ba.x, xa.y + ba.y, xa.z + ba.z, xa.w + ba.w};
+          acc[rt][2 * s + 1] = f32x4{xb.x + bb.x, xb.y + bb.y, xb.z + bb.z, xb.w + bb.w};
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    issue(0, 0);
+#pragma unroll 1
+    for (int p = 0; p < RR_FF / 32; ++p) {
+      const int buf = p & 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                    // stage p landed (every wave's DMA) and stage p-1 is consumed by every wave
+      if (p + 1 < RR_FF / 32) issue(p + 1, buf ^ 1);
+      f32x4 pre[2][2], dpre[2][2];
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl) {
+        const float4 bv = rr_ld4(b1s + 32 * p + 16 * tl + 4 * g);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) { pre[tl][rt] = f32x4{bv.x, bv.y, bv.z, bv.w}; dpre[tl][rt] = rr_zero4(); }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const bfrag ah = frag(buf, tl * 8 + s * 2), al = frag(buf, tl * 8 + s * 2 + 1);
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) pre[tl][rt] = td_mfma3(ah, al, Xh[rt][s], Xl[rt][s], pre[tl][rt]);
+          if (MODE == 1) {
+            const bfrag ch = frag(buf, 16 + tl * 8 + s * 2), cl = frag(buf, 16 + tl * 8 + s * 2 + 1);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) dpre[tl][rt] = td_mfma3(ch, cl, Yh[rt][s], Yl[rt][s], dpre[tl][rt]);
+          }
+        }
+      }
+      bfrag Hh[2], Hl[2];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        float hx[8];
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            hx[4 * tl + r] = MODE == 1 ? (pre[tl][rt][r] > 0.f ? dpre[tl][rt][r] : 0.f) : fmaxf(pre[tl][rt][r], 0.f);
+        td_split8(hx, Hh[rt], Hl[rt]);
+      }
+      constexpr int FB = MODE == 1 ? 32 : 16;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bfrag bh = frag(buf, FB + u * 2), bl = frag(buf, FB + u * 2 + 1);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) acc[rt][u] = td_mfma3(bh, bl, Hh[rt], Hl[rt], acc[rt][u]);
+      }
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+      if (vr[rt]) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          rr_st4(out + mrow[rt] * RR_E + 16 * u + 4 * g, make_float4(acc[rt][u][0], acc[rt][u][1], acc[rt][u][2], acc[rt][u][3]));
+      }
+    __syncthreads();                      // the next block's first stage overwrites buffer 0
+  }
+}
+
+extern "C" int rr_mlp_rows(const MlpRowsW* w, int mode, const float* X, const float* dY, float* out, int nseg, int seg_rows,
+                           long long seg_stride, hipStream_t st) {
+  if (w == nullptr || X == nullptr || out == nullptr || w->wa1 == nullptr || w->wb == nullptr || w->b1 == nullptr) return RR_EINVAL;
+  if (mode == 1 && (dY == nullptr || w->wa2 == nullptr)) return RR_EINVAL;
+  if (mode == 0 && w->b2 == nullptr) return RR_EINVAL;
+  if (mode < 0 || mode > 1 || nseg <= 0 || seg_rows <= 0 || seg_stride < seg_rows) return RR_EINVAL;
+  RowSegs rs{nseg, seg_rows, seg_stride};
+  const long long nblk = ((long long)nseg * seg_rows + 127) / 128;
+  const unsigned grid = (unsigned)(nblk < 256 * 8 ? nblk : 256 * 8);
+  if (mode == 1) {
+    const int shm = 2 * 48 * 1024 + RR_FF * 4;
+    (void)hipFuncSetAttribute((const void*)k_mlp_rows<1>, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+    hipLaunchKernelGGL((k_mlp_rows<1>), dim3(grid), dim3(256), shm, st, *w, X, dY, out, rs);
+  } else {
+    const int shm = 2 * 32 * 1024 + RR_FF * 4;
+    (void)hipFuncSetAttribute((const void*)k_mlp_rows<0>, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+    hipLaunchKernelGGL((k_mlp_rows<0>), dim3(grid), dim3(256), shm, st, *w, X, dY, out, rs);
+  }
+  return rr_check(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------ pointer MLP weight gradients
+struct MlpWgradW {
+  const void* w1n;    // W1   [512][128], natural-k B operands [32][4][2][64][8] bf16 (packing.pack_bf16x2_nat)
+  const void* w2tn;   // W2^T [512][128] likewise
+  const float* b1;
+};
+#define WG_RM 288     // bytes per row of the row-major bf16 images (128 values + 32 B: conflict-free ds_read_b128 by row)
+#define WG_TR 96      // bytes per feature of the transposed images (32 rows + 32 B)
+
+// dW1[hid][feat] += sum_m dH[m][hid] x[m][feat], db1 += sum_m dH, dW2[feat][hid] += sum_m dy[m][feat] H[m][hid], db2 += sum_m dy
+// with H = relu(W1 x + b1), dH = (W2^T dy) . 1(H > 0).  Workgroup (slab, split): hidden units [128 slab, +128), wave w the
+// tiles 2w, 2w+1 of them with their W1 / W2^T fragments resident in registers; rows in chunks of 32 through LDS: a row-major
+// image (A operand of the recomputation, k = feature) and a transposed one (A operand of the two outer products, k = row).
+__global__ __launch_bounds__(256, 1) void k_mlp_wgrad(MlpWgradW w, const float* __restrict__ X, const float* __restrict__ dY,
+                                                      float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2,
+                                                      float* __restrict__ db2, RowSegs rs, int nsplit) {
+  __shared__ __attribute__((aligned(16))) char rm[4][32 * WG_RM];     // x hi, x lo, dy hi, dy lo
+  __shared__ __attribute__((aligned(16))) char tr[4][RR_E * WG_TR];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  // the four slabs of one row split share an XCD (blocks idx, idx+8, ...): its L2 serves the re-reads of the rows
+  const int idx = blockIdx.x, xcd = idx & 7, kq = idx >> 3;
+  const int slab = kq & 3, split = (kq >> 2) * 8 + xcd;
+  if (split >= nsplit) return;
+  const long long total = (long long)rs.nseg * rs.seg_rows;
+  const long long chunks = (total + 31) / 32;
+  const long long cper = (chunks + nsplit - 1) / nsplit;
+  const long long c_lo = split * cper, c_hi = (c_lo + cper < chunks) ? c_lo + cper : chunks;
+  const int T0 = slab * 8 + wave * 2;                     // first of this wave's two hidden tiles
+  bfrag W1h[2][4], W1l[2][4], W2h[2][4], W2l[2][4];
+  float b1v[2];
+#pragma unroll
+  for (int tl = 0; tl < 2; ++tl) {
+    b1v[tl] = w.b1[16 * (T0 + tl) + j];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const size_t f = ((size_t)(T0 + tl) * 4 + s) * 2;
+      W1h[tl][s] = *reinterpret_cast<const bfrag*>((const char*)w.w1n + f * 1024 + lane * 16);
+      W1l[tl][s] = *reinterpret_cast<const bfrag*>((const char*)w.w1n + (f + 1) * 1024 + lane * 16);
+      W2h[tl][s] = *reinterpret_cast<const bfrag*>((const char*)w.w2tn + f * 1024 + lane * 16);
+      W2l[tl][s] = *reinterpret_cast<const bfrag*>((const char*)w.w2tn + (f + 1) * 1024 + lane * 16);
+    }
+  }
+  f32x4 aW2[8][2], aW1[8][2];
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl) { aW2[u][tl] = rr_zero4(); aW1[u][tl] = rr_zero4(); }
+  float ab1[2] = {0.f, 0.f};
+  float4 sb2 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // staging: thread -> column group c4 = tid & 31 (4 features), row pairs rp = (tid >> 5) and (tid >> 5) + 8
+  const int c4 = tid & 31, rp0 = tid >> 5;
+  float4 px[2][2], py[2][2];
+  auto g_load = [&](long long c) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const long long i = c * 32 + 2 * (rp0 + 8 * it) + e;
+        if (i < total) {
+          const long long m = td_row(rs, i);
+          px[it][e] = rr_ld4(X + m * RR_E + 4 * c4);
+          py[it][e] = rr_ld4(dY + m * RR_E + 4 * c4);
+        } else {
+          px[it][e] = make_float4(0.f, 0.f, 0.f, 0.f); py[it][e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+  };
+  auto put = [&](const float4 (&v)[2], int rp, char* rmh, char* rml, char* trh, char* trl) {
+    // rows 2rp, 2rp+1 of the chunk, features 4c4..4c4+3
+    uint16_t h[2][4], l[2][4];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float xs[4] = {v[e].x, v[e].y, v[e].z, v[e].w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const __bf16 hb = (__bf16)xs[q];
+        const __bf16 lb = (__bf16)(xs[q] - (float)hb);
+        h[e][q] = __builtin_bit_cast(uint16_t, hb); l[e][q] = __builtin_bit_cast(uint16_t, lb);
+      }
+      const int row = 2 * rp + e;
+      *reinterpret_cast<uint2*>(rmh + row * WG_RM + c4 * 8) = make_uint2(h[e][0] | ((uint32_t)h[e][1] << 16), h[e][2] | ((uint32_t)h[e][3] << 16));
+      *reinterpret_cast<uint2*>(rml + row * WG_RM + c4 * 8) = make_uint2(l[e][0] | ((uint32_t)l[e][1] << 16), l[e][2] | ((uint32_t)l[e][3] << 16));
+    }
+    // transposed: row rho = 16 rt + 4 gg + r sits at position 8 gg + 4 rt + r (the order a lane of the recomputed C tiles owns them)
+    const int rho = 2 * rp, pos = 8 * ((rho & 15) >> 2) + 4 * (rho >> 4) + (rho & 3);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      *reinterpret_cast<uint32_t*>(trh + (4 * c4 + q) * WG_TR + pos * 2) = h[0][q] | ((uint32_t)h[1][q] << 16);
+      *reinterpret_cast<uint32_t*>(trl + (4 * c4 + q) * WG_TR + pos * 2) = l[0][q] | ((uint32_t)l[1][q] << 16);
+    }
+  };
+  if (c_lo < c_hi) g_load(c_lo);
+  for (long long c = c_lo; c < c_hi; ++c) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      put(px[it], rp0 + 8 * it, rm[0], rm[1], tr[0], tr[1]);
+      put(py[it], rp0 + 8 * it, rm[2], rm[3], tr[2], tr[3]);
+      if (slab == 0) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { sb2.x += py[it][e].x; sb2.y += py[it][e].y; sb2.z += py[it][e].z; sb2.w += py[it][e].w; }
+      }
+    }
+    __syncthreads();
+    if (c + 1 < c_hi) g_load(c + 1);
+    // ---- recompute pre[row][hid] = x W1^T, dpre = dy W2 for this wave's two hidden tiles (A = activations, k = feature)
+    f32x4 pre[2][2], dpre[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl) { pre[rt][tl] = rr_zero4(); dpre[rt][tl] = rr_zero4(); }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const int off = (16 * rt + j) * WG_RM + (32 * s + 8 * g) * 2;
+        const bfrag xh = *reinterpret_cast<const bfrag*>(rm[0] + off), xl = *reinterpret_cast<const bfrag*>(rm[1] + off);
+        const bfrag yh = *reinterpret_cast<const bfrag*>(rm[2] + off), yl = *reinterpret_cast<const bfrag*>(rm[3] + off);
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+          pre[rt][tl] = td_mfma3(xh, xl, W1h[tl][s], W1l[tl][s], pre[rt][tl]);
+          dpre[rt][tl] = td_mfma3(yh, yl, W2h[tl][s], W2l[tl][s], dpre[rt][tl]);
+        }
+      }
+    // C layout here: lane (hid = j, g) holds rows 16 rt + 4g + r.  As the B operand of the outer products (k = row) a lane's
+    // eight values are rows {4g + r} u {16 + 4g + r}: positions 8g + 4 rt + r of the transposed images.
+    bfrag Hh[2], Hl[2], Gh[2], Gl[2];
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl) {
+      float hx[8], gx[8];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = pre[rt][tl][r] + b1v[tl];
+          hx[4 * rt + r] = fmaxf(pv, 0.f);
+          gx[4 * rt + r] = pv > 0.f ? dpre[rt][tl][r] : 0.f;
+          ab1[tl] += gx[4 * rt + r];
+        }
+      td_split8(hx, Hh[tl], Hl[tl]);
+      td_split8(gx, Gh[tl], Gl[tl]);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int off = (16 * u + j) * WG_TR + 16 * g;
+      const bfrag xh = *reinterpret_cast<const bfrag*>(tr[0] + off), xl = *reinterpret_cast<const bfrag*>(tr[1] + off);
+      const bfrag yh = *reinterpret_cast<const bfrag*>(tr[2] + off), yl = *reinterpret_cast<const bfrag*>(tr[3] + off);
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl) {
+        aW2[u][tl] = td_mfma3(yh, yl, Hh[tl], Hl[tl], aW2[u][tl]);      // [feat][hid] += dy^T H
+        aW1[u][tl] = td_mfma3(xh, xl, Gh[tl], Gl[tl], aW1[u][tl]);      // [feat][hid] += x^T dH  (= dW1^T)
+      }
+    }
+  }
+  // ---- epilogue: float atomics into the (zeroed) gradients
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int feat = 16 * u + 4 * g + r, hid = 16 * (T0 + tl) + j;
+        atomicAdd(dW2 + (size_t)feat * RR_FF + hid, aW2[u][tl][r]);
+        atomicAdd(dW1 + (size_t)hid * RR_E + feat, aW1[u][tl][r]);
+      }
+#pragma unroll
+  for (int tl = 0; tl < 2; ++tl) {
+    float v = ab1[tl];
+    v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+    if (g == 0) atomicAdd(db1 + 16 * (T0 + tl) + j, v);
+  }
+  if (slab == 0 && db2 != nullptr) {
+    atomicAdd(db2 + 4 * c4 + 0, sb2.x); atomicAdd(db2 + 4 * c4 + 1, sb2.y);
+    atomicAdd(db2 + 4 * c4 + 2, sb2.z); atomicAdd(db2 + 4 * c4 + 3, sb2.w);
+  }
+}
+
+// dW1 [512][128], db1 [512], dW2 [128][512], db2 [128]: ADDED to (caller zeroes them).
+extern "C" int rr_mlp_wgrad(const MlpWgradW* w, const float* X, const float* dY, float* dW1, float* db1, float* dW2, float* db2,
+                            int nseg, int seg_rows, long long seg_stride, hipStream_t st) {
+  if (w == nullptr || w->w1n == nullptr || w->w2tn == nullptr || w->b1 == nullptr || X == nullptr || dY == nullptr ||
+      dW1 == nullptr || db1 == nullptr || dW2 == nullptr)
+    return RR_EINVAL;
+  if (nseg <= 0 || seg_rows <= 0 || seg_stride < seg_rows) return RR_EINVAL;
+  RowSegs rs{nseg, seg_rows, seg_stride};
+  const long long chunks = ((long long)nseg * seg_rows + 31) / 32;
+  int nsplit = chunks >= 64 * 8 ? 64 : (chunks >= 64 ? 16 : 8);
+  hipLaunchKernelGGL(k_mlp_wgrad, dim3(4 * nsplit), dim3(256), 0, st, *w, X, dY, dW1, db1, dW2, db2, rs, nsplit);
+  return rr_check(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------ attention backward
+struct DecAttnIO {
+  const float* dg0;            // [rows][128] d loss / d (glimpse + query)
+  const uint32_t* meta;        // [rows][8]
+  const float* scal;           // [rows][4] VRP state scalars (NULL: none)
+  const int64_t* first;        // [S*Bp] first node per rollout (ATSP TSPContext) or NULL
+  const float *K, *V, *Kt;     // glimpse keys / values [Bp][N][128], keys transposed zero padded [Bp][128][112]
+  const float *ctxA, *ctxB;    // step-context tables [Bp][N][128] (ctxA NULL unless `first`)
+  const float* wstate;         // [nscal][128] state columns of project_context (NULL: none)
+  float *dK, *dV, *dctxA, *dctxB;   // [Bp][N][128], written (not added)
+  float* dwstate;              // [nscal][128], ADDED to with atomics
+  int Bp, N, S, T, nscal;
+  long long seg_stride;
+};
+
+// 16x16 tile held as C layout (lane (c = j, g) register r = X[4g + r][c])  ->  lane (a = j, g) register m = X[a][4g + m]
+// through a wave-private LDS strip [16][20] (LDS operations of one wave execute in order)
+__device__ __forceinline__ f32x4 td_xpose(f32x4 v, float* scr, int j, int g) {
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) scr[(4 * g + r) * 20 + j] = v[r];
+  __builtin_amdgcn_wave_barrier();
+  const float4 o = rr_ld4(scr + j * 20 + 4 * g);
+  __builtin_amdgcn_wave_barrier();
+  return f32x4{o.x, o.y, o.z, o.w};
+}
+
+__global__ __launch_bounds__(256, 1) void k_dec_attn_bwd(DecAttnIO io) {
+  __shared__ float accA[TD_LDK * 16], accB[TD_LDK * 16];
+  __shared__ __attribute__((aligned(16))) float xs[4][16 * 20];
+  __shared__ __attribute__((aligned(16))) float red[4][2 * TD_NT][64 * 4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int idx = blockIdx.x, xcd = idx & 7, kq = idx >> 3;
+  const int h = kq & 7, b = (kq >> 3) * 8 + xcd;          // the eight heads of an instance share an XCD (its L2 holds the rows)
+  if (b >= io.Bp) return;
+  const int N = io.N, S = io.S, rows_b = io.T * S;
+  for (int i = tid; i < TD_LDK * 16; i += 256) { accA[i] = 0.f; accB[i] = 0.f; }
+  __syncthreads();
+  float* scr = xs[wave];
+  // per-head operands, resident for the whole instance
+  float4 kf[TD_NT], vf[TD_NT], ktf[TD_NT];
+#pragma unroll
+  for (int kt = 0; kt < TD_NT; ++kt) {
+    int key = kt * 16 + j; key = key < N ? key : N - 1;
+    kf[kt] = rr_ld4(io.K + ((size_t)b * N + key) * RR_E + 16 * h + 4 * g);       // A[i = key][k = dim 4g+m]
+    vf[kt] = rr_ld4(io.V + ((size_t)b * N + key) * RR_E + 16 * h + 4 * g);
+    ktf[kt] = rr_ld4(io.Kt + ((size_t)b * RR_E + 16 * h + j) * TD_LDK + 16 * kt + 4 * g);   // A[i = dim j][k = key 16kt+4g+m]
+  }
+  f32x4 aK[TD_NT], aV[TD_NT];
+#pragma unroll
+  for (int kt = 0; kt < TD_NT; ++kt) { aK[kt] = rr_zero4(); aV[kt] = rr_zero4(); }
+  float dws[4][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dws[k][r] = 0.f;
+  const int ntile = (rows_b + 15) / 16;
+  for (int tile = wave; tile < ntile; tile += 4) {
+    int q = tile * 16 + j;
+    const bool vrow = q < rows_b;
+    q = vrow ? q : rows_b - 1;
+    const size_t m = (size_t)b * (size_t)io.seg_stride + (size_t)q;
+    const int t = q / S, s = q - t * S;
+    const uint4 m0 = *reinterpret_cast<const uint4*>(io.meta + m * 8);
+    const uint4 m1 = *reinterpret_cast<const uint4*>(io.meta + m * 8 + 4);
+    const int prev = min((int)m1.x, N - 1);
+    const bool live = vrow && m1.z != 0u;
+    const uint32_t mw[4] = {m0.x, m0.y, m0.z, m0.w};
+    int fst = 0;
+    // ---- query slice of this head (TSPContext / VRPContext / MTVRPContext as table gathers, see rr_rollout_w.inc)
+    float4 qv = rr_ld4(io.ctxB + ((size_t)b * N + prev) * RR_E + 16 * h + 4 * g);
+    if (io.first) {
+      fst = min((int)io.first[(size_t)s * io.Bp + b], N - 1);
+      const float4 a = rr_ld4(io.ctxA + ((size_t)b * N + fst) * RR_E + 16 * h + 4 * g);
+      qv.x += a.x; qv.y += a.y; qv.z += a.z; qv.w += a.w;
+    }
+    float sc4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (io.nscal > 0) {
+      const float4 sv = rr_ld4(io.scal + m * 4);
+      sc4[0] = sv.x; sc4[1] = sv.y; sc4[2] = sv.z; sc4[3] = sv.w;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k < io.nscal) {
+          const float4 wv = rr_ld4(io.wstate + k * RR_E + 16 * h + 4 * g);
+          qv.x = fmaf(wv.x, sc4[k], qv.x); qv.y = fmaf(wv.y, sc4[k], qv.y); qv.z = fmaf(wv.z, sc4[k], qv.z); qv.w = fmaf(wv.w, sc4[k], qv.w);
+        }
+    }
+    float4 dh = rr_ld4(io.dg0 + m * RR_E + 16 * h + 4 * g);
+    if (!live) dh = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float qs[4] = {qv.x * 0.25f, qv.y * 0.25f, qv.z * 0.25f, qv.w * 0.25f};          // 1/sqrt(head_dim)
+    const float dhv[4] = {dh.x, dh.y, dh.z, dh.w};
+    // ---- scores, masked softmax (decoder.py:308-323), d weights = V dhv
+    f32x4 a[TD_NT], ds[TD_NT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < TD_NT; ++kt) {
+      f32x4 c = rr_zero4(), d = rr_zero4();
+      c = rr_mfma(kf[kt].x, qs[0], c); c = rr_mfma(kf[kt].y, qs[1], c); c = rr_mfma(kf[kt].z, qs[2], c); c = rr_mfma(kf[kt].w, qs[3], c);
+      d = rr_mfma(vf[kt].x, dhv[0], d); d = rr_mfma(vf[kt].y, dhv[1], d); d = rr_mfma(vf[kt].z, dhv[2], d); d = rr_mfma(vf[kt].w, dhv[3], d);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + 4 * g + r;
+        const bool ok = key < N && ((mw[kt >> 1] >> (16 * (kt & 1) + 4 * g + r)) & 1u);
+        c[r] = ok ? c[r] : -INFINITY;
+        mx = fmaxf(mx, c[r]);
+      }
+      a[kt] = c; ds[kt] = d;
+    }
+    mx = rr_max_g(mx);
+    if (mx == -INFINITY) mx = 0.f;
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < TD_NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { a[kt][r] = rr_exp(a[kt][r] - mx); sum += a[kt][r]; }
+    sum = rr_sum_g(sum);
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+    float dot = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < TD_NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { a[kt][r] *= inv; dot = fmaf(a[kt][r], ds[kt][r], dot); }
+    dot = rr_sum_g(dot);
+#pragma unroll
+    for (int kt = 0; kt < TD_NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ds[kt][r] = a[kt][r] * (ds[kt][r] - dot);          // d scores (softmax backward)
+    // ---- d query = dhv (residual, decoder.py:294) + K^T ds / sqrt(d)
+    f32x4 dq0 = rr_zero4(), dq1 = rr_zero4();
+#pragma unroll
+    for (int kt = 0; kt < TD_NT; ++kt) {
+      dq0 = rr_mfma(ktf[kt].x, ds[kt][0], dq0); dq1 = rr_mfma(ktf[kt].y, ds[kt][1], dq1);
+      dq0 = rr_mfma(ktf[kt].z, ds[kt][2], dq0); dq1 = rr_mfma(ktf[kt].w, ds[kt][3], dq1);
+    }
+    float dq[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dq[r] = fmaf(dq0[r] + dq1[r], 0.25f, dhv[r]);
+    if (live) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        atomicAdd(&accB[prev * 16 + 4 * g + r], dq[r]);
+        if (io.first) atomicAdd(&accA[fst * 16 + 4 * g + r], dq[r]);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dws[k][r] = fmaf(dq[r], sc4[k], dws[k][r]);
+    }
+    // ---- dK_h[key][dim] += ds[row][key] q[row][dim] / sqrt(d),  dV_h[key][dim] += a[row][key] dhv[row][dim]  (k = row)
+    const f32x4 qT = td_xpose(f32x4{qs[0], qs[1], qs[2], qs[3]}, scr, j, g);
+    const f32x4 hT = td_xpose(f32x4{dhv[0], dhv[1], dhv[2], dhv[3]}, scr, j, g);
+#pragma unroll
+    for (int kt = 0; kt < TD_NT; ++kt) {
+      const f32x4 dT = td_xpose(ds[kt], scr, j, g);
+      const f32x4 pT = td_xpose(a[kt], scr, j, g);
+      aK[kt] = rr_mfma(qT[0], dT[0], aK[kt]); aV[kt] = rr_mfma(hT[0], pT[0], aV[kt]);
+      aK[kt] = rr_mfma(qT[1], dT[1], aK[kt]); aV[kt] = rr_mfma(hT[1], pT[1], aV[kt]);
+      aK[kt] = rr_mfma(qT[2], dT[2], aK[kt]); aV[kt] = rr_mfma(hT[2], pT[2], aV[kt]);
+      aK[kt] = rr_mfma(qT[3], dT[3], aK[kt]); aV[kt] = rr_mfma(hT[3], pT[3], aV[kt]);
+    }
+  }
+  // ---- fold the four waves' dK_h / dV_h (fixed order), write the head's slice of every table
+#pragma unroll
+  for (int kt = 0; kt < TD_NT; ++kt) {
+    rr_st4(&red[wave][kt][lane * 4], make_float4(aK[kt][0], aK[kt][1], aK[kt][2], aK[kt][3]));
+    rr_st4(&red[wave][TD_NT + kt][lane * 4], make_float4(aV[kt][0], aV[kt][1], aV[kt][2], aV[kt][3]));
+  }
+  __syncthreads();
+  for (int e = tid; e < 2 * TD_NT * 64; e += 256) {
+    const int ti = e >> 6, ln = e & 63;
+    float4 sacc = rr_ld4(&red[0][ti][ln * 4]);
+#pragma unroll
+    for (int wv = 1; wv < 4; ++wv) {
+      const float4 o = rr_ld4(&red[wv][ti][ln * 4]);
+      sacc.x += o.x; sacc.y += o.y; sacc.z += o.z; sacc.w += o.w;
+    }
+    const int kt = ti % TD_NT, key = 16 * kt + (ln & 15), gg = ln >> 4;
+    if (key < N) rr_st4((ti < TD_NT ? io.dK : io.dV) + ((size_t)b * N + key) * RR_E + 16 * h + 4 * gg, sacc);
+  }
+  for (int e = tid; e < N * 16; e += 256) {
+    const int n = e >> 4, d = e & 15;
+    io.dctxB[((size_t)b * N + n) * RR_E + 16 * h + d] = accB[e];
+    if (io.dctxA) io.dctxA[((size_t)b * N + n) * RR_E + 16 * h + d] = accA[e];
+  }
+  if (io.nscal > 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (k < io.nscal) {
+        float v = dws[k][r];
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+        if (j == 0) atomicAdd(io.dwstate + k * RR_E + 16 * h + 4 * g + r, v);
+      }
+  }
+}
+
+extern "C" int rr_dec_attn_bwd(const DecAttnIO* io, hipStream_t st) {
+  if (io == nullptr || io->dg0 == nullptr || io->meta == nullptr || io->K == nullptr || io->V == nullptr || io->Kt == nullptr ||
+      io->ctxB == nullptr || io->dK == nullptr || io->dV == nullptr || io->dctxB == nullptr)
+    return RR_EINVAL;
+  if ((io->first != nullptr) != (io->ctxA != nullptr) || (io->first != nullptr) != (io->dctxA != nullptr)) return RR_EINVAL;
+  if (io->nscal < 0 || io->nscal > 4 || (io->nscal > 0 && (io->scal == nullptr || io->wstate == nullptr || io->dwstate == nullptr))) return RR_EINVAL;
+  if (io->Bp <= 0 || io->N < 2 || io->N > TD_LDK || io->S < 1 || io->T < 1) return RR_EINVAL;
+  const unsigned grid = (unsigned)((io->Bp + 7) / 8) * 64u;
+  hipLaunchKernelGGL(k_dec_attn_bwd, dim3(grid), dim3(256), 0, st, *io);
+  return rr_check(hipGetLastError());
+}

@@ -57,7 +57,28 @@ class RolloutIO(C.Structure):
         "vcap", "ctime", "rlen", "done", "actions", "logp", "logits_out", "actions_in", "steps_out")] + \
         [(n, i32) for n in ("Bp", "N", "S", "T", "t0", "nsteps", "mode", "use_placeholder", "set_first",
                             "write_state", "logits_only", "stagger")] + \
-        [("tanh_clip", f32), ("temperature", f32), ("seed", u64)] + [(n, vp) for n in ("used_b", "open_route", "dist_limit", "demand_b", "bclass")]
+        [("tanh_clip", f32), ("temperature", f32), ("seed", u64)] + [(n, vp) for n in ("used_b", "open_route", "dist_limit", "demand_b", "bclass")] + \
+        [(n, vp) for n in ("dump_g0", "dump_g", "dump_meta", "dump_scal")] + [("dumpT", i32)]
+
+
+class DecLogitIO(C.Structure):          # csrc/rr_train_dec.hip
+    _fields_ = [(n, vp) for n in ("g", "meta", "L", "Lt", "D", "Dur", "gll", "dlg", "dg", "logp", "dscal")] + \
+        [(n, i32) for n in ("Bp", "N", "S", "T")] + [("seg_stride", C.c_longlong)] + \
+        [(n, f32) for n in ("alpha", "beta", "tanh_clip", "temperature")]
+
+
+class MlpRowsW(C.Structure):
+    _fields_ = [(n, vp) for n in ("wa1", "wa2", "wb", "b1", "b2")]
+
+
+class MlpWgradW(C.Structure):
+    _fields_ = [(n, vp) for n in ("w1n", "w2tn", "b1")]
+
+
+class DecAttnIO(C.Structure):
+    _fields_ = [(n, vp) for n in ("dg0", "meta", "scal", "first", "K", "V", "Kt", "ctxA", "ctxB", "wstate", "dK", "dV",
+                                  "dctxA", "dctxB", "dwstate")] + \
+        [(n, i32) for n in ("Bp", "N", "S", "T", "nscal")] + [("seg_stride", C.c_longlong)]
 
 
 class MtvrpExtra(C.Structure):
@@ -87,6 +108,11 @@ _SIGS = {
     "rr_select_matnet": [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, u64, u32, vp],
     "rr_nab_train_fwd": [vp, vp, vp, vp, C.c_long, vp],
     "rr_nab_train_bwd": [vp, vp, vp, vp, vp, C.c_long, vp],
+    "rr_dec_logit_bwd": [C.POINTER(DecLogitIO), vp],
+    "rr_gemm_tn": [vp, vp, vp, i32, i32, i32, i32, i32, i32, C.c_longlong, C.c_longlong, C.c_longlong, i32, i32, vp],
+    "rr_mlp_rows": [C.POINTER(MlpRowsW), i32, vp, vp, vp, i32, i32, C.c_longlong, vp],
+    "rr_mlp_wgrad": [C.POINTER(MlpWgradW), vp, vp, vp, vp, vp, vp, i32, i32, C.c_longlong, vp],
+    "rr_dec_attn_bwd": [C.POINTER(DecAttnIO), vp],
 }
 
 _lib = None

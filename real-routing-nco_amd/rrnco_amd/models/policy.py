@@ -50,7 +50,7 @@ class RRNetPolicy(nn.Module):
     @torch.no_grad()
     def forward(self, td, env=None, phase="train", calc_reward=True, return_actions=True, return_entropy=False,
                 return_hidden=False, return_init_embeds=False, return_sum_log_likelihood=True, actions=None,
-                max_steps=1_000_000, fused=True, **decoding_kwargs) -> dict:
+                max_steps=1_000_000, fused=True, capture=None, **decoding_kwargs) -> dict:
         if env is None or isinstance(env, str):
             raise ValueError("pass an instantiated rrnco_amd env")
         packed = self.packed(td.device)
@@ -73,7 +73,11 @@ class RRNetPolicy(nn.Module):
         # the fused rollout keeps one log-probability per step; full rows (store_all_logp / return_entropy) come from the step-wise loop
         if (fused and not strategy.store_all_logp and self.env_name in PROB_ID and strategy.mask_logits and strategy.top_k == 0 and not (0.0 < strategy.top_p < 1.0)
                 and not getattr(strategy, "is_beam_search", False)):
-            logprobs, actions_out, td = self._fused_rollout(td, env, cache, packed, strategy, actions)
+            dump = None
+            if capture is not None:      # training: keep what the hand-written backward needs (models/dec_backward.py)
+                dump = capture.setdefault("dump", {})
+                capture["cache"] = cache
+            logprobs, actions_out, td = self._fused_rollout(td, env, cache, packed, strategy, actions, dump=dump)
         else:
             step = 0
             while not td["done"].all():
@@ -103,7 +107,7 @@ class RRNetPolicy(nn.Module):
             out["hidden"] = (row_emb, col_emb)                                      # policy.py:250-251: the encoder output
         return out
 
-    def _fused_rollout(self, td, env, cache, packed, strategy, actions_in):
+    def _fused_rollout(self, td, env, cache, packed, strategy, actions_in, dump=None):
         """The whole `while not done` loop of policy.py:210-228 as ONE kernel launch."""
         R, N = td["action_mask"].shape
         dev = td.device
@@ -117,6 +121,15 @@ class RRNetPolicy(nn.Module):
         if t0:
             acts[:, 0] = strategy.actions[0]
         steps_out = torch.zeros(1, dtype=torch.int32, device=dev)
+        if dump is not None:      # training dump: one row per decoder evaluation (instance, step, start); see rollout.launch_rollout
+            Bp = td["distance_matrix"].shape[0]
+            Sd = R // Bp
+            dT = (N - t0 - 1) if self.env_name == "atsp" else (T - t0)      # ATSP: the forced last move is not evaluated
+            rows = Bp * dT * Sd
+            dump.update({"T": dT, "S": Sd, "Bp": Bp, "N": N, "t0": t0,
+                         "g0": torch.empty(rows, 128, device=dev), "g": torch.empty(rows, 128, device=dev),
+                         "meta": torch.empty(rows, 8, dtype=torch.int32, device=dev),
+                         "scal": None if self.env_name == "atsp" else torch.empty(rows, 4, device=dev)})
         ain = None
         if actions_in is not None:                      # evaluate: actions[..., step] feeds decode step `step`
             ain = torch.zeros(R, T, dtype=torch.int64, device=dev)
@@ -124,9 +137,13 @@ class RRNetPolicy(nn.Module):
         st = launch_rollout(self.env_name, packed, cache, td, strategy.num_starts, actions=acts, logp=logp, t0=t0,
                             nsteps=nsteps, mode=strategy.mode, actions_in=ain, write_state=True,
                             tanh_clip=strategy.tanh_clipping, temperature=strategy.temperature, seed=strategy.seed,
-                            steps_out=steps_out)
+                            steps_out=steps_out, dump=dump)
+        if dump is not None:
+            dump.update({"first": st["first"], "tanh_clip": strategy.tanh_clipping, "temperature": strategy.temperature})
         if self.env_name != "atsp":
             T_used = t0 + int(steps_out.item())
+            if dump is not None:
+                dump["T_used"] = T_used - t0
             acts, logp = acts[:, :T_used].contiguous(), logp[:, :T_used].contiguous()
         td.update({"current_node": st["cur"], "action_mask": st["mask"].bool(), "action": acts[:, -1]})
         if st["first"] is not None:

@@ -14,7 +14,7 @@ TIMING = None   # bench.py sets this to a list to collect (start, end) HIP event
 
 def launch_rollout(env_name, packed, cache, td, num_starts, *, actions=None, logp=None, t0=0, nsteps=1,
                    mode="greedy", actions_in=None, logits_out=None, logits_only=False, write_state=False,
-                   tanh_clip=10.0, temperature=1.0, seed=0, steps_out=None, state=None):
+                   tanh_clip=10.0, temperature=1.0, seed=0, steps_out=None, state=None, dump=None):
     """Runs `nsteps` decode steps (nsteps <= 0: until every rollout is done) for all rollouts of `td`.
     `td` is the batchified rollout state (R = S*Bp rows, per-instance keys left at Bp rows)."""
     if env_name not in PROB_ID:
@@ -80,6 +80,10 @@ def launch_rollout(env_name, packed, cache, td, num_starts, *, actions=None, log
     io.set_first = int(env_name == "atsp" and td.meta.get("i", 1) == 0)
     io.write_state, io.logits_only = int(write_state), int(logits_only)
     io.stagger = STAGGER
+    if dump is not None:      # training: per decoder evaluation, what csrc/rr_train_dec.hip differentiates (see RolloutIO::dump_*)
+        io.dump_g0, io.dump_g, io.dump_meta = L.ptr(dump["g0"]), L.ptr(dump["g"]), L.ptr(dump["meta"])
+        io.dump_scal = L.ptr(dump.get("scal"))
+        io.dumpT = int(dump["T"])
     io.tanh_clip, io.temperature, io.seed = float(tanh_clip), float(temperature), int(seed)
     timed = TIMING is not None and not logits_only
     if timed:

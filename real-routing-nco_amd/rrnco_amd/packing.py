@@ -66,6 +66,55 @@ def pack_a_bf16x3(Wm: torch.Tensor) -> torch.Tensor:
 
 
 
+def pack_bf16x2(Wm: torch.Tensor, k_major: bool = False) -> torch.Tensor:
+    """[M,K] fp32 -> two-piece bf16 split (hi = bf16(W), lo = bf16(W - hi)) as A operands of v_mfma_f32_16x16x32_bf16 in the
+    permuted k order of pack_a_bf16x3 (a lane's eight values = its four of two consecutive C-layout tiles): [M/16][K/32][2][64][8],
+    or k-slice-major [K/32][M/16][2][64][8] (the fragments one hidden pair of csrc/rr_train_dec.hip:k_mlp_rows needs are then
+    contiguous)."""
+    M, K = Wm.shape
+    assert M % 16 == 0 and K % 32 == 0
+    W = Wm.detach().float()
+    hi = W.to(torch.bfloat16)
+    lo = (W - hi.float()).to(torch.bfloat16)
+    out = []
+    for piece in (hi, lo):
+        x = piece.view(M // 16, 16, K // 32, 2, 4, 4)            # t, i, s, half, g, e4
+        out.append(x.permute(0, 2, 4, 1, 3, 5).reshape(M // 16, K // 32, 64, 8))
+    out = torch.stack(out, dim=2)                                # [t][s][piece][lane][8]
+    if k_major:
+        out = out.permute(1, 0, 2, 3, 4)
+    return out.contiguous()
+
+
+def pack_bf16x2_nat(Wm: torch.Tensor) -> torch.Tensor:
+    """The same split with the NATURAL k order (lane (i = l&15, g = l>>4), element e <-> W[16t+i][32s + 8g + e]):
+    [M/16][K/32][2][64][8] — the B operand of products whose A operand is read row-wise from memory (k_mlp_wgrad)."""
+    M, K = Wm.shape
+    assert M % 16 == 0 and K % 32 == 0
+    W = Wm.detach().float()
+    hi = W.to(torch.bfloat16)
+    lo = (W - hi.float()).to(torch.bfloat16)
+    out = []
+    for piece in (hi, lo):
+        x = piece.view(M // 16, 16, K // 32, 4, 8)                 # t, i, s, g, e
+        out.append(x.permute(0, 2, 3, 1, 4).reshape(M // 16, K // 32, 64, 8))
+    return torch.stack(out, dim=2).contiguous()
+
+
+def pack_mlp_train(W1: torch.Tensor, b1: torch.Tensor, W2: torch.Tensor, b2: torch.Tensor) -> dict:
+    """Operand packs of the training-side 128 -> 512 -> 128 MLP kernels (pointer MLP decoder.py:272-277, TransformerFFN
+    attn_freenet.py:330-357): forward, input gradient, weight gradient.  Built on the weights' device."""
+    keep = {"wa1": pack_bf16x2(W1), "wa2": pack_bf16x2(W2.t().contiguous()),
+            "wb_fwd": pack_bf16x2(W2, k_major=True), "wb_bwd": pack_bf16x2(W1.t().contiguous(), k_major=True),
+            "w1n": pack_bf16x2_nat(W1), "w2tn": pack_bf16x2_nat(W2.t().contiguous()),
+            "b1": b1.detach().float().contiguous(), "b2": b2.detach().float().contiguous()}
+    fw, bw, wg = L.MlpRowsW(), L.MlpRowsW(), L.MlpWgradW()
+    fw.wa1, fw.wa2, fw.wb, fw.b1, fw.b2 = keep["wa1"].data_ptr(), None, keep["wb_fwd"].data_ptr(), keep["b1"].data_ptr(), keep["b2"].data_ptr()
+    bw.wa1, bw.wa2, bw.wb, bw.b1, bw.b2 = keep["wa1"].data_ptr(), keep["wa2"].data_ptr(), keep["wb_bwd"].data_ptr(), keep["b1"].data_ptr(), None
+    wg.w1n, wg.w2tn, wg.b1 = keep["w1n"].data_ptr(), keep["w2tn"].data_ptr(), keep["b1"].data_ptr()
+    return {"keep": keep, "fwd": fw, "bwd": bw, "wgrad": wg}
+
+
 @contextlib.contextmanager
 def _few_threads():
     """The folds are a few hundred small float64 host ops.  On a many-core host (128 intra-op threads on the MI355X boxes)
