@@ -179,7 +179,7 @@ int rr_nab_train_bwd(const float* tab, const float* xd, const float* xa, const f
  * (RRNetDecoder.forward, RRNet_PointerAttention) and rrnco/models/decoding.py:311-361 (process_logits).  Rows are the
  * decoder evaluations the sampling rollout dumped (RolloutIO::dump_*): instance b owns rows b*seg_stride + t*S + s. */
 typedef struct {
-  const float *g; const uint32_t *meta; const float *L, *Lt, *D, *Dur, *gll;   /* Lt: [Bp][128][112] zero padded; gll [S*Bp] */
+  float *g; const uint32_t *meta; const float *L, *Lt, *D, *Dur, *gll;   /* Lt: [Bp][128][112] zero padded; gll [S*Bp]; dead rows of g are zeroed */
   float *dlg, *dg, *logp, *dscal;     /* dlg [rows][112], dg [rows][128], logp [rows], dscal[2] += d alpha, d beta */
   int Bp, N, S, T; long long seg_stride;
   float alpha, beta, tanh_clip, temperature;
@@ -198,12 +198,13 @@ typedef struct { const void *w1n, *w2tn; const float *b1; } MlpWgradW;
 /* The 128 -> 512 -> 128 ReLU MLP with residual on rows (pointer MLP decoder.py:272-277, 296; TransformerFFN
  * attn_freenet.py:330-357) on the bf16 matrix pipe with two-piece split fp32 operands:
  * mode 0: out = x + W2 relu(W1 x + b1) + b2;  mode 1: out = dy + W1^T[(W2^T dy) . 1(W1 x + b1 > 0)].
- * Rows: nseg segments of seg_rows rows, seg_stride rows apart. */
-int rr_mlp_rows(const MlpRowsW* w, int mode, const float* X, const float* dY, float* out, int nseg, int seg_rows,
-                long long seg_stride, hipStream_t stream);
+ * Rows: nseg segments of seg_rows rows, seg_stride rows apart; meta (optional, the rollout's [rows][8] dump): rows whose
+ * live flag meta[m][6] is 0 hold no data and are read as zero rows. */
+int rr_mlp_rows(const MlpRowsW* w, int mode, const float* X, const float* dY, float* out, const uint32_t* meta,
+                int nseg, int seg_rows, long long seg_stride, hipStream_t stream);
 /* dW1 [512][128], db1 [512], dW2 [128][512], db2 [128] of that MLP from (x, dy); ADDED to (caller zeroes). */
 int rr_mlp_wgrad(const MlpWgradW* w, const float* X, const float* dY, float* dW1, float* db1, float* dW2, float* db2,
-                 int nseg, int seg_rows, long long seg_stride, hipStream_t stream);
+                 const uint32_t* meta, int nseg, int seg_rows, long long seg_stride, hipStream_t stream);
 
 typedef struct {
   const float *dg0; const uint32_t *meta; const float *scal; const int64_t *first;

@@ -34,7 +34,7 @@ __device__ __forceinline__ long long td_row(const RowSegs& rs, long long i) {
 
 // ------------------------------------------------------------------------------------------------ logits backward
 struct DecLogitIO {
-  const float* g;             // [rows][128] pointer-MLP output (decoder.py:296)
+  float* g;                   // [rows][128] pointer-MLP output (decoder.py:296); dead rows are zeroed in place (the d L product reads them)
   const uint32_t* meta;       // [rows][8]
   const float *L, *Lt;        // logit keys [Bp][N][128] and transposed, zero padded [Bp][128][112]
   const float *D, *Dur;       // [Bp][N][N] (Dur NULL unless rcvrptw)
@@ -73,6 +73,7 @@ __global__ __launch_bounds__(256, 2) void k_dec_logit_bwd(DecLogitIO io, int til
   for (int kk = 0; kk < 8; ++kk) {
     const float4 v = rr_ld4(io.g + m * RR_E + 16 * kk + 4 * g);
     F[kk][0] = live ? v.x : 0.f; F[kk][1] = live ? v.y : 0.f; F[kk][2] = live ? v.z : 0.f; F[kk][3] = live ? v.w : 0.f;
+    if (vrow && !live) rr_st4(io.g + m * RR_E + 16 * kk + 4 * g, make_float4(0.f, 0.f, 0.f, 0.f));
   }
   // ---- logits^T[key][row] = L F^T (decoder.py:300-302)
   const size_t nE4 = (size_t)N * RR_E * 4;
@@ -362,7 +363,7 @@ struct MlpRowsW {
 // one stage ahead, one barrier per stage.
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void k_mlp_rows(MlpRowsW w, const float* __restrict__ X, const float* __restrict__ dY,
-                                                     float* __restrict__ out, RowSegs rs) {
+                                                     float* __restrict__ out, RowSegs rs, const uint32_t* __restrict__ meta) {
   constexpr int NF = MODE == 1 ? 48 : 32;                 // fragments (1 KB each) per stage
   extern __shared__ __attribute__((aligned(16))) char td_lds[];
   char* stage = td_lds;                                   // [2][NF * 1024]
@@ -395,13 +396,16 @@ __global__ __launch_bounds__(256, 1) void k_mlp_rows(MlpRowsW w, const float* __
       vr[rt] = i < total;
       i = vr[rt] ? i : total - 1;
       mrow[rt] = td_row(rs, i);
+      // rows the rollout never reached (finished routes) hold no data: they read as zero rows
+      const bool lv = meta == nullptr || meta[mrow[rt] * 8 + 6] != 0u;
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const float4 xa = rr_ld4(X + mrow[rt] * RR_E + 32 * s + 4 * g), xb = rr_ld4(X + mrow[rt] * RR_E + 32 * s + 16 + 4 * g);
+        const float4 xa = lv ? rr_ld4(X + mrow[rt] * RR_E + 32 * s + 4 * g) : z4, xb = lv ? rr_ld4(X + mrow[rt] * RR_E + 32 * s + 16 + 4 * g) : z4;
         const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
         td_split8(xv, Xh[rt][s], Xl[rt][s]);
         if (MODE == 1) {
-          const float4 ya = rr_ld4(dY + mrow[rt] * RR_E + 32 * s + 4 * g), yb = rr_ld4(dY + mrow[rt] * RR_E + 32 * s + 16 + 4 * g);
+          const float4 ya = lv ? rr_ld4(dY + mrow[rt] * RR_E + 32 * s + 4 * g) : z4, yb = lv ? rr_ld4(dY + mrow[rt] * RR_E + 32 * s + 16 + 4 * g) : z4;
           const float yv[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
           td_split8(yv, Yh[rt][s], Yl[rt][s]);
           acc[rt][2 * s] = f32x4{ya.x, ya.y, ya.z, ya.w}; acc[rt][2 * s + 1] = f32x4{yb.x, yb.y, yb.z, yb.w};
@@ -468,8 +472,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_rows(MlpRowsW w, const float* __
   }
 }
 
-extern "C" int rr_mlp_rows(const MlpRowsW* w, int mode, const float* X, const float* dY, float* out, int nseg, int seg_rows,
-                           long long seg_stride, hipStream_t st) {
+extern "C" int rr_mlp_rows(const MlpRowsW* w, int mode, const float* X, const float* dY, float* out, const uint32_t* meta,
+                           int nseg, int seg_rows, long long seg_stride, hipStream_t st) {
   if (w == nullptr || X == nullptr || out == nullptr || w->wa1 == nullptr || w->wb == nullptr || w->b1 == nullptr) return RR_EINVAL;
   if (mode == 1 && (dY == nullptr || w->wa2 == nullptr)) return RR_EINVAL;
   if (mode == 0 && w->b2 == nullptr) return RR_EINVAL;
@@ -480,11 +484,11 @@ extern "C" int rr_mlp_rows(const MlpRowsW* w, int mode, const float* X, const fl
   if (mode == 1) {
     const int shm = 2 * 48 * 1024 + RR_FF * 4;
     (void)hipFuncSetAttribute((const void*)k_mlp_rows<1>, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-    hipLaunchKernelGGL((k_mlp_rows<1>), dim3(grid), dim3(256), shm, st, *w, X, dY, out, rs);
+    hipLaunchKernelGGL((k_mlp_rows<1>), dim3(grid), dim3(256), shm, st, *w, X, dY, out, rs, meta);
   } else {
     const int shm = 2 * 32 * 1024 + RR_FF * 4;
     (void)hipFuncSetAttribute((const void*)k_mlp_rows<0>, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-    hipLaunchKernelGGL((k_mlp_rows<0>), dim3(grid), dim3(256), shm, st, *w, X, dY, out, rs);
+    hipLaunchKernelGGL((k_mlp_rows<0>), dim3(grid), dim3(256), shm, st, *w, X, dY, out, rs, meta);
   }
   return rr_check(hipGetLastError());
 }
@@ -504,7 +508,7 @@ struct MlpWgradW {
 // image (A operand of the recomputation, k = feature) and a transposed one (A operand of the two outer products, k = row).
 __global__ __launch_bounds__(256, 1) void k_mlp_wgrad(MlpWgradW w, const float* __restrict__ X, const float* __restrict__ dY,
                                                       float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2,
-                                                      float* __restrict__ db2, RowSegs rs, int nsplit) {
+                                                      float* __restrict__ db2, RowSegs rs, int nsplit, const uint32_t* __restrict__ meta) {
   __shared__ __attribute__((aligned(16))) char rm[4][32 * WG_RM];     // x hi, x lo, dy hi, dy lo
   __shared__ __attribute__((aligned(16))) char tr[4][RR_E * WG_TR];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -549,8 +553,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wgrad(MlpWgradW w, const float* 
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const long long i = c * 32 + 2 * (rp0 + 8 * it) + e;
-        if (i < total) {
-          const long long m = td_row(rs, i);
+        const long long m = i < total ? td_row(rs, i) : 0;
+        if (i < total && (meta == nullptr || meta[m * 8 + 6] != 0u)) {       // dead rows (finished routes) read as zero rows
           px[it][e] = rr_ld4(X + m * RR_E + 4 * c4);
           py[it][e] = rr_ld4(dY + m * RR_E + 4 * c4);
         } else {
@@ -670,7 +674,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wgrad(MlpWgradW w, const float* 
 
 // dW1 [512][128], db1 [512], dW2 [128][512], db2 [128]: ADDED to (caller zeroes them).
 extern "C" int rr_mlp_wgrad(const MlpWgradW* w, const float* X, const float* dY, float* dW1, float* db1, float* dW2, float* db2,
-                            int nseg, int seg_rows, long long seg_stride, hipStream_t st) {
+                            const uint32_t* meta, int nseg, int seg_rows, long long seg_stride, hipStream_t st) {
   if (w == nullptr || w->w1n == nullptr || w->w2tn == nullptr || w->b1 == nullptr || X == nullptr || dY == nullptr ||
       dW1 == nullptr || db1 == nullptr || dW2 == nullptr)
     return RR_EINVAL;
@@ -678,7 +682,7 @@ extern "C" int rr_mlp_wgrad(const MlpWgradW* w, const float* X, const float* dY,
   RowSegs rs{nseg, seg_rows, seg_stride};
   const long long chunks = ((long long)nseg * seg_rows + 31) / 32;
   int nsplit = chunks >= 64 * 8 ? 64 : (chunks >= 64 ? 16 : 8);
-  hipLaunchKernelGGL(k_mlp_wgrad, dim3(4 * nsplit), dim3(256), 0, st, *w, X, dY, dW1, db1, dW2, db2, rs, nsplit);
+  hipLaunchKernelGGL(k_mlp_wgrad, dim3(4 * nsplit), dim3(256), 0, st, *w, X, dY, dW1, db1, dW2, db2, rs, nsplit, meta);
   return rr_check(hipGetLastError());
 }
 

@@ -110,8 +110,8 @@ _SIGS = {
     "rr_nab_train_bwd": [vp, vp, vp, vp, vp, C.c_long, vp],
     "rr_dec_logit_bwd": [C.POINTER(DecLogitIO), vp],
     "rr_gemm_tn": [vp, vp, vp, i32, i32, i32, i32, i32, i32, C.c_longlong, C.c_longlong, C.c_longlong, i32, i32, vp],
-    "rr_mlp_rows": [C.POINTER(MlpRowsW), i32, vp, vp, vp, i32, i32, C.c_longlong, vp],
-    "rr_mlp_wgrad": [C.POINTER(MlpWgradW), vp, vp, vp, vp, vp, vp, i32, i32, C.c_longlong, vp],
+    "rr_mlp_rows": [C.POINTER(MlpRowsW), i32, vp, vp, vp, vp, i32, i32, C.c_longlong, vp],
+    "rr_mlp_wgrad": [C.POINTER(MlpWgradW), vp, vp, vp, vp, vp, vp, vp, i32, i32, C.c_longlong, vp],
     "rr_dec_attn_bwd": [C.POINTER(DecAttnIO), vp],
 }
 

@@ -570,3 +570,58 @@ def replay_backward(policy, td, actions, num_starts, grad_ll, sample_idx, enc_ch
                 ll.backward(gll[a:z])                             # decoder parameters + the detached embeddings
             torch.autograd.backward([row, col], [row_d.grad, col_d.grad])
     return ll_out.transpose(0, 1).reshape(-1)
+
+
+def replay_backward_hip(policy, td, capture, num_starts, grad_ll, sample_idx, enc_chunk=512):
+    """Same contract as replay_backward, with the decoder differentiated by the hand-written kernels of
+    csrc/rr_train_dec.hip (models/dec_backward.py) on what the sampling rollout dumped: no teacher-forced re-evaluation of
+    the decoder, no torch op over the S*N decoder rows.  The kernels return d loss / d (glimpse keys, values, logit keys,
+    step-context tables) per instance; the encoder side (embeddings -> those five Linear maps, decoder.py:214-232) is
+    differentiated by autograd from there."""
+    from .dec_backward import decoder_backward
+    env_name = policy.env_name
+    atsp, vrp, vtw = env_name == "atsp", env_name == "rcvrp", env_name == "rcvrptw"
+    P = dict(policy.named_parameters())
+    nl = 1 + max(int(n.split(".")[3]) for n in P if n.startswith("encoder.net.layers."))
+    D, locs = td["distance_matrix"].float().contiguous(), td["locs"].float()
+    Dur = td["duration_matrix"].float().contiguous() if vtw else None
+    res = decoder_backward(policy, capture["cache"], capture["dump"], D, Dur, grad_ll)
+
+    def acc(name, g):
+        p = P[name]
+        g = g.reshape(p.shape).to(p.dtype)
+        p.grad = g if p.grad is None else p.grad + g
+
+    acc("decoder.pointer.ffn.lins.0.weight", res["dW1"]); acc("decoder.pointer.ffn.lins.0.bias", res["db1"])
+    acc("decoder.pointer.ffn.lins.1.weight", res["dW2"]); acc("decoder.pointer.ffn.lins.1.bias", res["db2"])
+    acc("decoder.alpha", res["dalpha"])
+    if vtw:
+        acc("decoder.beta", res["dbeta"])
+    demand = td["demand"].float() if vrp else None
+    extra = None
+    if vtw:
+        dl_full = td["demand_linehaul"].float()
+        demand = dl_full[:, 1:]
+        extra = torch.cat([td["time_windows"].float(), td["service_time"].float()[..., None]], -1)
+    B = D.shape[0]
+    Wn, Wc = P["decoder.project_node_embeddings.weight"], P["decoder.context_embedding.project_context.weight"]
+    with torch.enable_grad():
+        for lo in range(0, B, enc_chunk):
+            hi = min(B, lo + enc_chunk)
+            row, col = encode(P, locs[lo:hi], D[lo:hi], sample_idx[lo:hi], nl, use_checkpoint=False,
+                              demand=demand[lo:hi] if (vrp or vtw) else None,
+                              extra=extra[lo:hi] if vtw else None, dur=Dur[lo:hi] if vtw else None)
+            k, v, lk = F.linear(col, Wn).chunk(3, dim=-1)                      # decoder.py:214-232
+            outs, grads = [k, v, lk], [res["dK"][lo:hi], res["dV"][lo:hi], res["dL"][lo:hi]]
+            if atsp:
+                outs += [F.linear(row, Wc[:, :E]), F.linear(row, Wc[:, E:])]
+                grads += [res["dctxA"][lo:hi], res["dctxB"][lo:hi]]
+            else:
+                outs.append(F.linear(row, Wc[:, :E]))
+                grads.append(res["dctxB"][lo:hi])
+            torch.autograd.backward(outs, grads)
+    if not atsp:       # the state columns of project_context (VRPContext / MTVRPContextEmbedding, context.py:51-70)
+        g = torch.zeros_like(Wc)
+        g[:, E:E + res["dwstate"].shape[0]] = res["dwstate"].t()
+        Wc.grad = g if Wc.grad is None else Wc.grad + g
+    return res["log_likelihood"]

@@ -128,7 +128,8 @@ class RRNetPolicy(nn.Module):
             rows = Bp * dT * Sd
             dump.update({"T": dT, "S": Sd, "Bp": Bp, "N": N, "t0": t0,
                          "g0": torch.empty(rows, 128, device=dev), "g": torch.empty(rows, 128, device=dev),
-                         "meta": torch.empty(rows, 8, dtype=torch.int32, device=dev),
+                         # zeroed: rows a finished tile of rollouts never reaches must read as "not live"
+                         "meta": torch.zeros(rows, 8, dtype=torch.int32, device=dev),
                          "scal": None if self.env_name == "atsp" else torch.empty(rows, 4, device=dev)})
         ain = None
         if actions_in is not None:                      # evaluate: actions[..., step] feeds decode step `step`

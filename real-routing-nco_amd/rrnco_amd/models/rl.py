@@ -12,7 +12,7 @@ import torch
 from .. import _lib as L
 from ..ops import gather_by_index, unbatchify
 from ..parallel import allreduce_flat_gradients
-from .grad_replay import replay_backward
+from .grad_replay import replay_backward, replay_backward_hip
 from .policy import RRNetPolicy
 from .transforms import StateAugmentation
 
@@ -47,7 +47,8 @@ class RRNet:
             if "multistart" not in getattr(self.policy, attr):
                 setattr(self.policy, attr, "multistart_" + getattr(self.policy, attr))
 
-    def training_step(self, batch, optimizer=None, world: int = 1, enc_chunk: int = 512, dec_chunk: int = None, **policy_kw) -> dict:
+    def training_step(self, batch, optimizer=None, world: int = 1, enc_chunk: int = 512, dec_chunk: int = None,
+                      replay: str = "hip", **policy_kw) -> dict:
         """One REINFORCE step on this rank's shard of instances (rl.py:96-128 + Lightning's DDP mean-reduction):
         sampling rollout, reward, shared-baseline loss and d loss / d ll on the HIP kernels; parameter gradients by the
         teacher-forced replay; one flat all-reduce (mean over ranks); optimizer step.  Returns the shared_step dict plus
@@ -67,15 +68,20 @@ class RRNet:
                 state.update({k: td[k] for k in ("demand_backhaul", "open_route", "distance_limit", "backhaul_class")})
         sidx = td["sample_idx"]
         n_start = self.env.get_num_starts(td) if self.num_starts is None else self.num_starts
-        out = self.policy(td, self.env, phase="train", num_starts=n_start, **policy_kw)
+        cap = {} if replay == "hip" else None
+        out = self.policy(td, self.env, phase="train", num_starts=n_start, capture=cap, **policy_kw)
         r = out["normalized_reward"] if self.env.normalize else out["reward"]
         out.update(reinforce_loss(r, out["log_likelihood"], n_start))
         out["max_reward"] = unbatchify(out["reward"], (0, n_start)).max(dim=-1).values
         params = [p for p in self.policy.parameters()]
         for p in params:
             p.grad = None
-        out["replay_log_likelihood"] = replay_backward(self.policy, state, out["actions"], n_start, out["grad_log_likelihood"],
-                                                       sidx, enc_chunk=enc_chunk, dec_chunk=dec_chunk)
+        if cap is not None and "dump" in cap:     # decoder backward on the hand-written kernels (csrc/rr_train_dec.hip)
+            out["replay_log_likelihood"] = replay_backward_hip(self.policy, state, cap, n_start, out["grad_log_likelihood"],
+                                                               sidx, enc_chunk=enc_chunk)
+        else:                                     # teacher-forced torch replay (the step-wise decode paths, A/B)
+            out["replay_log_likelihood"] = replay_backward(self.policy, state, out["actions"], n_start, out["grad_log_likelihood"],
+                                                           sidx, enc_chunk=enc_chunk, dec_chunk=dec_chunk)
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
         grads = allreduce_flat_gradients(grads, world)
         for p, g in zip(params, grads):

@@ -53,13 +53,13 @@ def test_mlp_rows_forward_and_input_gradient(nseg, seg_rows, stride):
     X, idx = _seg_rows(nseg, seg_rows, stride, E, gen, safe_for=(W1, b1))
     dY, _ = _seg_rows(nseg, seg_rows, stride, E, gen)
     out = torch.full_like(X, 7.0)
-    L.check(L.lib().rr_mlp_rows(mp["fwd"], 0, L.ptr(X), None, L.ptr(out), nseg, seg_rows, stride, L.stream()), "fwd")
+    L.check(L.lib().rr_mlp_rows(mp["fwd"], 0, L.ptr(X), None, L.ptr(out), None, nseg, seg_rows, stride, L.stream()), "fwd")
     Xd = X[idx].double().requires_grad_()
     ref = Xd + F.linear(F.relu(F.linear(Xd, W1.double(), b1.double())), W2.double(), b2.double())
     assert _rel(out[idx], ref.detach()) < 3e-5
     ref.backward(dY[idx].double())
     dX = torch.full_like(X, 7.0)
-    L.check(L.lib().rr_mlp_rows(mp["bwd"], 1, L.ptr(X), L.ptr(dY), L.ptr(dX), nseg, seg_rows, stride, L.stream()), "bwd")
+    L.check(L.lib().rr_mlp_rows(mp["bwd"], 1, L.ptr(X), L.ptr(dY), L.ptr(dX), None, nseg, seg_rows, stride, L.stream()), "bwd")
     assert _rel(dX[idx], Xd.grad) < 3e-5
     if stride > seg_rows:                      # rows between the segments are not touched
         gap = torch.ones(nseg * stride, dtype=torch.bool, device="cuda"); gap[idx] = False
@@ -77,7 +77,7 @@ def test_mlp_weight_gradients(nseg, seg_rows, stride):
     dW1, db1 = torch.zeros(512, E, device="cuda"), torch.zeros(512, device="cuda")
     dW2, db2 = torch.zeros(E, 512, device="cuda"), torch.zeros(E, device="cuda")
     L.check(L.lib().rr_mlp_wgrad(mp["wgrad"], L.ptr(X), L.ptr(dY), L.ptr(dW1), L.ptr(db1), L.ptr(dW2), L.ptr(db2),
-                                 nseg, seg_rows, stride, L.stream()), "wgrad")
+                                 None, nseg, seg_rows, stride, L.stream()), "wgrad")
     P = [t.double().requires_grad_() for t in (W1, b1, W2, b2)]
     y = F.linear(F.relu(F.linear(X[idx].double(), P[0], P[1])), P[2], P[3])
     y.backward(dY[idx].double())
