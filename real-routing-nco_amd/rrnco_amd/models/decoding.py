@@ -23,7 +23,7 @@ class DecodingStrategy:
 
     def __init__(self, temperature=1.0, top_p=0.0, top_k=0, mask_logits=True, tanh_clipping=0, num_samples=None,
                  multisample=False, num_starts=None, multistart=False, select_start_nodes_fn=None,
-                 improvement_method_mode=False, select_best=False, store_all_logp=False, seed=0, **kwargs):
+                 improvement_method_mode=False, select_best=False, store_all_logp=False, seed=None, **kwargs):
         if select_best or improvement_method_mode:
             raise NotImplementedError("select_best / improvement_method_mode are outside the MI355X hot path")
         if not 0.0 <= top_p <= 1.0:
@@ -40,7 +40,9 @@ class DecodingStrategy:
         self.num_starts = num_starts if multistart else num_samples
         self.select_start_nodes_fn = select_start_nodes_fn
         self.store_all_logp = store_all_logp
-        self.seed = seed
+        # the sampling noise is a pure function of (seed, rollout, step, key): without an explicit seed, draw a fresh one from
+        # torch's generator, as the reference's torch.multinomial advances it (decoding.py:282-298)
+        self.seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if seed is None else int(seed)
         self.actions, self.logprobs = [], []
 
     def pre_decoder_hook(self, td, env, action=None):

@@ -505,7 +505,17 @@ def decode_log_likelihood_rcvrptw(P, row_emb, col_emb, D, Dur, demand_l, tw, ser
     return logp.sum(-1)
 
 
-def replay_backward(policy, td, actions, num_starts, grad_ll, sample_idx, enc_chunk=512, dec_chunk=None):
+def _check_replay_supported(policy):
+    """The encoder replay (_inorm) tells the normalisation apart by its parameters; BatchNorm1d has the same two as
+    InstanceNorm1d but batch statistics in train mode (attn_freenet.py:82-83, 102-103): refuse instead of returning the
+    gradient of a different network."""
+    if any(k.endswith(".normalizer.running_mean") for k in policy.state_dict()):
+        raise NotImplementedError("gradient replay: normalization='batch' (batch statistics in train mode) is not implemented; "
+                                  "the published configuration uses 'instance' (configs/experiment/rrnet.yaml)")
+
+
+def replay_backward(policy, td, actions, num_starts, grad_ll, sample_idx, enc_chunk=512, dec_chunk=None, tanh_clipping=None,
+                    temperature=None, vehicle_capacity=1.0):
     """Accumulate d loss / d theta into policy parameters' .grad, given d loss / d log-likelihood.
 
     td: the reset state the rollout started from (`locs`, normalised `distance_matrix`); actions [S*B, N] and grad_ll [S*B]
@@ -513,6 +523,7 @@ def replay_backward(policy, td, actions, num_starts, grad_ll, sample_idx, enc_ch
     rollout's)."""
     if policy.env_name not in ("atsp", "rcvrp", "rcvrptw"):
         raise NotImplementedError(f"gradient replay for env '{policy.env_name}'")
+    _check_replay_supported(policy)
     vrp, vtw = policy.env_name == "rcvrp", policy.env_name == "rcvrptw"
     if dec_chunk is None:      # instances per teacher-forced decoder evaluation: measured optimum (tools/bench_train.py --dec-chunk);
         dec_chunk = 64 if vtw else 256      # RCVRPTW routes are ~1.8 N steps long: 4x the rows per instance
@@ -537,14 +548,17 @@ def replay_backward(policy, td, actions, num_starts, grad_ll, sample_idx, enc_ch
     acts = actions.view(S, B, actions.shape[-1]).transpose(0, 1)  # [B,S,T]
     gll = grad_ll.view(S, B).transpose(0, 1)
     ll_out = torch.empty(B, S, device=D.device)
+    tanh_clipping = policy.tanh_clipping if tanh_clipping is None else tanh_clipping     # the values the rollout ran with
+    temperature = policy.temperature if temperature is None else temperature
+    cap = float(vehicle_capacity)
     vstates = None
     if vtw:      # the env replay is data (no gradient) and ~40 tiny launches per decode step: once for the whole shard, not per chunk
         with torch.no_grad():
             replay = rcvrptw_replay_states_hip if D.is_cuda else rcvrptw_replay_states      # (CPU: the oracle-side unit tests)
-            vstates = replay(D, Dur, dl_full, tw, service, acts, variant=variant)
+            vstates = replay(D, Dur, dl_full, tw, service, acts, cap=cap, variant=variant)
     elif vrp:
         with torch.no_grad():
-            vstates = (rcvrp_replay_states_hip if D.is_cuda else rcvrp_replay_states)(demand, acts)
+            vstates = (rcvrp_replay_states_hip if D.is_cuda else rcvrp_replay_states)(demand, acts, cap=cap)
     with torch.enable_grad():
         for lo in range(0, B, enc_chunk):
             hi = min(B, lo + enc_chunk)
@@ -558,14 +572,14 @@ def replay_backward(policy, td, actions, num_starts, grad_ll, sample_idx, enc_ch
                 z = min(hi, a + dec_chunk)
                 if vtw:
                     ll = decode_log_likelihood_rcvrptw(P, row_d[a - lo:z - lo], col_d[a - lo:z - lo], D[a:z], Dur[a:z], dl_full[a:z],
-                                                       tw[a:z], service[a:z], acts[a:z], policy.tanh_clipping, policy.temperature,
+                                                       tw[a:z], service[a:z], acts[a:z], tanh_clipping, temperature,
                                                        states=tuple(u[a:z] for u in vstates))
                 elif vrp:
                     ll = decode_log_likelihood_rcvrp(P, row_d[a - lo:z - lo], col_d[a - lo:z - lo], D[a:z], demand[a:z], acts[a:z],
-                                                     policy.tanh_clipping, policy.temperature, states=tuple(u[a:z] for u in vstates))
+                                                     tanh_clipping, temperature, states=tuple(u[a:z] for u in vstates))
                 else:
                     ll = decode_log_likelihood(P, row_d[a - lo:z - lo], col_d[a - lo:z - lo], D[a:z], acts[a:z],
-                                               policy.tanh_clipping, policy.temperature)
+                                               tanh_clipping, temperature)
                 ll_out[a:z] = ll.detach()
                 ll.backward(gll[a:z])                             # decoder parameters + the detached embeddings
             torch.autograd.backward([row, col], [row_d.grad, col_d.grad])
@@ -580,6 +594,7 @@ def replay_backward_hip(policy, td, capture, num_starts, grad_ll, sample_idx, en
     differentiated by autograd from there."""
     from .dec_backward import decoder_backward
     env_name = policy.env_name
+    _check_replay_supported(policy)
     atsp, vrp, vtw = env_name == "atsp", env_name == "rcvrp", env_name == "rcvrptw"
     P = dict(policy.named_parameters())
     nl = 1 + max(int(n.split(".")[3]) for n in P if n.startswith("encoder.net.layers."))

@@ -41,16 +41,43 @@ class RRNetPolicy(nn.Module):
         self._pack_cache = None
 
     def packed(self, device):
-        key = (str(device), packing.mlp_split_enabled(), tuple(p._version for p in self.parameters()),
-               tuple(p.data_ptr() for p in self.parameters()), packing.weights_fingerprint(self))
+        # buffers too: BatchNorm running statistics are folded into the pack (packing.py), and a buffer-only load must repack
+        ts = list(self.parameters()) + list(self.buffers())
+        key = (str(device), packing.mlp_split_enabled(), tuple(p._version for p in ts),
+               tuple(p.data_ptr() for p in ts), packing.weights_fingerprint(self))
         if self._pack_cache is None or self._pack_cache[0] != key:
             self._pack_cache = (key, packing.pack_policy(self.state_dict(), self.env_name, device))
         return self._pack_cache[1]
 
+    def forward(self, td, env=None, phase="train", *args, capture=None, **kwargs) -> dict:
+        """rrnco/models/policy.py:138-255.  The kernels run without an autograd graph; when gradients are enabled, the module
+        is in training mode and the call is a training forward (phase="train", sampled, fused rollout), the returned
+        `log_likelihood` is attached to the parameters through `_PolicyLogLikelihood`, whose backward is the hand-written
+        decoder backward + the encoder replay (models/grad_replay.py:replay_backward_hip): `loss.backward()` of the
+        reference's training step (rrnco/models/rl.py:118-128) works unchanged."""
+        want = (capture is None and phase == "train" and self.training and torch.is_grad_enabled()
+                and kwargs.get("actions", None) is None and self.env_name in PROB_ID
+                and any(p.requires_grad for p in self.parameters()))
+        if not want:
+            return self._forward_impl(td, env, phase, *args, capture=capture, **kwargs)
+        from .encoder import ATSPInitEmbedding
+        if td.get("sample_idx", None) is None:       # forward and backward must see the same neighbour sample (atsp.py:55-67)
+            td.set("sample_idx", ATSPInitEmbedding.sample_indices(td["distance_matrix"], self.encoder.init_embedding.sample_size))
+        keys = ("distance_matrix", "locs", "demand", "duration_matrix", "demand_linehaul", "time_windows", "service_time")
+        state = {k: td[k] for k in keys if k in td.keys()}
+        sidx = td["sample_idx"]
+        cap = {}
+        out = self._forward_impl(td, env, phase, *args, capture=cap, **kwargs)
+        if "dump" not in cap:        # step-wise decode paths (top-k / top-p, entropy rows, beam search) leave no dump
+            return out
+        params = [p for p in self.parameters() if p.requires_grad]
+        out["log_likelihood"] = _PolicyLogLikelihood.apply(out["log_likelihood"], self, state, cap, sidx, *params)
+        return out
+
     @torch.no_grad()
-    def forward(self, td, env=None, phase="train", calc_reward=True, return_actions=True, return_entropy=False,
-                return_hidden=False, return_init_embeds=False, return_sum_log_likelihood=True, actions=None,
-                max_steps=1_000_000, fused=True, capture=None, **decoding_kwargs) -> dict:
+    def _forward_impl(self, td, env=None, phase="train", calc_reward=True, return_actions=True, return_entropy=False,
+                      return_hidden=False, return_init_embeds=False, return_sum_log_likelihood=True, actions=None,
+                      max_steps=1_000_000, fused=True, capture=None, **decoding_kwargs) -> dict:
         if env is None or isinstance(env, str):
             raise ValueError("pass an instantiated rrnco_amd env")
         packed = self.packed(td.device)
@@ -151,3 +178,28 @@ class RRNetPolicy(nn.Module):
             td.set("first_node", st["first"])
         td.set("done", torch.ones(R, dtype=torch.bool, device=dev))
         return logp, acts, td
+
+
+class _PolicyLogLikelihood(torch.autograd.Function):
+    """log-likelihood of the sampled tours as a differentiable function of the policy parameters: the forward value is the
+    rollout's; the backward turns d loss / d ll into parameter gradients with the hand-written decoder backward
+    (csrc/rr_train_dec.hip) and the encoder replay, exactly what RRNet.training_step does."""
+
+    @staticmethod
+    def forward(ctx, ll, policy, state, cap, sidx, *params):
+        ctx.policy, ctx.state, ctx.cap, ctx.sidx, ctx.params = policy, state, cap, sidx, params
+        return ll.detach().clone()
+
+    @staticmethod
+    def backward(ctx, gll):
+        from .grad_replay import replay_backward_hip
+        params = ctx.params
+        held = [p.grad for p in params]
+        for p in params:
+            p.grad = None
+        replay_backward_hip(ctx.policy, ctx.state, ctx.cap, ctx.cap["dump"]["S"], gll.contiguous(), ctx.sidx)
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
+        for p, h in zip(params, held):
+            p.grad = h
+        ctx.cap = ctx.state = None            # the dump is several GB: release it with the graph
+        return (None, None, None, None, None) + tuple(grads)

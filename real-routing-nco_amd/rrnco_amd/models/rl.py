@@ -48,7 +48,7 @@ class RRNet:
                 setattr(self.policy, attr, "multistart_" + getattr(self.policy, attr))
 
     def training_step(self, batch, optimizer=None, world: int = 1, enc_chunk: int = 512, dec_chunk: int = None,
-                      replay: str = "hip", **policy_kw) -> dict:
+                      replay: str = "hip", grad_clip: float = None, **policy_kw) -> dict:
         """One REINFORCE step on this rank's shard of instances (rl.py:96-128 + Lightning's DDP mean-reduction):
         sampling rollout, reward, shared-baseline loss and d loss / d ll on the HIP kernels; parameter gradients by the
         teacher-forced replay; one flat all-reduce (mean over ranks); optimizer step.  Returns the shared_step dict plus
@@ -80,16 +80,22 @@ class RRNet:
             out["replay_log_likelihood"] = replay_backward_hip(self.policy, state, cap, n_start, out["grad_log_likelihood"],
                                                                sidx, enc_chunk=enc_chunk)
         else:                                     # teacher-forced torch replay (the step-wise decode paths, A/B)
-            out["replay_log_likelihood"] = replay_backward(self.policy, state, out["actions"], n_start, out["grad_log_likelihood"],
-                                                           sidx, enc_chunk=enc_chunk, dec_chunk=dec_chunk)
+            gen = getattr(self.env, "generator", None)
+            out["replay_log_likelihood"] = replay_backward(
+                self.policy, state, out["actions"], n_start, out["grad_log_likelihood"], sidx, enc_chunk=enc_chunk, dec_chunk=dec_chunk,
+                tanh_clipping=policy_kw.get("tanh_clipping"), temperature=policy_kw.get("temperature"),
+                vehicle_capacity=float(getattr(gen, "vehicle_capacity", 1.0) or 1.0))
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
         grads = allreduce_flat_gradients(grads, world)
         for p, g in zip(params, grads):
             p.grad = g
         # one multi-tensor launch, not two per parameter (565 parameters: ~90 ms of launches per step on the host)
         out["grad_norm"] = torch.linalg.vector_norm(torch.stack(torch._foreach_norm([g.float() for g in grads])))
+        if grad_clip is not None and grad_clip > 0:      # Lightning's gradient_clip_val (configs/trainer/default.yaml:6 = 1.0): clip_grad_norm_
+            torch._foreach_mul_(grads, torch.clamp(grad_clip / (out["grad_norm"] + 1e-6), max=1.0))       # on the device, no host sync
         if optimizer is not None:
             optimizer.step()
+            self.policy.invalidate_pack()                # the packed (MFMA-ordered, folded) weights are stale by construction
         return out
 
     def shared_step(self, batch, batch_idx: int = 0, phase: str = "val", **policy_kw) -> dict:
@@ -105,7 +111,10 @@ class RRNet:
         if phase == "train":
             assert n_start > 1, "num_starts must be > 1 during training"
             r = out["normalized_reward"] if self.env.normalize else out["reward"]
-            out.update(reinforce_loss(r, out["log_likelihood"], n_start))
+            ll = out["log_likelihood"]
+            out.update(reinforce_loss(r, ll.detach(), n_start))
+            if ll.requires_grad:      # rl.py:123-128: loss = -(advantage * ll).mean(), here with the kernel's d loss / d ll as weights
+                out["loss"] = out["reinforce_loss"] = (out["grad_log_likelihood"] * ll).sum()
             out["max_reward"] = reward.max(dim=-1).values
             return out
         out.update({"reward": reward, "no_aug_reward": reward[:, [0], :] if n_aug > 1 else reward})

@@ -19,7 +19,7 @@ def weights_fingerprint(module) -> tuple:
     """Per-parameter L2 norms (one multi-tensor launch, one host read) for the pack caches.  Version counters alone are not
     enough: fused optimizers (torch.optim.Adam(fused=True)) update the parameters in place WITHOUT bumping `_version`, and a
     stale pack would silently roll out with the previous weights."""
-    ps = [q for q in module.parameters() if q.is_floating_point()]
+    ps = [q for q in list(module.parameters()) + list(module.buffers()) if q.is_floating_point() and q.numel() > 0]
     if not ps:
         return ()
     norms = torch._foreach_norm(ps)

@@ -30,6 +30,7 @@ def main(argv=None):
     ap.add_argument("--milestones", type=int, nargs="*", default=[180, 195])
     ap.add_argument("--gamma", type=float, default=0.1)
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--grad_clip", type=float, default=1.0, help="gradient_clip_val of configs/trainer/default.yaml:6")
     ap.add_argument("--checkpoint_dir", default="checkpoints")
     ap.add_argument("--resume", default=None, help="checkpoint written by this script (or a reference .ckpt: weights only)")
     ap.add_argument("--log_every", type=int, default=50)
@@ -60,7 +61,8 @@ def main(argv=None):
     env = {"atsp": lambda: ATSPEnv(check_solution=False, generator_params=gp, device=dev),
            "rcvrp": lambda: RCVRPEnv(check_solution=False, generator_params=gp, device=dev),
            "rcvrptw": lambda: RMTVRPEnv(generator_params=gp, device=dev)}[o.problem]()
-    model = RRNet(env, policy=policy)
+    # configs/experiment/rrnet.yaml:45-51: dihedral-8 augmentation of the coordinates at validation / test time
+    model = RRNet(env, policy=policy, num_augment=8, augment_fn="dihedral8", no_aug_coords=False)
     opt = torch.optim.Adam(policy.parameters(), lr=o.lr, weight_decay=o.weight_decay, fused=True)   # one launch per step, same update
     sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=o.milestones, gamma=o.gamma)
     start_epoch = 0
@@ -70,7 +72,8 @@ def main(argv=None):
         if isinstance(blob, dict) and "optimizer_states" in blob and "rrnco_amd" in blob:
             opt.load_state_dict(blob["optimizer_states"][0]); sched.load_state_dict(blob["lr_schedulers"][0])
             start_epoch = int(blob["epoch"]) + 1
-    gen = torch.Generator(device=dev).manual_seed(o.seed + 1000 * rank)
+    # a resumed run continues the instance stream instead of replaying epoch 0's data: the stream is keyed by the epoch it starts at
+    gen = torch.Generator(device=dev).manual_seed(o.seed + 1000 * rank + 1_000_003 * start_epoch)
     val_gen = torch.Generator(device=dev).manual_seed(o.seed + 7)     # same validation set every epoch, on every rank
     steps_per_epoch = max(o.train_data_size // (o.batch_size * world), 1)
     val_batch = env.generator(min(o.val_data_size, 4 * o.batch_size), generator=val_gen)
@@ -80,7 +83,8 @@ def main(argv=None):
         t0, seen, run_loss, run_rew = time.perf_counter(), 0, 0.0, 0.0
         for it in range(steps_per_epoch):
             out = model.training_step(env.generator(o.batch_size, generator=gen), optimizer=opt, world=world,
-                                      seed=o.seed + epoch * steps_per_epoch + it)
+                                      grad_clip=o.grad_clip,
+                                      seed=(o.seed + epoch * steps_per_epoch + it) * world + rank)      # every rank its own sampling noise
             seen += o.batch_size
             if (it + 1) % o.log_every == 0 or it + 1 == steps_per_epoch:
                 run_loss, run_rew = float(out["loss"]), float(out["reward"].mean())
