@@ -212,3 +212,35 @@ def test_rcvrptw_training_step_gradients_match_oracle_autograd(fixture):
         assert err <= 5e-2 * float((refs[n] ** 2).sum()) ** 0.5 + 2e-5 * gnorm, (n, err)
         num += err ** 2
     assert num ** 0.5 / gnorm < 5e-3
+
+
+def test_loss_backward_runs_the_reference_training_pattern_and_equals_training_step():
+    """rrnco/models/rl.py:111-128 as the reference runs it: out = shared_step(batch, phase="train"); out["loss"].backward().
+    The policy's log-likelihood carries the graph (policy._PolicyLogLikelihood); the gradients are training_step's."""
+    fx = H.load_fixture("atsp_n20_b4_pomo")
+    w, pol, model, st, td_in = _model(fx)
+    model.training_step(td_in, seed=11)
+    g1 = {n: p.grad.clone() for n, p in pol.named_parameters()}
+    for p in pol.parameters():
+        p.grad = None
+    out = model.shared_step(td_in, phase="train", seed=11)
+    assert out["log_likelihood"].requires_grad and out["loss"].requires_grad
+    out["loss"].backward()
+    gn = sum(float((g ** 2).sum()) for g in g1.values()) ** 0.5
+    for n, p in pol.named_parameters():
+        if p.grad is None:
+            assert float(g1[n].abs().max()) == 0.0, n
+            continue
+        assert float((p.grad - g1[n]).norm()) <= 1e-4 * gn + 1e-3 * float(g1[n].norm()), n      # float atomics: order-dependent sums
+    # under no_grad / in eval mode the same call returns plain tensors
+    with torch.no_grad():
+        assert not model.shared_step(td_in, phase="train", seed=11)["log_likelihood"].requires_grad
+
+
+def test_gradient_clipping_as_the_reference_trainer():
+    """configs/trainer/default.yaml:6 gradient_clip_val = 1.0: the gradients the optimizer sees have norm <= clip."""
+    fx = H.load_fixture("atsp_n20_b4_pomo")
+    w, pol, model, st, td_in = _model(fx)
+    out = model.training_step(td_in, seed=11, grad_clip=0.05)
+    total = torch.linalg.vector_norm(torch.stack([p.grad.norm() for p in pol.parameters()]))
+    assert float(out["grad_norm"]) > 0.05 and abs(float(total) - 0.05) < 1e-4
