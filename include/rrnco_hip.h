@@ -216,6 +216,28 @@ typedef struct {
  * the step-context tables (rl4co TSPContext / VRPContext, env_embeddings/context.py:34-70). */
 int rr_dec_attn_bwd(const DecAttnIO* io, hipStream_t stream);
 
+/* ---- hand-written backward of the encoder blocks (csrc/rr_train_enc.hip, csrc/rr_enc_w.inc) ---------------------------
+ * rr_enc_layer_train = rr_enc_layer (instance norm, gating NAB in-kernel or bias_pre) that also stores, per block, what
+ * the backward reads back (attn_freenet.py:417-441): r = norm1(x), c = norm2(y), q, ek = exp(softmax_nodes(k)), v,
+ * num = ea @ (ek v), den = ea @ ek, y = sigmoid(q) num / den, o (input of norm3), u1 (input of ffn.norm1), x1 = ffn.norm1(u1)
+ * [Bp][N][128] each, and eaT [Bp][112][112] = exp(softmax(alpha * NAB)) transposed. */
+typedef struct { float *r, *c, *q, *ek, *v, *num, *den, *y, *o, *u1, *x1, *eaT; } EncSave;
+int rr_enc_layer_train(const EncBlockW* wrow, const EncBlockW* wcol, const float* row_in, const float* col_in, float* row_out,
+                       float* col_out, const float* D, const float* theta, const float* bias_pre, int Bp, int N,
+                       const EncSave* save_row, const EncSave* save_col, hipStream_t stream);
+/* InstanceNorm1d backward (attn_freenet.py:84, 104-105) per instance over the node axis; dy = dy1 (+ dy2); statistics are
+ * recomputed from x; dgamma / dbeta [128] are ADDED to; accumulate != 0 adds dx to what dx holds. */
+int rr_inorm_bwd(const float* x, const float* dy1, const float* dy2, const float* gamma, float* dx, float* dgamma, float* dbeta,
+                 int Bp, int N, int accumulate, hipStream_t stream);
+/* out[m][:] = x[m][:] W^T (+ bias) (+ out), 128 -> 128, W as packing.pack_a(W) ([8][8][64][4]): Linear forward, or its input
+ * gradient with pack_a(W^T); colsum [128] (optional) += sum_m x[m][:] (the bias gradient when x is an output gradient). */
+int rr_linear_rows(const void* Wp, const float* bias, const float* X, float* out, long long M, int accumulate, float* colsum,
+                   hipStream_t stream);
+typedef struct { const float *dy, *q, *ek, *v, *num, *den, *eaT; float *dq, *dk, *dv, *dbias; int N; } AftBwdIO;
+/* AFTFull (attn_freenet.py:309-324) backward per instance from the saved forward tensors: d q, d k, d v [Bp][N][128] and
+ * d loss / d (alpha * NAB bias) [Bp][N][N]. */
+int rr_aft_bwd(const AftBwdIO* io, int Bp, hipStream_t stream);
+
 /* POMO shared-baseline REINFORCE loss, forward half + d loss / d log-likelihood
  * (rrnco/models/rl.py:112-128; in-tree formula rrnco/baselines/routefinder/model.py:182-202). reward / ll / adv /
  * grad_ll are [S*B] with r = s*B + b; bl and partial are [B] workspaces; loss is one float. */

@@ -400,9 +400,30 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_enc_block(EncBlockW wr, EncB
 
 #include "rr_enc_w.inc"
 
+static int rr_enc_layer_impl(const EncBlockW* wrow, const EncBlockW* wcol, const float* row_in, const float* col_in,
+                             float* row_out, float* col_out, const float* D, const float* locs, const float* theta,
+                             const float* bias_pre, int Bp, int N, int norm_affine_only, float* dbg, const EncSave2& svs, hipStream_t st);
+
 extern "C" int rr_enc_layer(const EncBlockW* wrow, const EncBlockW* wcol, const float* row_in, const float* col_in,
                             float* row_out, float* col_out, const float* D, const float* locs, const float* theta,
                             const float* bias_pre, int Bp, int N, int norm_affine_only, float* dbg, hipStream_t st) {
+  EncSave2 none = {};
+  return rr_enc_layer_impl(wrow, wcol, row_in, col_in, row_out, col_out, D, locs, theta, bias_pre, Bp, N, norm_affine_only, dbg, none, st);
+}
+
+// The same layer as a TRAINING forward: additionally stores what the block backward (csrc/rr_train_enc.hip) reads back.
+extern "C" int rr_enc_layer_train(const EncBlockW* wrow, const EncBlockW* wcol, const float* row_in, const float* col_in,
+                                  float* row_out, float* col_out, const float* D, const float* theta, const float* bias_pre,
+                                  int Bp, int N, const EncSave* save_row, const EncSave* save_col, hipStream_t st) {
+  if (save_row == nullptr || save_col == nullptr || save_row->r == nullptr || save_col->r == nullptr) return RR_EINVAL;
+  if (theta == nullptr && bias_pre == nullptr) return RR_EINVAL;
+  EncSave2 svs; svs.s[0] = *save_row; svs.s[1] = *save_col;
+  return rr_enc_layer_impl(wrow, wcol, row_in, col_in, row_out, col_out, D, nullptr, theta, bias_pre, Bp, N, 0, nullptr, svs, st);
+}
+
+static int rr_enc_layer_impl(const EncBlockW* wrow, const EncBlockW* wcol, const float* row_in, const float* col_in,
+                             float* row_out, float* col_out, const float* D, const float* locs, const float* theta,
+                             const float* bias_pre, int Bp, int N, int norm_affine_only, float* dbg, const EncSave2& svs, hipStream_t st) {
   if (Bp <= 0 || N < 2 || N > RR_MAXN || wrow == nullptr || wcol == nullptr) return RR_EINVAL;
   // BatchNorm (eval) as a per-feature affine map is implemented in the register-resident block only
   if (norm_affine_only < 0 || norm_affine_only > 3) return RR_EINVAL;           // 0 instance, 1 batch (eval), 2 layer, 3 rms
@@ -413,7 +434,7 @@ extern "C" int rr_enc_layer(const EncBlockW* wrow, const EncBlockW* wcol, const 
     EncBlockW2 ws; ws.blk[0] = *wrow; ws.blk[1] = *wcol;   // wave = node tile, register-resident (rr_enc_w.inc); stage dumps use the LDS-staged kernel
     const char* es = getenv("RR_MLP_SPLIT");
     const bool split = es != nullptr && atoi(es) != 0 && wrow->w1s && wrow->w2s && wcol->w1s && wcol->w2s;
-#define RR_ENCW(NTV, SP) hipLaunchKernelGGL((k_enc_block_w<NTV, SP>), grid, dim3(64 * NTV), 0, st, ws, row_in, col_in, row_out, col_out, D, theta, bias_pre, N, norm_affine_only)
+#define RR_ENCW(NTV, SP) hipLaunchKernelGGL((k_enc_block_w<NTV, SP>), grid, dim3(64 * NTV), 0, st, ws, row_in, col_in, row_out, col_out, D, theta, bias_pre, N, norm_affine_only, svs)
     if (N <= 32) { if (split) RR_ENCW(2, true); else RR_ENCW(2, false); }
     else if (N <= 64) { if (split) RR_ENCW(4, true); else RR_ENCW(4, false); }
     else { if (split) RR_ENCW(7, true); else RR_ENCW(7, false); }

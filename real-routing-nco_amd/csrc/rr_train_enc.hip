@@ -1,0 +1,344 @@
+// Hand-written backward of one AttnFree_Block of the encoder (rrnco/models/nn/attn_freenet.py:417-441: AFTFull :309-327,
+// Normalization :78-116 (instance), TransformerFFN :330-357) for the REINFORCE step (BASELINE configs[4]) — what Lightning
+// autograd does behind rrnco/models/rl.py:118-128 for the encoder.
+//
+// The training forward is the inference block kernel (csrc/rr_enc_w.inc) with EncSave stores; the backward of a block is a
+// short chain of row-parallel kernels over the [Bp*N, 128] activations (everything fits the 256 MB Infinity Cache):
+//   k_inorm_bwd    InstanceNorm1d backward per instance (statistics recomputed from the saved input), d gamma / d beta
+//   k_linear_rows  out = x W^T (+ bias) (+ out): Linear forward / input gradient (W^T packed) on the fp32 MFMA, optional column
+//                  sums of x (the bias gradient of the layer whose output gradient x is)
+//   k_aft_bwd      AFTFull mixing backward per instance: d q, d k, d v and d (NAB bias) [N][N]
+// plus csrc/rr_train_dec.hip's k_mlp_rows / k_mlp_wgrad (the FFN is the pointer MLP's shape) and k_gemm_tn (dW = dY^T X), and
+// csrc/rr_train.hip's NAB backward.
+#include "rr_common.h"
+
+#define TE_LDI 116                      // row stride (floats) of the [feature][node] LDS images (as EW_LDN)
+#define TE_NP 112                       // padded node count of the transposed exp(softmax(bias)) image
+
+// ------------------------------------------------------------------------------------------------ InstanceNorm1d backward
+// y = gamma * (x - mean) * rstd + beta over the node axis, per instance and feature (biased variance, eps 1e-5).
+// dx = gamma rstd (dy - mean_n(dy) - xhat mean_n(dy xhat)); dgamma += sum dy xhat; dbeta += sum dy.
+// dy = dy1 (+ dy2).  `accumulate`: dx is added to what dx_out holds.
+__global__ __launch_bounds__(256) void k_inorm_bwd(const float* __restrict__ x, const float* __restrict__ dy1, const float* __restrict__ dy2,
+                                                   const float* __restrict__ gamma, float* __restrict__ dx_out,
+                                                   float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int accumulate) {
+  __shared__ float red[3][256];
+  const int b = blockIdx.x, tid = threadIdx.x, f = tid & 127, half = tid >> 7;
+  const size_t base = (size_t)b * N * RR_E + f;
+  constexpr int MAXR = 56;               // nodes per thread (N <= 112)
+  float xv[MAXR], dv[MAXR];
+  float s0 = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXR; ++i) {
+    const int n = 2 * i + half;
+    if (n < N) {
+      xv[i] = x[base + (size_t)n * RR_E];
+      dv[i] = dy1[base + (size_t)n * RR_E] + (dy2 ? dy2[base + (size_t)n * RR_E] : 0.f);
+      s0 += xv[i];
+    } else { xv[i] = 0.f; dv[i] = 0.f; }
+  }
+  red[0][tid] = s0;
+  __syncthreads();
+  const float inv_n = 1.0f / (float)N;
+  const float mean = (red[0][f] + red[0][128 + f]) * inv_n;
+  float q = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXR; ++i) {
+    const int n = 2 * i + half;
+    const float d = n < N ? xv[i] - mean : 0.f;
+    xv[i] = d;
+    q = fmaf(d, d, q); s1 += dv[i]; s2 = fmaf(dv[i], d, s2);
+  }
+  __syncthreads();
+  red[0][tid] = q; red[1][tid] = s1; red[2][tid] = s2;
+  __syncthreads();
+  const float var = (red[0][f] + red[0][128 + f]) * inv_n;
+  const float rstd = 1.0f / sqrtf(var + 1e-5f);
+  const float t1 = (red[1][f] + red[1][128 + f]);
+  const float t2 = (red[2][f] + red[2][128 + f]) * rstd;             // sum dy xhat
+  const float gm = gamma[f];
+  const float m1 = t1 * inv_n, m2 = t2 * inv_n;
+#pragma unroll
+  for (int i = 0; i < MAXR; ++i) {
+    const int n = 2 * i + half;
+    if (n < N) {
+      const float xh = xv[i] * rstd;
+      float v = gm * rstd * (dv[i] - m1 - xh * m2);
+      float* dst = dx_out + base + (size_t)n * RR_E;
+      if (accumulate) v += *dst;
+      *dst = v;
+    }
+  }
+  if (half == 0) { atomicAdd(dgamma + f, t2); atomicAdd(dbeta + f, t1); }
+}
+
+extern "C" int rr_inorm_bwd(const float* x, const float* dy1, const float* dy2, const float* gamma, float* dx, float* dgamma,
+                            float* dbeta, int Bp, int N, int accumulate, hipStream_t st) {
+  if (x == nullptr || dy1 == nullptr || gamma == nullptr || dx == nullptr || dgamma == nullptr || dbeta == nullptr) return RR_EINVAL;
+  if (Bp <= 0 || N < 1 || N > 112) return RR_EINVAL;
+  hipLaunchKernelGGL(k_inorm_bwd, dim3(Bp), dim3(256), 0, st, x, dy1, dy2, gamma, dx, dgamma, dbeta, N, accumulate);
+  return rr_check(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------ Linear on rows (128 -> 128)
+// out[m][n] = sum_k x[m][k] W[n][k] (+ bias[n]) (+ out[m][n]);  W as an fp32 MFMA A operand pack [8][8][64][4] (packing.pack_a).
+// One wave = 64 rows (four 16-row tiles as B operands in registers), the eight output tiles in turn.
+// colsum (optional) += sum_m x[m][:]  (the bias gradient when x is an output gradient).
+__global__ __launch_bounds__(256, 2) void k_linear_rows(const float4* __restrict__ Wp, const float* __restrict__ bias,
+                                                        const float* __restrict__ X, float* __restrict__ out, long long M,
+                                                        int accumulate, float* __restrict__ colsum) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const long long r0 = ((long long)blockIdx.x * 4 + wave) * 64;
+  if (r0 >= M) return;
+  const __amdgpu_buffer_rsrc_t rW = rr_make_buf(Wp, RR_E * RR_E * 4);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  f32x4 x[4][8];
+  long long row[4]; bool vr[4];
+  f32x4 cs[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) cs[kk] = rr_zero4();
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    row[rt] = r0 + 16 * rt + j;
+    vr[rt] = row[rt] < M;
+    const long long rc = vr[rt] ? row[rt] : M - 1;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const float4 v = rr_ld4(X + rc * RR_E + 16 * kk + 4 * g);
+      x[rt][kk] = f32x4{v.x, v.y, v.z, v.w};
+      if (vr[rt]) cs[kk] += x[rt][kk];
+    }
+  }
+  if (colsum != nullptr) {
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = cs[kk][r];
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+        if (j == 0) atomicAdd(colsum + 16 * kk + 4 * g + r, v);
+      }
+  }
+  float4 a[8], an[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) a[kk] = rr_bld4(rW, lane16, kk * 1024u);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    if (t + 1 < 8) {
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) an[kk] = rr_bld4(rW, lane16, (unsigned)((t + 1) * 8 + kk) * 1024u);
+    }
+    float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias != nullptr) bb = rr_ld4(bias + 16 * t + 4 * g);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 c[4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) c[rt] = f32x4{bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) c[rt] = rr_mfma(a[kk].x, x[rt][kk][0], c[rt]);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) c[rt] = rr_mfma(a[kk].y, x[rt][kk][1], c[rt]);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) c[rt] = rr_mfma(a[kk].z, x[rt][kk][2], c[rt]);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) c[rt] = rr_mfma(a[kk].w, x[rt][kk][3], c[rt]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+      if (vr[rt]) {
+        float* dst = out + row[rt] * RR_E + 16 * t + 4 * g;
+        float4 v = make_float4(c[rt][0], c[rt][1], c[rt][2], c[rt][3]);
+        if (accumulate) { const float4 o = rr_ld4(dst); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        rr_st4(dst, v);
+      }
+    if (t + 1 < 8) {
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) a[kk] = an[kk];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+extern "C" int rr_linear_rows(const void* Wp, const float* bias, const float* X, float* out, long long M, int accumulate,
+                              float* colsum, hipStream_t st) {
+  if (Wp == nullptr || X == nullptr || out == nullptr || M <= 0) return RR_EINVAL;
+  const unsigned grid = (unsigned)((M + 255) / 256);
+  hipLaunchKernelGGL(k_linear_rows, dim3(grid), dim3(256), 0, st, (const float4*)Wp, bias, X, out, M, accumulate, colsum);
+  return rr_check(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------ AFTFull backward
+struct AftBwdIO {
+  const float *dy;                        // [Bp][N][128] d loss / d (sigmoid(q) num / den)
+  const float *q, *ek, *v, *num, *den;    // saved by the training forward (EncSave)
+  const float *eaT;                       // [Bp][112][112] exp(softmax(bias)) transposed
+  float *dq, *dk, *dv;                    // [Bp][N][128]
+  float *dbias;                           // [Bp][N][N] d loss / d (alpha * NAB), row i = query node
+  int N;
+};
+
+// sum over the 16 lanes of a row (same g) in every lane
+__device__ __forceinline__ float te_rowsum(float v) {
+  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+  return v;
+}
+
+// One workgroup = one instance, wave w = node tile w (rows i of the first half, columns j of the second).
+//   mix = num / den, y = sigmoid(q) mix:  dq = dy mix s (1 - s);  dnum = dy s / den;  dden = -dy s mix / den
+//   ea = exp(softmax_j(bias)):  dea[i][j] = dnum[i] . (ek v)[j] + dden[i] . ek[j];  dbias = sa (dea ea - sum_j sa dea ea), sa = log ea
+//   d(ek v)[j] = sum_i ea[i][j] dnum[i];  dek = sum_i ea[i][j] dden[i] + d(ek v) v;  dv = d(ek v) ek
+//   ek = exp(softmax_nodes(k)):  dk = sk (dek ek - sum_nodes sk dek ek), sk = log ek
+template <int NT>
+__global__ __launch_bounds__(64 * NT, 1) void k_aft_bwd(AftBwdIO io) {
+  __shared__ __attribute__((aligned(16))) float img[2 * RR_E * TE_LDI];          // dnum^T, dden^T as [feature][node i]
+  __shared__ float part[NT][RR_E];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int N = io.N;
+  const int node = 16 * wave + j;
+  const bool nvalid = node < N;
+  const int nc = nvalid ? node : N - 1;
+  const size_t roff = ((size_t)b * N + nc) * RR_E + 4 * g;
+  const float* eaT = io.eaT + (size_t)b * TE_NP * TE_NP;
+  // ---- phase 0: elementwise part for this wave's rows i; images of dnum, dden
+  f32x4 dnum[8], dden[8];
+  {
+    float* pn = img + (4 * g) * TE_LDI + node;
+    float* pd = pn + RR_E * TE_LDI;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float4 dy = rr_ld4(io.dy + roff + 16 * t), qq = rr_ld4(io.q + roff + 16 * t);
+      const float4 nm = rr_ld4(io.num + roff + 16 * t), dn = rr_ld4(io.den + roff + 16 * t);
+      const float dyv[4] = {dy.x, dy.y, dy.z, dy.w}, qv[4] = {qq.x, qq.y, qq.z, qq.w};
+      const float nv[4] = {nm.x, nm.y, nm.z, nm.w}, dv_[4] = {dn.x, dn.y, dn.z, dn.w};
+      float dqv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s = 1.0f / (1.0f + rr_exp(-qv[r]));
+        const float rd = 1.0f / dv_[r];
+        const float mix = nv[r] * rd;
+        const float dm = dyv[r] * s;
+        dqv[r] = dyv[r] * mix * s * (1.0f - s);
+        dnum[t][r] = nvalid ? dm * rd : 0.f;
+        dden[t][r] = nvalid ? -dm * mix * rd : 0.f;
+        pn[(16 * t + r) * TE_LDI] = dnum[t][r];
+        pd[(16 * t + r) * TE_LDI] = dden[t][r];
+      }
+      if (nvalid) rr_st4(io.dq + roff + 16 * t, make_float4(dqv[0], dqv[1], dqv[2], dqv[3]));
+    }
+  }
+  // ---- phase 1: dea^T[j][i] for this wave's rows i, all j; row-softmax backward -> dbias[i][:]
+  {
+    float sa[NT][4], dsa[NT][4];
+    float dot = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      int key = 16 * jt + j; key = key < N ? key : N - 1;
+      const float* pe = io.ek + ((size_t)b * N + key) * RR_E + 4 * g;
+      const float* pv = io.v + ((size_t)b * N + key) * RR_E + 4 * g;
+      f32x4 c0 = rr_zero4(), c1 = rr_zero4();
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const float4 e = rr_ld4(pe + 16 * kk), vv = rr_ld4(pv + 16 * kk);
+        c0 = rr_mfma(e.x * vv.x, dnum[kk][0], c0); c1 = rr_mfma(e.x, dden[kk][0], c1);
+        c0 = rr_mfma(e.y * vv.y, dnum[kk][1], c0); c1 = rr_mfma(e.y, dden[kk][1], c1);
+        c0 = rr_mfma(e.z * vv.z, dnum[kk][2], c0); c1 = rr_mfma(e.z, dden[kk][2], c1);
+        c0 = rr_mfma(e.w * vv.w, dnum[kk][3], c0); c1 = rr_mfma(e.w, dden[kk][3], c1);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int jj = 16 * jt + 4 * g + r;
+        const float ea = eaT[(size_t)jj * TE_NP + node];                // zero outside N x N
+        const bool ok = jj < N && nvalid;
+        sa[jt][r] = ok ? rr_log(ea) : 0.f;
+        dsa[jt][r] = ok ? (c0[r] + c1[r]) * ea : 0.f;
+        dot = fmaf(sa[jt][r], dsa[jt][r], dot);
+      }
+    }
+    dot = rr_sum_g(dot);
+    if (nvalid) {
+      float* dst = io.dbias + ((size_t)b * N + node) * N;
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int jj = 16 * jt + 4 * g + r;
+          if (jj < N) dst[jj] = sa[jt][r] * (dsa[jt][r] - dot);
+        }
+    }
+  }
+  __syncthreads();                      // images complete
+  // ---- phase 2: this wave's nodes j: d(ek v), dek, dv, dk
+  {
+    float4 ef[NT];                      // B operand: ea[i][j] for k = i = 16 it + 4g + m, col j = this lane's node
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+      ef[it] = rr_ld4(eaT + (size_t)node * TE_NP + 16 * it + 4 * g);     // node < 112: inside the padded image
+      if (!nvalid) ef[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    f32x4 dsk[8], skv[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      f32x4 c0 = rr_zero4(), c1 = rr_zero4();
+      const float* pa = img + (16 * t + j) * TE_LDI + 4 * g;
+#pragma unroll
+      for (int it = 0; it < NT; ++it) {
+        const float4 an = rr_ld4(pa + 16 * it), ad = rr_ld4(pa + RR_E * TE_LDI + 16 * it);
+        c0 = rr_mfma(an.x, ef[it].x, c0); c1 = rr_mfma(ad.x, ef[it].x, c1);
+        c0 = rr_mfma(an.y, ef[it].y, c0); c1 = rr_mfma(ad.y, ef[it].y, c1);
+        c0 = rr_mfma(an.z, ef[it].z, c0); c1 = rr_mfma(ad.z, ef[it].z, c1);
+        c0 = rr_mfma(an.w, ef[it].w, c0); c1 = rr_mfma(ad.w, ef[it].w, c1);
+      }
+      const float4 e = rr_ld4(io.ek + roff + 16 * t), vv = rr_ld4(io.v + roff + 16 * t);
+      const float ev[4] = {e.x, e.y, e.z, e.w}, vx[4] = {vv.x, vv.y, vv.z, vv.w};
+      float dvv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dvv[r] = c0[r] * ev[r];
+        const float dek = fmaf(c0[r], vx[r], c1[r]);
+        skv[t][r] = nvalid ? rr_log(ev[r]) : 0.f;
+        dsk[t][r] = nvalid ? dek * ev[r] : 0.f;
+      }
+      if (nvalid) rr_st4(io.dv + roff + 16 * t, make_float4(dvv[0], dvv[1], dvv[2], dvv[3]));
+    }
+    // per-feature sum over ALL nodes of sk dsk: 16 lanes of the wave, then the waves (fixed order)
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s = te_rowsum(skv[t][r] * dsk[t][r]);
+        if (j == 0) part[wave][16 * t + 4 * g + r] = s;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      float dkv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float tot = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < NT; ++wv) tot += part[wv][16 * t + 4 * g + r];
+        dkv[r] = skv[t][r] * (dsk[t][r] - tot);
+      }
+      if (nvalid) rr_st4(io.dk + roff + 16 * t, make_float4(dkv[0], dkv[1], dkv[2], dkv[3]));
+    }
+  }
+}
+
+extern "C" int rr_aft_bwd(const AftBwdIO* io, int Bp, hipStream_t st) {
+  if (io == nullptr || io->dy == nullptr || io->q == nullptr || io->ek == nullptr || io->v == nullptr || io->num == nullptr ||
+      io->den == nullptr || io->eaT == nullptr || io->dq == nullptr || io->dk == nullptr || io->dv == nullptr || io->dbias == nullptr)
+    return RR_EINVAL;
+  const int N = io->N;
+  if (Bp <= 0 || N < 2 || N > RR_MAXN) return RR_EINVAL;
+  if (N <= 32) hipLaunchKernelGGL((k_aft_bwd<2>), dim3(Bp), dim3(128), 0, st, *io);
+  else if (N <= 64) hipLaunchKernelGGL((k_aft_bwd<4>), dim3(Bp), dim3(256), 0, st, *io);
+  else hipLaunchKernelGGL((k_aft_bwd<7>), dim3(Bp), dim3(448), 0, st, *io);
+  return rr_check(hipGetLastError());
+}

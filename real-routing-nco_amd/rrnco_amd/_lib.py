@@ -81,6 +81,15 @@ class DecAttnIO(C.Structure):
         [(n, i32) for n in ("Bp", "N", "S", "T", "nscal")] + [("seg_stride", C.c_longlong)]
 
 
+class EncSave(C.Structure):             # csrc/rr_enc_w.inc: what the training forward of a block keeps for its backward
+    NAMES = ("r", "c", "q", "ek", "v", "num", "den", "y", "o", "u1", "x1", "eaT")
+    _fields_ = [(n, vp) for n in NAMES]
+
+
+class AftBwdIO(C.Structure):            # csrc/rr_train_enc.hip
+    _fields_ = [(n, vp) for n in ("dy", "q", "ek", "v", "num", "den", "eaT", "dq", "dk", "dv", "dbias")] + [("N", i32)]
+
+
 class MtvrpExtra(C.Structure):
     _fields_ = [(n, vp) for n in ("demand_b", "used_b", "open_route", "dist_limit", "bclass")]
 
@@ -108,6 +117,11 @@ _SIGS = {
     "rr_select_matnet": [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, u64, u32, vp],
     "rr_nab_train_fwd": [vp, vp, vp, vp, C.c_long, vp],
     "rr_nab_train_bwd": [vp, vp, vp, vp, vp, C.c_long, vp],
+    "rr_enc_layer_train": [C.POINTER(EncBlockW), C.POINTER(EncBlockW), vp, vp, vp, vp, vp, vp, vp, i32, i32,
+                           C.POINTER(EncSave), C.POINTER(EncSave), vp],
+    "rr_inorm_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "rr_linear_rows": [vp, vp, vp, vp, C.c_longlong, i32, vp, vp],
+    "rr_aft_bwd": [C.POINTER(AftBwdIO), i32, vp],
     "rr_dec_logit_bwd": [C.POINTER(DecLogitIO), vp],
     "rr_gemm_tn": [vp, vp, vp, i32, i32, i32, i32, i32, i32, C.c_longlong, C.c_longlong, C.c_longlong, i32, i32, vp],
     "rr_mlp_rows": [C.POINTER(MlpRowsW), i32, vp, vp, vp, vp, i32, i32, C.c_longlong, vp],

@@ -1,0 +1,205 @@
+"""Hand-written HIP backward of the encoder side of the REINFORCE step — host side of csrc/rr_train_enc.hip.
+
+Given d loss / d (glimpse keys, values, logit keys, step-context tables) from the decoder backward (models/dec_backward.py)
+this walks rrnco/models/decoder.py:214-232 (the five Linear maps of the embeddings) and the 2 x num_layers AttnFree_Blocks
+(rrnco/models/nn/attn_freenet.py:417-441, 444-488) backwards on kernels, using what the training forward stored
+(_lib.EncSave).  What stays in torch: the chain rule through the host-side folds (project o multi_head_combine, the NAB's
+second MLP layers: tiny tensors) and the init embedding (atsp.py:69-121 / rcvrp.py:88-150: a few [Bp*N, 128] ops).
+Covers instance norm + gating NAB without duration (ATSP, RCVRP: RRNetEncoder.supports_hip_backward)."""
+from __future__ import annotations
+
+import torch
+
+from .. import _lib as L
+from .. import packing
+
+E = 128
+_NORMS = (("n1", "norm1"), ("n2", "norm2"), ("n3", "norm3"), ("f1", "feed_forward.ops.norm1"), ("f2", "feed_forward.ops.norm2"))
+
+
+def train_packs(policy) -> dict:
+    """Operand packs of the backward (transposed weights as fp32 MFMA A operands, bf16 split packs of the FFNs), rebuilt when
+    the policy's weights change (keyed like policy.packed)."""
+    dev = next(policy.parameters()).device
+    policy.packed(dev)
+    key = policy._pack_cache[0]
+    cached = getattr(policy, "_enc_train_pack", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    sd = {k: v.detach() for k, v in policy.named_parameters()}
+    nl = 1 + max(int(n.split(".")[3]) for n in sd if n.startswith("encoder.net.layers."))
+    keep, blocks = [], []
+
+    def pa(W):
+        t = packing.pack_a(W.float().contiguous())
+        keep.append(t)
+        return t
+
+    with torch.no_grad():
+        for l in range(nl):
+            pair = {}
+            for side in ("row", "col"):
+                b = f"encoder.net.layers.{l}.{side}_encoding_block"
+                Wpc = (sd[f"{b}.multi_head_combine.weight"].double() @ sd[f"{b}.attn_free.project.weight"].double()).float()
+                pair[side] = {"wqT": pa(sd[f"{b}.attn_free.to_q.weight"].t()), "wkT": pa(sd[f"{b}.attn_free.to_k.weight"].t()),
+                              "wvT": pa(sd[f"{b}.attn_free.to_v.weight"].t()), "wpcT": pa(Wpc.t()),
+                              "mlp": packing.pack_mlp_train(sd[f"{b}.feed_forward.ops.ffn.W1.weight"], sd[f"{b}.feed_forward.ops.ffn.W1.bias"],
+                                                            sd[f"{b}.feed_forward.ops.ffn.W2.weight"], sd[f"{b}.feed_forward.ops.ffn.W2.bias"])}
+            blocks.append(pair)
+        Wn = sd["decoder.project_node_embeddings.weight"]
+        Wc = sd["decoder.context_embedding.project_context.weight"]
+        cache = {"wkT": pa(Wn[:E].t()), "wvT": pa(Wn[E:2 * E].t()), "wlT": pa(Wn[2 * E:].t()), "wc0T": pa(Wc[:, :E].t())}
+        if policy.env_name == "atsp":
+            cache["wc1T"] = pa(Wc[:, E:2 * E].t())
+    out = {"blocks": blocks, "cache": cache, "keep": keep, "num_layers": nl}
+    policy._enc_train_pack = (key, out)
+    return out
+
+
+def _nab_tab(P, p, alpha):
+    """The folded table of csrc/rr_train.hip as a torch expression of the module parameters (autograd carries d tab back)."""
+    from .grad_replay import _nab_table
+    rows, ks, bg, bo = _nab_table(P, p)
+    z = torch.zeros((), device=alpha.device, dtype=alpha.dtype)
+    return torch.cat([torch.cat(rows), torch.stack([ks[0], ks[1], ks[2], ks[3], bg, bo, alpha.reshape(()), z])]).float()
+
+
+class _Grads:
+    """Gradient buffers of the parameters the kernels write (zero-filled: float atomics add into them)."""
+
+    def __init__(self, P):
+        self.P, self.g = P, {}
+
+    def buf(self, name):
+        if name not in self.g:
+            self.g[name] = torch.zeros_like(self.P[name], dtype=torch.float32)
+        return self.g[name]
+
+    def flush(self):
+        for n, g in self.g.items():
+            p = self.P[n]
+            g = g.to(p.dtype)
+            p.grad = g if p.grad is None else p.grad + g
+
+
+def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
+    """capture: what policy._forward_impl kept ("enc": per-layer saves, "emb": final embeddings); dec: decoder_backward's
+    result.  Accumulates the gradients of every encoder-side parameter (and project_node_embeddings / project_context)."""
+    from . import grad_replay as GR
+    lib, st = L.lib(), L.stream()
+    P = dict(policy.named_parameters())
+    packs = train_packs(policy)
+    saves = capture["enc"]
+    theta, layers = saves[-1]["theta"], saves[:-1]
+    row_emb, col_emb = capture["emb"]
+    Bp, N = D.shape[0], D.shape[-1]
+    M = Bp * N
+    dev = D.device
+    atsp = policy.env_name == "atsp"
+    G = _Grads(P)
+    new = lambda: torch.empty(Bp, N, E, device=dev)                                         # noqa: E731
+    MS = 64                                                                                  # row splits of the weight-gradient products
+
+    def lin(wp, x, out, acc=0, colsum=None):
+        L.check(lib.rr_linear_rows(L.ptr(wp), None, L.ptr(x), L.ptr(out), M, acc, L.ptr(colsum), st), "rr_linear_rows")
+
+    def wgrad(dy, x, gbuf, off=0, ldc=E):
+        """gbuf (+ off floats) [128][ldc] += dy^T x"""
+        L.check(lib.rr_gemm_tn(L.ptr(dy), L.ptr(x), gbuf.data_ptr() + 4 * off, 1, M, E, E, E, ldc, 0, 0, 0, MS, 1, st), "rr_gemm_tn")
+
+    def inorm(x, dy1, dy2, pname, dx, acc=0):
+        L.check(lib.rr_inorm_bwd(L.ptr(x), L.ptr(dy1), L.ptr(dy2), L.ptr(P[pname + ".normalizer.weight"].detach()), L.ptr(dx),
+                                 L.ptr(G.buf(pname + ".normalizer.weight")), L.ptr(G.buf(pname + ".normalizer.bias")), Bp, N, acc, st),
+                "rr_inorm_bwd")
+
+    with torch.no_grad():
+        # ---- decoder.py:214-232 backwards: embeddings -> K, V, L (col) and the step-context tables (row)
+        cp = packs["cache"]
+        d_col, d_row = new(), new()
+        gWn = G.buf("decoder.project_node_embeddings.weight")
+        gWc = G.buf("decoder.context_embedding.project_context.weight")
+        ldc_c = gWc.shape[1]
+        lin(cp["wkT"], dec["dK"], d_col); lin(cp["wvT"], dec["dV"], d_col, 1); lin(cp["wlT"], dec["dL"], d_col, 1)
+        wgrad(dec["dK"], col_emb, gWn, 0); wgrad(dec["dV"], col_emb, gWn, E * E); wgrad(dec["dL"], col_emb, gWn, 2 * E * E)
+        if atsp:
+            lin(cp["wc0T"], dec["dctxA"], d_row); lin(cp["wc1T"], dec["dctxB"], d_row, 1)
+            wgrad(dec["dctxA"], row_emb, gWc, 0, ldc_c); wgrad(dec["dctxB"], row_emb, gWc, E, ldc_c)
+        else:
+            lin(cp["wc0T"], dec["dctxB"], d_row)
+            wgrad(dec["dctxB"], row_emb, gWc, 0, ldc_c)
+            gWc[:, E:E + dec["dwstate"].shape[0]] += dec["dwstate"].t()
+        Dt = D.transpose(1, 2).contiguous()
+        small = []            # (torch expression of parameters, its gradient): chained through autograd at the end
+        # ---- the blocks, last layer first
+        for l in reversed(range(packs["num_layers"])):
+            sv = layers[l]
+            n_row, n_col = new(), new()                                       # d loss / d (this layer's row / col input)
+            for si, side in enumerate(("row", "col")):
+                b = f"encoder.net.layers.{l}.{side}_encoding_block"
+                pk, S = packs["blocks"][l][side], sv[side]
+                dout = d_row if side == "row" else d_col
+                x_in, y_in = (sv["row_in"], sv["col_in"]) if side == "row" else (sv["col_in"], sv["row_in"])
+                dx_out, dy_out = (n_row, n_col) if side == "row" else (n_col, n_row)
+                mlp = pk["mlp"]
+                # x2 = ffn.norm2(x1 + FFN(x1)) (:356): recompute the norm's input, then norm and FFN backwards
+                F = new()
+                L.check(lib.rr_mlp_rows(mlp["fwd"], 0, L.ptr(S["x1"]), None, L.ptr(F), None, 1, M, M, st), "rr_mlp_rows")
+                dF = new()
+                inorm(F, dout, None, b + ".feed_forward.ops.norm2", dF)
+                dx1 = F                                                                   # reuse
+                L.check(lib.rr_mlp_rows(mlp["bwd"], 1, L.ptr(S["x1"]), L.ptr(dF), L.ptr(dx1), None, 1, M, M, st), "rr_mlp_rows")
+                f = b + ".feed_forward.ops.ffn"
+                L.check(lib.rr_mlp_wgrad(mlp["wgrad"], L.ptr(S["x1"]), L.ptr(dF), L.ptr(G.buf(f + ".W1.weight")), L.ptr(G.buf(f + ".W1.bias")),
+                                         L.ptr(G.buf(f + ".W2.weight")), L.ptr(G.buf(f + ".W2.bias")), None, 1, M, M, st), "rr_mlp_wgrad")
+                # x1 = ffn.norm1(r + norm3(o)) (:355, 436)
+                dU1 = dF                                                                  # reuse
+                inorm(S["u1"], dx1, None, b + ".feed_forward.ops.norm1", dU1)
+                dO = dx1
+                inorm(S["o"], dU1, None, b + ".norm3", dO)
+                # o = combine(project(y)) (:325, 435): one folded Linear Wpc = Wc Wp
+                dbpc = torch.zeros(E, device=dev)
+                dY = new()
+                lin(pk["wpcT"], dO, dY, 0, dbpc)
+                dWpc = torch.zeros(E, E, device=dev)
+                wgrad(dO, S["y"], dWpc)
+                with torch.enable_grad():
+                    Wc_, Wp_ = P[b + ".multi_head_combine.weight"], P[b + ".attn_free.project.weight"]
+                    small += [(Wc_ @ Wp_, dWpc), (Wc_ @ P[b + ".attn_free.project.bias"] + P[b + ".multi_head_combine.bias"], dbpc)]
+                # AFTFull (:309-324)
+                dq, dk, dv = new(), new(), new()
+                dbias = torch.empty(Bp, N, N, device=dev)
+                io = L.AftBwdIO()
+                io.dy, io.q, io.ek, io.v, io.num, io.den, io.eaT = (L.ptr(dY), L.ptr(S["q"]), L.ptr(S["ek"]), L.ptr(S["v"]), L.ptr(S["num"]),
+                                                                    L.ptr(S["den"]), L.ptr(S["eaT"]))
+                io.dq, io.dk, io.dv, io.dbias, io.N = L.ptr(dq), L.ptr(dk), L.ptr(dv), L.ptr(dbias), N
+                L.check(lib.rr_aft_bwd(io, Bp, st), "rr_aft_bwd")
+                # alpha * NAB (:427-429): the folded-table backward of csrc/rr_train.hip, chained to the module parameters by autograd
+                with torch.enable_grad():
+                    tab = _nab_tab(P, b + ".angle_distance_fusion", P[b + ".alpha"])
+                gtab = torch.zeros_like(tab)
+                xd = D if side == "row" else Dt
+                L.check(lib.rr_nab_train_bwd(L.ptr(tab.detach().contiguous()), L.ptr(xd), L.ptr(theta), L.ptr(dbias), L.ptr(gtab),
+                                             dbias.numel(), st), "rr_nab_train_bwd")
+                small.append((tab, gtab))
+                # q = to_q(r), k = to_k(c), v = to_v(c) (:313-315)
+                dr = dY                                                                   # reuse
+                lin(pk["wqT"], dq, dr, 0, G.buf(b + ".attn_free.to_q.bias"))
+                wgrad(dq, S["r"], G.buf(b + ".attn_free.to_q.weight"))
+                dc = dO
+                lin(pk["wkT"], dk, dc, 0, G.buf(b + ".attn_free.to_k.bias"))
+                lin(pk["wvT"], dv, dc, 1, G.buf(b + ".attn_free.to_v.bias"))
+                wgrad(dk, S["c"], G.buf(b + ".attn_free.to_k.weight"))
+                wgrad(dv, S["c"], G.buf(b + ".attn_free.to_v.weight"))
+                # r = norm1(x) (:421; also the residual into ffn.norm1), c = norm2(y) (:422)
+                inorm(x_in, dU1, dr, b + ".norm1", dx_out, acc=si)           # the col block adds to what the row block wrote
+                inorm(y_in, dc, None, b + ".norm2", dy_out, acc=si)
+            d_row, d_col = n_row, n_col
+    G.flush()
+    # ---- chain rule through the folds and the init embedding (autograd on tiny / [Bp*N,128] tensors)
+    vrp = policy.env_name == "rcvrp"
+    with torch.enable_grad():
+        if vrp:
+            row0, col0 = GR._init_embedding_vrp(P, locs, td["demand"].float(), D, sample_idx, None, "demand_init")
+        else:
+            row0, col0 = GR._init_embedding(P, locs, D, sample_idx)
+        torch.autograd.backward([t for t, _ in small] + [row0, col0], [g for _, g in small] + [d_row, d_col])

@@ -169,8 +169,14 @@ class RRNetEncoder(nn.Module):
         self.net = AttnFreeNet(embed_dim, feedforward_hidden, num_layers, nab_type=nab_type, normalization=normalization,
                                use_duration_matrix=self.env_name not in ("atsp", "rcvrp")) if net is None else net   # encoder.py:63-66
 
-    def forward(self, td, phase: str = "val", mask=None, packed=None):
-        """-> (row_emb, col_emb) [B,N,E].  `packed` = packing.pack_policy(...) (the policy caches it)."""
+    def supports_hip_backward(self, packed) -> bool:
+        """The hand-written block backward (csrc/rr_train_enc.hip) covers the published configuration: instance norm and the
+        gating NAB without duration (ATSP, RCVRP)."""
+        return (self.normalization == "instance" and packed.get("nab_kind", "gating") == "gating" and len(packed["nabdur"]) == 0)
+
+    def forward(self, td, phase: str = "val", mask=None, packed=None, train_saves=None):
+        """-> (row_emb, col_emb) [B,N,E].  `packed` = packing.pack_policy(...) (the policy caches it).  `train_saves` (a list):
+        training forward — every layer's inputs and the per-block tensors of _lib.EncSave are appended to it."""
         assert packed is not None, "RRNetEncoder.forward needs packed weights (call through RRNetPolicy or pass packed=)"
         bn = self.normalization == "batch"
         norm_mode = {"instance": 0, "batch": 1, "layer": 2, "rms": 3}[self.normalization]        # rr_enc_layer norm_affine_only
@@ -221,6 +227,21 @@ class RRNetEncoder(nn.Module):
             elif use_dur:
                 nr, nc = packed["nabdur"][l]
                 L.check(lib.rr_nab_dur(nr, nc, L.ptr(D), L.ptr(T), L.ptr(locs), L.ptr(bias), Bp, N, L.stream()), "rr_nab_dur")
+            if train_saves is not None:
+                sv = []
+                for _ in range(2):
+                    d = {n: torch.empty(Bp, N, 128, device=dev, dtype=torch.float32) for n in L.EncSave.NAMES[:-1]}
+                    d["eaT"] = torch.empty(Bp, 112, 112, device=dev, dtype=torch.float32)
+                    st_ = L.EncSave()
+                    for n in L.EncSave.NAMES:
+                        setattr(st_, n, L.ptr(d[n]))
+                    sv.append((d, st_))
+                L.check(lib.rr_enc_layer_train(wr, wc, L.ptr(row), L.ptr(col), L.ptr(row2), L.ptr(col2), L.ptr(D),
+                                               L.ptr(theta) if theta is not None else None, L.ptr(bias) if use_dur else None,
+                                               Bp, N, sv[0][1], sv[1][1], L.stream()), "rr_enc_layer_train")
+                train_saves.append({"row_in": row, "col_in": col, "row": sv[0][0], "col": sv[1][0]})
+                row, col, row2, col2 = row2, col2, torch.empty_like(row), torch.empty_like(col)
+                continue
             L.check(lib.rr_enc_layer(wr, wc, L.ptr(row), L.ptr(col), L.ptr(row2), L.ptr(col2), L.ptr(D), L.ptr(locs),
                                      L.ptr(theta) if theta is not None else None, L.ptr(bias) if use_dur else None,
                                      Bp, N, norm_mode, L.ptr(dbg) if (dbg is not None and l == 0) else None, L.stream()),
@@ -229,4 +250,6 @@ class RRNetEncoder(nn.Module):
                 row, col, row2, col2 = row2, col2, torch.empty_like(row), torch.empty_like(col)
             else:
                 row, col, row2, col2 = row2, col2, row, col
+        if train_saves is not None:
+            train_saves.append({"theta": theta})
         return row, col

@@ -612,6 +612,10 @@ def replay_backward_hip(policy, td, capture, num_starts, grad_ll, sample_idx, en
     acc("decoder.alpha", res["dalpha"])
     if vtw:
         acc("decoder.beta", res["dbeta"])
+    if "enc" in capture:      # encoder side on the hand-written kernels too (models/enc_backward.py): no torch replay of the blocks
+        from .enc_backward import encoder_backward
+        encoder_backward(policy, capture, res, D, locs, sample_idx, td)
+        return res["log_likelihood"]
     demand = td["demand"].float() if vrp else None
     extra = None
     if vtw:

@@ -81,7 +81,12 @@ class RRNetPolicy(nn.Module):
         if env is None or isinstance(env, str):
             raise ValueError("pass an instantiated rrnco_amd env")
         packed = self.packed(td.device)
-        row_emb, col_emb = self.encoder(td, phase=phase, packed=packed)
+        saves = None
+        if capture is not None and self.encoder.supports_hip_backward(packed) and capture.get("enc_saves", True):
+            saves = capture["enc"] = []          # training forward: the encoder keeps what its hand-written backward reads
+        row_emb, col_emb = self.encoder(td, phase=phase, packed=packed, train_saves=saves)
+        if capture is not None:
+            capture["emb"] = (row_emb, col_emb)
 
         decode_type = decoding_kwargs.pop("decode_type", None)
         if actions is not None:

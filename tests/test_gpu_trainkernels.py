@@ -163,3 +163,67 @@ def test_decoder_backward_matches_autograd_on_the_rollouts_own_cache(name):
         # recomputation (one such unit among the 10^4..10^6 of these batches moves them by a few 1e-3)
         tol = 1e-2 if nm in ("dW1", "db1") else 2e-3
         assert _rel(got, ref) < tol, (nm, _rel(got, ref))
+
+
+# ---------------------------------------------------------------- encoder block backward (csrc/rr_train_enc.hip)
+@pytest.mark.parametrize("B,N", [(3, 20), (2, 100), (2, 101)])
+def test_instance_norm_backward(B, N):
+    from rrnco_amd import _lib as L
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn(B, N, E, generator=gen).cuda()
+    dy1, dy2 = torch.randn(B, N, E, generator=gen).cuda(), torch.randn(B, N, E, generator=gen).cuda()
+    gamma = (1 + 0.3 * torch.randn(E, generator=gen)).cuda()
+    prev = torch.randn(B, N, E, generator=gen).cuda()
+    dx, dg, db = prev.clone(), torch.zeros(E, device="cuda"), torch.zeros(E, device="cuda")
+    L.check(L.lib().rr_inorm_bwd(L.ptr(x), L.ptr(dy1), L.ptr(dy2), L.ptr(gamma), L.ptr(dx), L.ptr(dg), L.ptr(db), B, N, 1, L.stream()), "inorm")
+    xd, gd = x.double().requires_grad_(), gamma.double().requires_grad_()
+    bd = torch.zeros(E, dtype=torch.float64, device="cuda", requires_grad=True)
+    mu = xd.mean(1, keepdim=True)
+    y = (xd - mu) * torch.rsqrt(((xd - mu) ** 2).mean(1, keepdim=True) + 1e-5) * gd + bd
+    y.backward((dy1 + dy2).double())
+    assert _rel(dx - prev, xd.grad) < 1e-5 and _rel(dg, gd.grad) < 1e-5 and _rel(db, bd.grad) < 1e-5
+
+
+@pytest.mark.parametrize("M", [100, 2000, 51200])
+def test_linear_rows(M):
+    from rrnco_amd import _lib as L, packing
+    gen = torch.Generator().manual_seed(8)
+    W = (torch.randn(E, E, generator=gen) / math.sqrt(E)).cuda()
+    bias = torch.randn(E, generator=gen).cuda()
+    x = torch.randn(M, E, generator=gen).cuda()
+    out = torch.randn(M, E, generator=gen).cuda()
+    out0 = out.clone()
+    cs = torch.zeros(E, device="cuda")
+    wp = packing.pack_a(W)
+    L.check(L.lib().rr_linear_rows(L.ptr(wp), L.ptr(bias), L.ptr(x), L.ptr(out), M, 1, L.ptr(cs), L.stream()), "linear")
+    assert _rel(out, out0.double() + F.linear(x.double(), W.double(), bias.double())) < 2e-6
+    assert _rel(cs, x.double().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("B,N", [(3, 20), (2, 50), (2, 100), (2, 101)])
+def test_aft_mixing_backward(B, N):
+    """AFTFull (attn_freenet.py:309-324) backward from the tensors the training forward stores."""
+    from rrnco_amd import _lib as L
+    gen = torch.Generator().manual_seed(9)
+    q, k, v = (torch.randn(B, N, E, generator=gen).cuda() for _ in range(3))
+    bias = torch.randn(B, N, N, generator=gen).cuda()
+    dy = torch.randn(B, N, E, generator=gen).cuda()
+    leaves = [t.double().requires_grad_() for t in (q, k, v, bias)]
+    qd, kd, vd, bd = leaves
+    ea = torch.exp(torch.softmax(bd, dim=-1))
+    ek = torch.exp(torch.softmax(kd, dim=1))
+    num, den = ea @ (ek * vd), ea @ ek
+    y = torch.sigmoid(qd) * num / den
+    y.backward(dy.double())
+    eaT = torch.zeros(B, 112, 112, device="cuda")
+    eaT[:, :N, :N] = ea.detach().float().transpose(1, 2)
+    f32 = lambda t: t.detach().float().contiguous()                                            # noqa: E731
+    dq, dk, dv = (torch.empty(B, N, E, device="cuda") for _ in range(3))
+    dbias = torch.empty(B, N, N, device="cuda")
+    io = L.AftBwdIO()
+    keep = [f32(ek), f32(num), f32(den)]
+    io.dy, io.q, io.ek, io.v, io.num, io.den, io.eaT = L.ptr(dy), L.ptr(q), L.ptr(keep[0]), L.ptr(v), L.ptr(keep[1]), L.ptr(keep[2]), L.ptr(eaT)
+    io.dq, io.dk, io.dv, io.dbias, io.N = L.ptr(dq), L.ptr(dk), L.ptr(dv), L.ptr(dbias), N
+    L.check(L.lib().rr_aft_bwd(io, B, L.stream()), "aft_bwd")
+    for got, leaf, nm in zip((dq, dk, dv, dbias), leaves, ("dq", "dk", "dv", "dbias")):
+        assert _rel(got, leaf.grad) < 2e-4, (nm, _rel(got, leaf.grad))
