@@ -28,8 +28,9 @@
 // rows of one launch: nseg segments (instances) of seg_rows live rows each, seg_stride rows apart
 struct RowSegs { int nseg; int seg_rows; long long seg_stride; };
 __device__ __forceinline__ long long td_row(const RowSegs& rs, long long i) {
-  const long long sg = i / rs.seg_rows;
-  return sg * rs.seg_stride + (i - sg * rs.seg_rows);
+  if (rs.nseg == 1) return i;                          // wave-uniform
+  const unsigned iu = (unsigned)i, sg = iu / (unsigned)rs.seg_rows;       // row counts stay far below 2^31: 32-bit divide
+  return (long long)sg * rs.seg_stride + (long long)(iu - sg * (unsigned)rs.seg_rows);
 }
 
 // ------------------------------------------------------------------------------------------------ logits backward
@@ -397,15 +398,23 @@ __global__ __launch_bounds__(256, 1) void k_mlp_rows(MlpRowsW w, const float* __
       i = vr[rt] ? i : total - 1;
       mrow[rt] = td_row(rs, i);
       // rows the rollout never reached (finished routes) hold no data: they read as zero rows
-      const bool lv = meta == nullptr || meta[mrow[rt] * 8 + 6] != 0u;
+      // (every load is issued unconditionally and zeroed by the flag afterwards: no dependent-load chain)
+      const unsigned lvw = meta == nullptr ? 1u : meta[mrow[rt] * 8 + 6];
       const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 xa4[4], xb4[4], ya4[4], yb4[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const float4 xa = lv ? rr_ld4(X + mrow[rt] * RR_E + 32 * s + 4 * g) : z4, xb = lv ? rr_ld4(X + mrow[rt] * RR_E + 32 * s + 16 + 4 * g) : z4;
+        xa4[s] = rr_ld4(X + mrow[rt] * RR_E + 32 * s + 4 * g); xb4[s] = rr_ld4(X + mrow[rt] * RR_E + 32 * s + 16 + 4 * g);
+        if (MODE == 1) { ya4[s] = rr_ld4(dY + mrow[rt] * RR_E + 32 * s + 4 * g); yb4[s] = rr_ld4(dY + mrow[rt] * RR_E + 32 * s + 16 + 4 * g); }
+      }
+      const bool lv = lvw != 0u;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float4 xa = lv ? xa4[s] : z4, xb = lv ? xb4[s] : z4;
         const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
         td_split8(xv, Xh[rt][s], Xl[rt][s]);
         if (MODE == 1) {
-          const float4 ya = lv ? rr_ld4(dY + mrow[rt] * RR_E + 32 * s + 4 * g) : z4, yb = lv ? rr_ld4(dY + mrow[rt] * RR_E + 32 * s + 16 + 4 * g) : z4;
+          const float4 ya = lv ? ya4[s] : z4, yb = lv ? yb4[s] : z4;
           const float yv[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
           td_split8(yv, Yh[rt][s], Yl[rt][s]);
           acc[rt][2 * s] = f32x4{ya.x, ya.y, ya.z, ya.w}; acc[rt][2 * s + 1] = f32x4{yb.x, yb.y, yb.z, yb.w};
@@ -547,19 +556,17 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wgrad(MlpWgradW w, const float* 
   // staging: thread -> column group c4 = tid & 31 (4 features), row pairs rp = (tid >> 5) and (tid >> 5) + 8
   const int c4 = tid & 31, rp0 = tid >> 5;
   float4 px[2][2], py[2][2];
-  auto g_load = [&](long long c) {
+  unsigned plv[2][2];
+  auto g_load = [&](long long c) {           // every load unconditional (clamped row), zeroed by the flag in `put`: no dependent loads
 #pragma unroll
     for (int it = 0; it < 2; ++it)
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const long long i = c * 32 + 2 * (rp0 + 8 * it) + e;
-        const long long m = i < total ? td_row(rs, i) : 0;
-        if (i < total && (meta == nullptr || meta[m * 8 + 6] != 0u)) {       // dead rows (finished routes) read as zero rows
-          px[it][e] = rr_ld4(X + m * RR_E + 4 * c4);
-          py[it][e] = rr_ld4(dY + m * RR_E + 4 * c4);
-        } else {
-          px[it][e] = make_float4(0.f, 0.f, 0.f, 0.f); py[it][e] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        const long long m = td_row(rs, i < total ? i : total - 1);
+        px[it][e] = rr_ld4(X + m * RR_E + 4 * c4);
+        py[it][e] = rr_ld4(dY + m * RR_E + 4 * c4);
+        plv[it][e] = (i < total) ? (meta == nullptr ? 1u : meta[m * 8 + 6]) : 0u;       // dead rows (finished routes) read as zero rows
       }
   };
   auto put = [&](const float4 (&v)[2], int rp, char* rmh, char* rml, char* trh, char* trl) {
@@ -591,6 +598,9 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wgrad(MlpWgradW w, const float* 
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+        if (plv[it][e] == 0u) { px[it][e] = make_float4(0.f, 0.f, 0.f, 0.f); py[it][e] = make_float4(0.f, 0.f, 0.f, 0.f); }
       put(px[it], rp0 + 8 * it, rm[0], rm[1], tr[0], tr[1]);
       put(py[it], rp0 + 8 * it, rm[2], rm[3], tr[2], tr[3]);
       if (slab == 0) {
@@ -745,29 +755,60 @@ __global__ __launch_bounds__(256, 1) void k_dec_attn_bwd(DecAttnIO io) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) dws[k][r] = 0.f;
   const int ntile = (rows_b + 15) / 16;
-  for (int tile = wave; tile < ntile; tile += 4) {
+  // Inputs of a tile are two dependent global round trips (meta -> gathers of the context rows): they are requested two /
+  // one tiles ahead, so that a tile's arithmetic runs under the next tiles' loads.
+  struct TMeta { uint4 m0, m1; size_t m; int s; bool vrow; };
+  struct TVals { float4 qb, qa, dh, sv; int fst; };
+  auto ld_meta = [&](int tile) {
+    TMeta r;
     int q = tile * 16 + j;
-    const bool vrow = q < rows_b;
-    q = vrow ? q : rows_b - 1;
-    const size_t m = (size_t)b * (size_t)io.seg_stride + (size_t)q;
-    const int t = q / S, s = q - t * S;
-    const uint4 m0 = *reinterpret_cast<const uint4*>(io.meta + m * 8);
-    const uint4 m1 = *reinterpret_cast<const uint4*>(io.meta + m * 8 + 4);
+    r.vrow = q < rows_b;
+    q = q < rows_b ? q : rows_b - 1;
+    r.m = (size_t)b * (size_t)io.seg_stride + (size_t)q;
+    const int t = q / S;
+    r.s = q - t * S;
+    r.m0 = *reinterpret_cast<const uint4*>(io.meta + r.m * 8);
+    r.m1 = *reinterpret_cast<const uint4*>(io.meta + r.m * 8 + 4);
+    return r;
+  };
+  auto ld_vals = [&](const TMeta& tm) {
+    TVals v;
+    const int prev = min((int)tm.m1.x, N - 1);
+    v.qb = rr_ld4(io.ctxB + ((size_t)b * N + prev) * RR_E + 16 * h + 4 * g);
+    v.fst = 0;
+    v.qa = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (io.first) {
+      v.fst = min((int)io.first[(size_t)tm.s * io.Bp + b], N - 1);
+      v.qa = rr_ld4(io.ctxA + ((size_t)b * N + v.fst) * RR_E + 16 * h + 4 * g);
+    }
+    v.sv = io.nscal > 0 ? rr_ld4(io.scal + tm.m * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    v.dh = rr_ld4(io.dg0 + tm.m * RR_E + 16 * h + 4 * g);
+    return v;
+  };
+  TMeta mA = ld_meta(wave < ntile ? wave : 0), mB = ld_meta(wave + 4 < ntile ? wave + 4 : 0);
+  TVals vA = ld_vals(mA);
+#pragma unroll 1
+  for (int tile = wave; tile < ntile; tile += 4) {
+    const TMeta tm = mA;
+    const TVals tv = vA;
+    {   // requests for the tiles after this one
+      const TMeta mC = ld_meta(tile + 8 < ntile ? tile + 8 : 0);
+      vA = ld_vals(mB);
+      mA = mB; mB = mC;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const bool vrow = tm.vrow;
+    const size_t m = tm.m;
+    const uint4 m0 = tm.m0, m1 = tm.m1;
     const int prev = min((int)m1.x, N - 1);
     const bool live = vrow && m1.z != 0u;
     const uint32_t mw[4] = {m0.x, m0.y, m0.z, m0.w};
-    int fst = 0;
+    const int fst = tv.fst;
     // ---- query slice of this head (TSPContext / VRPContext / MTVRPContext as table gathers, see rr_rollout_w.inc)
-    float4 qv = rr_ld4(io.ctxB + ((size_t)b * N + prev) * RR_E + 16 * h + 4 * g);
-    if (io.first) {
-      fst = min((int)io.first[(size_t)s * io.Bp + b], N - 1);
-      const float4 a = rr_ld4(io.ctxA + ((size_t)b * N + fst) * RR_E + 16 * h + 4 * g);
-      qv.x += a.x; qv.y += a.y; qv.z += a.z; qv.w += a.w;
-    }
-    float sc4[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 qv = tv.qb;
+    qv.x += tv.qa.x; qv.y += tv.qa.y; qv.z += tv.qa.z; qv.w += tv.qa.w;
+    float sc4[4] = {tv.sv.x, tv.sv.y, tv.sv.z, tv.sv.w};
     if (io.nscal > 0) {
-      const float4 sv = rr_ld4(io.scal + m * 4);
-      sc4[0] = sv.x; sc4[1] = sv.y; sc4[2] = sv.z; sc4[3] = sv.w;
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (k < io.nscal) {
@@ -775,7 +816,7 @@ __global__ __launch_bounds__(256, 1) void k_dec_attn_bwd(DecAttnIO io) {
           qv.x = fmaf(wv.x, sc4[k], qv.x); qv.y = fmaf(wv.y, sc4[k], qv.y); qv.z = fmaf(wv.z, sc4[k], qv.z); qv.w = fmaf(wv.w, sc4[k], qv.w);
         }
     }
-    float4 dh = rr_ld4(io.dg0 + m * RR_E + 16 * h + 4 * g);
+    float4 dh = tv.dh;
     if (!live) dh = make_float4(0.f, 0.f, 0.f, 0.f);
     const float qs[4] = {qv.x * 0.25f, qv.y * 0.25f, qv.z * 0.25f, qv.w * 0.25f};          // 1/sqrt(head_dim)
     const float dhv[4] = {dh.x, dh.y, dh.z, dh.w};

@@ -90,8 +90,13 @@ __global__ __launch_bounds__(256, 2) void k_linear_rows(const float4* __restrict
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, g = lane >> 4;
+  __shared__ float cs_s[RR_E];
   const long long r0 = ((long long)blockIdx.x * 4 + wave) * 64;
-  if (r0 >= M) return;
+  if (colsum != nullptr) {                    // wave-uniform
+    if (threadIdx.x < RR_E) cs_s[threadIdx.x] = 0.f;
+    __syncthreads();
+  }
+  const bool wvalid = r0 < M;
   const __amdgpu_buffer_rsrc_t rW = rr_make_buf(Wp, RR_E * RR_E * 4);
   const unsigned lane16 = (unsigned)lane * 16u;
   f32x4 x[4][8];
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void k_linear_rows(const float4* __restrict
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt) {
     row[rt] = r0 + 16 * rt + j;
-    vr[rt] = row[rt] < M;
+    vr[rt] = wvalid && row[rt] < M;
     const long long rc = vr[rt] ? row[rt] : M - 1;
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
@@ -118,9 +123,12 @@ __global__ __launch_bounds__(256, 2) void k_linear_rows(const float4* __restrict
       for (int r = 0; r < 4; ++r) {
         float v = cs[kk][r];
         v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-        if (j == 0) atomicAdd(colsum + 16 * kk + 4 * g + r, v);
+        if (j == 0) atomicAdd(&cs_s[16 * kk + 4 * g + r], v);
       }
+    __syncthreads();                          // one global atomic per workgroup and column (800 waves on 128 addresses serialise)
+    if (threadIdx.x < RR_E) atomicAdd(colsum + threadIdx.x, cs_s[threadIdx.x]);
   }
+  if (!wvalid) return;
   float4 a[8], an[8];
 #pragma unroll
   for (int kk = 0; kk < 8; ++kk) a[kk] = rr_bld4(rW, lane16, kk * 1024u);

@@ -76,11 +76,13 @@ def decoder_backward(policy, cache, dump, D, Dur, grad_ll) -> dict:
     # ---- pointer MLP: input gradient and weight gradients
     mp = mlp_train_pack(policy)
     dg0 = torch.empty(rows, E, device=dev)
-    L.check(lib.rr_mlp_rows(mp["bwd"], 1, L.ptr(dump["g0"]), L.ptr(dg), L.ptr(dg0), L.ptr(dump["meta"]), Bp, T * S, seg, st), "rr_mlp_rows")
+    # ATSP tours all have the same length: every dumped row is live, no flag to consult
+    live = None if env_name == "atsp" else dump["meta"]
+    L.check(lib.rr_mlp_rows(mp["bwd"], 1, L.ptr(dump["g0"]), L.ptr(dg), L.ptr(dg0), L.ptr(live), Bp, T * S, seg, st), "rr_mlp_rows")
     dW1, db1 = torch.zeros(4 * E, E, device=dev), torch.zeros(4 * E, device=dev)
     dW2, db2 = torch.zeros(E, 4 * E, device=dev), torch.zeros(E, device=dev)
     L.check(lib.rr_mlp_wgrad(mp["wgrad"], L.ptr(dump["g0"]), L.ptr(dg), L.ptr(dW1), L.ptr(db1), L.ptr(dW2), L.ptr(db2),
-                             L.ptr(dump["meta"]), Bp, T * S, seg, st), "rr_mlp_wgrad")
+                             L.ptr(live), Bp, T * S, seg, st), "rr_mlp_wgrad")
     del dg
     # ---- masked multi-head attention: d keys, d values, d query -> the step-context tables
     atsp = env_name == "atsp"

@@ -98,7 +98,7 @@ def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
     atsp = policy.env_name == "atsp"
     G = _Grads(P)
     new = lambda: torch.empty(Bp, N, E, device=dev)                                         # noqa: E731
-    MS = 64                                                                                  # row splits of the weight-gradient products
+    MS = 256                                                                                 # row splits of the weight-gradient products
 
     def lin(wp, x, out, acc=0, colsum=None):
         L.check(lib.rr_linear_rows(L.ptr(wp), None, L.ptr(x), L.ptr(out), M, acc, L.ptr(colsum), st), "rr_linear_rows")

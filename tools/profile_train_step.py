@@ -19,4 +19,10 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CUDA]) as prof:
     model.training_step(ATSPGenerator(num_loc=100, device=dev)(B, generator=gen), optimizer=opt, seed=9)
     torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=22, max_name_column_width=64))
+ev = sorted(prof.key_averages(), key=lambda e: -e.self_device_time_total)
+tot = sum(e.self_device_time_total for e in ev)
+print(f"GPU time of one training step: {tot / 1e3:.2f} ms over {sum(e.count for e in ev)} launches")
+acc = 0.0
+for e in ev[:40]:
+    acc += e.self_device_time_total
+    print(f"{e.self_device_time_total / 1e3:9.3f} ms {100 * e.self_device_time_total / tot:5.1f}% cum {100 * acc / tot:5.1f}%  x{e.count:<4d} {e.key[:110]}")
