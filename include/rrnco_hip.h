@@ -238,6 +238,12 @@ typedef struct { const float *dy, *q, *ek, *v, *num, *den, *eaT; float *dq, *dk,
  * d loss / d (alpha * NAB bias) [Bp][N][N]. */
 int rr_aft_bwd(const AftBwdIO* io, int Bp, hipStream_t stream);
 
+/* The same NAB backward in O(1) per edge: pwl = the piecewise-linear table the encoder evaluates (EncBlockW.nab,
+ * packing.fold_nab_pwl); hist [2][129][4] (+1) += per family and segment (sum w_out, sum w_out x, sum w_gate, sum w_gate x)
+ * and d alpha; the prefix sums that turn the moments into d (folded table) are the caller's (tiny). */
+int rr_nab_hist_bwd(const float* pwl, const float* xd, const float* xa, const float* gout, float* hist, long M,
+                    hipStream_t stream);
+
 /* POMO shared-baseline REINFORCE loss, forward half + d loss / d log-likelihood
  * (rrnco/models/rl.py:112-128; in-tree formula rrnco/baselines/routefinder/model.py:182-202). reward / ll / adv /
  * grad_ll are [S*B] with r = s*B + b; bl and partial are [B] workspaces; loss is one float. */

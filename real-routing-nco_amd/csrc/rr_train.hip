@@ -103,6 +103,77 @@ __global__ __launch_bounds__(TR_THREADS) void k_nab_train_bwd(const float* __res
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same backward in O(1) per edge instead of O(128).  Each of the four scalar functions of the folded NAB,
+//   f(x) = sum_k c_k relu(a_k x + b_k) + const,
+// is piecewise linear between the sorted breakpoints t_k = -b_k / a_k (the table the encoder kernel evaluates,
+// packing.fold_nab_pwl), and unit k is active on a prefix or a suffix of the segments.  So
+//   d loss / d c_k = sum_e w_e relu(a_k x_e + b_k) = a_k S1_k + b_k S0_k,   S0_k = sum_{e: k active} w_e,  S1_k = sum_{..} w_e x_e
+// (and likewise d a_k, d b_k) only need, per family and SEGMENT, the four moments sum w_out, sum w_out x, sum w_gate, sum w_gate x
+// of the edges that fall into it: eight LDS float atomics per edge here, a prefix sum over 129 segments on the host
+// (models/enc_backward.py:nab_grad_from_hist).  hist: [2][129][4] moments + [1] d alpha, ADDED to (caller zeroes).
+#define NH_TAB (256 + 2 * 129 * 4 + 8)
+#define NH_HIST (2 * 129 * 4)
+__device__ __forceinline__ int nh_segment(const float* t, float x) {        // number of breakpoints <= x (bisection, as nab_family)
+  int m = 0;
+#pragma unroll
+  for (int s = 128; s >= 1; s >>= 1) {
+    const int idx = m + s - 1;
+    const float tv = t[idx < 128 ? idx : 127];
+    m += (idx < 128 && tv <= x) ? s : 0;
+  }
+  return m;
+}
+__global__ __launch_bounds__(256) void k_nab_hist_bwd(const float* __restrict__ pwl, const float* __restrict__ xd,
+                                                      const float* __restrict__ xa, const float* __restrict__ gout,
+                                                      float* __restrict__ hist, long M) {
+  __shared__ __attribute__((aligned(16))) float tab[NH_TAB];
+  __shared__ float hs[NH_HIST];
+  const int t = threadIdx.x;
+  for (int i = t; i < NH_TAB; i += 256) tab[i] = pwl[i];
+  for (int i = t; i < NH_HIST; i += 256) hs[i] = 0.f;
+  __syncthreads();
+  const float bg = tab[256 + 1032], bo = tab[256 + 1033], alpha = tab[256 + 1034];
+  float s_alpha = 0.f;
+  for (long e = (long)blockIdx.x * 256 + t; e < M; e += (long)gridDim.x * 256) {
+    const float x[2] = {fminf(xd[e], 3.0e38f), fminf(xa[e], 3.0e38f)};
+    const float G = gout[e];
+    int m[2]; float fo[2], fg[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      m[f] = nh_segment(tab + 128 * f, x[f]);
+      float anchor = tab[128 * f + (m[f] > 0 ? m[f] - 1 : 0)];
+      anchor = anchor < INFINITY ? anchor : 0.f;
+      const float4 sg = rr_ld4(tab + 256 + 516 * f + 4 * m[f]);
+      const float dx = x[f] - anchor;
+      fo[f] = fmaf(sg.x, dx, sg.y); fg[f] = fmaf(sg.z, dx, sg.w);
+    }
+    const float gt = 1.0f / (1.0f + expf(-(fg[0] + fg[1] + bg)));
+    const float val = gt * fo[0] + (1.0f - gt) * fo[1] + bo;
+    const float Gv = G * alpha;
+    const float wo[2] = {Gv * gt, Gv * (1.0f - gt)};
+    const float wg = Gv * (fo[0] - fo[1]) * gt * (1.0f - gt);
+    s_alpha = fmaf(G, val, s_alpha);
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      float* h = hs + (129 * f + m[f]) * 4;
+      atomicAdd(h + 0, wo[f]); atomicAdd(h + 1, wo[f] * x[f]); atomicAdd(h + 2, wg); atomicAdd(h + 3, wg * x[f]);
+    }
+  }
+  __syncthreads();
+  for (int i = t; i < NH_HIST; i += 256) atomicAdd(hist + i, hs[i]);
+  s_alpha = rr_wave_sum(s_alpha);
+  if ((t & 63) == 0) atomicAdd(hist + NH_HIST, s_alpha);
+}
+
+extern "C" int rr_nab_hist_bwd(const float* pwl, const float* xd, const float* xa, const float* gout, float* hist, long M,
+                               hipStream_t st) {
+  if (pwl == nullptr || xd == nullptr || xa == nullptr || gout == nullptr || hist == nullptr || M <= 0) return RR_EINVAL;
+  const long want = (M + 255) / 256;
+  hipLaunchKernelGGL(k_nab_hist_bwd, dim3((unsigned)(want < 512 ? want : 512)), dim3(256), 0, st, pwl, xd, xa, gout, hist, M);
+  return rr_check(hipGetLastError());
+}
+
 extern "C" int rr_nab_train_fwd(const float* tab, const float* xd, const float* xa, float* out, long M, hipStream_t st) {
   if (tab == nullptr || xd == nullptr || xa == nullptr || out == nullptr || M <= 0) return RR_EINVAL;
   const long want = (M + TR_THREADS - 1) / TR_THREADS;

@@ -712,20 +712,17 @@ struct DecAttnIO {
 };
 
 // 16x16 tile held as C layout (lane (c = j, g) register r = X[4g + r][c])  ->  lane (a = j, g) register m = X[a][4g + m]
-// through a wave-private LDS strip [16][20] (LDS operations of one wave execute in order)
-__device__ __forceinline__ f32x4 td_xpose(f32x4 v, float* scr, int j, int g) {
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int r = 0; r < 4; ++r) scr[(4 * g + r) * 20 + j] = v[r];
-  __builtin_amdgcn_wave_barrier();
-  const float4 o = rr_ld4(scr + j * 20 + 4 * g);
-  __builtin_amdgcn_wave_barrier();
-  return f32x4{o.x, o.y, o.z, o.w};
+// (the A / B operand layout with the former lane index on the k axis), on the matrix pipe: register r as the A operand is
+// A_r[i][k] = X[4k + r][i]; with the constant selector B_r[k][col] = [col == 4k + r] the four products sum to X[col][i], exact
+// in fp32 (one non-zero term per output).  No LDS round trip, and sixteen of these per (tile, head) pipeline like any MFMA.
+__device__ __forceinline__ f32x4 td_xpose(f32x4 v, const float (&sel)[4]) {
+  f32x4 d = rr_zero4();
+  d = rr_mfma(v[0], sel[0], d); d = rr_mfma(v[1], sel[1], d); d = rr_mfma(v[2], sel[2], d); d = rr_mfma(v[3], sel[3], d);
+  return d;
 }
 
 __global__ __launch_bounds__(256, 1) void k_dec_attn_bwd(DecAttnIO io) {
   __shared__ float accA[TD_LDK * 16], accB[TD_LDK * 16];
-  __shared__ __attribute__((aligned(16))) float xs[4][16 * 20];
   __shared__ __attribute__((aligned(16))) float red[4][2 * TD_NT][64 * 4];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -736,7 +733,9 @@ __global__ __launch_bounds__(256, 1) void k_dec_attn_bwd(DecAttnIO io) {
   const int N = io.N, S = io.S, rows_b = io.T * S;
   for (int i = tid; i < TD_LDK * 16; i += 256) { accA[i] = 0.f; accB[i] = 0.f; }
   __syncthreads();
-  float* scr = xs[wave];
+  float sel[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) sel[r] = (j == 4 * g + r) ? 1.0f : 0.f;
   // per-head operands, resident for the whole instance
   float4 kf[TD_NT], vf[TD_NT], ktf[TD_NT];
 #pragma unroll
@@ -878,12 +877,12 @@ __global__ __launch_bounds__(256, 1) void k_dec_attn_bwd(DecAttnIO io) {
         for (int r = 0; r < 4; ++r) dws[k][r] = fmaf(dq[r], sc4[k], dws[k][r]);
     }
     // ---- dK_h[key][dim] += ds[row][key] q[row][dim] / sqrt(d),  dV_h[key][dim] += a[row][key] dhv[row][dim]  (k = row)
-    const f32x4 qT = td_xpose(f32x4{qs[0], qs[1], qs[2], qs[3]}, scr, j, g);
-    const f32x4 hT = td_xpose(f32x4{dhv[0], dhv[1], dhv[2], dhv[3]}, scr, j, g);
+    const f32x4 qT = td_xpose(f32x4{qs[0], qs[1], qs[2], qs[3]}, sel);
+    const f32x4 hT = td_xpose(f32x4{dhv[0], dhv[1], dhv[2], dhv[3]}, sel);
 #pragma unroll
     for (int kt = 0; kt < TD_NT; ++kt) {
-      const f32x4 dT = td_xpose(ds[kt], scr, j, g);
-      const f32x4 pT = td_xpose(a[kt], scr, j, g);
+      const f32x4 dT = td_xpose(ds[kt], sel);
+      const f32x4 pT = td_xpose(a[kt], sel);
       aK[kt] = rr_mfma(qT[0], dT[0], aK[kt]); aV[kt] = rr_mfma(hT[0], pT[0], aV[kt]);
       aK[kt] = rr_mfma(qT[1], dT[1], aK[kt]); aV[kt] = rr_mfma(hT[1], pT[1], aV[kt]);
       aK[kt] = rr_mfma(qT[2], dT[2], aK[kt]); aV[kt] = rr_mfma(hT[2], pT[2], aV[kt]);

@@ -117,6 +117,7 @@ _SIGS = {
     "rr_select_matnet": [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, u64, u32, vp],
     "rr_nab_train_fwd": [vp, vp, vp, vp, C.c_long, vp],
     "rr_nab_train_bwd": [vp, vp, vp, vp, vp, C.c_long, vp],
+    "rr_nab_hist_bwd": [vp, vp, vp, vp, vp, C.c_long, vp],
     "rr_enc_layer_train": [C.POINTER(EncBlockW), C.POINTER(EncBlockW), vp, vp, vp, vp, vp, vp, vp, i32, i32,
                            C.POINTER(EncSave), C.POINTER(EncSave), vp],
     "rr_inorm_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],

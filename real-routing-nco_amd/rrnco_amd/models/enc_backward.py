@@ -64,6 +64,30 @@ def _nab_tab(P, p, alpha):
     return torch.cat([torch.cat(rows), torch.stack([ks[0], ks[1], ks[2], ks[3], bg, bo, alpha.reshape(()), z])]).float()
 
 
+def nab_grad_from_hist(tabs: torch.Tensor, hist: torch.Tensor) -> torch.Tensor:
+    """d loss / d (folded table) from the per-segment moments of csrc/rr_train.hip:k_nab_hist_bwd, for a batch of blocks.
+    tabs [nb, 8*128+8] (rows a_d, b_d, co_d, cg_d, a_a, b_a, co_a, cg_a + scalars, models/grad_replay._nab_table);
+    hist [nb, 2*129*4 + 1].  Unit k of a family is active (a_k x + b_k > 0) on the segments after its breakpoint
+    t_k = -b_k / a_k when a_k > 0, on those up to it when a_k < 0: prefix sums over the 129 segments, float64."""
+    nb = tabs.shape[0]
+    R = tabs[:, :8 * E].double().view(nb, 2, 4, E)                    # family, (a, b, co, cg), unit
+    a, b, co, cg = R[:, :, 0], R[:, :, 1], R[:, :, 2], R[:, :, 3]
+    H = hist[:, :2 * 129 * 4].double().view(nb, 2, 129, 4)
+    t = torch.where(a != 0, -b / torch.where(a != 0, a, torch.ones_like(a)), torch.full_like(a, float("inf")))
+    rank = torch.argsort(torch.argsort(t, dim=-1, stable=True), dim=-1, stable=True)         # position among the sorted breakpoints
+    C = H.cumsum(dim=2)
+    T = C[:, :, -1:, :]                                                  # [nb,2,1,4]
+    Cr = C.gather(2, rank[..., None].expand(-1, -1, -1, 4))              # C[rho_k]: segments 0..rho_k
+    pos, neg = (a > 0)[..., None], (a < 0)[..., None]
+    A = torch.where(pos, T - Cr, torch.where(neg, Cr, torch.where((b > 0)[..., None], T.expand_as(Cr), torch.zeros_like(Cr))))
+    A0, A1, A2, A3 = A.unbind(-1)
+    g = torch.stack([co * A1 + cg * A3, co * A0 + cg * A2, a * A1 + b * A0, a * A3 + b * A2], dim=2)      # d a, d b, d co, d cg
+    T0, T2 = T[:, :, 0, 0], T[:, :, 0, 2]
+    z = torch.zeros(nb, dtype=torch.float64, device=tabs.device)
+    scal = torch.stack([T0[:, 0], T2[:, 0], T0[:, 1], T2[:, 1], T2[:, 0], T0[:, 0] + T0[:, 1], hist[:, -1].double(), z], dim=1)
+    return torch.cat([g.reshape(nb, 8 * E), scal], dim=1).float()
+
+
 class _Grads:
     """Gradient buffers of the parameters the kernels write (zero-filled: float atomics add into them)."""
 
@@ -130,6 +154,8 @@ def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
             gWc[:, E:E + dec["dwstate"].shape[0]] += dec["dwstate"].t()
         Dt = D.transpose(1, 2).contiguous()
         small = []            # (torch expression of parameters, its gradient): chained through autograd at the end
+        packed = policy.packed(dev)
+        nab_tabs, nab_hists = [], torch.zeros(2 * packs["num_layers"], 2 * 129 * 4 + 1, device=dev)
         # ---- the blocks, last layer first
         for l in reversed(range(packs["num_layers"])):
             sv = layers[l]
@@ -176,11 +202,11 @@ def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
                 # alpha * NAB (:427-429): the folded-table backward of csrc/rr_train.hip, chained to the module parameters by autograd
                 with torch.enable_grad():
                     tab = _nab_tab(P, b + ".angle_distance_fusion", P[b + ".alpha"])
-                gtab = torch.zeros_like(tab)
                 xd = D if side == "row" else Dt
-                L.check(lib.rr_nab_train_bwd(L.ptr(tab.detach().contiguous()), L.ptr(xd), L.ptr(theta), L.ptr(dbias), L.ptr(gtab),
-                                             dbias.numel(), st), "rr_nab_train_bwd")
-                small.append((tab, gtab))
+                hist = nab_hists[len(nab_tabs)]
+                L.check(lib.rr_nab_hist_bwd(packed["blocks"][l][si].nab, L.ptr(xd), L.ptr(theta), L.ptr(dbias), L.ptr(hist),
+                                            dbias.numel(), st), "rr_nab_hist_bwd")
+                nab_tabs.append(tab)
                 # q = to_q(r), k = to_k(c), v = to_v(c) (:313-315)
                 dr = dY                                                                   # reuse
                 lin(pk["wqT"], dq, dr, 0, G.buf(b + ".attn_free.to_q.bias"))
@@ -194,6 +220,9 @@ def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
                 inorm(x_in, dU1, dr, b + ".norm1", dx_out, acc=si)           # the col block adds to what the row block wrote
                 inorm(y_in, dc, None, b + ".norm2", dy_out, acc=si)
             d_row, d_col = n_row, n_col
+        # the NAB moments of all blocks -> d (folded tables), one batched prefix-sum pass
+        gtabs = nab_grad_from_hist(torch.stack([t.detach() for t in nab_tabs]), nab_hists)
+        small += [(t, gtabs[i]) for i, t in enumerate(nab_tabs)]
     G.flush()
     # ---- chain rule through the folds and the init embedding (autograd on tiny / [Bp*N,128] tensors)
     vrp = policy.env_name == "rcvrp"

@@ -227,3 +227,30 @@ def test_aft_mixing_backward(B, N):
     L.check(L.lib().rr_aft_bwd(io, B, L.stream()), "aft_bwd")
     for got, leaf, nm in zip((dq, dk, dv, dbias), leaves, ("dq", "dk", "dv", "dbias")):
         assert _rel(got, leaf.grad) < 2e-4, (nm, _rel(got, leaf.grad))
+
+
+def test_nab_backward_from_segment_moments_matches_the_per_unit_kernel():
+    """csrc/rr_train.hip: k_nab_hist_bwd (O(1) per edge: per-segment moments + host prefix sums) against k_nab_train_bwd
+    (O(128) per edge) and, through it, the torch formula (tests/test_gpu_train.py::test_nab_training_kernels_...)."""
+    from oracle import restate
+    from rrnco_amd import _lib as L, packing
+    from rrnco_amd.models import enc_backward as EB
+    fx = H.load_fixture("atsp_n100_b2_pomo")
+    w = H.atsp_weights(fx)
+    P = {k: v.cuda() for k, v in w.items()}
+    st0 = restate.atsp_reset(H.fixture_state(fx))
+    D = st0["distance_matrix"].cuda().contiguous()
+    theta = restate.pairwise_angles(st0["locs"]).cuda().contiguous()
+    gout = torch.randn(D.shape, generator=torch.Generator().manual_seed(0)).cuda()
+    for blk in ("encoder.net.layers.3.col_encoding_block", "encoder.net.layers.0.row_encoding_block"):
+        tab = EB._nab_tab(P, blk + ".angle_distance_fusion", P[blk + ".alpha"]).contiguous()
+        ref = torch.zeros_like(tab)
+        L.check(L.lib().rr_nab_train_bwd(L.ptr(tab), L.ptr(D), L.ptr(theta), L.ptr(gout), L.ptr(ref), D.numel(), L.stream()), "bwd")
+        pwl = packing.fold_nab_pwl(w, blk + ".angle_distance_fusion", w[blk + ".alpha"]).cuda()
+        hist = torch.zeros(1, 2 * 129 * 4 + 1, device="cuda")
+        L.check(L.lib().rr_nab_hist_bwd(L.ptr(pwl), L.ptr(D), L.ptr(theta), L.ptr(gout), L.ptr(hist), D.numel(), L.stream()), "hist")
+        got = EB.nab_grad_from_hist(tab[None], hist)[0]
+        for i, nm in enumerate(("a_d", "b_d", "co_d", "cg_d", "a_a", "b_a", "co_a", "cg_a")):
+            r_, g_ = ref[128 * i:128 * (i + 1)], got[128 * i:128 * (i + 1)]
+            assert float((g_ - r_).abs().max()) < 2e-3 * float(r_.abs().max()) + 1e-4, (blk, nm, float((g_ - r_).abs().max()), float(r_.abs().max()))
+        assert torch.allclose(got[1024:1031], ref[1024:1031], rtol=2e-3, atol=1e-3), (got[1024:1032], ref[1024:1032])
