@@ -509,7 +509,7 @@ struct MlpWgradW {
   const float* b1;
 };
 #define WG_RM 288     // bytes per row of the row-major bf16 images (128 values + 32 B: conflict-free ds_read_b128 by row)
-#define WG_TR 96      // bytes per feature of the transposed images (32 rows + 32 B)
+#define WG_TR 80      // bytes per feature of the transposed images (32 rows + 16 B; 96 would be conflict-free but two buffers must fit 160 KB)
 
 // dW1[hid][feat] += sum_m dH[m][hid] x[m][feat], db1 += sum_m dH, dW2[feat][hid] += sum_m dy[m][feat] H[m][hid], db2 += sum_m dy
 // with H = relu(W1 x + b1), dH = (W2^T dy) . 1(H > 0).  Workgroup (slab, split): hidden units [128 slab, +128), wave w the
@@ -518,8 +518,8 @@ struct MlpWgradW {
 __global__ __launch_bounds__(256, 1) void k_mlp_wgrad(MlpWgradW w, const float* __restrict__ X, const float* __restrict__ dY,
                                                       float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2,
                                                       float* __restrict__ db2, RowSegs rs, int nsplit, const uint32_t* __restrict__ meta) {
-  __shared__ __attribute__((aligned(16))) char rm[4][32 * WG_RM];     // x hi, x lo, dy hi, dy lo
-  __shared__ __attribute__((aligned(16))) char tr[4][RR_E * WG_TR];
+  __shared__ __attribute__((aligned(16))) char rm[2][4][32 * WG_RM];     // [buffer][x hi, x lo, dy hi, dy lo]
+  __shared__ __attribute__((aligned(16))) char tr[2][4][RR_E * WG_TR];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, g = lane >> 4;
@@ -555,18 +555,19 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wgrad(MlpWgradW w, const float* 
   float4 sb2 = make_float4(0.f, 0.f, 0.f, 0.f);
   // staging: thread -> column group c4 = tid & 31 (4 features), row pairs rp = (tid >> 5) and (tid >> 5) + 8
   const int c4 = tid & 31, rp0 = tid >> 5;
-  float4 px[2][2], py[2][2];
-  unsigned plv[2][2];
-  auto g_load = [&](long long c) {           // every load unconditional (clamped row), zeroed by the flag in `put`: no dependent loads
+  float4 px[2][2], py[2][2], qx[2][2], qy[2][2];     // chunk being staged / chunk in flight
+  unsigned plv[2][2], qlv[2][2];
+  auto g_load = [&](long long c, bool real, float4 (&ox)[2][2], float4 (&oy)[2][2], unsigned (&olv)[2][2]) {      // !real: a chunk past the end (all rows zero)
+    // every load unconditional (clamped row), zeroed by the flag in `stage`: no dependent loads
 #pragma unroll
     for (int it = 0; it < 2; ++it)
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const long long i = c * 32 + 2 * (rp0 + 8 * it) + e;
         const long long m = td_row(rs, i < total ? i : total - 1);
-        px[it][e] = rr_ld4(X + m * RR_E + 4 * c4);
-        py[it][e] = rr_ld4(dY + m * RR_E + 4 * c4);
-        plv[it][e] = (i < total) ? (meta == nullptr ? 1u : meta[m * 8 + 6]) : 0u;       // dead rows (finished routes) read as zero rows
+        ox[it][e] = rr_ld4(X + m * RR_E + 4 * c4);
+        oy[it][e] = rr_ld4(dY + m * RR_E + 4 * c4);
+        olv[it][e] = (real && i < total) ? (meta == nullptr ? 1u : meta[m * 8 + 6]) : 0u;       // dead rows (finished routes) read as zero rows
       }
   };
   auto put = [&](const float4 (&v)[2], int rp, char* rmh, char* rml, char* trh, char* trl) {
@@ -593,23 +594,55 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wgrad(MlpWgradW w, const float* 
       *reinterpret_cast<uint32_t*>(trl + (4 * c4 + q) * WG_TR + pos * 2) = l[0][q] | ((uint32_t)l[1][q] << 16);
     }
   };
-  if (c_lo < c_hi) g_load(c_lo);
-  for (long long c = c_lo; c < c_hi; ++c) {
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
+  // Double-buffered images: chunk c is consumed from buffer c & 1 while chunk c + 1 (already in registers) is converted and
+  // written to the other one BETWEEN the matrix instructions of chunk c (the conversions are VALU work the matrix pipe does not
+  // wait for), and chunk c + 2 is requested from memory.  One barrier per chunk.
+  auto stage = [&](int it, int which, int buf) {      // which: 0 = the x rows, 1 = the dy rows of row pairs `it`
+    if (which == 0) {
 #pragma unroll
       for (int e = 0; e < 2; ++e)
-        if (plv[it][e] == 0u) { px[it][e] = make_float4(0.f, 0.f, 0.f, 0.f); py[it][e] = make_float4(0.f, 0.f, 0.f, 0.f); }
-      put(px[it], rp0 + 8 * it, rm[0], rm[1], tr[0], tr[1]);
-      put(py[it], rp0 + 8 * it, rm[2], rm[3], tr[2], tr[3]);
-      if (slab == 0) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) { sb2.x += py[it][e].x; sb2.y += py[it][e].y; sb2.z += py[it][e].z; sb2.w += py[it][e].w; }
+        {
+        const float k = plv[it][e] != 0u ? 1.0f : 0.f;      // (selects, not branches: NaN-safe zeroing of dead rows)
+        px[it][e] = make_float4(k != 0.f ? px[it][e].x : 0.f, k != 0.f ? px[it][e].y : 0.f, k != 0.f ? px[it][e].z : 0.f, k != 0.f ? px[it][e].w : 0.f);
+        py[it][e] = make_float4(k != 0.f ? py[it][e].x : 0.f, k != 0.f ? py[it][e].y : 0.f, k != 0.f ? py[it][e].z : 0.f, k != 0.f ? py[it][e].w : 0.f);
       }
+      put(px[it], rp0 + 8 * it, rm[buf][0], rm[buf][1], tr[buf][0], tr[buf][1]);
+    } else {
+      put(py[it], rp0 + 8 * it, rm[buf][2], rm[buf][3], tr[buf][2], tr[buf][3]);
+      const float k0 = slab == 0 ? 1.0f : 0.f;        // branch-free: the staging must stay in the matrix instructions' basic block
+#pragma unroll
+      for (int e = 0; e < 2; ++e) { sb2.x = fmaf(k0, py[it][e].x, sb2.x); sb2.y = fmaf(k0, py[it][e].y, sb2.y); sb2.z = fmaf(k0, py[it][e].z, sb2.z); sb2.w = fmaf(k0, py[it][e].w, sb2.w); }
     }
-    __syncthreads();
-    if (c + 1 < c_hi) g_load(c + 1);
+  };
+  // scheduling hint for a region of 48 matrix instructions, 16 LDS reads and one `stage` (~50 VALU, 6 LDS writes): the
+  // conversions go between the matrix instructions instead of behind them
+#define WG_INTERLEAVE()                                                                        \
+  do {                                                                                         \
+    _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) {                                        \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                       \
+      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                       \
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                       \
+    }                                                                                          \
+    __builtin_amdgcn_sched_group_barrier(0x200, 8, 0);                                         \
+  } while (0)
+  if (c_lo < c_hi) {
+    g_load(c_lo, true, px, py, plv);
+    stage(0, 0, 0); stage(0, 1, 0); stage(1, 0, 0); stage(1, 1, 0);
+    g_load(c_lo + 1 < c_hi ? c_lo + 1 : c_lo, c_lo + 1 < c_hi, px, py, plv);
+  }
+  __syncthreads();
+  for (long long c = c_lo; c < c_hi; ++c) {
+    const int buf = (int)((c - c_lo) & 1);
+    // chunk c + 2 goes into flight now; chunk c + 1 (requested an iteration ago) has landed: the opaque pass-through makes that
+    // visible to the scheduler (values of a load are otherwise pushed behind every matrix instruction of the region)
+    g_load(c + 2 < c_hi ? c + 2 : c, c + 2 < c_hi, qx, qy, qlv);
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        asm volatile("" : "+v"(px[it][e].x), "+v"(px[it][e].y), "+v"(px[it][e].z), "+v"(px[it][e].w), "+v"(py[it][e].x), "+v"(py[it][e].y),
+                     "+v"(py[it][e].z), "+v"(py[it][e].w), "+v"(plv[it][e]));
+      }
     // ---- recompute pre[row][hid] = x W1^T, dpre = dy W2 for this wave's two hidden tiles (A = activations, k = feature)
     f32x4 pre[2][2], dpre[2][2];
 #pragma unroll
@@ -617,18 +650,21 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wgrad(MlpWgradW w, const float* 
 #pragma unroll
       for (int tl = 0; tl < 2; ++tl) { pre[rt][tl] = rr_zero4(); dpre[rt][tl] = rr_zero4(); }
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < 4; ++s) {
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
         const int off = (16 * rt + j) * WG_RM + (32 * s + 8 * g) * 2;
-        const bfrag xh = *reinterpret_cast<const bfrag*>(rm[0] + off), xl = *reinterpret_cast<const bfrag*>(rm[1] + off);
-        const bfrag yh = *reinterpret_cast<const bfrag*>(rm[2] + off), yl = *reinterpret_cast<const bfrag*>(rm[3] + off);
+        const bfrag xh = *reinterpret_cast<const bfrag*>(rm[buf][0] + off), xl = *reinterpret_cast<const bfrag*>(rm[buf][1] + off);
+        const bfrag yh = *reinterpret_cast<const bfrag*>(rm[buf][2] + off), yl = *reinterpret_cast<const bfrag*>(rm[buf][3] + off);
 #pragma unroll
         for (int tl = 0; tl < 2; ++tl) {
           pre[rt][tl] = td_mfma3(xh, xl, W1h[tl][s], W1l[tl][s], pre[rt][tl]);
           dpre[rt][tl] = td_mfma3(yh, yl, W2h[tl][s], W2l[tl][s], dpre[rt][tl]);
         }
       }
+      if (s & 1) { stage(0, s >> 1, buf ^ 1); }      // (also for the last chunk: the rows past the end stage as zeros)
+      if (s & 1) { WG_INTERLEAVE(); __builtin_amdgcn_sched_barrier(0); }
+    }
     // C layout here: lane (hid = j, g) holds rows 16 rt + 4g + r.  As the B operand of the outer products (k = row) a lane's
     // eight values are rows {4g + r} u {16 + 4g + r}: positions 8g + 4 rt + r of the transposed images.
     bfrag Hh[2], Hl[2], Gh[2], Gl[2];
@@ -647,17 +683,25 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wgrad(MlpWgradW w, const float* 
       td_split8(hx, Hh[tl], Hl[tl]);
       td_split8(gx, Gh[tl], Gl[tl]);
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int off = (16 * u + j) * WG_TR + 16 * g;
-      const bfrag xh = *reinterpret_cast<const bfrag*>(tr[0] + off), xl = *reinterpret_cast<const bfrag*>(tr[1] + off);
-      const bfrag yh = *reinterpret_cast<const bfrag*>(tr[2] + off), yl = *reinterpret_cast<const bfrag*>(tr[3] + off);
+      const bfrag xh = *reinterpret_cast<const bfrag*>(tr[buf][0] + off), xl = *reinterpret_cast<const bfrag*>(tr[buf][1] + off);
+      const bfrag yh = *reinterpret_cast<const bfrag*>(tr[buf][2] + off), yl = *reinterpret_cast<const bfrag*>(tr[buf][3] + off);
 #pragma unroll
       for (int tl = 0; tl < 2; ++tl) {
         aW2[u][tl] = td_mfma3(yh, yl, Hh[tl], Hl[tl], aW2[u][tl]);      // [feat][hid] += dy^T H
         aW1[u][tl] = td_mfma3(xh, xl, Gh[tl], Gl[tl], aW1[u][tl]);      // [feat][hid] += x^T dH  (= dW1^T)
       }
+      if ((u & 3) == 3) { stage(1, u >> 2, buf ^ 1); }
+      if ((u & 3) == 3) { WG_INTERLEAVE(); __builtin_amdgcn_sched_barrier(0); }
     }
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) { px[it][e] = qx[it][e]; py[it][e] = qy[it][e]; plv[it][e] = qlv[it][e]; }
+    __syncthreads();                      // buffer buf is consumed by every wave, buffer buf ^ 1 is complete
   }
   // ---- epilogue: float atomics into the (zeroed) gradients
 #pragma unroll
