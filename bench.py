@@ -26,11 +26,38 @@ import torch  # noqa: E402
 
 N_NODES, BATCH, STARTS, AUG = 100, 512, 100, 8
 FLOP_PER_ROLLOUT_STEP = 404_480          # pointer step K6-K7, per rollout per decode step
+# what the matrix pipe executes per rollout-step: 2 720 v_mfma_f32_16x16x4_f32 x 2 048 flop x 16 rollouts per tile / 16 =
+# 348 160 (keys padded 100 -> 112; the 65 536-flop context projection is two table gathers, not a GEMM: DESIGN.md §3)
+EXECUTED_FLOP_PER_ROLLOUT_STEP = 348_160
 PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: fp32 matrix peak
-# HBM-side traffic of ONE rollout launch at the default workload, from rocprofv3 PMC (separate FETCH_SIZE / WRITE_SIZE
-# passes, profiles/r01/bench_v10_pmc_hbm_traffic.txt): (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B — FETCH_SIZE doubled for
-# gfx950's 16-B/lane reads as MI355X_MICROARCH.md §HBM prescribes; Infinity-Cache hits are included in the counter.
-ROLLOUT_TRAFFIC_BYTES_DEFAULT = (2 * 1.9590e8 + 4.0033e6) * 1024
+ROLLOUT_KERNEL = "k_rollout_w<7, 0, 0, false>"
+# HBM-side traffic of ONE rollout launch at the default workload: rocprofv3 PMC, separate FETCH_SIZE / WRITE_SIZE passes,
+# (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B — FETCH_SIZE doubled for gfx950's 16-B/lane reads as MI355X_MICROARCH.md §HBM
+# prescribes; Infinity-Cache hits are included in the counter.  Read at run time from the committed summary
+# (tools/pmc_traffic.sh writes it together with a hash of the rollout's sources): a summary of other sources -> null.
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02", "bench_pmc_hbm_traffic.json")
+ROLLOUT_SOURCES = ("rr_decode.hip", "rr_rollout_w.inc", "rr_common.h")
+
+
+def rollout_source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for f in ROLLOUT_SOURCES:
+        with open(os.path.join(ROOT, "real-routing-nco_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def measured_rollout_traffic(batch):
+    """-> (bytes per launch or None, provenance string)."""
+    try:
+        with open(TRAFFIC_FILE) as fh:
+            rec = json.load(fh)
+    except (OSError, ValueError):
+        return None, "no PMC summary committed"
+    if rec.get("source_hash") != rollout_source_hash() or rec.get("batch") != batch:
+        return None, f"PMC summary is of other rollout sources / batch ({rec.get('source_hash')}, batch {rec.get('batch')})"
+    return (2 * rec["FETCH_SIZE_KB"] + rec["WRITE_SIZE_KB"]) * 1024.0, os.path.relpath(TRAFFIC_FILE, ROOT)
 
 
 def make_policy(device, seed=1234):
@@ -47,14 +74,15 @@ def make_policy(device, seed=1234):
     return pol.to(device).eval(), w
 
 
-def hot_path_step(pol, env, inst, sample_idx):
-    """test.py:188-213 shaped: augment -> reset -> policy -> reward -> max over starts, then over augs."""
+def hot_path_step(pol, env, inst):
+    """test.py:188-213 shaped: augment -> reset -> policy -> reward -> max over starts, then over augs.  The encoder's
+    neighbour sample is drawn INSIDE the step, per forward and over all 8 x B instance-augmentations, as the reference does
+    (rrnco/models/env_embeddings/atsp.py:55-67) — on the device (csrc/rr_sample.hip)."""
     from rrnco_amd import TensorDict
     from rrnco_amd.models.transforms import StateAugmentation
     from rrnco_amd.ops import unbatchify
     td = TensorDict(dict(inst), batch_size=[inst["locs"].shape[0]])
     td = StateAugmentation(augment_fn="dihedral8", no_aug_coords=False)(td)
-    td["sample_idx"] = sample_idx
     td = env.reset(td)
     out = pol(td, env, phase="val", decode_type="multistart_greedy", num_starts=STARTS, return_actions=True)
     rew = unbatchify(out["reward"], (AUG, STARTS))          # [B, A, S]
@@ -115,10 +143,7 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     inst_td = ATSPGenerator(num_loc=N_NODES, device=dev)(args.batch, generator=gen)
     inst = {"locs": inst_td["locs"], "distance_matrix": inst_td["distance_matrix"]}
-    # neighbour-sample indices are an input of the hot path; drawn once, on device
-    from rrnco_amd.models.encoder import ATSPInitEmbedding
-    nd = env.reset(inst_td)["distance_matrix"]
-    sample_idx = ATSPInitEmbedding.sample_indices(nd, 25).repeat(AUG, 1, 1).contiguous()
+    torch.manual_seed(4242 + rank)           # the neighbour samples of the timed steps come from this stream
 
     def sync_all():
         torch.cuda.synchronize()
@@ -129,12 +154,13 @@ def main():
     # the headline number is always the fp32-MFMA rollout; the opt-in bf16-pipe MLP is measured separately below
     split_env = os.environ.pop("RR_MLP_SPLIT", None)
     for _ in range(args.warmup):
-        hot_path_step(pol, env, inst, sample_idx)
+        hot_path_step(pol, env, inst)
     R.TIMING = []
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        best, out = hot_path_step(pol, env, inst, sample_idx)
+    for k in range(args.steps):
+        torch.manual_seed(4242 + rank + 1000 * k)      # the step's neighbour sample (the variant below replays the same draws)
+        best, out = hot_path_step(pol, env, inst)
     sync_all()
     dt = time.perf_counter() - t0
     kern_ms = [a.elapsed_time(b) for a, b in R.TIMING]
@@ -146,6 +172,8 @@ def main():
         rollout_steps = args.batch * AUG * STARTS * (N_NODES - 1)
         k_ms = sum(kern_ms) / max(len(kern_ms), 1)
         achieved = rollout_steps * FLOP_PER_ROLLOUT_STEP / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        executed = rollout_steps * EXECUTED_FLOP_PER_ROLLOUT_STEP / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        traffic, traffic_src = measured_rollout_traffic(args.batch)
         line = {
             "metric": "solved instances/sec (ATSP n=100, B=512, POMO greedy)", "value": total_inst / dt,
             "unit": "instances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -154,22 +182,26 @@ def main():
             "config": {"workload": f"ATSP n={N_NODES}, batch={args.batch}/GPU, POMO S={STARTS} starts x {AUG} dihedral aug, greedy "
                                    "(BASELINE.json configs[1]); random-init RRNet E=128 L=6",
                        "rollouts_per_gpu": args.batch * AUG * STARTS, "sharding": f"instances over {world} rank(s), no collective"},
-            "roofline": {"bound": "mfma", "kernel": "k_rollout_w<7,0,0> (persistent wave-autonomous POMO decode)", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": ROLLOUT_KERNEL + " (persistent wave-autonomous POMO decode)", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": ROLLOUT_TRAFFIC_BYTES_DEFAULT if args.batch == BATCH else None, "kernel_ms": k_ms,
-                         "algorithmic_flop_per_launch": rollout_steps * FLOP_PER_ROLLOUT_STEP},
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": k_ms,
+                         "algorithmic_flop_per_launch": rollout_steps * FLOP_PER_ROLLOUT_STEP,
+                         # the same launch priced by the flop the matrix pipe executes (no context GEMM, keys padded to 112)
+                         "executed_mfma": {"achieved": executed, "frac": executed / PEAK_F32_MFMA_TFLOPS,
+                                           "flop_per_launch": rollout_steps * EXECUTED_FLOP_PER_ROLLOUT_STEP}},
             "mean_best_cost": float(-best.mean().item()),
         }
         if world == 1:
             # Opt-in variant, NOT part of `value`: the rollout's pointer MLP and the encoder's FFN on the bf16 matrix pipe with
             # 3-way split fp32 operands (six partial products, fp32 accumulate; same tolerances, tests/test_gpu_atsp.py)
             os.environ["RR_MLP_SPLIT"] = "1"
-            hot_path_step(pol, env, inst, sample_idx)              # (warm-up of the variant's kernels)
+            hot_path_step(pol, env, inst)              # (warm-up of the variant's kernels)
             R.TIMING = []
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(args.steps):
-                best_s, _ = hot_path_step(pol, env, inst, sample_idx)
+            for k in range(args.steps):
+                torch.manual_seed(4242 + rank + 1000 * k)
+                best_s, _ = hot_path_step(pol, env, inst)
             torch.cuda.synchronize()
             dts = time.perf_counter() - t1
             ks = [a.elapsed_time(b) for a, b in R.TIMING]

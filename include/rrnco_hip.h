@@ -71,12 +71,18 @@ typedef struct {                /* arguments of the persistent rollout: see csrc
    * output g [m][128], meta [m][8] = 4 action-mask words seen, node decided at, node chosen, live flag, 0; VRP state
    * scalars scal [m][4] (context.py:51-70).  Consumed by rr_dec_* below (the REINFORCE backward of decoder.py:151-329). */
   float *dump_g0, *dump_g; uint32_t *dump_meta; float *dump_scal; int dumpT;
+  int use_split;                /* 1: pointer MLP on the bf16 pipe with 3-way split fp32 operands for this launch (needs DecW.w1s / w2s) */
 } RolloutIO;
 
 /* ATSPEnv._reset / RCVRPEnv._reset / RMTVRPEnv._reset min-max normalisation
  * (rrnco/envs/atsp/env.py:113-120, rcvrp/env.py:137-146, rmtvrp/env.py:289-300): out = (in-min)/(max-min+1e-6)
  * per matrix of M elements; mn/mx [B]. */
 int rr_minmax_normalize(const float* in, float* out, float* mn, float* mx, int B, int M, hipStream_t stream);
+
+/* Neighbour sampling of the init embeddings (rrnco/models/env_embeddings/atsp.py:55-67, rcvrp.py:170-182):
+ * torch.multinomial(1 / (d + 1e-6), K, replacement=False) per node (diagonal as d = 1e6) as a Gumbel top-K with counter-based
+ * noise keyed by (seed, row, j).  out [Bp][N][K] int64, in draw order. */
+int rr_sample_neighbors(const float* D, int64_t* out, int Bp, int N, int K, unsigned long long seed, hipStream_t stream);
 
 /* ATSPEnv._step (rrnco/envs/atsp/env.py:80-105): mask_out[r, action[r]] = 0, done[r] = no node left. */
 int rr_atsp_step(const int64_t* action, const uint8_t* mask_in, uint8_t* mask_out, uint8_t* done,

@@ -70,6 +70,7 @@ struct RolloutIO {
   // rollout), 0; VRP: the step-context state scalars scal [m][4] (available load, current time, open route, remaining distance).
   float* dump_g0; float* dump_g; uint32_t* dump_meta; float* dump_scal;
   int dumpT;
+  int use_split;                         // 1: pointer MLP on the bf16 matrix pipe with 3-way split operands for this launch (as RR_MLP_SPLIT=1), if DecW has the packs
 };
 
 template <int NT, int PROB>  // PROB 0 = ATSP, 1 = RCVRP
@@ -403,7 +404,7 @@ extern "C" int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStrea
   if (io->mode == 2 && io->actions_in == nullptr) return RR_EINVAL;
   static const int variant = getenv("RR_ROLLOUT_VARIANT") ? atoi(getenv("RR_ROLLOUT_VARIANT")) : 1;
   const char* es = getenv("RR_MLP_SPLIT");
-  const bool mlp_split = es != nullptr && atoi(es) != 0 && w->w1s != nullptr && w->w2s != nullptr;
+  const bool mlp_split = ((es != nullptr && atoi(es) != 0) || io->use_split != 0) && w->w1s != nullptr && w->w2s != nullptr;
   if (variant == 0 && prob < 2) {   // workgroup-per-instance variant (kept for A/B measurements; ATSP / RCVRP only)
     dim3 grid(io->Bp, (S + ROWS - 1) / ROWS), blk(DEC_THREADS);
     const int need = N > (S < ROWS ? S : ROWS) ? N : (S < ROWS ? S : ROWS);

@@ -139,6 +139,14 @@ class ATSPInitEmbedding(nn.Module):   # env_embeddings/atsp.py:5-35
     def sample_indices(distance, sample_size):
         """env_embeddings/atsp.py:55-67: multinomial without replacement on 1/(d+1e-6), diagonal 1e6."""
         B, N, _ = distance.shape
+        if distance.is_cuda and N <= 112:
+            # on the device: Gumbel top-k (the same Plackett-Luce law as multinomial without replacement), one pass, keyed
+            # counter-based noise; the seed advances torch's CPU generator like any draw would (csrc/rr_sample.hip)
+            out = torch.empty(B, N, sample_size, dtype=torch.int64, device=distance.device)
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            L.check(L.lib().rr_sample_neighbors(L.ptr(distance.float().contiguous()), L.ptr(out), B, N, int(sample_size), seed,
+                                                L.stream()), "rr_sample_neighbors")
+            return out
         ar = torch.arange(N, device=distance.device)
         pd = distance.clone()
         pd[:, ar, ar] = 1e6

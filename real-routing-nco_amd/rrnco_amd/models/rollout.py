@@ -84,6 +84,9 @@ def launch_rollout(env_name, packed, cache, td, num_starts, *, actions=None, log
         io.dump_g0, io.dump_g, io.dump_meta = L.ptr(dump["g0"]), L.ptr(dump["g"]), L.ptr(dump["meta"])
         io.dump_scal = L.ptr(dump.get("scal"))
         io.dumpT = int(dump["T"])
+        # training rollouts run their pointer MLP on the bf16 matrix pipe with 3-way split fp32 operands (error <= 2^-23 of a
+        # product, the size of one fp32 rounding; the reference trains in 16-bit mixed precision, configs/trainer/default.yaml:8)
+        io.use_split = int(os.environ.get("RR_TRAIN_SPLIT", "1") != "0")
     io.tanh_clip, io.temperature, io.seed = float(tanh_clip), float(temperature), int(seed)
     timed = TIMING is not None and not logits_only
     if timed:

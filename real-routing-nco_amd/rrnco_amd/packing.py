@@ -479,9 +479,9 @@ def _pack_policy(sd: dict, env_name: str, device) -> dict:
     dw.w1 = ar.put(pack_a(sd["decoder.pointer.ffn.lins.0.weight"].detach().float()))
     dw.w2 = ar.put(pack_a(sd["decoder.pointer.ffn.lins.1.weight"].detach().float()))
     # the same matrices as 3-way bf16 splits for the opt-in bf16-pipe MLP (RR_MLP_SPLIT=1); kept as raw 16-bit words
-    if split:
-        dw.w1s = ar.put_raw(pack_a_bf16x3(sd["decoder.pointer.ffn.lins.0.weight"]))
-        dw.w2s = ar.put_raw(pack_a_bf16x3(sd["decoder.pointer.ffn.lins.1.weight"]))
+    # (always for the decoder: training rollouts use them, RolloutIO.use_split; two small device-side packs)
+    dw.w1s = ar.put_raw(pack_a_bf16x3(sd["decoder.pointer.ffn.lins.0.weight"].to(device)))
+    dw.w2s = ar.put_raw(pack_a_bf16x3(sd["decoder.pointer.ffn.lins.1.weight"].to(device)))
     dw.b1, dw.b2 = ar.put(sd["decoder.pointer.ffn.lins.0.bias"]), ar.put(sd["decoder.pointer.ffn.lins.1.bias"])
     dw.alpha = float(sd["decoder.alpha"].reshape(-1)[0])
     dw.beta = float(sd["decoder.beta"].reshape(-1)[0]) if "decoder.beta" in sd else 0.0

@@ -1,0 +1,14 @@
+"""FETCH_SIZE / WRITE_SIZE (KB, mean per dispatch) of the default rollout kernel from the two pmc_summary outputs -> the JSON
+bench.py reads (with the hash of the rollout's sources, so that a stale summary is never reported)."""
+import json, os, re, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+out = {"kernel": bench.ROLLOUT_KERNEL, "source_hash": bench.rollout_source_hash(), "batch": bench.BATCH}
+for path in sys.argv[1:]:
+    lines = open(path).read().splitlines()
+    for i, l in enumerate(lines):
+        if l.startswith("void k_rollout_w<7, 0, 0, false>"):
+            m = re.search(r"(FETCH_SIZE|WRITE_SIZE)\s+n=\s*(\d+) mean=([0-9.e+]+)", lines[i + 1])
+            out[m.group(1) + "_KB"] = float(m.group(3)); out[m.group(1) + "_n"] = int(m.group(2))
+print(json.dumps(out))
