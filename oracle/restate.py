@@ -711,7 +711,9 @@ def rcvrp_init_embedding(w: W, locs: Tensor, demand: Tensor, distance: Tensor, s
     depot, cities = locs[:, :1, :], locs[:, 1:, :]
     c = cities - depot
     ang = torch.atan2(c[..., 1:], c[..., :1])
-    node = torch.cat([lin(w, p + ".coord_expert.init_embed_depot", depot),
+    # depot is a strided slice [B,1,2]: F.linear on a NON-contiguous input takes a different CPU path for plain tensors
+    # than for the reference module's Parameters (requires_grad) — 1 ulp apart; on a contiguous input both take the same one
+    node = torch.cat([lin(w, p + ".coord_expert.init_embed_depot", depot.contiguous()),
                       lin(w, p + ".coord_expert.init_embed", torch.cat([cities, ang], dim=-1))], dim=-2)
     rowd = distance.gather(2, sidx)
     cold = distance.transpose(1, 2).gather(2, sidx)

@@ -11,10 +11,10 @@ from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
 
-ENC_ATOL = 5e-4        # encoder embeddings (values up to ~5): 6 layers x 5 instance norms of fp32 reassociation
+ENC_ATOL = 2e-4        # encoder embeddings (values up to ~5): 6 layers x 5 instance norms of fp32 reassociation
 LOGIT_ATOL = 2e-5      # decoder logits given identical embeddings
 LL_RTOL = 2e-5         # log-likelihood (sum of ~N log-probs, each carrying ~1e-5 of encoder fp32 noise)
-LL_ATOL = 2e-3
+LL_ATOL = 1e-3
 COST_ATOL = 2e-5       # tour cost
 GAP_TOL = 1e-3         # decision gap below which a greedy flip is attributed to fp32 noise
 
@@ -369,3 +369,41 @@ def test_return_entropy_and_hidden_follow_the_reference_out_dict():
     row, col = out["hidden"]
     assert torch.allclose(row.cpu(), fx["row_emb"], atol=ENC_ATOL) and torch.allclose(col.cpu(), fx["col_emb"], atol=ENC_ATOL)
 
+
+
+def test_embedding_error_attribution_nab_fold_vs_the_rest():
+    """How much of |embedding - reference| is the algebraic fold of the Neural Adaptive Bias (exact piecewise-linear evaluation
+    of the folded scalar functions) and how much is everything else (fp32 MFMA summation order, instance
+    norm statistics, rr_exp)?  The encoder is run a second time with the bias of every block evaluated UNFOLDED — the
+    reference's own [edges, E] x [E, E] contraction in torch ops on the GPU (oracle.restate.nab_gating) — and handed to the
+    block kernel as `bias_pre`; both runs are compared with the reference's embeddings."""
+    from rrnco_amd import _lib as L
+    name = "atsp_n20_b4_pomo"
+    fx, w, pol, st, env, td_in = _setup(name)
+    dev = torch.device("cuda")
+    packed = pol.packed(dev)
+    td = env.reset(td_in)
+    row_f, col_f = pol.encoder(td, packed=packed)                                   # folded NAB, in-kernel
+    D, locs = td["distance_matrix"].contiguous(), td["locs"].float().contiguous()
+    Bp, N = D.shape[0], D.shape[-1]
+    wg = {k: v.cuda() for k, v in w.items()}
+    with torch.no_grad():          # the init embedding from the oracle (the encoder's own buffers are recycled by its layers)
+        st0 = restate.atsp_reset(st)
+        row, col = (t.cuda().contiguous() for t in restate.atsp_init_embedding(w, st0["locs"], st0["distance_matrix"], fx["sample_idx"]))
+    for l, (wr, wc) in enumerate(packed["blocks"]):
+        p = f"encoder.net.layers.{l}"
+        with torch.no_grad():
+            br = restate.nab_gating(wg, p + ".row_encoding_block.angle_distance_fusion", locs, D, None) * wg[p + ".row_encoding_block.alpha"]
+            bc = restate.nab_gating(wg, p + ".col_encoding_block.angle_distance_fusion", locs, D.transpose(1, 2), None) * wg[p + ".col_encoding_block.alpha"]
+        bias = torch.stack([br.reshape(Bp, -1), bc.reshape(Bp, -1)], 1).contiguous()
+        row2, col2 = torch.empty_like(row), torch.empty_like(col)
+        L.check(L.lib().rr_enc_layer(wr, wc, L.ptr(row), L.ptr(col), L.ptr(row2), L.ptr(col2), L.ptr(D), L.ptr(locs), None, L.ptr(bias),
+                                     Bp, N, 0, None, L.stream()), "rr_enc_layer")
+        row, col = row2, col2
+    ref_r, ref_c = fx["row_emb"].cuda(), fx["col_emb"].cuda()
+    e_fold = max(float((row_f - ref_r).abs().max()), float((col_f - ref_c).abs().max()))
+    e_unf = max(float((row - ref_r).abs().max()), float((col - ref_c).abs().max()))
+    d_fold = max(float((row_f - row).abs().max()), float((col_f - col).abs().max()))
+    print(f"\\n[{name}] |emb - reference|: folded NAB {e_fold:.2e}, unfolded NAB {e_unf:.2e}; |folded - unfolded| {d_fold:.2e}")
+    assert e_fold < ENC_ATOL and e_unf < ENC_ATOL
+    assert d_fold < ENC_ATOL          # the fold moves the embeddings by no more than the rest of the fp32 noise does

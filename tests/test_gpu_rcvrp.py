@@ -6,7 +6,7 @@ from oracle import restate
 from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
-ENC_ATOL, LL_RTOL, LL_ATOL, COST_ATOL, GAP_TOL = 5e-4, 2e-5, 2e-3, 5e-5, 1e-3
+ENC_ATOL, LL_RTOL, LL_ATOL, COST_ATOL, GAP_TOL = 2e-4, 2e-5, 1e-3, 5e-5, 1e-3
 FIXTURES = ["rcvrp_n20_b4_pomo", "rcvrp_n20_b4_greedy", "rcvrp_n100_b2_pomo"]
 
 
