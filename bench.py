@@ -30,7 +30,13 @@ FLOP_PER_ROLLOUT_STEP = 404_480          # pointer step K6-K7,
 # 348 160 (keys padded 100 -> 112; the 65 536-flop context projection is two table gathers, not a GEMM: DESIGN.md §3)
 EXECUTED_FLOP_PER_ROLLOUT_STEP = 348_160
 PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: fp32 matrix peak
-ROLLOUT_KERNEL = "k_rollout_w<7, 0, 0, false>"
+PEAK_BF16_MFMA_TFLOPS = 2500.0           # ... dense bf16 matrix peak
+# The default rollout runs its pointer MLP (262 144 of the 404 480 flop of a rollout-step) on the bf16 pipe with every fp32
+# operand split in three bf16 pieces and six partial products kept: 6 x 262 144 bf16 flop per rollout-step; the rest
+# (attention, logits, context: 142 336 flop) stays on the fp32 MFMA.  Its roofline is the time both pipes need at their peaks.
+MLP_FLOP_PER_ROLLOUT_STEP = 262_144
+ROLLOUT_KERNEL = "k_rollout_w<7, 0, 0, true>"
+ROLLOUT_KERNEL_FP32 = "k_rollout_w<7, 0, 0, false>"
 # HBM-side traffic of ONE rollout launch at the default workload: rocprofv3 PMC, separate FETCH_SIZE / WRITE_SIZE passes,
 # (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B — FETCH_SIZE doubled for gfx950's 16-B/lane reads as MI355X_MICROARCH.md §HBM
 # prescribes; Infinity-Cache hits are included in the counter.  Read at run time from the committed summary
@@ -151,8 +157,10 @@ def main():
             td_.barrier()
             torch.cuda.synchronize()
 
-    # the headline number is always the fp32-MFMA rollout; the opt-in bf16-pipe MLP is measured separately below
-    split_env = os.environ.pop("RR_MLP_SPLIT", None)
+    # headline = the default build (rollout pointer MLP on split-bf16 operands, everything else fp32 MFMA); the all-fp32-MFMA
+    # rollout and the build with the encoder FFN on split operands too are measured separately below
+    os.environ.pop("RR_MLP_SPLIT", None)
+    R.SPLIT_MLP = True
     for _ in range(args.warmup):
         hot_path_step(pol, env, inst)
     R.TIMING = []
@@ -172,45 +180,63 @@ def main():
         rollout_steps = args.batch * AUG * STARTS * (N_NODES - 1)
         k_ms = sum(kern_ms) / max(len(kern_ms), 1)
         achieved = rollout_steps * FLOP_PER_ROLLOUT_STEP / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-        executed = rollout_steps * EXECUTED_FLOP_PER_ROLLOUT_STEP / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        # time the two matrix pipes need at their peaks for one rollout-step of this instruction mix -> blended peak
+        t_min = ((FLOP_PER_ROLLOUT_STEP - MLP_FLOP_PER_ROLLOUT_STEP) / (PEAK_F32_MFMA_TFLOPS * 1e12)
+                 + 6 * MLP_FLOP_PER_ROLLOUT_STEP / (PEAK_BF16_MFMA_TFLOPS * 1e12))
+        peak_blend = FLOP_PER_ROLLOUT_STEP / t_min / 1e12
         traffic, traffic_src = measured_rollout_traffic(args.batch)
         line = {
             "metric": "solved instances/sec (ATSP n=100, B=512, POMO greedy)", "value": total_inst / dt,
             "unit": "instances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "arithmetic": "fp32 throughout; the rollout's pointer MLP multiplies 3-way bf16-split fp32 operands on the bf16 matrix "
+                          "pipe (6 partial products, fp32 accumulate, dropped terms <= 2^-23 of a product) — tours identical to the "
+                          "all-fp32-MFMA rollout (tests/test_gpu_fullsize.py), which is timed under `variants`",
             "config": {"workload": f"ATSP n={N_NODES}, batch={args.batch}/GPU, POMO S={STARTS} starts x {AUG} dihedral aug, greedy "
                                    "(BASELINE.json configs[1]); random-init RRNet E=128 L=6",
                        "rollouts_per_gpu": args.batch * AUG * STARTS, "sharding": f"instances over {world} rank(s), no collective"},
             "roofline": {"bound": "mfma", "kernel": ROLLOUT_KERNEL + " (persistent wave-autonomous POMO decode)", "achieved": achieved,
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                         "peak": peak_blend, "unit": "TFLOP/s", "frac": achieved / peak_blend,
+                         "peak_note": "algorithmic flop / (fp32-MFMA part at 157.3 TFLOP/s + 6 x MLP flop at 2 500 TFLOP/s bf16): the "
+                                      "time both matrix pipes need at their dense peaks for this instruction mix",
                          "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": k_ms,
-                         "algorithmic_flop_per_launch": rollout_steps * FLOP_PER_ROLLOUT_STEP,
-                         # the same launch priced by the flop the matrix pipe executes (no context GEMM, keys padded to 112)
-                         "executed_mfma": {"achieved": executed, "frac": executed / PEAK_F32_MFMA_TFLOPS,
-                                           "flop_per_launch": rollout_steps * EXECUTED_FLOP_PER_ROLLOUT_STEP}},
+                         "algorithmic_flop_per_launch": rollout_steps * FLOP_PER_ROLLOUT_STEP},
             "mean_best_cost": float(-best.mean().item()),
         }
         if world == 1:
-            # Opt-in variant, NOT part of `value`: the rollout's pointer MLP and the encoder's FFN on the bf16 matrix pipe with
-            # 3-way split fp32 operands (six partial products, fp32 accumulate; same tolerances, tests/test_gpu_atsp.py)
+            def timed(label):
+                hot_path_step(pol, env, inst)                          # (warm-up of the variant's kernels / packs)
+                R.TIMING = []
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for k in range(args.steps):
+                    torch.manual_seed(4242 + rank + 1000 * k)
+                    best_v, _ = hot_path_step(pol, env, inst)
+                torch.cuda.synchronize()
+                dtv = time.perf_counter() - t1
+                ks = [a.elapsed_time(b) for a, b in R.TIMING]
+                R.TIMING = None
+                kv = sum(ks) / max(len(ks), 1)
+                return {"value": args.batch * args.steps / dtv, "unit": "instances/s", "ms_per_step": dtv / args.steps * 1e3,
+                        "kernel_ms": kv, "mean_best_cost": float(-best_v.mean().item()),
+                        "instances_with_identical_best_cost": float((best_v == best).float().mean().item())}, kv
+            line["variants"] = {}
+            # (a) the all-fp32-MFMA rollout (round 1's default): priced against the fp32 matrix peak, algorithmic and executed flop
+            R.SPLIT_MLP = False
+            v32, k32 = timed("fp32")
+            a32 = rollout_steps * FLOP_PER_ROLLOUT_STEP / (k32 * 1e-3) / 1e12
+            e32 = rollout_steps * EXECUTED_FLOP_PER_ROLLOUT_STEP / (k32 * 1e-3) / 1e12
+            v32["roofline"] = {"bound": "mfma", "kernel": ROLLOUT_KERNEL_FP32, "achieved": a32, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": a32 / PEAK_F32_MFMA_TFLOPS,
+                               "executed_mfma": {"achieved": e32, "frac": e32 / PEAK_F32_MFMA_TFLOPS,
+                                                 "note": "348 160 flop per rollout-step actually issued (no context GEMM, keys padded to 112)"}}
+            line["variants"]["fp32_mfma_rollout (RR_MLP_SPLIT=0)"] = v32
+            R.SPLIT_MLP = True
+            # (b) opt-in: the encoder's FFN on the same split-operand pipe too (embeddings move at the 1e-6 level)
             os.environ["RR_MLP_SPLIT"] = "1"
-            hot_path_step(pol, env, inst)              # (warm-up of the variant's kernels)
-            R.TIMING = []
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for k in range(args.steps):
-                torch.manual_seed(4242 + rank + 1000 * k)
-                best_s, _ = hot_path_step(pol, env, inst)
-            torch.cuda.synchronize()
-            dts = time.perf_counter() - t1
-            ks = [a.elapsed_time(b) for a, b in R.TIMING]
-            R.TIMING = None
+            line["variants"]["encoder_ffn_split_too (RR_MLP_SPLIT=1 at pack time)"] = timed("encsplit")[0]
             os.environ.pop("RR_MLP_SPLIT")
-            line["variants"] = {"mlp_3xbf16_split: rollout pointer MLP + encoder FFN (RR_MLP_SPLIT=1, off by default)": {
-                "value": args.batch * args.steps / dts, "unit": "instances/s", "ms_per_step": dts / args.steps * 1e3,
-                "kernel_ms": sum(ks) / max(len(ks), 1), "mean_best_cost": float(-best_s.mean().item()),
-                "instances_with_identical_best_cost": float((best_s == best).float().mean().item())}}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(line))

@@ -404,7 +404,8 @@ extern "C" int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStrea
   if (io->mode == 2 && io->actions_in == nullptr) return RR_EINVAL;
   static const int variant = getenv("RR_ROLLOUT_VARIANT") ? atoi(getenv("RR_ROLLOUT_VARIANT")) : 1;
   const char* es = getenv("RR_MLP_SPLIT");
-  const bool mlp_split = ((es != nullptr && atoi(es) != 0) || io->use_split != 0) && w->w1s != nullptr && w->w2s != nullptr;
+  // RolloutIO.use_split decides; the environment variable only forces it on for callers that leave the field 0
+  const bool mlp_split = (io->use_split != 0 || (es != nullptr && atoi(es) != 0 && io->use_split < 0)) && w->w1s != nullptr && w->w2s != nullptr;
   if (variant == 0 && prob < 2) {   // workgroup-per-instance variant (kept for A/B measurements; ATSP / RCVRP only)
     dim3 grid(io->Bp, (S + ROWS - 1) / ROWS), blk(DEC_THREADS);
     const int need = N > (S < ROWS ? S : ROWS) ? N : (S < ROWS ? S : ROWS);

@@ -154,10 +154,11 @@ def test_split_bf16_mlp_rollout_meets_the_fp32_contract(name, monkeypatch, capsy
     fx, w, pol, st, env, td_in = _setup(name)
     S = fx["S"]
     kw = dict(phase="val", decode_type="multistart_greedy", num_starts=S, return_actions=True, fused=True)
+    from rrnco_amd.models import rollout as R
+    monkeypatch.setattr(R, "SPLIT_MLP", False)
     ref32 = pol(env.reset(td_in), env, **kw)
-    monkeypatch.setenv("RR_MLP_SPLIT", "1")
+    monkeypatch.setattr(R, "SPLIT_MLP", True)
     out = pol(env.reset(td_in), env, **kw)
-    monkeypatch.delenv("RR_MLP_SPLIT")
     acts = out["actions"].cpu()
     assert restate.atsp_check(acts)
     frac, first = H.tour_agreement(acts, fx["actions"])

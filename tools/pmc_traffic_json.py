@@ -8,7 +8,7 @@ out = {"kernel": bench.ROLLOUT_KERNEL, "source_hash": bench.rollout_source_hash(
 for path in sys.argv[1:]:
     lines = open(path).read().splitlines()
     for i, l in enumerate(lines):
-        if l.startswith("void k_rollout_w<7, 0, 0, false>"):
+        if l.startswith("void " + bench.ROLLOUT_KERNEL):
             m = re.search(r"(FETCH_SIZE|WRITE_SIZE)\s+n=\s*(\d+) mean=([0-9.e+]+)", lines[i + 1])
             out[m.group(1) + "_KB"] = float(m.group(3)); out[m.group(1) + "_n"] = int(m.group(2))
 print(json.dumps(out))
