@@ -47,20 +47,38 @@ model = RRNet(env, policy=pol)
 opt = torch.optim.Adam(pol.parameters(), lr=1e-4, fused=True)
 gen = torch.Generator(device=dev).manual_seed(1234 + rank)
 batches = [env.generator(args.batch, generator=gen) for _ in range(args.steps + 1)]
-out = model.training_step(batches[0], optimizer=opt, world=world, enc_chunk=args.enc_chunk, dec_chunk=args.dec_chunk, seed=1)
+from rrnco_amd.models import rollout as R
+out = model.training_step(batches[0], optimizer=opt, world=world, enc_chunk=args.enc_chunk, dec_chunk=args.dec_chunk, seed=1, grad_clip=1.0)
 torch.cuda.synchronize()
 if world > 1:
     dist.barrier()
+R.TIMING = []
 t0 = time.perf_counter()
 for i in range(args.steps):
-    out = model.training_step(batches[i + 1], optimizer=opt, world=world, enc_chunk=args.enc_chunk, dec_chunk=args.dec_chunk, seed=2 + i)
+    out = model.training_step(batches[i + 1], optimizer=opt, world=world, enc_chunk=args.enc_chunk, dec_chunk=args.dec_chunk, seed=2 + i,
+                              grad_clip=1.0)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
+kern_ms = [a.elapsed_time(b) for a, b in R.TIMING]
+R.TIMING = None
 units, tmax = aggregate_throughput(args.batch * args.steps, dt, world > 1, dev if backend == "nccl" else torch.device("cpu"))
 if rank == 0:
-    print(json.dumps({"config": "%s n=100 REINFORCE training step, %d instances/GPU, multistart sampling, %d GPU(s)" % (args.problem.upper(), args.batch, world),
-                      "instances_per_s": units / tmax, "ms_per_step": tmax / args.steps * 1e3, "loss": float(out["loss"]),
-                      "grad_norm": float(out["grad_norm"]), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2**30,
-                      "gradient_path": "teacher-forced autograd replay: HIP NAB forward/backward kernels + torch ops; rollout + loss on HIP kernels"}))
+    line = {"config": "%s n=100 REINFORCE training step, %d instances/GPU, multistart sampling, %d GPU(s)" % (args.problem.upper(), args.batch, world),
+            "metric": "trained instances/sec (REINFORCE step: sampling rollout + backward + flat all-reduce + Adam)", "value": units / tmax,
+            "unit": "instances/s", "n_gpus": world, "instances_per_s": units / tmax, "ms_per_step": tmax / args.steps * 1e3, "loss": float(out["loss"]),
+            "grad_norm": float(out["grad_norm"]), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2**30,
+            "gradient_path": "hand-written HIP backward (csrc/rr_train_dec.hip, rr_train_enc.hip, rr_train.hip) on what the sampling rollout "
+                             "dumped; torch only for the init embedding and the host-side folds"}
+    if args.problem == "atsp" and kern_ms:
+        # the step's largest kernel is still the sampling rollout: priced like bench.py's (pointer MLP on split-bf16 operands)
+        k_ms = sum(kern_ms) / len(kern_ms)
+        steps_ = args.batch * 100 * 98          # rollouts x evaluated decode steps (the forced last move is not evaluated)
+        t_min = (bench.FLOP_PER_ROLLOUT_STEP - bench.MLP_FLOP_PER_ROLLOUT_STEP) / (bench.PEAK_F32_MFMA_TFLOPS * 1e12) + \
+            6 * bench.MLP_FLOP_PER_ROLLOUT_STEP / (bench.PEAK_BF16_MFMA_TFLOPS * 1e12)
+        ach = steps_ * bench.FLOP_PER_ROLLOUT_STEP / (k_ms * 1e-3) / 1e12
+        peak = bench.FLOP_PER_ROLLOUT_STEP / t_min / 1e12
+        line["roofline"] = {"bound": "mfma", "kernel": "k_rollout_w<7, 0, 1, true> (sampling rollout with the training dump)", "achieved": ach,
+                            "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "kernel_ms": k_ms, "traffic": None}
+    print(json.dumps(line))
 if world > 1:
     dist.destroy_process_group()
