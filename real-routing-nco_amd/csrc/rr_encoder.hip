@@ -433,7 +433,8 @@ static int rr_enc_layer_impl(const EncBlockW* wrow, const EncBlockW* wcol, const
   if ((variant == 1 || norm_affine_only) && dbg == nullptr && (theta != nullptr || bias_pre != nullptr)) {
     EncBlockW2 ws; ws.blk[0] = *wrow; ws.blk[1] = *wcol;   // wave = node tile, register-resident (rr_enc_w.inc); stage dumps use the LDS-staged kernel
     const char* es = getenv("RR_MLP_SPLIT");
-    const bool split = es != nullptr && atoi(es) != 0 && wrow->w1s && wrow->w2s && wcol->w1s && wcol->w2s;
+    // FFN on 3-way bf16-split operands whenever the packs carry them (packing.mlp_split_enabled: default on; RR_MLP_SPLIT=0 off)
+    const bool split = (es == nullptr || atoi(es) != 0) && wrow->w1s && wrow->w2s && wcol->w1s && wcol->w2s;
 #define RR_ENCW(NTV, SP) hipLaunchKernelGGL((k_enc_block_w<NTV, SP>), grid, dim3(64 * NTV), 0, st, ws, row_in, col_in, row_out, col_out, D, theta, bias_pre, N, norm_affine_only, svs)
     if (N <= 32) { if (split) RR_ENCW(2, true); else RR_ENCW(2, false); }
     else if (N <= 64) { if (split) RR_ENCW(4, true); else RR_ENCW(4, false); }

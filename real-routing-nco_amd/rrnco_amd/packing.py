@@ -40,10 +40,11 @@ def pack_a(Wm: torch.Tensor) -> torch.Tensor:
 
 
 def mlp_split_enabled() -> bool:
-    """RR_MLP_SPLIT=1: pointer MLP / encoder FFN on the bf16 matrix pipe with 3-way split operands (opt-in)."""
+    """Pointer MLP / encoder FFN on the bf16 matrix pipe with 3-way split fp32 operands: the default since round 2 (the whole
+    GPU suite — golden tours, embeddings to 2e-4, gradients — is green with it, and the full-size rollouts equal the
+    fp32-MFMA build's, tests/test_gpu_fullsize.py); RR_MLP_SPLIT=0 builds and runs the all-fp32-MFMA kernels."""
     import os
-    v = os.environ.get("RR_MLP_SPLIT", "")
-    return v not in ("", "0")
+    return os.environ.get("RR_MLP_SPLIT", "1") != "0"
 
 
 def pack_a_bf16x3(Wm: torch.Tensor) -> torch.Tensor:

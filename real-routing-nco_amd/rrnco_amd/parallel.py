@@ -33,7 +33,12 @@ def allreduce_flat_gradients(grads, world: int):
     import torch.distributed as dist
     flat = torch.cat([g.reshape(-1).float() for g in grads])
     if world > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if flat.is_cuda and dist.get_backend() != "nccl":      # gloo (ranks sharing a GPU in the tests): through the host
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat /= world
     out, off = [], 0
     for g in grads:

@@ -143,7 +143,7 @@ def test_c2_split_bf16_pointer_mlp_rollout_equals_the_fp32_mfma_rollout(monkeypa
     td = env.reset(StateAugmentation(augment_fn="dihedral8", no_aug_coords=False)(inst))
     td["sample_idx"] = ATSPInitEmbedding.sample_indices(td["distance_matrix"], 25)
     kw = dict(phase="val", decode_type="multistart_greedy", num_starts=S, return_sum_log_likelihood=False)
-    monkeypatch.setattr(R, "SPLIT_MLP", False)
+    monkeypatch.setattr(R, "SPLIT_MLP", False)        # (the encoder is the same build in both runs: same embeddings)
     a32 = pol(td.clone(), env, **kw)
     monkeypatch.setattr(R, "SPLIT_MLP", True)
     asp = pol(td.clone(), env, **kw)
@@ -165,3 +165,22 @@ def test_c2_split_bf16_pointer_mlp_rollout_equals_the_fp32_mfma_rollout(monkeypa
         gap = lp_max - lp_other
         print(f"[C2] {rows.numel()} diverging rollouts, largest fp32 decision gap at the parting step {float(gap.max()):.2e}")
         assert float(gap.min()) > -1e-5 and float(gap.max()) < 1e-3
+
+
+def test_c5_training_step_full_size_properties():
+    """BASELINE configs[4] per-GPU shard (ATSP n=100, 512 instances, 100 sampled starts): sampled tours are permutations, the
+    backward's replayed log-likelihood is the rollout's, every gradient is finite."""
+    from rrnco_amd.envs import ATSPEnv, ATSPGenerator
+    from rrnco_amd.models.rl import RRNet
+    B, N, S = 512, 100, 100
+    pol = _policy("atsp", restate.atsp_weight_template()).train()
+    env = ATSPEnv(generator_params=dict(num_loc=N, device=DEV), check_solution=False, device=DEV)
+    model = RRNet(env, policy=pol)
+    batch = ATSPGenerator(num_loc=N, device=DEV)(B, generator=torch.Generator(device=DEV).manual_seed(21))
+    out = model.training_step(batch, seed=3, grad_clip=1.0)
+    acts = out["actions"]
+    assert acts.shape == (S * B, N) and bool((acts.sort(1).values == torch.arange(N, device=DEV)).all())
+    assert torch.allclose(out["replay_log_likelihood"], out["log_likelihood"], rtol=2e-5, atol=2e-3)
+    assert bool(torch.isfinite(out["log_likelihood"]).all()) and float(out["grad_norm"]) > 0
+    total = torch.linalg.vector_norm(torch.stack([p.grad.norm() for p in pol.parameters()]))
+    assert bool(torch.isfinite(total)) and float(total) <= 1.0 + 1e-4                  # clipped to gradient_clip_val = 1.0
