@@ -58,8 +58,9 @@ class RMTVRPEnv(EnvBase):
         super().__init__(check_solution=check_solution, **kwargs)
         if generator is None:
             generator = RMTVRPGenerator(**{k: v for k, v in dict(generator_params).items() if k != "_target_"})
-        if select_start_nodes_fn != "all":
-            raise NotImplementedError("only the 'all' start-node selector (selectstartnodes.py:42-50) is implemented")
+        if select_start_nodes_fn not in ("all", "random"):
+            raise NotImplementedError("start-node selectors: 'all' (selectstartnodes.py:42-50) or 'random' (:37-40)")
+        self.select_start_nodes_fn = select_start_nodes_fn
         self.generator, self.normalize = generator, normalize
 
     def get_num_starts(self, td):                      # selectstartnodes.py: AllSelectStartNodes -> num_loc
@@ -67,6 +68,10 @@ class RMTVRPEnv(EnvBase):
 
     def select_start_nodes(self, td, num_starts):      # selectstartnodes.py:42-50
         n = td["locs"].shape[-2] - 1
+        if self.select_start_nodes_fn == "random":
+            # RandomStartNodes (:37-40) draws torch.randint(0, N+1, (B, num_starts)); flattened here in the (start, instance)
+            # order the batchified state has (the reference's [B, S] tensor does not fit its own td.set("action", .)), customers only
+            return torch.randint(1, n + 1, (num_starts * td.shape[0],), device=td.device)
         return torch.arange(num_starts, device=td.device).repeat_interleave(td.shape[0]) % n + 1
 
     def _reset(self, td, batch_size=None) -> TensorDict:

@@ -24,8 +24,9 @@ class DecodingStrategy:
     def __init__(self, temperature=1.0, top_p=0.0, top_k=0, mask_logits=True, tanh_clipping=0, num_samples=None,
                  multisample=False, num_starts=None, multistart=False, select_start_nodes_fn=None,
                  improvement_method_mode=False, select_best=False, store_all_logp=False, seed=None, **kwargs):
-        if select_best or improvement_method_mode:
-            raise NotImplementedError("select_best / improvement_method_mode are outside the MI355X hot path")
+        if improvement_method_mode:
+            raise NotImplementedError("improvement_method_mode is outside the MI355X hot path")
+        self.select_best = bool(select_best)
         if not 0.0 <= top_p <= 1.0:
             raise AssertionError("top-p should be in (0, 1].")                      # decoding.py:357
         # decoding.py:352-358 filters; evaluated by rr_select in the step-wise loop (the fused rollout has no sort)
@@ -70,7 +71,20 @@ class DecodingStrategy:
 
     def post_decoder_hook(self, td, env):
         assert len(self.logprobs) > 0, "No logprobs were collected because all environments were done"
-        return torch.stack(self.logprobs, 1), torch.stack(self.actions, 1), td, env
+        logprobs, actions = torch.stack(self.logprobs, 1), torch.stack(self.actions, 1)
+        if self.num_starts > 0 and self.select_best:                                   # decoding.py:214-216
+            logprobs, actions, td, env = self._select_best(logprobs, actions, td, env)
+        return logprobs, actions, td, env
+
+    def _select_best(self, logprobs, actions, td, env):
+        """decoding.py:300-309: keep, per instance, the start / sample with the best reward.  (The reference takes `.max` of
+        env.get_reward's return value, which is a (real, normalised) tuple for these envs: the real reward is used here.)"""
+        rew = env.get_reward(td, actions)
+        rew = rew[0] if isinstance(rew, tuple) else rew
+        B = rew.shape[0] // self.num_starts
+        best = rew.view(self.num_starts, B).argmax(0)                                  # unbatchify(rew, S).max(-1)
+        rows = best * B + torch.arange(B, device=rew.device)                           # r = s * B + b
+        return logprobs[rows], actions[rows], td.index_rollouts(rows), env
 
     def step(self, logits, mask, td=None, action=None, **kwargs):
         """decoding.py:219-270."""

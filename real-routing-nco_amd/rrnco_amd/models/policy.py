@@ -110,6 +110,8 @@ class RRNetPolicy(nn.Module):
                 dump = capture.setdefault("dump", {})
                 capture["cache"] = cache
             logprobs, actions_out, td = self._fused_rollout(td, env, cache, packed, strategy, actions, dump=dump)
+            if strategy.num_starts > 0 and getattr(strategy, "select_best", False) and dump is None:
+                logprobs, actions_out, td, env = strategy._select_best(logprobs, actions_out, td, env)
         else:
             step = 0
             while not td["done"].all():

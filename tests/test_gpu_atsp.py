@@ -408,3 +408,21 @@ def test_embedding_error_attribution_nab_fold_vs_the_rest():
     print(f"\\n[{name}] |emb - reference|: folded NAB {e_fold:.2e}, unfolded NAB {e_unf:.2e}; |folded - unfolded| {d_fold:.2e}")
     assert e_fold < ENC_ATOL and e_unf < ENC_ATOL
     assert d_fold < ENC_ATOL          # the fold moves the embeddings by no more than the rest of the fp32 noise does
+
+
+def test_select_best_and_multisample_decoding():
+    """decoding.py:157-217, 300-309: select_best keeps the best start per instance; multisample (num_samples) runs S sampled
+    rollouts per instance from the placeholder context (no start-node selection)."""
+    fx, w, pol, st, env, td_in = _setup("atsp_n20_b4_pomo")
+    S, B = fx["S"], fx["B"]
+    full = pol(env.reset(td_in), env, phase="val", decode_type="multistart_greedy", num_starts=S)
+    best = pol(env.reset(td_in), env, phase="val", decode_type="multistart_greedy", num_starts=S, select_best=True)
+    Bp = full["reward"].shape[0] // S
+    assert best["reward"].shape == (Bp,) and best["actions"].shape == (Bp, fx["N"])
+    assert torch.equal(best["reward"], full["reward"].view(S, Bp).amax(0))
+    rows = full["reward"].view(S, Bp).argmax(0) * Bp + torch.arange(Bp, device="cuda")
+    assert torch.equal(best["actions"], full["actions"][rows]) and torch.allclose(best["log_likelihood"], full["log_likelihood"][rows])
+    for fused in (True, False):
+        ms = pol(env.reset(td_in), env, phase="val", decode_type="sampling", num_samples=6, seed=3, fused=fused)
+        assert ms["actions"].shape == (6 * Bp, fx["N"]) and restate.atsp_check(ms["actions"].cpu())
+        assert len({tuple(r) for r in ms["actions"].view(6, Bp, -1)[:, 0].tolist()}) > 1          # the samples differ
