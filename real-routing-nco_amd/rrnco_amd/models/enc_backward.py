@@ -29,28 +29,30 @@ def train_packs(policy) -> dict:
     sd = {k: v.detach() for k, v in policy.named_parameters()}
     nl = 1 + max(int(n.split(".")[3]) for n in sd if n.startswith("encoder.net.layers."))
     keep, blocks = [], []
-
-    def pa(W):
-        t = packing.pack_a(W.float().contiguous())
-        keep.append(t)
-        return t
-
     with torch.no_grad():
+        # all blocks' matrices packed together (a handful of launches per shape, not per matrix: this runs every step)
+        names = [f"encoder.net.layers.{l}.{side}_encoding_block" for l in range(nl) for side in ("row", "col")]
+        stk = lambda k: torch.stack([sd[f"{b}.{k}"].float() for b in names])                  # noqa: E731
+        Wpc = torch.bmm(stk("multi_head_combine.weight").double(), stk("attn_free.project.weight").double()).float()
+        T = packing.pack_a(torch.stack([stk("attn_free.to_q.weight"), stk("attn_free.to_k.weight"), stk("attn_free.to_v.weight"), Wpc])
+                           .transpose(-1, -2).contiguous())                                     # [4][nb] packs of the TRANSPOSED matrices
+        mlps = packing.pack_mlp_train_batched([sd[f"{b}.feed_forward.ops.ffn.W1.weight"] for b in names], [sd[f"{b}.feed_forward.ops.ffn.W1.bias"] for b in names],
+                                              [sd[f"{b}.feed_forward.ops.ffn.W2.weight"] for b in names], [sd[f"{b}.feed_forward.ops.ffn.W2.bias"] for b in names])
+        keep.append(T)
         for l in range(nl):
             pair = {}
-            for side in ("row", "col"):
-                b = f"encoder.net.layers.{l}.{side}_encoding_block"
-                Wpc = (sd[f"{b}.multi_head_combine.weight"].double() @ sd[f"{b}.attn_free.project.weight"].double()).float()
-                pair[side] = {"wqT": pa(sd[f"{b}.attn_free.to_q.weight"].t()), "wkT": pa(sd[f"{b}.attn_free.to_k.weight"].t()),
-                              "wvT": pa(sd[f"{b}.attn_free.to_v.weight"].t()), "wpcT": pa(Wpc.t()),
-                              "mlp": packing.pack_mlp_train(sd[f"{b}.feed_forward.ops.ffn.W1.weight"], sd[f"{b}.feed_forward.ops.ffn.W1.bias"],
-                                                            sd[f"{b}.feed_forward.ops.ffn.W2.weight"], sd[f"{b}.feed_forward.ops.ffn.W2.bias"])}
+            for si, side in enumerate(("row", "col")):
+                bi = 2 * l + si
+                pair[side] = {"wqT": T[0, bi], "wkT": T[1, bi], "wvT": T[2, bi], "wpcT": T[3, bi], "mlp": mlps[bi]}
             blocks.append(pair)
-        Wn = sd["decoder.project_node_embeddings.weight"]
-        Wc = sd["decoder.context_embedding.project_context.weight"]
-        cache = {"wkT": pa(Wn[:E].t()), "wvT": pa(Wn[E:2 * E].t()), "wlT": pa(Wn[2 * E:].t()), "wc0T": pa(Wc[:, :E].t())}
+        Wn = sd["decoder.project_node_embeddings.weight"].float()
+        Wc = sd["decoder.context_embedding.project_context.weight"].float()
+        mats = [Wn[:E], Wn[E:2 * E], Wn[2 * E:], Wc[:, :E]] + ([Wc[:, E:2 * E]] if policy.env_name == "atsp" else [])
+        C = packing.pack_a(torch.stack(mats).transpose(-1, -2).contiguous())
+        keep.append(C)
+        cache = {"wkT": C[0], "wvT": C[1], "wlT": C[2], "wc0T": C[3]}
         if policy.env_name == "atsp":
-            cache["wc1T"] = pa(Wc[:, E:2 * E].t())
+            cache["wc1T"] = C[4]
     out = {"blocks": blocks, "cache": cache, "keep": keep, "num_layers": nl}
     policy._enc_train_pack = (key, out)
     return out
@@ -93,10 +95,16 @@ class _Grads:
 
     def __init__(self, P):
         self.P, self.g = P, {}
+        self.off, n = {}, 0
+        for k, p in P.items():                      # one zero-filled flat buffer (one memset), views per parameter
+            self.off[k] = n
+            n += (p.numel() + 3) // 4 * 4           # 16-byte aligned views (float4 stores / atomics on rows)
+        self.flat = torch.zeros(n, dtype=torch.float32, device=next(iter(P.values())).device)
 
     def buf(self, name):
         if name not in self.g:
-            self.g[name] = torch.zeros_like(self.P[name], dtype=torch.float32)
+            p = self.P[name]
+            self.g[name] = self.flat[self.off[name]:self.off[name] + p.numel()].view(p.shape)
         return self.g[name]
 
     def flush(self):

@@ -31,12 +31,16 @@ def weights_fingerprint(module) -> tuple:
 def pack_a(Wm: torch.Tensor) -> torch.Tensor:
     """[M,K] -> [M/16, K/16, 64, 4] float32: lane (i = l&15, g = l>>4) of tile t, k-group kk holds
     W[16t+i][16kk+4g+m], m = 0..3 (csrc/rr_common.h).  M, K zero-padded to multiples of 16."""
-    M, K = Wm.shape
+    *lead, M, K = Wm.shape                     # leading dims = a batch of matrices packed by the same few launches
     Mp, Kp = (M + 15) // 16 * 16, (K + 15) // 16 * 16
-    Wp = torch.zeros(Mp, Kp, dtype=torch.float32, device=Wm.device)
-    Wp[:M, :K] = Wm
-    x = Wp.view(Mp // 16, 16, Kp // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous()
-    return x.view(Mp // 16, Kp // 16, 64, 4)
+    if (Mp, Kp) != (M, K):
+        Wp = torch.zeros(*lead, Mp, Kp, dtype=torch.float32, device=Wm.device)
+        Wp[..., :M, :K] = Wm
+    else:
+        Wp = Wm.float()
+    n = len(lead)
+    x = Wp.reshape(*lead, Mp // 16, 16, Kp // 16, 4, 4).permute(*range(n), n, n + 2, n + 3, n + 1, n + 4).contiguous()
+    return x.view(*lead, Mp // 16, Kp // 16, 64, 4)
 
 
 def mlp_split_enabled() -> bool:
@@ -52,18 +56,17 @@ def pack_a_bf16x3(Wm: torch.Tensor) -> torch.Tensor:
     W = hi + mid + lo (each rounded to nearest bf16 of what is left; the sum is exactly W).  Lane (i = l&15, g = l>>4) of
     tile t, k-slice s holds, for e = 0..7, W[16t+i][32s + 4g + e] (e < 4) and W[16t+i][32s + 16 + 4g + e - 4] (e >= 4): the
     order in which a lane owns the values of two consecutive C-layout tiles (csrc/rr_rollout_w.inc, SPLIT)."""
-    M, K = Wm.shape
+    *lead, M, K = Wm.shape                                   # leading dims: a batch of matrices
     assert M % 16 == 0 and K % 32 == 0
+    n = len(lead)
     W = Wm.detach().float()                                  # stays on the weights' device: this runs on every repack
     hi = W.to(torch.bfloat16)
     r1 = W - hi.float()
     mid = r1.to(torch.bfloat16)
     lo = (r1 - mid.float()).to(torch.bfloat16)
-    out = []
-    for piece in (hi, mid, lo):
-        x = piece.view(M // 16, 16, K // 32, 2, 4, 4)            # t, i, s, half, g, e4
-        out.append(x.permute(0, 2, 4, 1, 3, 5).reshape(M // 16, K // 32, 64, 8))     # t, s, (g, i), (half, e4)
-    return torch.stack(out, dim=2).contiguous()                  # [t][s][piece][lane][8]
+    x = torch.stack((hi, mid, lo), dim=n).reshape(*lead, 3, M // 16, 16, K // 32, 2, 4, 4)      # piece, t, i, s, half, g, e4
+    x = x.permute(*range(n), n + 1, n + 3, n, n + 5, n + 2, n + 4, n + 6)                       # t, s, piece, g, i, half, e4
+    return x.reshape(*lead, M // 16, K // 32, 3, 64, 8).contiguous()                            # [t][s][piece][lane][8]
 
 
 
@@ -72,48 +75,57 @@ def pack_bf16x2(Wm: torch.Tensor, k_major: bool = False) -> torch.Tensor:
     permuted k order of pack_a_bf16x3 (a lane's eight values = its four of two consecutive C-layout tiles): [M/16][K/32][2][64][8],
     or k-slice-major [K/32][M/16][2][64][8] (the fragments one hidden pair of csrc/rr_train_dec.hip:k_mlp_rows needs are then
     contiguous)."""
-    M, K = Wm.shape
+    *lead, M, K = Wm.shape                                   # leading dims: a batch of matrices
     assert M % 16 == 0 and K % 32 == 0
+    n = len(lead)
     W = Wm.detach().float()
     hi = W.to(torch.bfloat16)
     lo = (W - hi.float()).to(torch.bfloat16)
-    out = []
-    for piece in (hi, lo):
-        x = piece.view(M // 16, 16, K // 32, 2, 4, 4)            # t, i, s, half, g, e4
-        out.append(x.permute(0, 2, 4, 1, 3, 5).reshape(M // 16, K // 32, 64, 8))
-    out = torch.stack(out, dim=2)                                # [t][s][piece][lane][8]
+    x = torch.stack((hi, lo), dim=n).reshape(*lead, 2, M // 16, 16, K // 32, 2, 4, 4)           # piece, t, i, s, half, g, e4
     if k_major:
-        out = out.permute(1, 0, 2, 3, 4)
-    return out.contiguous()
+        x = x.permute(*range(n), n + 3, n + 1, n, n + 5, n + 2, n + 4, n + 6)                   # s, t, piece, g, i, half, e4
+        return x.reshape(*lead, K // 32, M // 16, 2, 64, 8).contiguous()
+    x = x.permute(*range(n), n + 1, n + 3, n, n + 5, n + 2, n + 4, n + 6)                       # t, s, piece, g, i, half, e4
+    return x.reshape(*lead, M // 16, K // 32, 2, 64, 8).contiguous()
 
 
 def pack_bf16x2_nat(Wm: torch.Tensor) -> torch.Tensor:
     """The same split with the NATURAL k order (lane (i = l&15, g = l>>4), element e <-> W[16t+i][32s + 8g + e]):
     [M/16][K/32][2][64][8] — the B operand of products whose A operand is read row-wise from memory (k_mlp_wgrad)."""
-    M, K = Wm.shape
+    *lead, M, K = Wm.shape
     assert M % 16 == 0 and K % 32 == 0
+    n = len(lead)
     W = Wm.detach().float()
     hi = W.to(torch.bfloat16)
     lo = (W - hi.float()).to(torch.bfloat16)
+    x = torch.stack((hi, lo), dim=n).reshape(*lead, 2, M // 16, 16, K // 32, 4, 8)              # piece, t, i, s, g, e
+    x = x.permute(*range(n), n + 1, n + 3, n, n + 4, n + 2, n + 5)                               # t, s, piece, g, i, e
+    return x.reshape(*lead, M // 16, K // 32, 2, 64, 8).contiguous()
+
+
+def pack_mlp_train_batched(W1s, b1s, W2s, b2s) -> list:
+    """Operand packs of the training-side 128 -> 512 -> 128 MLP kernels (pointer MLP decoder.py:272-277, TransformerFFN
+    attn_freenet.py:330-357) for a LIST of MLPs at once (the packs of all of them cost the launches of one): forward, input
+    gradient, weight gradient.  Built on the weights' device.  -> one dict of kernel descriptors per MLP."""
+    W1 = torch.stack([w.detach().float() for w in W1s])              # [n,512,128]
+    W2 = torch.stack([w.detach().float() for w in W2s])              # [n,128,512]
+    W1t, W2t = W1.transpose(1, 2).contiguous(), W2.transpose(1, 2).contiguous()
+    keep = {"wa1": pack_bf16x2(W1), "wa2": pack_bf16x2(W2t), "wb_fwd": pack_bf16x2(W2, k_major=True),
+            "wb_bwd": pack_bf16x2(W1t, k_major=True), "w1n": pack_bf16x2_nat(W1), "w2tn": pack_bf16x2_nat(W2t),
+            "b1": [b.detach().float().contiguous() for b in b1s], "b2": [b.detach().float().contiguous() for b in b2s]}
     out = []
-    for piece in (hi, lo):
-        x = piece.view(M // 16, 16, K // 32, 4, 8)                 # t, i, s, g, e
-        out.append(x.permute(0, 2, 3, 1, 4).reshape(M // 16, K // 32, 64, 8))
-    return torch.stack(out, dim=2).contiguous()
+    for i in range(W1.shape[0]):
+        fw, bw, wg = L.MlpRowsW(), L.MlpRowsW(), L.MlpWgradW()
+        b1p, b2p = keep["b1"][i].data_ptr(), keep["b2"][i].data_ptr()
+        fw.wa1, fw.wa2, fw.wb, fw.b1, fw.b2 = keep["wa1"][i].data_ptr(), None, keep["wb_fwd"][i].data_ptr(), b1p, b2p
+        bw.wa1, bw.wa2, bw.wb, bw.b1, bw.b2 = keep["wa1"][i].data_ptr(), keep["wa2"][i].data_ptr(), keep["wb_bwd"][i].data_ptr(), b1p, None
+        wg.w1n, wg.w2tn, wg.b1 = keep["w1n"][i].data_ptr(), keep["w2tn"][i].data_ptr(), b1p
+        out.append({"keep": keep, "fwd": fw, "bwd": bw, "wgrad": wg})
+    return out
 
 
 def pack_mlp_train(W1: torch.Tensor, b1: torch.Tensor, W2: torch.Tensor, b2: torch.Tensor) -> dict:
-    """Operand packs of the training-side 128 -> 512 -> 128 MLP kernels (pointer MLP decoder.py:272-277, TransformerFFN
-    attn_freenet.py:330-357): forward, input gradient, weight gradient.  Built on the weights' device."""
-    keep = {"wa1": pack_bf16x2(W1), "wa2": pack_bf16x2(W2.t().contiguous()),
-            "wb_fwd": pack_bf16x2(W2, k_major=True), "wb_bwd": pack_bf16x2(W1.t().contiguous(), k_major=True),
-            "w1n": pack_bf16x2_nat(W1), "w2tn": pack_bf16x2_nat(W2.t().contiguous()),
-            "b1": b1.detach().float().contiguous(), "b2": b2.detach().float().contiguous()}
-    fw, bw, wg = L.MlpRowsW(), L.MlpRowsW(), L.MlpWgradW()
-    fw.wa1, fw.wa2, fw.wb, fw.b1, fw.b2 = keep["wa1"].data_ptr(), None, keep["wb_fwd"].data_ptr(), keep["b1"].data_ptr(), keep["b2"].data_ptr()
-    bw.wa1, bw.wa2, bw.wb, bw.b1, bw.b2 = keep["wa1"].data_ptr(), keep["wa2"].data_ptr(), keep["wb_bwd"].data_ptr(), keep["b1"].data_ptr(), None
-    wg.w1n, wg.w2tn, wg.b1 = keep["w1n"].data_ptr(), keep["w2tn"].data_ptr(), keep["b1"].data_ptr()
-    return {"keep": keep, "fwd": fw, "bwd": bw, "wgrad": wg}
+    return pack_mlp_train_batched([W1], [b1], [W2], [b2])[0]
 
 
 @contextlib.contextmanager
@@ -192,6 +204,55 @@ def fold_nab_pwl(sd, p: str, alpha: torch.Tensor) -> torch.Tensor:
     tail[0], tail[1], tail[2] = bg, bo, float(alpha.detach().double().cpu().reshape(()))
     tab = np.concatenate(ts + segs + [tail]).astype(np.float32)
     return torch.from_numpy(np.concatenate([tab, nab_grid_cells(tab)]))
+
+
+def fold_nab_pwl_batched(sd, prefixes, alphas) -> torch.Tensor:
+    """fold_nab_pwl + nab_grid_cells for several blocks at once, in torch float64 ON THE WEIGHTS' DEVICE: the training step
+    repacks after every optimizer step, and the numpy fold costs a dozen blocking device-to-host copies per block (the host
+    then cannot run ahead of the GPU).  Same tables (the float64 sums may differ from numpy's in the last bit before the
+    float32 cast).  -> [len(prefixes), NAB_TAB2_FLOATS] float32."""
+    dev = sd[prefixes[0] + ".out_lin.weight"].device
+    nb = len(prefixes)
+    st = lambda k: torch.stack([sd[p + k].detach().double() for p in prefixes])           # noqa: E731
+    wo, bo = st(".out_lin.weight")[:, 0], st(".out_lin.bias")[:, 0]                        # [nb,E], [nb]
+    wg, bg = st(".gate.0.weight")[:, 0], st(".gate.0.bias")[:, 0]                          # [nb,2E], [nb]
+    ts, segs, cells = [], [], []
+    m_idx = torch.arange(129, device=dev)
+    for f, nm in enumerate(("dist_emb", "angle_emb")):
+        wgh = wg[:, f * E:(f + 1) * E]
+        a, b = st(f".{nm}.0.weight")[:, :, 0], st(f".{nm}.0.bias")                         # [nb,E]
+        W2, b2 = st(f".{nm}.2.weight"), st(f".{nm}.2.bias")                                # [nb,E,E], [nb,E]
+        co, cg = torch.einsum("bji,bj->bi", W2, wo), torch.einsum("bji,bj->bi", W2, wgh)   # W2^T wo, W2^T wg
+        ko, kg = (wo * b2).sum(1), (wgh * b2).sum(1)
+        nz = a != 0
+        t = torch.where(nz, -b / torch.where(nz, a, torch.ones_like(a)), torch.full_like(a, float("inf"))).sort(dim=1).values
+        M = nz.sum(1)                                                                      # breakpoints per block
+        Mi = M.clamp(min=1)
+        g = lambda idx: t.gather(1, idx.clamp(0, E - 1))                                   # noqa: E731
+        mm = torch.minimum(m_idx[None].expand(nb, -1), M[:, None])                         # segments beyond M repeat segment M
+        lo_, hi_ = g(mm - 1), g(torch.minimum(mm, (Mi - 1)[:, None]))
+        first, last = g(torch.zeros_like(mm)), g((Mi - 1)[:, None].expand(-1, 129))
+        xm = torch.where(mm == 0, first - 1.0, torch.where(mm == M[:, None], last + 1.0, 0.5 * (lo_ + hi_)))
+        anchor = torch.where(mm == 0, first, lo_)
+        none = (M == 0)[:, None]
+        xm, anchor = torch.where(none, torch.zeros_like(xm), xm), torch.where(none, torch.zeros_like(anchor), anchor)
+        act = (a[:, None, :] * xm[:, :, None] + b[:, None, :]) > 0                         # [nb,129,E]
+        h = torch.clamp(a[:, None, :] * anchor[:, :, None] + b[:, None, :], min=0.0)
+        seg = torch.stack([(act * (co * a)[:, None, :]).sum(2), (h * co[:, None, :]).sum(2) + ko[:, None],
+                           (act * (cg * a)[:, None, :]).sum(2), (h * cg[:, None, :]).sum(2) + kg[:, None]], dim=2)      # [nb,129,4]
+        ts.append(t); segs.append(seg.reshape(nb, -1))
+        # grid-start bounds (nab_grid_cells) on the float32 breakpoints the kernel sees
+        t32 = t.float().double()
+        lo, hi = NAB_RANGES[f]
+        wdt = (hi - lo) / NAB_G
+        edges = lo + wdt * torch.arange(NAB_G, device=dev, dtype=torch.float64) - 1e-2 * wdt - 1e-6
+        cells.append(torch.searchsorted(t32.contiguous(), edges[None].expand(nb, -1).contiguous(), right=True).clamp(max=128).to(torch.uint8))
+    alpha = torch.stack([x.detach().double().reshape(()) for x in alphas])
+    tail = torch.zeros(nb, 8, dtype=torch.float64, device=dev)
+    tail[:, 0], tail[:, 1], tail[:, 2] = bg, bo, alpha
+    tab = torch.cat(ts + segs + [tail], dim=1).float()
+    cellw = torch.cat(cells, dim=1).contiguous().view(torch.float32)                       # 4 bounds per word
+    return torch.cat([tab, cellw], dim=1).contiguous()
 
 
 NAB_G = 1024            # csrc/rr_encoder.hip: NAB_G
@@ -371,39 +432,55 @@ def _pack_policy(sd: dict, env_name: str, device) -> dict:
     ar = _Arena(device)
     split = mlp_split_enabled()          # the bf16 split copies are only built when the opt-in switch is on at pack time
     nl = 1 + max(int(k.split(".")[3]) for k in sd if k.startswith("encoder.net.layers."))
-    blocks, nabdur, nabsimple = [], {}, {}
+    blocks, nabdur, nabsimple, pwl_todo = [], {}, {}, []
     nabname = "angle_distance_fusion" if env_name in ("atsp", "rcvrp") else "neural_adaptive_bias"
     q0 = "encoder.net.layers.0.row_encoding_block.neural_adaptive_bias"
     nab_kind = "naive" if (q0 + ".mlp.0.weight") in sd else "heuristic" if (q0 + ".alpha") in sd else "gating"
-    for l in range(nl):
-        pair = []
-        for rc in ("row", "col"):
-            b = f"encoder.net.layers.{l}.{rc}_encoding_block"
+    # The weight matrices of all 2 * nl blocks are packed together, one short launch sequence per shape instead of one per
+    # matrix: the training step repacks after every optimizer step and was bound by these thousands of small launches.
+    names = [f"encoder.net.layers.{l}.{rc}_encoding_block" for l in range(nl) for rc in ("row", "col")]
+    dv = lambda t: t.detach().to(device)                                                    # noqa: E731
+    stk = lambda k: torch.stack([dv(sd[f"{b}.{k}"]).float() for b in names])               # noqa: E731
+    sq = pack_a(torch.stack([stk("attn_free.to_q.weight"), stk("attn_free.to_k.weight"), stk("attn_free.to_v.weight")]))    # [3][nb]...
+    W1s, W2s = stk("feed_forward.ops.ffn.W1.weight"), stk("feed_forward.ops.ffn.W2.weight")
+    p1, p2 = pack_a(W1s), pack_a(W2s)
+    # AFTFull.project (attn_freenet.py:325) feeds multi_head_combine (:435) directly: one Linear, folded in float64
+    Wc64, Wp64 = stk("multi_head_combine.weight").double(), stk("attn_free.project.weight").double()
+    ppc = pack_a(torch.bmm(Wc64, Wp64).float())
+    bpc = (torch.bmm(Wc64, stk("attn_free.project.bias").double()[:, :, None])[:, :, 0] + stk("multi_head_combine.bias").double()).float().contiguous()
+    ar.keep += [sq, p1, p2, ppc, bpc]
+    if split:      # FFN weights again as 3-way bf16 splits for the bf16-pipe FFN
+        p1s, p2s = pack_a_bf16x3(W1s), pack_a_bf16x3(W2s)
+        ar.keep += [p1s, p2s]
+    for bi, b in enumerate(names):
+        l = bi // 2
+        if bi % 2 == 0:
+            pair = []
+        if True:
             w = L.EncBlockW()
             for f, k in (("n1", "norm1"), ("n2", "norm2"), ("n3", "norm3"),
                          ("f1", "feed_forward.ops.norm1"), ("f2", "feed_forward.ops.norm2")):
-                # "layer" has no parameters, RMSNorm a weight only (attn_freenet.py:13-26, 92-93): identity where absent
-                gam = sd[f"{b}.{k}.normalizer.weight"].detach().double() if f"{b}.{k}.normalizer.weight" in sd else torch.ones(E, dtype=torch.float64)
-                bet = sd[f"{b}.{k}.normalizer.bias"].detach().double() if f"{b}.{k}.normalizer.bias" in sd else torch.zeros(E, dtype=torch.float64)
-                if f"{b}.{k}.normalizer.running_mean" in sd:      # BatchNorm1d (eval): fold the running statistics
+                kg, kb = f"{b}.{k}.normalizer.weight", f"{b}.{k}.normalizer.bias"
+                if f"{b}.{k}.normalizer.running_mean" in sd:      # BatchNorm1d (eval): fold the running statistics (float64)
+                    gam, bet = sd[kg].detach().double(), sd[kb].detach().double()
                     rm, rv = sd[f"{b}.{k}.normalizer.running_mean"].double(), sd[f"{b}.{k}.normalizer.running_var"].double()
                     gam = gam / torch.sqrt(rv + 1e-5)
                     bet = bet - rm * gam
-                setattr(w, f + "g", ar.put(gam.float()))
-                setattr(w, f + "b", ar.put(bet.float()))
+                    setattr(w, f + "g", ar.put(gam.float())); setattr(w, f + "b", ar.put(bet.float()))
+                else:
+                    # "layer" has no parameters, RMSNorm a weight only (attn_freenet.py:13-26, 92-93): identity where absent;
+                    # an existing float32 parameter on the device is used in place (no copy)
+                    setattr(w, f + "g", ar.put(sd[kg] if kg in sd else torch.ones(E)))
+                    setattr(w, f + "b", ar.put(sd[kb] if kb in sd else torch.zeros(E)))
+            w.wq, w.wk, w.wv = sq[0, bi].data_ptr(), sq[1, bi].data_ptr(), sq[2, bi].data_ptr()
+            w.w1, w.w2 = p1[bi].data_ptr(), p2[bi].data_ptr()
             for f, k in (("q", "attn_free.to_q"), ("k", "attn_free.to_k"), ("v", "attn_free.to_v"),
                          ("1", "feed_forward.ops.ffn.W1"), ("2", "feed_forward.ops.ffn.W2")):
-                setattr(w, "w" + f, ar.put(pack_a(sd[f"{b}.{k}.weight"].detach().float())))
                 setattr(w, "b" + f, ar.put(sd[f"{b}.{k}.bias"]))
-            # AFTFull.project (attn_freenet.py:325) feeds multi_head_combine (:435) directly: one Linear, folded in float64
-            Wp, bp = sd[f"{b}.attn_free.project.weight"].detach().double(), sd[f"{b}.attn_free.project.bias"].detach().double()
-            Wc, bc = sd[f"{b}.multi_head_combine.weight"].detach().double(), sd[f"{b}.multi_head_combine.bias"].detach().double()
-            w.wp, w.bp = ar.put(pack_a((Wc @ Wp).float())), ar.put((Wc @ bp + bc).float())
+            w.wp, w.bp = ppc[bi].data_ptr(), bpc[bi].data_ptr()
             w.wc, w.bc = None, None
-            # FFN weights again as 3-way bf16 splits for the opt-in bf16-pipe FFN (RR_MLP_SPLIT=1)
             if split:
-                w.w1s = ar.put_raw(pack_a_bf16x3(sd[f"{b}.feed_forward.ops.ffn.W1.weight"]))
-                w.w2s = ar.put_raw(pack_a_bf16x3(sd[f"{b}.feed_forward.ops.ffn.W2.weight"]))
+                w.w1s, w.w2s = p1s[bi].data_ptr(), p2s[bi].data_ptr()
             if nab_kind != "gating":          # ablation modules: bias computed by rr_nab_simple, fed as bias_pre
                 w.nab = None
                 q, sw = f"{b}.neural_adaptive_bias", L.NabSimpleW()
@@ -419,12 +496,20 @@ def _pack_policy(sd: dict, env_name: str, device) -> dict:
                     sw.tw = float(sd[q + ".duration_weight"]) if (q + ".duration_weight") in sd else 0.0
                 nabsimple.setdefault(l, []).append(sw)
             elif nabname == "angle_distance_fusion":
-                w.nab = ar.put(fold_nab_pwl(sd, f"{b}.{nabname}", sd[f"{b}.alpha"]))
+                w.nab = None
+                pwl_todo.append((w, f"{b}.{nabname}", sd[f"{b}.alpha"]))
             else:
                 w.nab = None
                 nabdur.setdefault(l, []).append(fold_nab_dur(sd, f"{b}.{nabname}", sd[f"{b}.alpha"], ar))
             pair.append(w)
-        blocks.append(tuple(pair))
+        if bi % 2 == 1:
+            blocks.append(tuple(pair))
+    if pwl_todo:      # the gating NABs of all blocks in one batched fold on the weights' device (no host round trips)
+        tabs = fold_nab_pwl_batched({k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in sd.items()
+                                     if ".angle_distance_fusion." in k}, [p for _, p, _ in pwl_todo], [a.to(device) for _, _, a in pwl_todo])
+        ar.keep.append(tabs)
+        for i, (w, _, _) in enumerate(pwl_todo):
+            w.nab = tabs[i].data_ptr()
 
     out = {"arena": ar, "blocks": blocks, "num_layers": nl, "nabdur": [tuple(nabdur[l]) for l in sorted(nabdur)],
            "nab_kind": nab_kind, "nabsimple": [tuple(nabsimple[l]) for l in sorted(nabsimple)]}

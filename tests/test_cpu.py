@@ -576,3 +576,19 @@ def test_pack_cache_fingerprint_sees_in_place_updates_without_version_bumps():
     with packing._few_threads():
         assert torch.get_num_threads() == 1
     assert torch.get_num_threads() == n
+
+
+def test_batched_device_fold_of_the_nab_tables_equals_the_numpy_fold():
+    """packing.fold_nab_pwl_batched (torch float64, any device, all blocks at once) against packing.fold_nab_pwl (numpy)."""
+    from rrnco_amd import packing
+    fx = H.load_fixture("atsp_n20_b4_pomo")
+    w = H.atsp_weights(fx)
+    ps = [f"encoder.net.layers.{l}.{rc}_encoding_block" for l in range(fx["layers"]) for rc in ("row", "col")]
+    got = packing.fold_nab_pwl_batched(w, [p + ".angle_distance_fusion" for p in ps], [w[p + ".alpha"] for p in ps])
+    for i, p in enumerate(ps):
+        ref = packing.fold_nab_pwl(w, p + ".angle_distance_fusion", w[p + ".alpha"])
+        n = 256 + 2 * 129 * 4 + 8
+        assert got[i].shape == ref.shape
+        assert torch.equal(got[i, :256], ref[:256])                                   # breakpoints
+        assert torch.allclose(got[i, 256:n], ref[256:n], rtol=2e-6, atol=1e-6)       # segment slopes / values
+        assert torch.equal(got[i, n:].view(torch.uint8), ref[n:].view(torch.uint8))   # grid-start bounds

@@ -16,10 +16,15 @@ B = int(os.environ.get("PB", "512"))
 for i in range(2):
     model.training_step(ATSPGenerator(num_loc=100, device=dev)(B, generator=gen), optimizer=opt, seed=i)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CUDA]) as prof:
+with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
     model.training_step(ATSPGenerator(num_loc=100, device=dev)(B, generator=gen), optimizer=opt, seed=9)
     torch.cuda.synchronize()
-ev = sorted(prof.key_averages(), key=lambda e: -e.self_device_time_total)
+cpu = sorted([e for e in prof.key_averages() if e.key.startswith("aten::") or e.key.startswith("hip")], key=lambda e: -e.count)
+if os.environ.get("PROFILE_HOST"):
+    print("host-side ops by call count:")
+    for e in cpu[:25]:
+        print(f"  x{e.count:<6d} {e.self_cpu_time_total / 1e3:8.2f} ms self-cpu  {e.key[:80]}")
+ev = sorted([e for e in prof.key_averages() if e.self_device_time_total > 0], key=lambda e: -e.self_device_time_total)
 tot = sum(e.self_device_time_total for e in ev)
 print(f"GPU time of one training step: {tot / 1e3:.2f} ms over {sum(e.count for e in ev)} launches")
 acc = 0.0
