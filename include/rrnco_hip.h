@@ -250,6 +250,28 @@ int rr_aft_bwd(const AftBwdIO* io, int Bp, hipStream_t stream);
 int rr_nab_hist_bwd(const float* pwl, const float* xd, const float* xa, const float* gout, float* hist, long M,
                     hipStream_t stream);
 
+/* ---- instances with 104 .. 208 nodes (csrc/rr_bign.hip): the same operators as row-parallel kernels over HBM-resident
+ * tensors, the decode loop step by step.  rr_enc_layer / rr_rollout keep one instance's activations on chip (N <= 103). */
+/* Normalization "instance" (attn_freenet.py:84, 104-105) of x (+ res) over the node axis. */
+int rr_inorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* out, int Bp, int N, hipStream_t stream);
+/* alpha * DistAngleFusion (attn_freenet.py:242-289) per edge from the folded piecewise-linear table (EncBlockW.nab);
+ * transpose_d: the col block's D^T (:480-486). out [Bp][N][N]. */
+int rr_nab_pwl_fwd(const float* pwl, const float* D, const float* theta, float* out, int Bp, int N, int transpose_d, hipStream_t stream);
+/* ekT = exp(softmax_nodes(K))^T, kvT = (ek * V)^T as [Bp][128][NP] (NP = 16 ceil(N/16), zero padded): attn_freenet.py:319-321. */
+int rr_colsoftmax_exp(const float* K, const float* V, float* ekT, float* kvT, int Bp, int N, int NP, hipStream_t stream);
+/* y = sigmoid(q) * (exp(softmax(bias)) @ kv) / (exp(softmax(bias)) @ ek): AFTFull mixing (attn_freenet.py:318-324). */
+int rr_aft_mix_big(const float* bias, const float* q, const float* ekT, const float* kvT, float* y, int Bp, int N, int NP, hipStream_t stream);
+typedef struct {
+  const float *K, *Vt, *L, *ctxA, *ctxB, *D, *Dur; const int64_t *cur, *first; const float *scal, *wstate; const uint8_t *mask;
+  const void *w1, *w2; const float *b1, *b2; float *logits; int Bp, N, NP, S, nscal; float alpha, beta;
+} DecBigIO;
+/* RRNetDecoder.forward (decoder.py:151-206, 281-323) for all S*Bp rollouts: logits [R][N] after the inductive-bias transform. */
+int rr_dec_fwd_big(const DecBigIO* io, hipStream_t stream);
+/* process_logits + greedy / sampling / evaluate (decoding.py:311-361) for rows of up to 256 keys. */
+int rr_select_big(const float* logits, const uint8_t* mask, const int64_t* action_in, int64_t* action_out, float* logp_out,
+                  float* logp_all, int R, int N, float tanh_clip, float temperature, int mode, unsigned long long seed,
+                  unsigned int step, hipStream_t stream);
+
 /* POMO shared-baseline REINFORCE loss, forward half + d loss / d log-likelihood
  * (rrnco/models/rl.py:112-128; in-tree formula rrnco/baselines/routefinder/model.py:182-202). reward / ll / adv /
  * grad_ll are [S*B] with r = s*B + b; bl and partial are [B] workspaces; loss is one float. */

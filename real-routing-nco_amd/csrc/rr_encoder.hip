@@ -144,7 +144,7 @@ __global__ void k_edge_angles(const float* __restrict__ locs, float* __restrict_
   theta[(size_t)b * N * N + e] = atan2f(lc[2 * i + 1] - lc[2 * j + 1], lc[2 * i] - lc[2 * j]);
 }
 extern "C" int rr_edge_angles(const float* locs, float* theta, int Bp, int N, hipStream_t st) {
-  if (Bp <= 0 || N < 2 || N > RR_MAXN || locs == nullptr || theta == nullptr) return RR_EINVAL;
+  if (Bp <= 0 || N < 2 || locs == nullptr || theta == nullptr) return RR_EINVAL;
   hipLaunchKernelGGL(k_edge_angles, dim3((N * N + 255) / 256, Bp), dim3(256), 0, st, locs, theta, N);
   return rr_check(hipGetLastError());
 }

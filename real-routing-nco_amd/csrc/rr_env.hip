@@ -579,12 +579,16 @@ template <int CTRL> __device__ __forceinline__ void rr_row16_best(float& bv, int
   bv = take ? ov : bv; bi = take ? oi : bi; blp = take ? ol : blp;
 }
 
-template <bool VEC>
+// MODE is a compile-time copy of `mode` (0 greedy, 1 sampling, 2 evaluate; -1: decided at run time, the MatNet variant): the
+// greedy instantiation carries no Gumbel / evaluate code, and without a full log-probability row to write it needs no third
+// pass over the keys at all — the winner is the first key equal to the row maximum and its log-probability is -lse.
+template <bool VEC, int MODE = -1>
 __global__ __launch_bounds__(256) void k_select16(const float* __restrict__ logits, const uint8_t* __restrict__ mask,
                                                   const int64_t* __restrict__ action_in, int64_t* __restrict__ action_out,
                                                   float* __restrict__ logp_out, float* __restrict__ logp_all,
-                                                  int R, int N, float tanh_clip, float temperature, int mode,
+                                                  int R, int N, float tanh_clip, float temperature, int mode_rt,
                                                   uint64_t seed, uint32_t step, int shift_clamp) {
+  const int mode = MODE >= 0 ? MODE : mode_rt;
   const int lane = threadIdx.x & 63, p = lane & 15, rw = lane >> 4;
   const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (4 * SEL16_PASSES) + rw;
   float raw[SEL16_PASSES][8];
@@ -651,6 +655,17 @@ __global__ __launch_bounds__(256) void k_select16(const float* __restrict__ logi
       ssum += j < N ? rr_exp_fast(x[e] - m) : 0.f;       // arguments in [-2 clip / T, 0]; same form as the fused rollout
     }
     const float lse = rr_log(rr_row16_sum(ssum));
+    if (MODE == 0 && logp_all == nullptr) {          // greedy: argmax by equality with the row maximum, first index on ties
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int e = 7; e >= 0; --e) {
+        const int j = 4 * (p + 16 * (e >> 2)) + (e & 3);
+        bi = (j < N && x[e] == m) ? j : bi;             // descending e: the lowest key of the lane survives
+      }
+      bi = min(bi, rr_dppi<0xB1>(bi)); bi = min(bi, rr_dppi<0x4E>(bi)); bi = min(bi, rr_dppi<0x141>(bi)); bi = min(bi, rr_dppi<0x140>(bi));
+      if (p == 0 && r < R) { action_out[r] = bi; logp_out[r] = -lse; }      // x[best] - m - lse with x[best] == m
+      continue;
+    }
     const int want = (mode == 2 && r < R) ? (int)action_in[r] : -1;
     float bv = -INFINITY, blp = 0.f;
     int bi = 0x7fffffff;
@@ -696,10 +711,11 @@ extern "C" int rr_select(const float* logits, const uint8_t* mask, const int64_t
     const uintptr_t al = reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(logp_all);
     const bool vec = N % 4 == 0 && (al & 15) == 0 && (reinterpret_cast<uintptr_t>(mask) & 3) == 0;
     const dim3 grid((R + 16 * SEL16_PASSES - 1) / (16 * SEL16_PASSES));
-    if (vec) hipLaunchKernelGGL(k_select16<true>, grid, dim3(256), 0, st, logits, mask, action_in, action_out, logp_out, logp_all, R, N,
-                                tanh_clip, temperature, mode, seed, step, 0);
-    else hipLaunchKernelGGL(k_select16<false>, grid, dim3(256), 0, st, logits, mask, action_in, action_out, logp_out, logp_all, R, N,
-                            tanh_clip, temperature, mode, seed, step, 0);
+#define RR_SEL16(V, M) hipLaunchKernelGGL((k_select16<V, M>), grid, dim3(256), 0, st, logits, mask, action_in, action_out, logp_out, logp_all, R, N, \
+                                         tanh_clip, temperature, mode, seed, step, 0)
+    if (vec) { if (mode == 0) RR_SEL16(true, 0); else if (mode == 1) RR_SEL16(true, 1); else RR_SEL16(true, 2); }
+    else { if (mode == 0) RR_SEL16(false, 0); else if (mode == 1) RR_SEL16(false, 1); else RR_SEL16(false, 2); }
+#undef RR_SEL16
     return rr_check(hipGetLastError());
   }
   hipLaunchKernelGGL(k_select, dim3((R + 4 * SEL_ROWS - 1) / (4 * SEL_ROWS)), dim3(256), 0, st, logits, mask, action_in, action_out, logp_out,

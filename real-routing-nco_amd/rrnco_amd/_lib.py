@@ -90,6 +90,11 @@ class AftBwdIO(C.Structure):            # csrc/rr_train_enc.hip
     _fields_ = [(n, vp) for n in ("dy", "q", "ek", "v", "num", "den", "eaT", "dq", "dk", "dv", "dbias")] + [("N", i32)]
 
 
+class DecBigIO(C.Structure):            # csrc/rr_bign.hip
+    _fields_ = [(n, vp) for n in ("K", "Vt", "L", "ctxA", "ctxB", "D", "Dur", "cur", "first", "scal", "wstate", "mask", "w1", "w2",
+                                  "b1", "b2", "logits")] + [(n, i32) for n in ("Bp", "N", "NP", "S", "nscal")] + [("alpha", f32), ("beta", f32)]
+
+
 class MtvrpExtra(C.Structure):
     _fields_ = [(n, vp) for n in ("demand_b", "used_b", "open_route", "dist_limit", "bclass")]
 
@@ -124,6 +129,12 @@ _SIGS = {
     "rr_inorm_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "rr_linear_rows": [vp, vp, vp, vp, C.c_longlong, i32, vp, vp],
     "rr_aft_bwd": [C.POINTER(AftBwdIO), i32, vp],
+    "rr_inorm_fwd": [vp, vp, vp, vp, vp, i32, i32, vp],
+    "rr_nab_pwl_fwd": [vp, vp, vp, vp, i32, i32, i32, vp],
+    "rr_colsoftmax_exp": [vp, vp, vp, vp, i32, i32, i32, vp],
+    "rr_aft_mix_big": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "rr_dec_fwd_big": [C.POINTER(DecBigIO), vp],
+    "rr_select_big": [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, u64, u32, vp],
     "rr_dec_logit_bwd": [C.POINTER(DecLogitIO), vp],
     "rr_gemm_tn": [vp, vp, vp, i32, i32, i32, i32, i32, i32, C.c_longlong, C.c_longlong, C.c_longlong, i32, i32, vp],
     "rr_mlp_rows": [C.POINTER(MlpRowsW), i32, vp, vp, vp, vp, i32, i32, C.c_longlong, vp],

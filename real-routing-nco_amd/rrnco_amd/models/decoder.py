@@ -81,6 +81,9 @@ class RRNetDecoder(nn.Module):
         row, col = (e.contiguous() for e in embeddings)
         L.require_gpu(row)
         Bp, N, E = row.shape
+        if N > 103:
+            from . import bign
+            return bign.precompute_cache(self, row, col, packed)
         K, Lk, cb = torch.empty_like(row), torch.empty_like(row), torch.empty_like(row)
         ca = torch.empty_like(row) if self.env_name == "atsp" else None
         Vt = torch.empty(Bp, E, 112, device=row.device, dtype=torch.float32)
@@ -93,6 +96,9 @@ class RRNetDecoder(nn.Module):
         One launch of the rollout kernel in `logits_only` mode; the state is not modified."""
         from .rollout import launch_rollout
         R, N = td["action_mask"].shape
+        if N > 103:
+            from . import bign
+            return bign.decoder_forward(self, td, cached, packed)
         logits = torch.empty(R, N, device=td.device, dtype=torch.float32)
         launch_rollout(self.env_name, packed, cached, td, num_starts, logits_out=logits, logits_only=True)
         return logits, td["action_mask"]

@@ -193,6 +193,12 @@ class RRNetEncoder(nn.Module):
                                       "statistics across instances (train mode) are not implemented")
         D = td["distance_matrix"].contiguous()
         L.require_gpu(D)
+        if D.shape[-1] > 103:                 # more nodes than the on-chip kernels hold: row-parallel kernels (csrc/rr_bign.hip)
+            from . import bign
+            if D.shape[-1] > bign.MAX_N_BIG or not bign.supported(self.env_name, packed, self.normalization) or train_saves is not None:
+                raise NotImplementedError(f"{D.shape[-1]} nodes: the encoder kernels cover N <= 103 for every configuration and "
+                                          f"N <= {bign.MAX_N_BIG} for ATSP / RCVRP with instance norm and the gating NAB (inference)")
+            return bign.encode(self, td, packed)
         locs = td["locs"].float().contiguous()
         Bp, N = D.shape[0], D.shape[-1]
         dev = D.device

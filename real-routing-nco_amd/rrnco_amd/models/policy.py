@@ -103,6 +103,8 @@ class RRNetPolicy(nn.Module):
         td, env, cache = self.decoder.pre_decoder_hook(td, env, (row_emb, col_emb), num_starts, packed=packed)
 
         # the fused rollout keeps one log-probability per step; full rows (store_all_logp / return_entropy) come from the step-wise loop
+        if td["action_mask"].shape[-1] > 103:
+            fused = False          # N > 103: the reference's own step-by-step loop on the row-parallel kernels (models/bign.py)
         if (fused and not strategy.store_all_logp and self.env_name in PROB_ID and strategy.mask_logits and strategy.top_k == 0 and not (0.0 < strategy.top_p < 1.0)
                 and not getattr(strategy, "is_beam_search", False)):
             dump = None

@@ -511,7 +511,7 @@ def _pack_policy(sd: dict, env_name: str, device) -> dict:
         for i, (w, _, _) in enumerate(pwl_todo):
             w.nab = tabs[i].data_ptr()
 
-    out = {"arena": ar, "blocks": blocks, "num_layers": nl, "nabdur": [tuple(nabdur[l]) for l in sorted(nabdur)],
+    out = {"arena": ar, "sd_ref": sd, "blocks": blocks, "num_layers": nl, "nabdur": [tuple(nabdur[l]) for l in sorted(nabdur)],
            "nab_kind": nab_kind, "nabsimple": [tuple(nabsimple[l]) for l in sorted(nabsimple)]}
     p = "encoder.init_embedding"
     if env_name == "atsp":

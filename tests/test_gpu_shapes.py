@@ -61,15 +61,74 @@ def test_atsp_max_nodes_103_and_more_starts_than_a_workgroup_tile_set():
     _run(103, 2, 103, 25, seed=7)
 
 
-def test_more_than_103_nodes_is_rejected_loudly():
+@pytest.mark.parametrize("N,S", [(128, 16), (200, 24)])
+def test_atsp_more_than_103_nodes_matches_the_live_oracle(N, S):
+    """N > 103: the row-parallel kernels of csrc/rr_bign.hip under the same policy API (step-by-step decode loop), against the
+    oracle run live: embeddings, greedy POMO tours (every divergence at an oracle decision gap < GAP_TOL), costs, log-likelihoods."""
+    from rrnco_amd import TensorDict
+    from rrnco_amd.envs import ATSPEnv
+    ss, B = 25, 2
+    w = restate.make_weights(restate.atsp_weight_template(128, 2, 512, ss), 3)
+    pol = H.make_policy(w)
+    inst = restate.atsp_synthetic(B, N, 11)
+    st0 = restate.atsp_reset(inst)
+    sidx = restate.sample_neighbor_indices(st0["distance_matrix"], ss, generator=torch.Generator().manual_seed(5))
+    trace = {}
+    with torch.inference_mode():
+        ref = restate.atsp_policy(w, st0, sidx, S, "greedy", trace=trace)
+    env = ATSPEnv(generator_params=dict(num_loc=N))
+    td = TensorDict({k: v.cuda() for k, v in inst.items()}, batch_size=[B])
+    td["sample_idx"] = sidx.cuda()
+    td = env.reset(td)
+    row, col = pol.encoder(td, packed=pol.packed(torch.device("cuda")))
+    assert torch.allclose(row.cpu(), trace["row_emb"], atol=2e-4) and torch.allclose(col.cpu(), trace["col_emb"], atol=2e-4)
+    out = pol(td, env, phase="val", decode_type="multistart_greedy", num_starts=S)
+    acts = out["actions"].cpu()
+    assert restate.atsp_check(acts)
+    frac, first = H.tour_agreement(acts, ref["actions"])
+    if frac < 1.0:
+        lp = torch.stack(trace["logp"], 1)
+        top2 = torch.nan_to_num(lp, neginf=-1e9).topk(2, -1).values
+        gap = top2[..., 0] - top2[..., 1]
+        for r in torch.nonzero(first >= 0).flatten().tolist():
+            assert gap[r, int(first[r]) - 1] < 1e-3
+    assert frac >= 0.9
+    same = first < 0
+    assert torch.allclose(out["reward"].cpu()[same], ref["reward"][same], atol=1e-4)
+    assert torch.allclose(out["log_likelihood"].cpu()[same], ref["log_likelihood"][same], rtol=2e-5, atol=2e-3)
+    # sampling and evaluate on the same path
+    smp = pol(env.reset(TensorDict({k: v.cuda() for k, v in inst.items()}, batch_size=[B])), env, phase="val",
+              decode_type="multistart_sampling", num_starts=S, seed=9)
+    assert restate.atsp_check(smp["actions"].cpu())
+    with torch.inference_mode():
+        ev = restate.atsp_policy(w, st0, sidx, S, "evaluate", actions=acts[:, 1:])
+    td2 = TensorDict({k: v.cuda() for k, v in inst.items()}, batch_size=[B]); td2["sample_idx"] = sidx.cuda()
+    mine = pol(env.reset(td2), env, phase="val", actions=acts[:, 1:].cuda(), num_starts=S)
+    assert torch.allclose(mine["log_likelihood"].cpu(), ev["log_likelihood"], rtol=2e-5, atol=2e-3)
+
+
+def test_rcvrp_more_than_103_nodes_roundtrip_properties():
+    """RCVRP with 150 customers on the row-parallel path: every customer once, capacity never exceeded, cost = route length."""
+    from rrnco_amd.envs import RCVRPEnv
+    w = restate.make_weights(restate.rcvrp_weight_template(128, 2, 512, 20), 5)
+    pol = H.make_policy(w, env_name="rcvrp")
+    env = RCVRPEnv(generator_params=dict(num_loc=150), check_solution=True)
+    td_in = env.generator(3, generator=torch.Generator(device="cuda").manual_seed(2))
+    out = pol(env.reset(td_in), env, phase="val", decode_type="multistart_greedy", num_starts=12)
+    a = out["actions"]
+    served = torch.zeros(a.shape[0], 151, dtype=torch.bool, device="cuda").scatter_(1, a, True)
+    assert bool(served[:, 1:].all()) and bool(torch.isfinite(out["reward"]).all())
+
+
+def test_more_than_208_nodes_is_rejected_loudly():
     from rrnco_amd import TensorDict
     from rrnco_amd.envs import ATSPEnv
     w = restate.make_weights(restate.atsp_weight_template(128, 1, 512, 25), 1)
     pol = H.make_policy(w)
-    inst = restate.atsp_synthetic(1, 104, 1)
-    env = ATSPEnv(generator_params=dict(num_loc=104))
+    inst = restate.atsp_synthetic(1, 209, 1)
+    env = ATSPEnv(generator_params=dict(num_loc=209))
     td = TensorDict({k: v.cuda() for k, v in inst.items()}, batch_size=[1])
-    with pytest.raises(RuntimeError, match="status -1"):
+    with pytest.raises(NotImplementedError, match="nodes"):
         pol(env.reset(td), env, phase="val", decode_type="greedy")
 
 
