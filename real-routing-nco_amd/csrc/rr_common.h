@@ -106,6 +106,33 @@ __device__ __forceinline__ rr_bf16x8 rr_bldh(__amdgpu_buffer_rsrc_t r, unsigned 
   rr_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, soff_bytes, 0);
   return __builtin_bit_cast(rr_bf16x8, v);
 }
+// ---- fp16 matrix pipe with two-piece split fp32 operands: x = hi + 2^-11 lo', hi = fp16(x), lo' = fp16(2^11 (x - hi)).
+// x - hi is exact in fp32 and lo' keeps 11 of its <= 13 bits, so |x - hi - 2^-11 lo'| <= 2^-23 |x| (down to 2^-36 absolute: the
+// f16 MFMA keeps subnormal inputs, tools/clockprobe/f16probe.hip); a product keeps hi*hi + 2^-11 (hi*lo' + lo'*hi), each term
+// exact in the fp32 accumulator, the dropped lo'*lo' term is <= 2^-22 |x w|.  Measured error of a K = 128 .. 512 dot product:
+// 4e-8 of sum |a b|, against 1.1e-7 .. 1.6e-7 for v_mfma_f32_16x16x4_f32 (same probe) — three MFMAs at 16x the fp32 rate.
+typedef _Float16 rr_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 rr_f16x2 __attribute__((ext_vector_type(2)));
+#define RR_LO_SCALE 2048.0f
+#define RR_LO_INV (1.0f / 2048.0f)
+__device__ __forceinline__ f32x4 rr_mfma_f16(rr_f16x8 a, rr_f16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ void rr_split8h(const float (&x)[8], rr_f16x8& hi, rr_f16x8& lo) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const rr_f32x2 v = {x[2 * q], x[2 * q + 1]};
+    const rr_f16x2 h = __builtin_convertvector(v, rr_f16x2);
+    const rr_f32x2 r = (v - __builtin_convertvector(h, rr_f32x2)) * RR_LO_SCALE;
+    const rr_f16x2 l = __builtin_convertvector(r, rr_f16x2);
+    hi[2 * q] = h[0]; hi[2 * q + 1] = h[1]; lo[2 * q] = l[0]; lo[2 * q + 1] = l[1];
+  }
+}
+// LDS-DMA: 16 bytes per lane from global memory straight into LDS at ldst + 16 * lane (ldst wave-uniform); completes on vmcnt
+__device__ __forceinline__ void rr_glds16(const void* gsrc, void* ldst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
+}
 // x[0..7] -> hi + mid + lo, each bf16 with round-to-nearest (v_cvt_pk_bf16_f32): x - hi and (x - hi) - mid are exact in fp32
 __device__ __forceinline__ void rr_split8(const float (&x)[8], rr_bf16x8& hi, rr_bf16x8& mid, rr_bf16x8& lo) {
 #pragma unroll

@@ -431,13 +431,14 @@ extern "C" int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStrea
   const size_t per_wg = (size_t)(160 * 1024) / (512 / WTHREADS) - 512;
   const int lds_inst = 2 * tile <= per_wg ? 2 : (tile <= per_wg ? 1 : 0);
   const size_t shmem = (size_t)lds_inst * tile;
-  // split-MLP variant: three 24 KB weight stage buffers behind the distance tiles
-  const int lds_inst_s = 2 * tile + 3 * 24576 + 16 <= per_wg ? 2 : (tile + 3 * 24576 + 16 <= per_wg ? 1 : 0);
+  // split-MLP variant: three 16 KB weight stage buffers behind the distance tiles
+  const size_t wstg = 3 * 16384;
+  const int lds_inst_s = 2 * tile + wstg + 16 <= per_wg ? 2 : (tile + wstg + 16 <= per_wg ? 1 : 0);
   const dim3 grid_s = grid, blk_s = blk;
   const int mode = io->logits_only ? 3 : io->mode;
 #define RR_LAUNCHW4(NTV, P, M, SP)                                                                            \
   do {                                                                                                       \
-    const size_t shm = (SP) ? (((size_t)lds_inst_s * tile + 15) / 16) * 16 + 3 * 24576 : shmem;              \
+    const size_t shm = (SP) ? (((size_t)lds_inst_s * tile + 15) / 16) * 16 + wstg : shmem;                    \
     (void)hipFuncSetAttribute((const void*)k_rollout_w<NTV, P, M, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
     hipLaunchKernelGGL((k_rollout_w<NTV, P, M, SP>), (SP) ? grid_s : grid, (SP) ? blk_s : blk, shm, st, *w, *io, tail_g, \
                        (SP) ? lds_inst_s : lds_inst);                                                        \

@@ -70,6 +70,20 @@ def pack_a_bf16x3(Wm: torch.Tensor) -> torch.Tensor:
 
 
 
+def pack_a_f16x2(Wm: torch.Tensor) -> torch.Tensor:
+    """[M,K] fp32 -> [M/16, K/32, 2, 64, 8] fp16: A operands of v_mfma_f32_16x16x32_f16 for the two pieces of
+    W = hi + 2^-11 lo' (hi = fp16(W), lo' = fp16(2^11 (W - hi)); csrc/rr_common.h), in the lane / k order of pack_a_bf16x3."""
+    *lead, M, K = Wm.shape
+    assert M % 16 == 0 and K % 32 == 0
+    n = len(lead)
+    W = Wm.detach().float()
+    hi = W.to(torch.float16)
+    lo = ((W - hi.float()) * 2048.0).to(torch.float16)
+    x = torch.stack((hi, lo), dim=n).reshape(*lead, 2, M // 16, 16, K // 32, 2, 4, 4)           # piece, t, i, s, half, g, e4
+    x = x.permute(*range(n), n + 1, n + 3, n, n + 5, n + 2, n + 4, n + 6)                       # t, s, piece, g, i, half, e4
+    return x.reshape(*lead, M // 16, K // 32, 2, 64, 8).contiguous()                            # [t][s][piece][lane][8]
+
+
 def pack_bf16x2(Wm: torch.Tensor, k_major: bool = False) -> torch.Tensor:
     """[M,K] fp32 -> two-piece bf16 split (hi = bf16(W), lo = bf16(W - hi)) as A operands of v_mfma_f32_16x16x32_bf16 in the
     permuted k order of pack_a_bf16x3 (a lane's eight values = its four of two consecutive C-layout tiles): [M/16][K/32][2][64][8],
@@ -566,8 +580,8 @@ def _pack_policy(sd: dict, env_name: str, device) -> dict:
     dw.w2 = ar.put(pack_a(sd["decoder.pointer.ffn.lins.1.weight"].detach().float()))
     # the same matrices as 3-way bf16 splits for the opt-in bf16-pipe MLP (RR_MLP_SPLIT=1); kept as raw 16-bit words
     # (always for the decoder: training rollouts use them, RolloutIO.use_split; two small device-side packs)
-    dw.w1s = ar.put_raw(pack_a_bf16x3(sd["decoder.pointer.ffn.lins.0.weight"].to(device)))
-    dw.w2s = ar.put_raw(pack_a_bf16x3(sd["decoder.pointer.ffn.lins.1.weight"].to(device)))
+    dw.w1s = ar.put_raw(pack_a_f16x2(sd["decoder.pointer.ffn.lins.0.weight"].to(device)))
+    dw.w2s = ar.put_raw(pack_a_f16x2(sd["decoder.pointer.ffn.lins.1.weight"].to(device)))
     dw.b1, dw.b2 = ar.put(sd["decoder.pointer.ffn.lins.0.bias"]), ar.put(sd["decoder.pointer.ffn.lins.1.bias"])
     dw.alpha = float(sd["decoder.alpha"].reshape(-1)[0])
     dw.beta = float(sd["decoder.beta"].reshape(-1)[0]) if "decoder.beta" in sd else 0.0

@@ -3,7 +3,7 @@ import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "real-routing-nco_amd"))
 from rrnco_amd import _lib
-_lib.LIB_PATH = _lib.LIB_PATH.replace("librrnco_hip.so", "librrnco_hip_stamp.so")
+_lib.LIB_PATH = os.environ.get("RR_STAMP_LIB") or _lib.LIB_PATH.replace("librrnco_hip.so", "librrnco_hip_stamp.so")
 import torch
 import bench
 from rrnco_amd.envs import ATSPEnv, ATSPGenerator
@@ -15,14 +15,14 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 inst_td = ATSPGenerator(num_loc=100, device=dev)(B, generator=torch.Generator(device=dev).manual_seed(1))
 inst = {"locs": inst_td["locs"], "distance_matrix": inst_td["distance_matrix"]}
 sidx = ATSPInitEmbedding.sample_indices(env.reset(inst_td)["distance_matrix"], 25).repeat(8, 1, 1).contiguous()
-bench.hot_path_step(pol, env, inst, sidx); torch.cuda.synchronize()
+bench.hot_path_step(pol, env, inst); torch.cuda.synchronize()
 lib = _lib.lib(); lib.rr_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 out = (ctypes.c_ulonglong * 8)()
 lib.rr_debug_stamps(out, 1)
 lib.rr_debug_enc_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 eout = (ctypes.c_ulonglong * 8)()
 lib.rr_debug_enc_stamps(eout, 1)
-bench.hot_path_step(pol, env, inst, sidx); torch.cuda.synchronize()
+bench.hot_path_step(pol, env, inst); torch.cuda.synchronize()
 lib.rr_debug_stamps(out, 0)
 names = ["loop-top", "ctx gather", "attention", "MLP", "logits MFMA", "select+step"]
 waves = out[7]; tot = sum(out[i] for i in range(6))
