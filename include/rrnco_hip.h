@@ -50,7 +50,7 @@ typedef struct { const void *wk, *wv, *wl, *wca, *wcb; } CacheW;   /* rrnco/mode
 
 typedef struct {                /* pointer MLP + inductive-bias scalars: rrnco/models/decoder.py:186-198, 272-277 */
   const void *w1, *w2; const float *b1, *b2, *q0, *wstate; float alpha, beta;
-  const void *w1s, *w2s;        /* optional 3-way bf16 splits of w1 / w2 (packing.pack_a_bf16x3) for the opt-in RR_MLP_SPLIT=1 rollout */
+  const void *w1s, *w2s;        /* optional two-piece fp16 splits of w1 / w2 (packing.pack_a_f16x2) for the split rollout (RolloutIO.use_split) */
 } DecW;
 
 typedef struct {                /* arguments of the persistent rollout: see csrc/rr_decode.hip */
@@ -71,8 +71,15 @@ typedef struct {                /* arguments of the persistent rollout: see csrc
    * output g [m][128], meta [m][8] = 4 action-mask words seen, node decided at, node chosen, live flag, 0; VRP state
    * scalars scal [m][4] (context.py:51-70).  Consumed by rr_dec_* below (the REINFORCE backward of decoder.py:151-329). */
   float *dump_g0, *dump_g; uint32_t *dump_meta; float *dump_scal; int dumpT;
-  int use_split;                /* 1: pointer MLP on the bf16 pipe with 3-way split fp32 operands for this launch (needs DecW.w1s / w2s) */
+  int use_split;                /* 1: greedy / sampling launch on the fp16 matrix pipe with two-piece split fp32 operands (x = hi + 2^-11 lo',
+                                 * three f16 MFMAs per product, error of a dot product 4e-8 of sum |a b|: csrc/rr_common.h); needs DecW.w1s /
+                                 * w2s and the three images below, otherwise the fp32 MFMA kernel runs */
+  const void *Ks, *Vts, *Ls;    /* rr_pack_f16x2 images of K / Vt / L (same shapes) */
 } RolloutIO;
+
+/* fp32 -> two-piece fp16 image: every group of four values becomes its four hi and four lo' halves at the same byte offset
+ * (n_floats % 4 == 0).  Used for the K / Vt / L operands of the split rollout (rrnco/models/decoder.py:214-232 products). */
+int rr_pack_f16x2(const float* src, void* dst, long long n_floats, hipStream_t stream);
 
 /* ATSPEnv._reset / RCVRPEnv._reset / RMTVRPEnv._reset min-max normalisation
  * (rrnco/envs/atsp/env.py:113-120, rcvrp/env.py:137-146, rmtvrp/env.py:289-300): out = (in-min)/(max-min+1e-6)

@@ -128,6 +128,21 @@ __device__ __forceinline__ void rr_split8h(const float (&x)[8], rr_f16x8& hi, rr
     hi[2 * q] = h[0]; hi[2 * q + 1] = h[1]; lo[2 * q] = l[0]; lo[2 * q + 1] = l[1];
   }
 }
+typedef _Float16 rr_f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void rr_split4h(const float (&x)[4], rr_f16x4& hi, rr_f16x4& lo) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const rr_f32x2 v = {x[2 * q], x[2 * q + 1]};
+    const rr_f16x2 h = __builtin_convertvector(v, rr_f16x2);
+    const rr_f32x2 r = (v - __builtin_convertvector(h, rr_f32x2)) * RR_LO_SCALE;
+    const rr_f16x2 l = __builtin_convertvector(r, rr_f16x2);
+    hi[2 * q] = h[0]; hi[2 * q + 1] = h[1]; lo[2 * q] = l[0]; lo[2 * q + 1] = l[1];
+  }
+}
+// k = 32 operand from two 16-deep halves.  With A = [hi | lo'] of one operand (16 bytes per lane: the footprint of its four fp32
+// values) the other operand enters as [hi | 0] for the large term and as [lo' | hi] for the two small ones.
+__device__ __forceinline__ rr_f16x8 rr_cat4(rr_f16x4 a, rr_f16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+__device__ __forceinline__ rr_f16x8 rr_as_f16x8(float4 v) { return __builtin_bit_cast(rr_f16x8, v); }
 // LDS-DMA: 16 bytes per lane from global memory straight into LDS at ldst + 16 * lane (ldst wave-uniform); completes on vmcnt
 __device__ __forceinline__ void rr_glds16(const void* gsrc, void* ldst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,

@@ -25,7 +25,7 @@ struct DecW {
   const float* q0;             // project_context(W_placeholder) [E] (ATSP first step without multistart)
   const float* wstate;         // VRP: step-context state columns of project_context [nstate][E]
   float alpha, beta;
-  const void *w1s, *w2s;       // optional: the same two matrices as 3-way bf16 splits (packing.pack_a_bf16x3), RR_MLP_SPLIT=1
+  const void *w1s, *w2s;       // optional: the same two matrices as two-piece fp16 splits (packing.pack_a_f16x2) for the split rollout
 };
 
 struct RolloutIO {
@@ -70,7 +70,8 @@ struct RolloutIO {
   // rollout), 0; VRP: the step-context state scalars scal [m][4] (available load, current time, open route, remaining distance).
   float* dump_g0; float* dump_g; uint32_t* dump_meta; float* dump_scal;
   int dumpT;
-  int use_split;                         // 1: pointer MLP on the bf16 matrix pipe with 3-way split operands for this launch (as RR_MLP_SPLIT=1), if DecW has the packs
+  int use_split;                         // 1: this launch runs on the fp16 matrix pipe with two-piece split operands (rr_common.h), if DecW has w1s / w2s and Ks / Vts / Ls are given
+  const void *Ks, *Vts, *Ls;             // fp16 two-piece images of K / Vt / L (rr_pack_f16x2), same shapes and byte offsets
 };
 
 template <int NT, int PROB>  // PROB 0 = ATSP, 1 = RCVRP
@@ -389,6 +390,26 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_rollout(DecW w, RolloutIO io
 
 #include "rr_rollout_w.inc"
 
+// fp32 -> two-piece fp16 image (rr_common.h): every group of four values becomes its four hi and four lo' halves (16 bytes in,
+// 16 bytes out, same offset): K / Vt / L of the decoder cache for the split rollout's attention and logits
+__global__ __launch_bounds__(256) void k_pack_f16x2(const float4* __restrict__ src, float4* __restrict__ dst, long long n4) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 v = src[i];
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    rr_f16x4 hi, lo;
+    rr_split4h(x, hi, lo);
+    dst[i] = __builtin_bit_cast(float4, rr_cat4(hi, lo));
+  }
+}
+extern "C" int rr_pack_f16x2(const float* src, void* dst, long long n_floats, hipStream_t st) {
+  if (n_floats <= 0) return RR_OK;
+  if (n_floats % 4 != 0) return RR_EINVAL;
+  const long long n4 = n_floats / 4;
+  const long long blocks = (n4 + 255) / 256;
+  hipLaunchKernelGGL(k_pack_f16x2, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st, (const float4*)src, (float4*)dst, n4);
+  return rr_check(hipGetLastError());
+}
+
 extern "C" int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStream_t st) {
   if (w == nullptr || io == nullptr) return RR_EINVAL;
   const int N = io->N, S = io->S;
@@ -405,7 +426,8 @@ extern "C" int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStrea
   static const int variant = getenv("RR_ROLLOUT_VARIANT") ? atoi(getenv("RR_ROLLOUT_VARIANT")) : 1;
   const char* es = getenv("RR_MLP_SPLIT");
   // RolloutIO.use_split decides; the environment variable only forces it on for callers that leave the field 0
-  const bool mlp_split = (io->use_split != 0 || (es != nullptr && atoi(es) != 0 && io->use_split < 0)) && w->w1s != nullptr && w->w2s != nullptr;
+  const bool mlp_split = (io->use_split != 0 || (es != nullptr && atoi(es) != 0 && io->use_split < 0)) && w->w1s != nullptr && w->w2s != nullptr &&
+                         io->Ks != nullptr && io->Vts != nullptr && io->Ls != nullptr;
   if (variant == 0 && prob < 2) {   // workgroup-per-instance variant (kept for A/B measurements; ATSP / RCVRP only)
     dim3 grid(io->Bp, (S + ROWS - 1) / ROWS), blk(DEC_THREADS);
     const int need = N > (S < ROWS ? S : ROWS) ? N : (S < ROWS ? S : ROWS);
@@ -431,14 +453,19 @@ extern "C" int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStrea
   const size_t per_wg = (size_t)(160 * 1024) / (512 / WTHREADS) - 512;
   const int lds_inst = 2 * tile <= per_wg ? 2 : (tile <= per_wg ? 1 : 0);
   const size_t shmem = (size_t)lds_inst * tile;
-  // split-MLP variant: three 16 KB weight stage buffers behind the distance tiles
-  const size_t wstg = 3 * 16384;
-  const int lds_inst_s = 2 * tile + wstg + 16 <= per_wg ? 2 : (tile + wstg + 16 <= per_wg ? 1 : 0);
-  const dim3 grid_s = grid, blk_s = blk;
+  // split variant: two 16 KB weight stage buffers, then the logit-key images of two instances (NT x 8 KB each) if they fit
+  const size_t wstg = 2 * 16384;
+  // split variant: XCD-aware workgroup order (rr_rollout_w.inc), grid padded to (heavy rounded up to 8) + 8 * per
+  const int ntail_l = tail_g ? (io->Bp + tail_g - 1) / tail_g : 0;
+  const int theavy = ((ntail_l + WWAVES - 1) / WWAVES + 7) & ~7;
+  const int nwg = (ntask + WWAVES - 1) / WWAVES;
+  const int per_x = nwg > theavy ? (nwg - theavy + 7) / 8 : 0;
+  const dim3 grid_s(theavy + 8 * per_x), blk_s = blk;
   const int mode = io->logits_only ? 3 : io->mode;
 #define RR_LAUNCHW4(NTV, P, M, SP)                                                                            \
   do {                                                                                                       \
-    const size_t shm = (SP) ? (((size_t)lds_inst_s * tile + 15) / 16) * 16 + wstg : shmem;                    \
+    const int lds_inst_s = wstg + 2 * (size_t)(NTV) * 8192 <= per_wg ? 2 : 0;                               \
+    const size_t shm = (SP) ? wstg + (size_t)lds_inst_s * (NTV) * 8192 : shmem;              \
     (void)hipFuncSetAttribute((const void*)k_rollout_w<NTV, P, M, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
     hipLaunchKernelGGL((k_rollout_w<NTV, P, M, SP>), (SP) ? grid_s : grid, (SP) ? blk_s : blk, shm, st, *w, *io, tail_g, \
                        (SP) ? lds_inst_s : lds_inst);                                                        \

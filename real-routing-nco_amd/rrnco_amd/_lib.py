@@ -58,7 +58,7 @@ class RolloutIO(C.Structure):
         [(n, i32) for n in ("Bp", "N", "S", "T", "t0", "nsteps", "mode", "use_placeholder", "set_first",
                             "write_state", "logits_only", "stagger")] + \
         [("tanh_clip", f32), ("temperature", f32), ("seed", u64)] + [(n, vp) for n in ("used_b", "open_route", "dist_limit", "demand_b", "bclass")] + \
-        [(n, vp) for n in ("dump_g0", "dump_g", "dump_meta", "dump_scal")] + [("dumpT", i32), ("use_split", i32)]
+        [(n, vp) for n in ("dump_g0", "dump_g", "dump_meta", "dump_scal")] + [("dumpT", i32), ("use_split", i32), ("Ks", vp), ("Vts", vp), ("Ls", vp)]
 
 
 class DecLogitIO(C.Structure):          # csrc/rr_train_dec.hip
@@ -103,6 +103,7 @@ _SIGS = {
     "rr_minmax_normalize": [vp, vp, vp, vp, i32, i32, vp],
     "rr_atsp_step": [vp, vp, vp, vp, i32, i32, vp],
     "rr_sample_neighbors": [vp, vp, i32, i32, i32, u64, vp],
+    "rr_pack_f16x2": [vp, vp, C.c_longlong, vp],
     "rr_rcvrp_step": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "rr_tour_cost": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp],
     "rr_select": [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, u64, u32, i32, f32, vp],

@@ -18,6 +18,18 @@ class PrecomputedCache:              # decoder.py:25-44 plus the per-node step-c
     logit_key: torch.Tensor          # [B,N,E]
     ctx_a: torch.Tensor              # Wctx[:, :E] row_emb (ATSP first-node half) or None
     ctx_b: torch.Tensor              # Wctx[:, E:2E] row_emb (ATSP) / Wctx[:, :E] row_emb (VRP)
+    split: tuple = None              # fp16 two-piece images of (glimpse_key, glimpse_val_t, logit_key) for the split rollout
+
+    def split_images(self):
+        """K / V^T / L as hi + 2^-11 lo' fp16 pairs (csrc/rr_common.h), built once per cache by rr_pack_f16x2."""
+        if self.split is None:
+            out = []
+            for t in (self.glimpse_key, self.glimpse_val_t, self.logit_key):
+                d = torch.empty_like(t)
+                L.check(L.lib().rr_pack_f16x2(L.ptr(t), L.ptr(d), t.numel(), L.stream()), "rr_pack_f16x2")
+                out.append(d)
+            self.split = tuple(out)
+        return self.split
 
     @property
     def glimpse_val(self):

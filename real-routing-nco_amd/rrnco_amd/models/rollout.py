@@ -8,10 +8,11 @@ from .. import _lib as L
 PROB_ID = {"atsp": 0, "rcvrp": 1, "rcvrptw": 2}
 MODE_ID = {"greedy": 0, "sampling": 1, "evaluate": 2}
 import os
-# Pointer MLP of the fused greedy / sampling rollouts on the bf16 matrix pipe with 3-way split fp32 operands (six partial
-# products, fp32 accumulate; the dropped terms are <= 2^-23 of a product, one fp32 rounding): the default since round 2 —
-# tours identical to the fp32-MFMA build on the golden fixtures and on >= 99.9 % of the full-size rollouts with every
-# divergence at a decision gap < 1e-3 (tests/test_gpu_fullsize.py).  RR_MLP_SPLIT=0 (or SPLIT_MLP = False) runs the fp32 MFMA.
+# Fused greedy / sampling rollouts on the fp16 matrix pipe with two-piece split fp32 operands (x = hi + 2^-11 lo'; per product
+# hi*hi + 2^-11 (hi*lo' + lo'*hi), fp32 accumulate; measured error of a dot product 4e-8 of sum |a b|, below the fp32 MFMA's own
+# 1.1e-7: tools/clockprobe/f16probe.hip): attention scores, P.V, pointer MLP and logits.  The default since round 2 — tours
+# identical to the fp32-MFMA build on the golden fixtures and on >= 99.9 % of the full-size rollouts with every divergence at
+# a decision gap < 1e-3 (tests/test_gpu_fullsize.py).  RR_MLP_SPLIT=0 (or SPLIT_MLP = False) runs the fp32 MFMA kernel.
 SPLIT_MLP = os.environ.get("RR_MLP_SPLIT", "1") != "0"
 STAGGER = int(os.environ.get("RR_STAGGER", "0"))   # initial delay of the second wave of every SIMD (units of ~8k cycles)
 TIMING = None   # bench.py sets this to a list to collect (start, end) HIP events around each full rollout launch
@@ -90,9 +91,12 @@ def launch_rollout(env_name, packed, cache, td, num_starts, *, actions=None, log
         io.dump_g0, io.dump_g, io.dump_meta = L.ptr(dump["g0"]), L.ptr(dump["g"]), L.ptr(dump["meta"])
         io.dump_scal = L.ptr(dump.get("scal"))
         io.dumpT = int(dump["T"])
-        # training rollouts run their pointer MLP on the bf16 matrix pipe with 3-way split fp32 operands (error <= 2^-23 of a
-        # product, the size of one fp32 rounding; the reference trains in 16-bit mixed precision, configs/trainer/default.yaml:8)
+        # training rollouts run on the same split-operand kernel (fp32-level accuracy; the reference trains in 16-bit mixed
+        # precision, configs/trainer/default.yaml:8)
         io.use_split = int(os.environ.get("RR_TRAIN_SPLIT", "1") != "0" and SPLIT_MLP)
+    if io.use_split and not logits_only and mode != "evaluate":
+        ks, vts, ls = cache.split_images()
+        io.Ks, io.Vts, io.Ls = L.ptr(ks), L.ptr(vts), L.ptr(ls)
     io.tanh_clip, io.temperature, io.seed = float(tanh_clip), float(temperature), int(seed)
     timed = TIMING is not None and not logits_only
     if timed:
