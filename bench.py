@@ -30,11 +30,15 @@ FLOP_PER_ROLLOUT_STEP = 404_480          # pointer step K6-K7,
 # 348 160 (keys padded 100 -> 112; the 65 536-flop context projection is two table gathers, not a GEMM: DESIGN.md §3)
 EXECUTED_FLOP_PER_ROLLOUT_STEP = 348_160
 PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: fp32 matrix peak
-PEAK_BF16_MFMA_TFLOPS = 2500.0           # ... dense bf16 matrix peak
-# The default rollout runs its pointer MLP (262 144 of the 404 480 flop of a rollout-step) on the bf16 pipe with every fp32
-# operand split in three bf16 pieces and six partial products kept: 6 x 262 144 bf16 flop per rollout-step; the rest
-# (attention, logits, context: 142 336 flop) stays on the fp32 MFMA.  Its roofline is the time both pipes need at their peaks.
-MLP_FLOP_PER_ROLLOUT_STEP = 262_144
+PEAK_F16_MFMA_TFLOPS = 2500.0            # ... dense fp16 / bf16 matrix peak (measured 2 360-2 380 on both: tools/clockprobe/f16probe.hip)
+# The default rollout runs every product of a rollout-step (attention scores, P.V, pointer MLP, logits) on the fp16 matrix pipe
+# with each fp32 operand split in two fp16 pieces x = hi + 2^-11 lo' and three partial products kept (hi*hi, hi*lo', lo'*hi; fp32
+# accumulate; measured error 4e-8 of sum |a b|, below the fp32 MFMA's own): 3 x 404 480 fp16 flop per rollout-step.  Its MFMA
+# roofline is the time the fp16 pipe needs for that at its dense peak: 2 500 / 3 = 833 TFLOP/s of fp32-equivalent work.
+# What the pipe executes per 16-rollout tile and decode step: 768 (MLP) + 3 x 112 (scores, P.V, logits: the k = 16 products ride
+# in k = 32 instructions as [hi | lo'] x [hi | 0] and [hi | lo'] x [lo' | hi]) = 1 104 v_mfma_f32_16x16x32_f16 of 16 384 flop.
+SPLIT_PRODUCTS = 3
+EXECUTED_F16_FLOP_PER_ROLLOUT_STEP = 1104 * 16384 // 16
 ROLLOUT_KERNEL = "k_rollout_w<7, 0, 0, true>"
 ROLLOUT_KERNEL_FP32 = "k_rollout_w<7, 0, 0, false>"
 # HBM-side traffic of ONE rollout launch at the default workload: rocprofv3 PMC, separate FETCH_SIZE / WRITE_SIZE passes,
@@ -180,26 +184,28 @@ def main():
         rollout_steps = args.batch * AUG * STARTS * (N_NODES - 1)
         k_ms = sum(kern_ms) / max(len(kern_ms), 1)
         achieved = rollout_steps * FLOP_PER_ROLLOUT_STEP / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-        # time the two matrix pipes need at their peaks for one rollout-step of this instruction mix -> blended peak
-        t_min = ((FLOP_PER_ROLLOUT_STEP - MLP_FLOP_PER_ROLLOUT_STEP) / (PEAK_F32_MFMA_TFLOPS * 1e12)
-                 + 6 * MLP_FLOP_PER_ROLLOUT_STEP / (PEAK_BF16_MFMA_TFLOPS * 1e12))
-        peak_blend = FLOP_PER_ROLLOUT_STEP / t_min / 1e12
+        peak_split = PEAK_F16_MFMA_TFLOPS / SPLIT_PRODUCTS
+        executed = rollout_steps * EXECUTED_F16_FLOP_PER_ROLLOUT_STEP / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         traffic, traffic_src = measured_rollout_traffic(args.batch)
         line = {
             "metric": "solved instances/sec (ATSP n=100, B=512, POMO greedy)", "value": total_inst / dt,
             "unit": "instances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "arithmetic": "fp32 throughout; the two 128-512-128 MLPs (rollout pointer MLP, encoder FFN) multiply 3-way bf16-split fp32 "
-                          "operands on the bf16 matrix pipe (6 partial products, fp32 accumulate, dropped terms <= 2^-23 of a product) — "
-                          "tours equal to the all-fp32-MFMA build's (tests/test_gpu_fullsize.py), which is timed under `variants`",
+            "arithmetic": "fp32 operands and fp32 accumulation throughout; the rollout's products (scores, P.V, pointer MLP, logits) "
+                          "multiply two-piece fp16 splits x = hi + 2^-11 lo' on the fp16 matrix pipe (3 partial products; error of a dot "
+                          "product 4e-8 of sum|ab| against 1.1e-7 for the fp32 MFMA, tools/clockprobe/f16probe.hip), the encoder FFN "
+                          "3-way bf16 splits (6 products); tours equal to the all-fp32-MFMA build's (tests/test_gpu_fullsize.py), which "
+                          "is timed under `variants`",
             "config": {"workload": f"ATSP n={N_NODES}, batch={args.batch}/GPU, POMO S={STARTS} starts x {AUG} dihedral aug, greedy "
                                    "(BASELINE.json configs[1]); random-init RRNet E=128 L=6",
                        "rollouts_per_gpu": args.batch * AUG * STARTS, "sharding": f"instances over {world} rank(s), no collective"},
             "roofline": {"bound": "mfma", "kernel": ROLLOUT_KERNEL + " (persistent wave-autonomous POMO decode)", "achieved": achieved,
-                         "peak": peak_blend, "unit": "TFLOP/s", "frac": achieved / peak_blend,
-                         "peak_note": "algorithmic flop / (fp32-MFMA part at 157.3 TFLOP/s + 6 x MLP flop at 2 500 TFLOP/s bf16): the "
-                                      "time both matrix pipes need at their dense peaks for this instruction mix",
+                         "peak": peak_split, "unit": "TFLOP/s", "frac": achieved / peak_split,
+                         "peak_note": "fp32-equivalent flop/s of the fp16 matrix pipe at its dense peak with 3 partial products per product "
+                                      "(2 500 / 3); round 1's all-fp32-MFMA kernel (peak 157.3) is under `variants`",
+                         "executed_mfma": {"achieved": executed, "peak": PEAK_F16_MFMA_TFLOPS, "frac": executed / PEAK_F16_MFMA_TFLOPS,
+                                           "note": "1 104 v_mfma_f32_16x16x32_f16 per 16-rollout tile and decode step"},
                          "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": k_ms,
                          "algorithmic_flop_per_launch": rollout_steps * FLOP_PER_ROLLOUT_STEP},
             "mean_best_cost": float(-best.mean().item()),

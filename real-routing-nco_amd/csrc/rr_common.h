@@ -139,10 +139,35 @@ __device__ __forceinline__ void rr_split4h(const float (&x)[4], rr_f16x4& hi, rr
     hi[2 * q] = h[0]; hi[2 * q + 1] = h[1]; lo[2 * q] = l[0]; lo[2 * q + 1] = l[1];
   }
 }
-// k = 32 operand from two 16-deep halves.  With A = [hi | lo'] of one operand (16 bytes per lane: the footprint of its four fp32
-// values) the other operand enters as [hi | 0] for the large term and as [lo' | hi] for the two small ones.
+// A k = 16 product on two-piece operands takes two instructions.  With A = [hi | lo'] of one operand in ONE 16-byte fragment
+// (the footprint of its four fp32 values) and the other operand kept as the tuple S = [lo' | hi]:
+//   large term:  v_mfma_f32_16x16x16_f16(A.hi, S.hi)            (the low 8 bytes of A, the high 8 bytes of S)
+//   small terms: v_mfma_f32_16x16x32_f16(A, S) = hi*lo' + lo'*hi (scaled 2^11)
+// so no operand is ever assembled by register moves.  (Both instructions take 16 cycles: tools/clockprobe/f16probe.hip.)
 __device__ __forceinline__ rr_f16x8 rr_cat4(rr_f16x4 a, rr_f16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+__device__ __forceinline__ rr_f16x4 rr_lo4(rr_f16x8 v) { return __builtin_shufflevector(v, v, 0, 1, 2, 3); }
+__device__ __forceinline__ rr_f16x4 rr_hi4(rr_f16x8 v) { return __builtin_shufflevector(v, v, 4, 5, 6, 7); }
 __device__ __forceinline__ rr_f16x8 rr_as_f16x8(float4 v) { return __builtin_bit_cast(rr_f16x8, v); }
+__device__ __forceinline__ f32x4 rr_mfma_f16k16(rr_f16x4 a, rr_f16x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+}
+// x[0..3] -> the tuple [lo' | hi]
+__device__ __forceinline__ rr_f16x8 rr_split4s(const float (&x)[4]) {
+  rr_f16x4 hi, lo;
+  rr_split4h(x, hi, lo);
+  return rr_cat4(lo, hi);
+}
+// MI355X, ROCm 7.2: a VALU write to a source register of a v_mfma_f32_16x16x32_f16 issued just before it can reach the
+// register file before the MFMA has read it when the other wave of the SIMD keeps the matrix pipe busy (seen as run-to-run
+// differences of the rollout's P.V, whose B operand is rebuilt for every key tile; hipcc inserts no wait states for this
+// write-after-read).  Operands that are rebuilt within a few instructions of their use are fenced: nothing is scheduled
+// across, and the MFMA has a full instruction time before the next write.
+#define RR_MFMA_SRC_FENCE()                      \
+  do {                                           \
+    __builtin_amdgcn_sched_barrier(0);           \
+    asm volatile("s_nop 15");                    \
+    __builtin_amdgcn_sched_barrier(0);           \
+  } while (0)
 // LDS-DMA: 16 bytes per lane from global memory straight into LDS at ldst + 16 * lane (ldst wave-uniform); completes on vmcnt
 __device__ __forceinline__ void rr_glds16(const void* gsrc, void* ldst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,

@@ -464,7 +464,7 @@ def _pack_policy(sd: dict, env_name: str, device) -> dict:
     bpc = (torch.bmm(Wc64, stk("attn_free.project.bias").double()[:, :, None])[:, :, 0] + stk("multi_head_combine.bias").double()).float().contiguous()
     ar.keep += [sq, p1, p2, ppc, bpc]
     if split:      # FFN weights again as 3-way bf16 splits for the bf16-pipe FFN
-        p1s, p2s = pack_a_bf16x3(W1s), pack_a_bf16x3(W2s)
+        p1s, p2s = pack_a_f16x2(W1s), pack_a_f16x2(W2s)
         ar.keep += [p1s, p2s]
     for bi, b in enumerate(names):
         l = bi // 2

@@ -70,13 +70,11 @@ if rank == 0:
             "gradient_path": "hand-written HIP backward (csrc/rr_train_dec.hip, rr_train_enc.hip, rr_train.hip) on what the sampling rollout "
                              "dumped; torch only for the init embedding and the host-side folds"}
     if args.problem == "atsp" and kern_ms:
-        # the step's largest kernel is still the sampling rollout: priced like bench.py's (pointer MLP on split-bf16 operands)
+        # the step's largest kernel is still the sampling rollout: priced like bench.py's (every product on two-piece fp16 splits)
         k_ms = sum(kern_ms) / len(kern_ms)
         steps_ = args.batch * 100 * 98          # rollouts x evaluated decode steps (the forced last move is not evaluated)
-        t_min = (bench.FLOP_PER_ROLLOUT_STEP - bench.MLP_FLOP_PER_ROLLOUT_STEP) / (bench.PEAK_F32_MFMA_TFLOPS * 1e12) + \
-            6 * bench.MLP_FLOP_PER_ROLLOUT_STEP / (bench.PEAK_BF16_MFMA_TFLOPS * 1e12)
         ach = steps_ * bench.FLOP_PER_ROLLOUT_STEP / (k_ms * 1e-3) / 1e12
-        peak = bench.FLOP_PER_ROLLOUT_STEP / t_min / 1e12
+        peak = bench.PEAK_F16_MFMA_TFLOPS / bench.SPLIT_PRODUCTS
         line["roofline"] = {"bound": "mfma", "kernel": "k_rollout_w<7, 0, 1, true> (sampling rollout with the training dump)", "achieved": ach,
                             "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "kernel_ms": k_ms, "traffic": None}
     print(json.dumps(line))

@@ -77,6 +77,21 @@ __global__ void k_denorm(float* out) {   // one wave: A = 2^-20 (fp16 subnormal)
   c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
   if (threadIdx.x == 0) { out[0] = c[0]; out[1] = (float)a[0]; }
 }
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512) void k_rate16(float* sink, int iters) {     // v_mfma_f32_16x16x16_f16 (k = 16)
+  f32x4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+  f16x4 p, q4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { p[q] = (_Float16)(1.0f + threadIdx.x * 1e-3f + q); q4[q] = (_Float16)(0.5f - q); }
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a0 = __builtin_amdgcn_mfma_f32_16x16x16f16(p, q4, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x16f16(q4, p, a1, 0, 0, 0);
+      a2 = __builtin_amdgcn_mfma_f32_16x16x16f16(p, p, a2, 0, 0, 0); a3 = __builtin_amdgcn_mfma_f32_16x16x16f16(q4, q4, a3, 0, 0, 0);
+    }
+  }
+  if (a0[0] + a1[1] + a2[2] + a3[3] == 12345.f) sink[0] = 1.f;
+}
 template <bool F16>
 __global__ __launch_bounds__(512) void k_rate(float* sink, int iters) {
   f32x4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
@@ -130,6 +145,13 @@ int main() {
     if (f) hipLaunchKernelGGL(k_rate<true>, dim3(256), dim3(512), 0, 0, d, it); else hipLaunchKernelGGL(k_rate<false>, dim3(256), dim3(512), 0, 0, d, it);
     hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
     printf("%s 16x16x32 MFMA: %.1f TFLOP/s\n", f ? "f16 " : "bf16", 256.0 * 8 * it * 16.0 * 16384 / (ms * 1e-3) / 1e12);
+  }
+  {
+    const int it = 200000; float ms;
+    hipLaunchKernelGGL(k_rate16, dim3(256), dim3(512), 0, 0, d, 1000);
+    hipEventRecord(e0); hipLaunchKernelGGL(k_rate16, dim3(256), dim3(512), 0, 0, d, it); hipEventRecord(e1); hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("f16  16x16x16 MFMA: %.1f TFLOP/s (%.2f x the time of a 16x16x32 per instruction)\n", 256.0 * 8 * it * 16.0 * 8192 / (ms * 1e-3) / 1e12, 0.0);
   }
   return 0;
 }
