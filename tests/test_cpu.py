@@ -493,6 +493,38 @@ def test_pack_a_bf16x3_is_an_exact_three_way_split_in_kernel_order():
     assert (mid.abs() <= hi.abs() * 2.0 ** -8 + 1e-45).all() and (lo.abs() <= hi.abs() * 2.0 ** -16 + 1e-45).all()
 
 
+def test_pack_a_f16x2_is_a_two_piece_split_to_2pow23_in_kernel_order():
+    """packing.pack_a_f16x2 (A operands of the fp16-pipe pointer MLP / encoder FFN, csrc/rr_common.h): hi + 2^-11 lo' reproduces
+    the fp32 weight to 2^-23 relative (2^-36 absolute below the fp16 normal range), in the lane / k order of pack_a_bf16x3; and
+    the scheme's dot products (hi*hi + 2^-11 (hi*lo' + lo'*hi), fp32 accumulate) are at least as close to float64 as a
+    sequential fp32 dot product."""
+    from rrnco_amd.packing import pack_a_f16x2
+    g = torch.Generator().manual_seed(5)
+    W = torch.randn(48, 96, generator=g) * torch.logspace(-6, 2, 96)[None, :]
+    P = pack_a_f16x2(W)
+    assert P.shape == (3, 3, 2, 64, 8) and P.dtype == torch.float16
+    rec = P[:, :, 0].double() + P[:, :, 1].double() / 2048.0
+    for t in range(3):
+        for s_ in range(3):
+            for lane in (0, 17, 37, 63):
+                i, gg = lane & 15, lane >> 4
+                for e in range(8):
+                    k = 32 * s_ + (4 * gg + e if e < 4 else 16 + 4 * gg + e - 4)
+                    w = W[16 * t + i, k].double().item()
+                    assert abs(rec[t, s_, lane, e].item() - w) <= max(abs(w) * 2.0 ** -23, 2.0 ** -36)
+    # the three-term product against float64 and against a plain fp32 accumulation
+    a, b = torch.randn(64, 512, generator=g), torch.randn(512, generator=g)
+    ah = a.half(); al = ((a - ah.float()) * 2048).half()
+    bh = b.half(); bl = ((b - bh.float()) * 2048).half()
+    big = (ah.float() * bh.float()).sum(1)                      # every product of two fp16 values is exact in fp32
+    small = (ah.float() * bl.float() + al.float() * bh.float()).sum(1)
+    got = (big + small / 2048.0).double()
+    ref = a.double() @ b.double()
+    f32 = torch.stack([torch.tensor(sum((float(x) * float(y) for x, y in zip(r.tolist(), b.tolist())), 0.0)) for r in a[:4]])
+    scale = (a.double().abs() @ b.double().abs())
+    assert ((got - ref).abs() / scale).max() < 2e-7
+
+
 def test_state_augmentation_matches_reference_functions():
     """models/transforms.py against the reference's formulas (transforms.py:15-154): dihedral-8 blocks, the random 'symmetric'
     transform (an isometry about (0.5, 0.5), identity on the first block, reproducible from torch's RNG like the reference's
