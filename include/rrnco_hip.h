@@ -24,7 +24,8 @@ typedef struct {                /* one AttnFree_Block: rrnco/models/nn/attn_free
   const void *wq, *wk, *wv, *wp, *wc, *w1, *w2;   /* MFMA A-operand packs [M/16][K/16][64 lanes][4]; wp = Wc Wp (project and multi_head_combine folded), wc unused */
   const float *bq, *bk, *bv, *bp, *bc, *b1, *b2;
   const float *nab;             /* folded DistAngleFusion (:201-289): piecewise-linear tables, packing.fold_nab_pwl */
-  const void *w1s, *w2s;        /* optional 3-way bf16 splits of w1 / w2 (packing.pack_a_bf16x3) for the opt-in RR_MLP_SPLIT=1 FFN */
+  const void *w1s, *w2s;        /* optional two-piece fp16 splits of w1 / w2 (packing.pack_a_f16x2): FFN on the fp16 pipe (default; RR_MLP_SPLIT=0 turns it off) */
+  const void *wqs, *wks, *wvs, *wps;   /* likewise for the four 128 x 128 projections (all six or none) */
 } EncBlockW;
 
 typedef struct {                /* ATSPInitEmbedding (rrnco/models/env_embeddings/atsp.py:5-121) and

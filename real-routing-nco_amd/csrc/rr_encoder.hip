@@ -30,7 +30,8 @@ struct EncBlockW {
   const float4 *wq, *wk, *wv, *wp, *wc, *w1, *w2;                             // packed A operands; wp = Wc Wp (folded), wc unused
   const float *bq, *bk, *bv, *bp, *bc, *b1, *b2;
   const float* nab;  // folded NAB: rows a_d,b_d,co_d,cg_d,a_a,b_a,co_a,cg_a [8][E] + 8 scalars
-  const void *w1s, *w2s;  // optional 3-way bf16 splits of w1 / w2 (packing.pack_a_bf16x3): FFN on the bf16 pipe, RR_MLP_SPLIT=1
+  const void *w1s, *w2s;  // optional two-piece fp16 splits of w1 / w2 (packing.pack_a_f16x2): FFN on the fp16 pipe
+  const void *wqs, *wks, *wvs, *wps;   // likewise for the four 128 x 128 projections
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -434,7 +435,8 @@ static int rr_enc_layer_impl(const EncBlockW* wrow, const EncBlockW* wcol, const
     EncBlockW2 ws; ws.blk[0] = *wrow; ws.blk[1] = *wcol;   // wave = node tile, register-resident (rr_enc_w.inc); stage dumps use the LDS-staged kernel
     const char* es = getenv("RR_MLP_SPLIT");
     // FFN on 3-way bf16-split operands whenever the packs carry them (packing.mlp_split_enabled: default on; RR_MLP_SPLIT=0 off)
-    const bool split = (es == nullptr || atoi(es) != 0) && wrow->w1s && wrow->w2s && wcol->w1s && wcol->w2s;
+    const bool split = (es == nullptr || atoi(es) != 0) && wrow->w1s && wrow->w2s && wcol->w1s && wcol->w2s &&
+                       wrow->wqs && wrow->wks && wrow->wvs && wrow->wps && wcol->wqs && wcol->wks && wcol->wvs && wcol->wps;
 #define RR_ENCW(NTV, SP) hipLaunchKernelGGL((k_enc_block_w<NTV, SP>), grid, dim3(64 * NTV), 0, st, ws, row_in, col_in, row_out, col_out, D, theta, bias_pre, N, norm_affine_only, svs)
     if (N <= 32) { if (split) RR_ENCW(2, true); else RR_ENCW(2, false); }
     else if (N <= 64) { if (split) RR_ENCW(4, true); else RR_ENCW(4, false); }

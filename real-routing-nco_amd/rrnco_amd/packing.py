@@ -465,7 +465,9 @@ def _pack_policy(sd: dict, env_name: str, device) -> dict:
     ar.keep += [sq, p1, p2, ppc, bpc]
     if split:      # FFN weights again as 3-way bf16 splits for the bf16-pipe FFN
         p1s, p2s = pack_a_f16x2(W1s), pack_a_f16x2(W2s)
-        ar.keep += [p1s, p2s]
+        sqs = pack_a_f16x2(torch.stack([stk("attn_free.to_q.weight"), stk("attn_free.to_k.weight"), stk("attn_free.to_v.weight"),
+                                        torch.bmm(Wc64, Wp64).float()]))                       # [4][nb][8][4][2][64][8]
+        ar.keep += [p1s, p2s, sqs]
     for bi, b in enumerate(names):
         l = bi // 2
         if bi % 2 == 0:
@@ -495,6 +497,7 @@ def _pack_policy(sd: dict, env_name: str, device) -> dict:
             w.wc, w.bc = None, None
             if split:
                 w.w1s, w.w2s = p1s[bi].data_ptr(), p2s[bi].data_ptr()
+                w.wqs, w.wks, w.wvs, w.wps = (sqs[i, bi].data_ptr() for i in range(4))
             if nab_kind != "gating":          # ablation modules: bias computed by rr_nab_simple, fed as bias_pre
                 w.nab = None
                 q, sw = f"{b}.neural_adaptive_bias", L.NabSimpleW()
