@@ -128,6 +128,9 @@ def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
     M = Bp * N
     dev = D.device
     atsp = policy.env_name == "atsp"
+    vtw = policy.env_name == "rcvrptw"
+    Dur = td["duration_matrix"].float().contiguous() if vtw else None
+    dur_todo = []             # rcvrptw: (block name, side index, d loss / d bias) — differentiated after the kernels' gradients are flushed
     G = _Grads(P)
     new = lambda: torch.empty(Bp, N, E, device=dev)                                         # noqa: E731
     MS = 256                                                                                 # row splits of the weight-gradient products
@@ -207,14 +210,17 @@ def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
                                                                     L.ptr(S["den"]), L.ptr(S["eaT"]))
                 io.dq, io.dk, io.dv, io.dbias, io.N = L.ptr(dq), L.ptr(dk), L.ptr(dv), L.ptr(dbias), N
                 L.check(lib.rr_aft_bwd(io, Bp, st), "rr_aft_bwd")
-                # alpha * NAB (:427-429): the folded-table backward of csrc/rr_train.hip, chained to the module parameters by autograd
-                with torch.enable_grad():
-                    tab = _nab_tab(P, b + ".angle_distance_fusion", P[b + ".alpha"])
-                xd = D if side == "row" else Dt
-                hist = nab_hists[len(nab_tabs)]
-                L.check(lib.rr_nab_hist_bwd(packed["blocks"][l][si].nab, L.ptr(xd), L.ptr(theta), L.ptr(dbias), L.ptr(hist),
-                                            dbias.numel(), st), "rr_nab_hist_bwd")
-                nab_tabs.append(tab)
+                if vtw:       # alpha * NAB with duration (:226-237, 265-286): d bias is all the kernels contribute
+                    dur_todo.append((b, si, dbias))
+                else:
+                    # alpha * NAB (:427-429): the folded-table backward of csrc/rr_train.hip, chained to the module parameters by autograd
+                    with torch.enable_grad():
+                        tab = _nab_tab(P, b + ".angle_distance_fusion", P[b + ".alpha"])
+                    xd = D if side == "row" else Dt
+                    hist = nab_hists[len(nab_tabs)]
+                    L.check(lib.rr_nab_hist_bwd(packed["blocks"][l][si].nab, L.ptr(xd), L.ptr(theta), L.ptr(dbias), L.ptr(hist),
+                                                dbias.numel(), st), "rr_nab_hist_bwd")
+                    nab_tabs.append(tab)
                 # q = to_q(r), k = to_k(c), v = to_v(c) (:313-315)
                 dr = dY                                                                   # reuse
                 lin(pk["wqT"], dq, dr, 0, G.buf(b + ".attn_free.to_q.bias"))
@@ -228,14 +234,26 @@ def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
                 inorm(x_in, dU1, dr, b + ".norm1", dx_out, acc=si)           # the col block adds to what the row block wrote
                 inorm(y_in, dc, None, b + ".norm2", dy_out, acc=si)
             d_row, d_col = n_row, n_col
-        # the NAB moments of all blocks -> d (folded tables), one batched prefix-sum pass
-        gtabs = nab_grad_from_hist(torch.stack([t.detach() for t in nab_tabs]), nab_hists)
-        small += [(t, gtabs[i]) for i, t in enumerate(nab_tabs)]
+        if nab_tabs:          # the NAB moments of all blocks -> d (folded tables), one batched prefix-sum pass
+            gtabs = nab_grad_from_hist(torch.stack([t.detach() for t in nab_tabs]), nab_hists)
+            small += [(t, gtabs[i]) for i, t in enumerate(nab_tabs)]
     G.flush()
     # ---- chain rule through the folds and the init embedding (autograd on tiny / [Bp*N,128] tensors)
     vrp = policy.env_name == "rcvrp"
     with torch.enable_grad():
-        if vrp:
+        # duration NAB of every block: the folded form recomputed per block (three GEMMs over all edges) and differentiated
+        # against the kernels' d bias; the angles are the same for row and col blocks, cost / duration transposed (:480-486)
+        Tt = Dur.transpose(1, 2).contiguous() if vtw else None
+        for b, si, dbias in dur_todo:
+            cost_, dur_ = (D, Dur) if si == 0 else (Dt, Tt)
+            for lo in range(0, Bp, 128):           # [edges, 384] intermediates: 2 GB each per 128 instances of 101 nodes
+                sl = slice(lo, min(Bp, lo + 128))
+                out = GR._nab_duration(P, b + ".neural_adaptive_bias", cost_[sl], theta[sl], dur_[sl], P[b + ".alpha"])
+                torch.autograd.backward(out, dbias[sl])
+        if vtw:
+            extra = torch.cat([td["time_windows"].float(), td["service_time"].float()[..., None]], -1)
+            row0, col0 = GR._init_embedding_vrp(P, locs, td["demand_linehaul"].float()[:, 1:], D, sample_idx, extra, "init_embed")
+        elif vrp:
             row0, col0 = GR._init_embedding_vrp(P, locs, td["demand"].float(), D, sample_idx, None, "demand_init")
         else:
             row0, col0 = GR._init_embedding(P, locs, D, sample_idx)

@@ -179,8 +179,9 @@ class RRNetEncoder(nn.Module):
 
     def supports_hip_backward(self, packed) -> bool:
         """The hand-written block backward (csrc/rr_train_enc.hip) covers the published configuration: instance norm and the
-        gating NAB without duration (ATSP, RCVRP)."""
-        return (self.normalization == "instance" and packed.get("nab_kind", "gating") == "gating" and len(packed["nabdur"]) == 0)
+        gating NAB — without duration (ATSP, RCVRP: moment-histogram kernel) or with it (RCVRPTW: the bias gradient d loss / d bias
+        [Bp,N,N] of every block comes from the kernels, the duration NAB itself is differentiated by grad_replay._NabDurationFolded)."""
+        return self.normalization == "instance" and packed.get("nab_kind", "gating") == "gating"
 
     def forward(self, td, phase: str = "val", mask=None, packed=None, train_saves=None):
         """-> (row_emb, col_emb) [B,N,E].  `packed` = packing.pack_policy(...) (the policy caches it).  `train_saves` (a list):
@@ -265,5 +266,8 @@ class RRNetEncoder(nn.Module):
             else:
                 row, col, row2, col2 = row2, col2, row, col
         if train_saves is not None:
+            if theta is None:      # duration NAB: the kernels take the angles from the coordinates; the backward wants the matrix
+                theta = torch.empty(Bp, N, N, device=dev, dtype=torch.float32)
+                L.check(lib.rr_edge_angles(L.ptr(locs), L.ptr(theta), Bp, N, L.stream()), "rr_edge_angles")
             train_saves.append({"theta": theta})
         return row, col

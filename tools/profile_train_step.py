@@ -7,17 +7,28 @@ from rrnco_amd.envs import ATSPEnv, ATSPGenerator
 from rrnco_amd.models.rl import RRNet
 from torch.profiler import profile, ProfilerActivity
 dev = torch.device("cuda")
-pol, w = bench.make_policy(dev); pol.train()
-env = ATSPEnv(generator_params=dict(num_loc=100, device=dev), check_solution=False, device=dev)
+PROBLEM = os.environ.get("PROBLEM", "atsp")               # atsp | rcvrp | rcvrptw
+if PROBLEM == "atsp":
+    pol, w = bench.make_policy(dev)
+    env = ATSPEnv(generator_params=dict(num_loc=100, device=dev), check_solution=False, device=dev)
+else:
+    from rrnco_amd.envs import RCVRPEnv, RMTVRPEnv
+    from rrnco_amd.models import RRNetPolicy
+    torch.manual_seed(1234)
+    pol = RRNetPolicy(env_name=PROBLEM, embed_dim=128, num_heads=8, num_encoder_layers=6, normalization="instance",
+                      use_graph_context=False, nab_type="gating", init_embedding_kwargs=dict(sample_size=25)).to(dev)
+    gp = dict(num_loc=100, device=dev)
+    env = RCVRPEnv(generator_params=gp, check_solution=False, device=dev) if PROBLEM == "rcvrp" else RMTVRPEnv(generator_params=gp, device=dev)
+pol.train()
 model = RRNet(env, policy=pol)
 opt = torch.optim.Adam(pol.parameters(), lr=1e-4, fused=True)
 gen = torch.Generator(device=dev).manual_seed(1)
 B = int(os.environ.get("PB", "512"))
 for i in range(2):
-    model.training_step(ATSPGenerator(num_loc=100, device=dev)(B, generator=gen), optimizer=opt, seed=i)
+    model.training_step(env.generator(B, generator=gen), optimizer=opt, seed=i)
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
-    model.training_step(ATSPGenerator(num_loc=100, device=dev)(B, generator=gen), optimizer=opt, seed=9)
+    model.training_step(env.generator(B, generator=gen), optimizer=opt, seed=9)
     torch.cuda.synchronize()
 cpu = sorted([e for e in prof.key_averages() if e.key.startswith("aten::") or e.key.startswith("hip")], key=lambda e: -e.count)
 if os.environ.get("PROFILE_HOST"):
