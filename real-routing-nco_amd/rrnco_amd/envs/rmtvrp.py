@@ -17,14 +17,31 @@ def vrptw_capacity(n: int) -> float:
     return 30.0 + (n // 5 if n > 20 else 0)          # rmtvrp/generator.py:20-33
 
 
-class RMTVRPGenerator:
-    """Synthetic VRPTW instances: LazyRMTVRPGenerator(variant_preset='vrptw') synthetic branch
-    (rmtvrp/generator_lazy.py:302-348, generator.py:445-513) plus explicit asymmetric distance / duration matrices."""
+# rmtvrp/generator.py:37-58: which of the four optional features (open routes, time windows, distance limits, backhauls) a
+# preset keeps; "all" / "single_feat" / "cvrp" draw ONE feature (or none) per instance, the others keep exactly the listed ones
+VARIANT_PRESETS = {
+    "all": "OTLB?", "single_feat": "OTLB?", "cvrp": "?", "ovrp": "O", "vrpb": "B", "vrpl": "L", "vrptw": "T", "ovrptw": "OT",
+    "ovrpb": "OB", "ovrpl": "OL", "vrpbl": "LB", "vrpbtw": "TB", "vrpltw": "TL", "ovrpbl": "OLB", "ovrpbtw": "OTB",
+    "ovrpltw": "OTL", "vrpbltw": "TLB", "ovrpbltw": "OTLB",
+}
 
-    def __init__(self, num_loc: int = 20, max_time: float = 4.6, variant_preset: str = "vrptw", device="cuda", **unused):
-        if variant_preset != "vrptw":
-            raise NotImplementedError("rrnco_amd implements the vrptw preset (configs/env/rcvrptw.yaml)")
-        self.num_loc, self.max_time, self.device = num_loc, max_time, device
+
+class RMTVRPGenerator:
+    """Synthetic multi-task VRP instances: the synthetic branch of RMTVRPGenerator / LazyRMTVRPGenerator
+    (rmtvrp/generator.py:183-351, 352-432, 445-513; generator_lazy.py:302-348) for every `variant_preset` of
+    VARIANT_GENERATION_PRESETS (the published configuration uses "vrptw", configs/env/rcvrptw.yaml), plus explicit asymmetric
+    distance / duration matrices.  Features a preset does not keep take the reference's defaults (`subsample_problems`):
+    closed routes, time windows [0, inf) with zero service time, infinite distance limit, backhaul demand folded into linehaul."""
+
+    def __init__(self, num_loc: int = 20, max_time: float = 4.6, variant_preset: str = "vrptw", device="cuda",
+                 backhaul_ratio: float = 0.2, backhaul_class: int = 1, sample_backhaul_class: bool = False,
+                 max_distance_limit: float = 2.8, **unused):
+        if variant_preset not in VARIANT_PRESETS:
+            raise NotImplementedError(f"variant_preset '{variant_preset}' (known: {sorted(VARIANT_PRESETS)})")
+        assert backhaul_class in (1, 2)
+        self.num_loc, self.max_time, self.device, self.variant_preset = num_loc, max_time, device, variant_preset
+        self.backhaul_ratio, self.backhaul_class, self.sample_backhaul_class = backhaul_ratio, backhaul_class, sample_backhaul_class
+        self.max_distance_limit = max_distance_limit
 
     def __call__(self, batch_size, generator=None):
         bs = [batch_size] if isinstance(batch_size, int) else list(batch_size)
@@ -46,8 +63,39 @@ class RMTVRPGenerator:
         tw_start = (1 + (h_max - 1) * rnd(B, n)) * d0
         z, full = torch.zeros(B, 1, device=dev), torch.full((B, 1), self.max_time, device=dev)
         tw = torch.stack((torch.cat((z, tw_start), -1), torch.cat((full, tw_start + tw_len), -1)), dim=-1)
-        return TensorDict({"locs": locs, "distance_matrix": D, "duration_matrix": T, "demand_linehaul": demand,
-                           "time_windows": tw, "service_time": torch.cat((z, service), -1)}, batch_size=bs)
+        out = {"locs": locs, "distance_matrix": D, "duration_matrix": T, "demand_linehaul": demand,
+               "time_windows": tw, "service_time": torch.cat((z, service), -1)}
+        if self.variant_preset == "vrptw":              # the published preset: nothing else in the instance (as before)
+            return TensorDict(out, batch_size=bs)
+        # ---- the other features (generator.py:445-470, 577-612) and the per-instance choice of which to keep (:352-432)
+        backhaul = (rnd(B, n) * 9).int().add(1).float() / vrptw_capacity(n)
+        is_line = rnd(B, n) > self.backhaul_ratio
+        backhaul, demand = backhaul * ~is_line, demand * is_line
+        bclass = (torch.randint(1, 3, (B, 1), device=dev, generator=generator) if self.sample_backhaul_class
+                  else torch.full((B, 1), self.backhaul_class, device=dev)).float()
+        lower = 2 * d0.amax(dim=1) + 1e-6
+        upper = torch.maximum(torch.full_like(lower, self.max_distance_limit), lower + 1e-6)
+        limit = (lower + (upper - lower) * rnd(B))[:, None]
+        keys = VARIANT_PRESETS[self.variant_preset]
+        if "?" in keys:                                  # one feature (or plain CVRP, weight 0.5) per instance
+            probs = torch.tensor([0.5 if k in keys else 0.0 for k in "OTLB"] + [0.5], device=dev)
+            if self.variant_preset == "cvrp":
+                probs = torch.tensor([0.0, 0.0, 0.0, 0.0, 1.0], device=dev)
+            idx = torch.multinomial(probs.expand(B, 5), 1, generator=generator)[:, 0]
+            keep = torch.zeros(B, 5, dtype=torch.bool, device=dev)
+            keep[torch.arange(B, device=dev), idx] = True
+        else:
+            keep = torch.tensor([k in keys for k in "OTLB"], device=dev).expand(B, 4)
+        ko, kt, kl, kb = keep[:, 0], keep[:, 1], keep[:, 2], keep[:, 3]
+        open_route = ko[:, None].clone()
+        tw = torch.where(kt[:, None, None], tw, torch.stack((torch.zeros_like(tw[..., 0]), torch.full_like(tw[..., 1], float("inf"))), -1))
+        service_full = torch.where(kt[:, None], out["service_time"], torch.zeros_like(out["service_time"]))
+        limit = torch.where(kl[:, None], limit, torch.full_like(limit, float("inf")))
+        demand = torch.where(kb[:, None], demand, demand + backhaul)
+        backhaul = torch.where(kb[:, None], backhaul, torch.zeros_like(backhaul))
+        out.update(demand_linehaul=demand, demand_backhaul=backhaul, backhaul_class=bclass, distance_limit=limit,
+                   open_route=open_route, time_windows=tw, service_time=service_full)
+        return TensorDict(out, batch_size=bs)
 
 
 class RMTVRPEnv(EnvBase):

@@ -624,3 +624,27 @@ def test_batched_device_fold_of_the_nab_tables_equals_the_numpy_fold():
         assert torch.equal(got[i, :256], ref[:256])                                   # breakpoints
         assert torch.allclose(got[i, 256:n], ref[256:n], rtol=2e-6, atol=1e-6)       # segment slopes / values
         assert torch.equal(got[i, n:].view(torch.uint8), ref[n:].view(torch.uint8))   # grid-start bounds
+
+
+def test_rmtvrp_generator_presets_keep_exactly_their_features():
+    """envs/rmtvrp.py:RMTVRPGenerator against rmtvrp/generator.py:37-58, 352-432: a preset keeps the listed features on every
+    instance and gives the others the reference's defaults; "all" draws at most one feature per instance."""
+    from rrnco_amd.envs.rmtvrp import RMTVRPGenerator, VARIANT_PRESETS
+    g = torch.Generator().manual_seed(0)
+    for preset, keys in VARIANT_PRESETS.items():
+        td = RMTVRPGenerator(num_loc=12, variant_preset=preset, device="cpu")(16, generator=g)
+        if preset == "vrptw":
+            assert "open_route" not in td.keys() and bool(torch.isfinite(td["time_windows"]).all())
+            continue
+        o, lim, bh = td["open_route"][:, 0], torch.isfinite(td["distance_limit"][:, 0]), (td["demand_backhaul"] > 0).any(1)
+        tw = torch.isfinite(td["time_windows"][..., 1]).all(1)
+        if "?" in keys:
+            assert ((o.int() + lim.int() + tw.int() + bh.int()) <= 1).all()
+            if preset == "cvrp":
+                assert not (o | lim | tw | bh).any()
+        else:
+            assert bool((o == ("O" in keys)).all()) and bool((lim == ("L" in keys)).all()) and bool((tw == ("T" in keys)).all())
+            if "B" not in keys:
+                assert not bh.any()
+        assert bool((td["service_time"][~tw] == 0).all()) and bool((td["demand_linehaul"] >= 0).all())
+        assert bool(((td["demand_linehaul"] > 0) ^ (td["demand_backhaul"] > 0)).all())      # every customer is one or the other

@@ -191,3 +191,33 @@ def test_rcvrptw_policy_greedy_routes_match_reference(name, fused):
     same = first < 0
     assert torch.allclose(out["reward"].cpu()[same], fx["reward"][same], atol=COST_ATOL)
     assert torch.allclose(out["log_likelihood"].cpu()[same], fx["log_likelihood"][same], rtol=LL_RTOL, atol=LL_ATOL)
+
+
+@pytest.mark.parametrize("preset", ["cvrp", "ovrp", "vrpb", "vrpl", "ovrpbl", "vrpbltw", "ovrpbltw", "all"])
+def test_rmtvrp_generator_presets_env_dynamics_match_oracle(preset):
+    """rmtvrp/generator.py:37-58, 352-432: every feature combination the presets produce (infinite time windows and limits,
+    backhaul demands folded into linehaul, open routes) through reset / step / get_action_mask on the kernels against the
+    oracle, along random feasible walks.  (The RRNet policy itself needs finite time windows: RVRPTWInitEmbedding feeds the raw
+    windows to a Linear, in the reference as here — the non-TW presets are an environment feature.)"""
+    from rrnco_amd.envs import RMTVRPEnv
+    dev = torch.device("cuda")
+    env = RMTVRPEnv(generator_params=dict(num_loc=20, variant_preset=preset, device=dev, sample_backhaul_class=True), device=dev)
+    td_in = env.generator(8, generator=torch.Generator(device=dev).manual_seed(11))
+    inst = {k: td_in[k].cpu() for k in td_in.keys()}
+    td = env.reset(td_in)
+    otd = restate.rmtvrp_reset(inst)
+    assert torch.equal(td["action_mask"].cpu(), otd["action_mask"])
+    otd = {k: v for k, v in otd.items() if k not in ("locs", "min_distance", "max_distance")}
+    g = torch.Generator().manual_seed(3)
+    for t in range(80):
+        m = otd["action_mask"]
+        a = torch.multinomial(m.float() + 1e-9 * (m.sum(-1, keepdim=True) == 0), 1, generator=g)[:, 0]
+        td.set("action", a.cuda()); td = env.step(td)["next"]
+        otd["action"] = a; otd = restate.rmtvrp_step(otd)
+        assert torch.equal(td["action_mask"].cpu(), otd["action_mask"]), (preset, t)
+        assert torch.equal(td["visited"].cpu(), otd["visited"]) and torch.equal(td["done"].cpu(), otd["done"])
+        for k in ("current_time", "used_capacity_linehaul", "used_capacity_backhaul", "current_route_length"):
+            assert torch.equal(td[k].cpu(), otd[k]), (preset, k, t)
+        if bool(otd["done"].all()):
+            break
+    assert bool(otd["done"].all())
