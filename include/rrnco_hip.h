@@ -78,6 +78,18 @@ typedef struct {                /* arguments of the persistent rollout: see csrc
   const void *Ks, *Vts, *Ls;    /* rr_pack_f16x2 images of K / Vt / L (same shapes) */
 } RolloutIO;
 
+/* Backward of the Neural Adaptive Bias with the duration matrix (rrnco/models/nn/attn_freenet.py:226-237, 265-286) in its folded
+ * form: h_f = relu(a_f x_f + b_f) (f = distance, angle, duration; 128 units each), z = Mcat h + cg, gate = softmax((Wg2 silu(z) +
+ * bg2) / tau), bias = sum_f gate_f (co_f . h_f + ko_f) + bo, out = alpha bias.  Given d loss / d out per edge: grads [1680] =
+ * d a [384] | d b [384] | d co [384] | d cg [128] | d Wg2 [3][128] | d bg2 [3] | d ko [3] | d (1/tau) | d bo | d alpha, and
+ * dmcat [128][384]; both are ADDED to (zero them first).  dzf: scratch of ceil(M / 16) * 16 * 128 floats. */
+typedef struct {
+  const float *a, *b, *co, *cg, *wg2, *scal;   /* scal = bg2[3], ko[3], 1/tau, bo, alpha */
+  const void *mcat, *mcatT;                    /* pack_a(Mcat [128][384]), pack_a(Mcat^T [384][128]) */
+} NabDurBwdW;
+int rr_nabdur_bwd(const NabDurBwdW* w, const float* xd, const float* xa, const float* xt, const float* gout, float* dzf,
+                  float* grads, float* dmcat, long long M, hipStream_t stream);
+
 /* fp32 -> two-piece fp16 image: every group of four values becomes its four hi and four lo' halves at the same byte offset
  * (n_floats % 4 == 0).  Used for the K / Vt / L operands of the split rollout (rrnco/models/decoder.py:214-232 products). */
 int rr_pack_f16x2(const float* src, void* dst, long long n_floats, hipStream_t stream);

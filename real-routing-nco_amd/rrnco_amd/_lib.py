@@ -90,6 +90,11 @@ class AftBwdIO(C.Structure):            # csrc/rr_train_enc.hip
     _fields_ = [(n, vp) for n in ("dy", "q", "ek", "v", "num", "den", "eaT", "dq", "dk", "dv", "dbias")] + [("N", i32)]
 
 
+class NabDurBwdW(C.Structure):
+    """csrc/rr_train_nabdur.hip: folded parameters of the duration NAB (models/grad_replay._nab_duration_params)."""
+    _fields_ = [(n, vp) for n in ("a", "b", "co", "cg", "wg2", "scal", "mcat", "mcatT")]
+
+
 class DecBigIO(C.Structure):            # csrc/rr_bign.hip
     _fields_ = [(n, vp) for n in ("K", "Vt", "L", "ctxA", "ctxB", "D", "Dur", "cur", "first", "scal", "wstate", "mask", "w1", "w2",
                                   "b1", "b2", "logits")] + [(n, i32) for n in ("Bp", "N", "NP", "S", "nscal")] + [("alpha", f32), ("beta", f32)]
@@ -104,6 +109,7 @@ _SIGS = {
     "rr_atsp_step": [vp, vp, vp, vp, i32, i32, vp],
     "rr_sample_neighbors": [vp, vp, i32, i32, i32, u64, vp],
     "rr_pack_f16x2": [vp, vp, C.c_longlong, vp],
+    "rr_nabdur_bwd": [C.POINTER(NabDurBwdW), vp, vp, vp, vp, vp, vp, vp, C.c_longlong, vp],
     "rr_rcvrp_step": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "rr_tour_cost": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp],
     "rr_select": [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, u64, u32, i32, f32, vp],

@@ -241,15 +241,12 @@ def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
     # ---- chain rule through the folds and the init embedding (autograd on tiny / [Bp*N,128] tensors)
     vrp = policy.env_name == "rcvrp"
     with torch.enable_grad():
-        # duration NAB of every block: the folded form recomputed per block (three GEMMs over all edges) and differentiated
-        # against the kernels' d bias; the angles are the same for row and col blocks, cost / duration transposed (:480-486)
+        # duration NAB of every block: csrc/rr_train_nabdur.hip on the kernels' d bias; the angles are the same for row and col
+        # blocks, cost / duration transposed (:480-486)
         Tt = Dur.transpose(1, 2).contiguous() if vtw else None
         for b, si, dbias in dur_todo:
             cost_, dur_ = (D, Dur) if si == 0 else (Dt, Tt)
-            for lo in range(0, Bp, 128):           # [edges, 384] intermediates: 2 GB each per 128 instances of 101 nodes
-                sl = slice(lo, min(Bp, lo + 128))
-                out = GR._nab_duration(P, b + ".neural_adaptive_bias", cost_[sl], theta[sl], dur_[sl], P[b + ".alpha"])
-                torch.autograd.backward(out, dbias[sl])
+            GR.nab_duration_backward_hip(P, b + ".neural_adaptive_bias", cost_, theta, dur_, P[b + ".alpha"], dbias)
         if vtw:
             extra = torch.cat([td["time_windows"].float(), td["service_time"].float()[..., None]], -1)
             row0, col0 = GR._init_embedding_vrp(P, locs, td["demand_linehaul"].float()[:, 1:], D, sample_idx, extra, "init_embed")

@@ -158,9 +158,10 @@ class _NabDurationFolded(torch.autograd.Function):
         return None, da, db, dMcat, dcg, dco, dko, dWg2, dbg2, dinv_tau, dbo, dalpha
 
 
-def _nab_duration(P, p, cost, theta, dur, alpha):
-    """alpha * DistAngleFusion(use_duration_matrix=True) attn_freenet.py:226-237, 265-286 through _NabDurationFolded; the fold
-    (M_f = Wg0_f W2_f, cg = sum_f Wg0_f b2_f + bg0, co_f = W2_f^T wo, ko_f = wo . b2_f) is packing.py's, in torch ops."""
+def _nab_duration_params(P, p, alpha):
+    """The folded parameters of DistAngleFusion(use_duration_matrix=True) as torch expressions of the module's (packing.py's fold:
+    M_f = Wg0_f W2_f, cg = sum_f Wg0_f b2_f + bg0, co_f = W2_f^T wo, ko_f = wo . b2_f): (a [384], b [384], Mcat [128,384],
+    cg [128], co [384], ko [3], Wg2 [3,128], bg2 [3], inv_tau, bo, alpha)."""
     Wg0, bg0 = P[p + ".gate.0.weight"], P[p + ".gate.0.bias"]
     wo, bo = P[p + ".out_lin.weight"][0], P[p + ".out_lin.bias"][0]
     a_, b_, Ms, cos, kos = [], [], [], [], []
@@ -171,11 +172,42 @@ def _nab_duration(P, p, cost, theta, dur, alpha):
         a_.append(P[f"{p}.{nm}.0.weight"][:, 0]); b_.append(P[f"{p}.{nm}.0.bias"])
         Ms.append(Wg0f @ W2); cg = cg + Wg0f @ b2
         cos.append(W2.t() @ wo); kos.append(wo @ b2)
+    return (torch.cat(a_), torch.cat(b_), torch.cat(Ms, dim=1), cg, torch.cat(cos), torch.stack(kos),
+            P[p + ".gate.2.weight"], P[p + ".gate.2.bias"], torch.exp(-P[p + ".gate_temperature"]), bo, alpha.reshape(()))
+
+
+def _nab_duration(P, p, cost, theta, dur, alpha):
+    """alpha * DistAngleFusion(use_duration_matrix=True) attn_freenet.py:226-237, 265-286 through _NabDurationFolded."""
     x3 = torch.stack([cost.reshape(-1), theta.reshape(-1), dur.reshape(-1)], dim=1)
-    out = _NabDurationFolded.apply(x3, torch.cat(a_), torch.cat(b_), torch.cat(Ms, dim=1), cg, torch.cat(cos), torch.stack(kos),
-                                   P[p + ".gate.2.weight"], P[p + ".gate.2.bias"], torch.exp(-P[p + ".gate_temperature"]), bo,
-                                   alpha.reshape(()))
+    out = _NabDurationFolded.apply(x3, *_nab_duration_params(P, p, alpha))
     return out.view(cost.shape)
+
+
+def nab_duration_backward_hip(P, p, cost, theta, dur, alpha, gout):
+    """d loss / d (parameters of the duration NAB of block `p`) from d loss / d bias `gout` [Bp,N,N] on the kernels of
+    csrc/rr_train_nabdur.hip (fp32 MFMA; no [edges, 384] tensor ever exists), chained to the module parameters by autograd
+    through the fold.  `cost`, `theta`, `dur` [Bp,N,N] contiguous (the col block passes the transposed matrices)."""
+    from .. import _lib as L
+    from ..packing import pack_a
+    with torch.enable_grad():
+        fp = _nab_duration_params(P, p, alpha)
+    a, b, Mcat, cg, co, ko, Wg2, bg2, inv_tau, bo, al = [t.detach().float().contiguous() for t in fp]
+    dev = cost.device
+    w = L.NabDurBwdW()
+    scal = torch.cat([bg2.reshape(3), ko.reshape(3), inv_tau.reshape(1), bo.reshape(1), al.reshape(1)]).contiguous()
+    mc, mct = pack_a(Mcat), pack_a(Mcat.t().contiguous())
+    w.a, w.b, w.co, w.cg, w.wg2, w.scal, w.mcat, w.mcatT = (L.ptr(a), L.ptr(b), L.ptr(co), L.ptr(cg), L.ptr(Wg2), L.ptr(scal),
+                                                           L.ptr(mc), L.ptr(mct))
+    M = cost.numel()
+    grads = torch.zeros(1680, device=dev)
+    dmcat = torch.zeros(128, 384, device=dev)
+    dzf = torch.empty(((M + 15) // 16) * 16 * 128, device=dev)
+    L.check(L.lib().rr_nabdur_bwd(w, L.ptr(cost), L.ptr(theta), L.ptr(dur), L.ptr(gout.contiguous()), L.ptr(dzf), L.ptr(grads),
+                                  L.ptr(dmcat), M, L.stream()), "rr_nabdur_bwd")
+    g = grads
+    gl = [g[0:384], g[384:768], dmcat, g[1152:1280], g[768:1152], g[1667:1670], g[1280:1664].view(3, 128), g[1664:1667],
+          g[1670].reshape(fp[8].shape), g[1671].reshape(fp[9].shape), g[1672].reshape(fp[10].shape)]
+    torch.autograd.backward(list(fp), [x.to(t.dtype).reshape(t.shape) for x, t in zip(gl, fp)])
 
 
 def _block(P, p, x, y, cost, theta, dur=None):

@@ -254,3 +254,42 @@ def test_nab_backward_from_segment_moments_matches_the_per_unit_kernel():
             r_, g_ = ref[128 * i:128 * (i + 1)], got[128 * i:128 * (i + 1)]
             assert float((g_ - r_).abs().max()) < 2e-3 * float(r_.abs().max()) + 1e-4, (blk, nm, float((g_ - r_).abs().max()), float(r_.abs().max()))
         assert torch.allclose(got[1024:1031], ref[1024:1031], rtol=2e-3, atol=1e-3), (got[1024:1032], ref[1024:1032])
+
+
+def test_duration_nab_backward_kernels_match_float64_autograd():
+    """csrc/rr_train_nabdur.hip against float64 autograd through the folded duration NAB (models/grad_replay._NabDurationFolded's
+    own forward): every folded-parameter gradient, on edges that are not a multiple of the 16-edge tile."""
+    from rrnco_amd import _lib as L
+    from rrnco_amd.packing import pack_a
+    from rrnco_amd.models.grad_replay import _NabDurationFolded as F
+    torch.manual_seed(3)
+    dev = torch.device("cuda")
+    M = 16 * 37 + 5
+    a, b = torch.randn(384, device=dev), torch.randn(384, device=dev) * 0.5
+    Mcat, cg = torch.randn(128, 384, device=dev) * 0.08, torch.randn(128, device=dev) * 0.1
+    co, ko = torch.randn(384, device=dev) * 0.1, torch.randn(3, device=dev) * 0.1
+    Wg2, bg2 = torch.randn(3, 128, device=dev) * 0.2, torch.randn(3, device=dev) * 0.1
+    inv_tau, bo, alpha = torch.tensor(1.3, device=dev), torch.tensor(0.2, device=dev), torch.tensor(0.7, device=dev)
+    x3 = torch.rand(M, 3, device=dev) * torch.tensor([1.0, 6.28, 1.0], device=dev) - torch.tensor([0.0, 3.14, 0.0], device=dev)
+    gout = torch.randn(M, device=dev)
+    prm = [a, b, Mcat, cg, co, ko, Wg2, bg2, inv_tau, bo, alpha]
+    p64 = [t.double().requires_grad_(True) for t in prm]
+    _, _, _, _, _, _, g64, po64 = F._forward_parts(x3.double(), *p64[:9])
+    out = ((g64 * po64).sum(-1) + p64[9]) * p64[10]
+    ref = torch.autograd.grad(out, p64, gout.double())
+    w = L.NabDurBwdW()
+    scal = torch.cat([bg2, ko, inv_tau.reshape(1), bo.reshape(1), alpha.reshape(1)]).contiguous()
+    mc, mct = pack_a(Mcat), pack_a(Mcat.t().contiguous())
+    w.a, w.b, w.co, w.cg, w.wg2, w.scal, w.mcat, w.mcatT = (L.ptr(a), L.ptr(b), L.ptr(co), L.ptr(cg), L.ptr(Wg2), L.ptr(scal), L.ptr(mc), L.ptr(mct))
+    grads, dmcat = torch.zeros(1680, device=dev), torch.zeros(128, 384, device=dev)
+    dzf = torch.empty(((M + 15) // 16) * 16 * 128, device=dev)
+    xs = [x3[:, i].contiguous() for i in range(3)]
+    L.check(L.lib().rr_nabdur_bwd(w, L.ptr(xs[0]), L.ptr(xs[1]), L.ptr(xs[2]), L.ptr(gout), L.ptr(dzf), L.ptr(grads), L.ptr(dmcat), M,
+                                  L.stream()), "rr_nabdur_bwd")
+    g = grads.double()
+    got = [g[0:384], g[384:768], dmcat.double(), g[1152:1280], g[768:1152], g[1667:1670], g[1280:1664].view(3, 128), g[1664:1667],
+           g[1670], g[1671], g[1672]]
+    names = ["a", "b", "Mcat", "cg", "co", "ko", "Wg2", "bg2", "inv_tau", "bo", "alpha"]
+    for n, x, r in zip(names, got, ref):
+        err = (x.reshape(r.shape) - r).norm() / (r.norm() + 1e-12)
+        assert err < (5e-3 if n in ("a", "b") else 2e-4), (n, float(err))       # a / b: ReLU-kink flips of single units (see the MLP tests)
