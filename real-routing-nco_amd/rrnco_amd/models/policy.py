@@ -40,12 +40,26 @@ class RRNetPolicy(nn.Module):
     def invalidate_pack(self) -> None:
         self._pack_cache = None
 
+    def train(self, mode: bool = True):
+        self._pack_dirty = True          # any train() / eval() switch: re-check the weights' fingerprint once (see packed())
+        return super().train(mode)
+
     def packed(self, device):
         # buffers too: BatchNorm running statistics are folded into the pack (packing.py), and a buffer-only load must repack
         ts = list(self.parameters()) + list(self.buffers())
-        key = (str(device), packing.mlp_split_enabled(), tuple(p._version for p in ts),
-               tuple(p.data_ptr() for p in ts), packing.weights_fingerprint(self))
+        key = (str(device), packing.mlp_split_enabled(), tuple(p._version for p in ts), tuple(p.data_ptr() for p in ts))
+        # The norm fingerprint (one multi-tensor launch + ONE HOST READ) catches in-place updates that do not bump the version
+        # counters (fused optimizers).  Those only happen around training-mode calls: an eval-mode module that has not been in
+        # training mode since its last pack is checked by versions and pointers alone — no host synchronisation per inference call.
+        dirty = self.training or getattr(self, "_pack_dirty", True)
+        if dirty:
+            key = key + (packing.weights_fingerprint(self),)
+            self._pack_dirty = self.training
+        elif self._pack_cache is not None:
+            key = key + (self._pack_cache[0][-1],)
         if self._pack_cache is None or self._pack_cache[0] != key:
+            if not dirty:
+                key = key[:4] + (packing.weights_fingerprint(self),)
             self._pack_cache = (key, packing.pack_policy(self.state_dict(), self.env_name, device))
         return self._pack_cache[1]
 
