@@ -82,6 +82,8 @@ def test_c3_rcvrp_full_batch_feasibility():
     assert float(load.max()) <= 1.0 + 1e-5
     cost = _route_cost(td["distance_matrix"], acts, b_of_r, closed_by_depot=True)
     assert float((out["normalized_reward"].double() + cost).abs().max()) < 5e-4                     # rcvrp/env.py:197-219
+    out2 = pol(td, env, phase="val", decode_type="multistart_greedy", num_starts=S)                  # bit-identical repeat
+    assert torch.equal(out2["actions"], acts) and torch.equal(out2["log_likelihood"], out["log_likelihood"])
 
 
 def test_c4_rcvrptw_full_batch_sampling_feasibility():
@@ -122,7 +124,7 @@ def test_c4_rcvrptw_full_batch_sampling_feasibility():
     ll = out["log_likelihood"]
     assert bool(torch.isfinite(ll).all()) and bool((ll <= 0).all())
     out2 = pol(td, env, phase="val", decode_type="multistart_sampling", num_starts=S, seed=3)        # counter-based generator
-    assert torch.equal(out2["actions"], acts)
+    assert torch.equal(out2["actions"], acts) and torch.equal(out2["log_likelihood"], ll)              # bit-identical repeat
     out3 = pol(td, env, phase="val", decode_type="multistart_sampling", num_starts=S, seed=4)
     assert not torch.equal(out3["actions"][:, :out2["actions"].shape[1]][: , :10], acts[:, :10])
 
