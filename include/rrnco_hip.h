@@ -82,10 +82,12 @@ typedef struct {                /* arguments of the persistent rollout: see csrc
  * form: h_f = relu(a_f x_f + b_f) (f = distance, angle, duration; 128 units each), z = Mcat h + cg, gate = softmax((Wg2 silu(z) +
  * bg2) / tau), bias = sum_f gate_f (co_f . h_f + ko_f) + bo, out = alpha bias.  Given d loss / d out per edge: grads [1680] =
  * d a [384] | d b [384] | d co [384] | d cg [128] | d Wg2 [3][128] | d bg2 [3] | d ko [3] | d (1/tau) | d bo | d alpha, and
- * dmcat [128][384]; both are ADDED to (zero them first).  dzf: scratch of ceil(M / 16) * 16 * 128 floats. */
+ * dmcat [128][384]; both are ADDED to (zero them first).  dzf: scratch of ceil(M / 32) * 32 * 128 floats. */
 typedef struct {
   const float *a, *b, *co, *cg, *wg2, *scal;   /* scal = bg2[3], ko[3], 1/tau, bo, alpha */
   const void *mcat, *mcatT;                    /* pack_a(Mcat [128][384]), pack_a(Mcat^T [384][128]) */
+  const void *mcat_s, *mcatT_s;                /* optional packing.pack_bf16x2 of the same two: the kernels then run on the bf16 pipe with
+                                                * two-piece split operands (error 2^-16 of a product); NULL: fp32 MFMA */
 } NabDurBwdW;
 int rr_nabdur_bwd(const NabDurBwdW* w, const float* xd, const float* xa, const float* xt, const float* gout, float* dzf,
                   float* grads, float* dmcat, long long M, hipStream_t stream);

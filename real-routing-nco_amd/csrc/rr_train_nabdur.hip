@@ -14,12 +14,14 @@
 //       recomputes H from the three scalars of an edge (nothing but dZ is read back), accumulates 24 output tiles in registers
 //       over a grid-strided set of 16-edge tiles, one atomic add per entry and workgroup at the end.
 #include "rr_common.h"
+#include <cstdlib>
 
 struct NabDurBwdW {
   const float *a, *b, *co;       // [384] each (family-major)
   const float *cg, *wg2;         // [128], [3][128]
   const float* scal;             // bg2[3], ko[3], inv_tau, bo, alpha
   const float4 *mcat, *mcatT;    // pack_a(Mcat [128][384]) = [8][24][64], pack_a(Mcat^T [384][128]) = [24][8][64]
+  const void *mcat_s, *mcatT_s;  // optional: packing.pack_bf16x2 of the same two matrices ([8][12][2][64][8], [24][4][2][64][8]): bf16 pipe
 };
 // gradient buffer layout (floats)
 #define ND_DA 0
@@ -260,11 +262,293 @@ __global__ __launch_bounds__(512, 2) void k_nabdur_bwd_mcat(NabDurBwdW w, const 
       if (acc[t][r] != 0.f) atomicAdd(&dmcat[(size_t)(16 * u + 4 * g + r) * 384 + 16 * t + j], acc[t][r]);
 }
 
-// grads [ND_GRADS] and dmcat [128 * 384] must be zero-filled by the caller (the kernels add); dzf: M rounded up to 16 x 128 floats
+// ------------------------------------------------------------------------------------------------
+// The same two kernels on the bf16 matrix pipe with two-piece split operands (x = hi + lo, three partial products, error
+// 2^-16 of a product: the scheme of csrc/rr_train_dec.hip): 576 MFMAs of 16 cycles per 16 edges instead of 1 536 of 32, and a
+// d Mcat kernel that shares the dZ fragments of a 32-edge tile through LDS (LDS-DMA, double buffered) among eight waves that
+// each own three of the 24 unit tiles.
+typedef rr_bf16x8 ndfrag;
+__device__ __forceinline__ void nd_split8(const float (&x)[8], ndfrag& hi, ndfrag& lo) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const rr_f32x2 v = {x[2 * q], x[2 * q + 1]};
+    const rr_bf16x2 h = __builtin_convertvector(v, rr_bf16x2);
+    const rr_f32x2 r1 = v - __builtin_convertvector(h, rr_f32x2);
+    const rr_bf16x2 l = __builtin_convertvector(r1, rr_bf16x2);
+    hi[2 * q] = h[0]; hi[2 * q + 1] = h[1]; lo[2 * q] = l[0]; lo[2 * q + 1] = l[1];
+  }
+}
+__device__ __forceinline__ f32x4 nd_mfma3(ndfrag ah, ndfrag al, ndfrag bh, ndfrag bl, f32x4 c) {
+  c = rr_mfma_bf16(ah, bl, c);
+  c = rr_mfma_bf16(al, bh, c);
+  return rr_mfma_bf16(ah, bh, c);
+}
+
+__global__ __launch_bounds__(256, 2) void k_nabdur_bwd_edges2(NabDurBwdW w, const float* __restrict__ xd, const float* __restrict__ xa,
+                                                              const float* __restrict__ xt, const float* __restrict__ gout,
+                                                              char* __restrict__ dzf, float* __restrict__ grads, long long M) {
+  __shared__ __attribute__((aligned(16))) float par[3 * 384 + 128 + 384 + 16];
+  __shared__ __attribute__((aligned(16))) float acc[ND_GRADS];
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < 384; i += 256) { par[i] = w.a[i]; par[384 + i] = w.b[i]; par[768 + i] = w.co[i]; par[1280 + i] = w.wg2[i]; }
+  for (int i = tid; i < 128; i += 256) par[1152 + i] = w.cg[i];
+  if (tid < 9) par[1664 + tid] = w.scal[tid];
+  for (int i = tid; i < ND_GRADS; i += 256) acc[i] = 0.f;
+  __syncthreads();
+  const float *pa = par, *pb = par + 384, *pco = par + 768, *pcg = par + 1152, *pw = par + 1280, *ps = par + 1664;
+  const float inv_tau = ps[6], bo = ps[7], alpha = ps[8];
+  const long long ntile = ((M + 31) / 32) * 2;                // 16-edge tiles, an even number: both halves of every 32-edge dZ tile are written
+  const __amdgpu_buffer_rsrc_t rM = rr_make_buf(w.mcat_s, 128 * 384 * 4), rMT = rr_make_buf(w.mcatT_s, 128 * 384 * 4);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  float s_bg[3] = {0.f, 0.f, 0.f}, s_ko[3] = {0.f, 0.f, 0.f}, s_tau = 0.f, s_bo = 0.f, s_al = 0.f;
+  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntile; tile += (long long)gridDim.x * 4) {
+    const long long e = tile * 16 + j;
+    const bool valid = e < M;
+    const float x[3] = {valid ? xd[e] : 0.f, valid ? xa[e] : 0.f, valid ? xt[e] : 0.f};
+    const float go = valid ? gout[e] : 0.f;
+    // ---- H^T (unit 16t + 4g + r of edge j), po = co . h per family, then H as bf16 pieces in k = 32 operand order
+    float po[3] = {0.f, 0.f, 0.f};
+    ndfrag Hh[12], Hl[12];
+#pragma unroll
+    for (int sl = 0; sl < 12; ++sl) {
+      if ((sl & 1) == 0) __builtin_amdgcn_sched_barrier(0);
+      float hv[8];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int t = 2 * sl + q;
+        const float4 a4 = rr_ld4(pa + 16 * t + 4 * g), b4 = rr_ld4(pb + 16 * t + 4 * g), c4 = rr_ld4(pco + 16 * t + 4 * g);
+        const float xx = x[t >> 3];
+        hv[4 * q] = fmaxf(fmaf(a4.x, xx, b4.x), 0.f); hv[4 * q + 1] = fmaxf(fmaf(a4.y, xx, b4.y), 0.f);
+        hv[4 * q + 2] = fmaxf(fmaf(a4.z, xx, b4.z), 0.f); hv[4 * q + 3] = fmaxf(fmaf(a4.w, xx, b4.w), 0.f);
+        po[t >> 3] += hv[4 * q] * c4.x + hv[4 * q + 1] * c4.y + hv[4 * q + 2] * c4.z + hv[4 * q + 3] * c4.w;
+      }
+      nd_split8(hv, Hh[sl], Hl[sl]);
+    }
+    // ---- Z^T = Mcat H^T + cg
+    f32x4 Z[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float4 c4 = rr_ld4(pcg + 16 * u + 4 * g);
+      f32x4 c0 = {c4.x, c4.y, c4.z, c4.w}, c1 = rr_zero4();
+#pragma unroll
+      for (int sl = 0; sl < 12; sl += 2) {
+        if ((sl & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+        const ndfrag a0h = rr_bldh(rM, lane16, (unsigned)((u * 12 + sl) * 2) * 1024u), a0l = rr_bldh(rM, lane16, (unsigned)((u * 12 + sl) * 2 + 1) * 1024u);
+        const ndfrag a1h = rr_bldh(rM, lane16, (unsigned)((u * 12 + sl + 1) * 2) * 1024u), a1l = rr_bldh(rM, lane16, (unsigned)((u * 12 + sl + 1) * 2 + 1) * 1024u);
+        c0 = nd_mfma3(a0h, a0l, Hh[sl], Hl[sl], c0);
+        c1 = nd_mfma3(a1h, a1l, Hh[sl + 1], Hl[sl + 1], c1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Z[u][r] = c0[r] + c1[r];
+    }
+    // ---- gate and output
+    float l[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if ((u & 1) == 0) __builtin_amdgcn_sched_barrier(0);
+      const float4 w0 = rr_ld4(pw + 16 * u + 4 * g), w1 = rr_ld4(pw + 128 + 16 * u + 4 * g), w2 = rr_ld4(pw + 256 + 16 * u + 4 * g);
+      const float ww0[4] = {w0.x, w0.y, w0.z, w0.w}, ww1[4] = {w1.x, w1.y, w1.z, w1.w}, ww2[4] = {w2.x, w2.y, w2.z, w2.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float sv = Z[u][r] / (1.0f + __expf(-Z[u][r]));
+        l[0] = fmaf(ww0[r], sv, l[0]); l[1] = fmaf(ww1[r], sv, l[1]); l[2] = fmaf(ww2[r], sv, l[2]);
+      }
+    }
+    float gt[3], lr[3];
+#pragma unroll
+    for (int f = 0; f < 3; ++f) { lr[f] = rr_sum_g(l[f]) + ps[f]; po[f] = rr_sum_g(po[f]) + ps[3 + f]; }
+    const float mx = fmaxf(fmaxf(lr[0], lr[1]), lr[2]) * inv_tau;
+    float es = 0.f;
+#pragma unroll
+    for (int f = 0; f < 3; ++f) { gt[f] = __expf(lr[f] * inv_tau - mx); es += gt[f]; }
+    float bias = bo;
+#pragma unroll
+    for (int f = 0; f < 3; ++f) { gt[f] /= es; bias = fmaf(gt[f], po[f], bias); }
+    const float dbias = go * alpha;
+    float dpo[3], dg[3], gdg = 0.f, dlr[3];
+#pragma unroll
+    for (int f = 0; f < 3; ++f) { dpo[f] = dbias * gt[f]; dg[f] = dbias * po[f]; gdg = fmaf(gt[f], dg[f], gdg); }
+    float dtau = 0.f;
+#pragma unroll
+    for (int f = 0; f < 3; ++f) { const float dl = gt[f] * (dg[f] - gdg); dtau = fmaf(dl, lr[f], dtau); dlr[f] = dl * inv_tau; }
+    if (g == 0) {
+#pragma unroll
+      for (int f = 0; f < 3; ++f) { s_bg[f] += dlr[f]; s_ko[f] += dpo[f]; }
+      s_tau += dtau; s_bo += dbias; s_al += go * bias;
+    }
+    // ---- dZ (in place), d cg / d Wg2 row sums, dZ as bf16 pieces: B fragments of the 32-edge tile for k_nabdur_bwd_mcat2
+    f32x4 (&DZ)[8] = Z;
+    const long long t32 = tile >> 1;
+    const int eo = (int)(tile & 1) * 16 + j;                  // edge within the 32-edge tile
+    char* dst0 = dzf + (size_t)t32 * 16 * 1024 + ((eo >> 3) * 16) * 16 + (eo & 7) * 2;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      __builtin_amdgcn_sched_barrier(0);
+      const float4 w0 = rr_ld4(pw + 16 * u + 4 * g), w1 = rr_ld4(pw + 128 + 16 * u + 4 * g), w2 = rr_ld4(pw + 256 + 16 * u + 4 * g);
+      const float ww0[4] = {w0.x, w0.y, w0.z, w0.w}, ww1[4] = {w1.x, w1.y, w1.z, w1.w}, ww2[4] = {w2.x, w2.y, w2.z, w2.w};
+      f32x4 r0, r1, r2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float z = Z[u][r];
+        const float sg = 1.0f / (1.0f + __expf(-z)), sv = z * sg;
+        const float ds = ww0[r] * dlr[0] + ww1[r] * dlr[1] + ww2[r] * dlr[2];
+        DZ[u][r] = ds * (sg * (1.0f + z * (1.0f - sg)));
+        r0[r] = dlr[0] * sv; r1[r] = dlr[1] * sv; r2[r] = dlr[2] * sv;
+        // fragment (t32, u, piece): lane' = g' * 16 + (4g + r) with g' = eo >> 3, element eo & 7
+        const __bf16 hi = (__bf16)DZ[u][r];
+        const __bf16 lo = (__bf16)(DZ[u][r] - (float)hi);
+        char* d = dst0 + (size_t)(u * 2) * 1024 + (4 * g + r) * 16;
+        *reinterpret_cast<__bf16*>(d) = hi;
+        *reinterpret_cast<__bf16*>(d + 1024) = lo;
+      }
+      f32x4 dc = DZ[u];
+      nd_rowsum4(dc); nd_rowsum4(r0); nd_rowsum4(r1); nd_rowsum4(r2);
+      if (j == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          atomicAdd(&acc[ND_DCG + 16 * u + 4 * g + r], dc[r]);
+          atomicAdd(&acc[ND_DWG2 + 16 * u + 4 * g + r], r0[r]);
+          atomicAdd(&acc[ND_DWG2 + 128 + 16 * u + 4 * g + r], r1[r]);
+          atomicAdd(&acc[ND_DWG2 + 256 + 16 * u + 4 * g + r], r2[r]);
+        }
+      }
+    }
+    ndfrag Dh[4], Dl[4];
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      const float dv[8] = {DZ[2 * sl][0], DZ[2 * sl][1], DZ[2 * sl][2], DZ[2 * sl][3], DZ[2 * sl + 1][0], DZ[2 * sl + 1][1], DZ[2 * sl + 1][2], DZ[2 * sl + 1][3]};
+      nd_split8(dv, Dh[sl], Dl[sl]);
+    }
+    // ---- dH^T = Mcat^T dZ^T tile by tile; d pre-activation; d a, d b, d co row sums
+#pragma unroll 1
+    for (int t = 0; t < 24; ++t) {
+      f32x4 c0 = rr_zero4(), c1 = rr_zero4();
+#pragma unroll
+      for (int sl = 0; sl < 4; sl += 2) {
+        const ndfrag a0h = rr_bldh(rMT, lane16, (unsigned)((t * 4 + sl) * 2) * 1024u), a0l = rr_bldh(rMT, lane16, (unsigned)((t * 4 + sl) * 2 + 1) * 1024u);
+        const ndfrag a1h = rr_bldh(rMT, lane16, (unsigned)((t * 4 + sl + 1) * 2) * 1024u), a1l = rr_bldh(rMT, lane16, (unsigned)((t * 4 + sl + 1) * 2 + 1) * 1024u);
+        c0 = nd_mfma3(a0h, a0l, Dh[sl], Dl[sl], c0);
+        c1 = nd_mfma3(a1h, a1l, Dh[sl + 1], Dl[sl + 1], c1);
+      }
+      const int f = t >> 3;
+      const float4 c4 = rr_ld4(pco + 16 * t + 4 * g);
+      const float cc[4] = {c4.x, c4.y, c4.z, c4.w};
+      const float4 a4 = rr_ld4(pa + 16 * t + 4 * g), b4 = rr_ld4(pb + 16 * t + 4 * g);
+      const float aa[4] = {a4.x, a4.y, a4.z, a4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
+      const float xx = f == 0 ? x[0] : f == 1 ? x[1] : x[2];
+      const float dpf = f == 0 ? dpo[0] : f == 1 ? dpo[1] : dpo[2];
+      f32x4 da, db, dco;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float h = fmaxf(fmaf(aa[r], xx, bb[r]), 0.f);
+        const float dpre = h > 0.f ? (c0[r] + c1[r]) + cc[r] * dpf : 0.f;
+        da[r] = dpre * xx; db[r] = dpre; dco[r] = h * dpf;
+      }
+      nd_rowsum4(da); nd_rowsum4(db); nd_rowsum4(dco);
+      if (j == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          atomicAdd(&acc[ND_DA + 16 * t + 4 * g + r], da[r]);
+          atomicAdd(&acc[ND_DB + 16 * t + 4 * g + r], db[r]);
+          atomicAdd(&acc[ND_DCO + 16 * t + 4 * g + r], dco[r]);
+        }
+      }
+    }
+  }
+  {
+    float v[9] = {s_bg[0], s_bg[1], s_bg[2], s_ko[0], s_ko[1], s_ko[2], s_tau, s_bo, s_al};
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { const float r = nd_rowsum1(v[q]); if (lane == 0) atomicAdd(&acc[ND_DSC + q], r); }
+  }
+  __syncthreads();
+  for (int i = tid; i < ND_GRADS; i += 256) { const float v = acc[i]; if (v != 0.f) atomicAdd(&grads[i], v); }
+}
+
+__global__ __launch_bounds__(512, 2) void k_nabdur_bwd_mcat2(NabDurBwdW w, const float* __restrict__ xd, const float* __restrict__ xa,
+                                                             const float* __restrict__ xt, const char* __restrict__ dzf,
+                                                             float* __restrict__ dmcat, long long M) {
+  __shared__ __attribute__((aligned(16))) char stage[2][16 * 1024];      // dZ fragments of a 32-edge tile: (u, piece) x 1 KB
+  const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // this wave's unit tiles t = 3 wave .. 3 wave + 2; lane (i, g) = unit 16t + i, edges 8g .. 8g + 7 of the tile
+  float ua[3], ub[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) { ua[q] = w.a[16 * (3 * wave + q) + i]; ub[q] = w.b[16 * (3 * wave + q) + i]; }
+  f32x4 acc[3][8];
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[q][u] = rr_zero4();
+  const long long ntile = (M + 31) / 32;
+  auto issue = [&](long long tile, int buf) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int f = 2 * wave + q;
+      rr_glds16(dzf + (size_t)tile * 16 * 1024 + f * 1024 + lane * 16, stage[buf] + f * 1024);
+    }
+  };
+  int buf = 0;
+  if ((long long)blockIdx.x < ntile) issue(blockIdx.x, 0);
+  for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tile + gridDim.x < ntile) issue(tile + gridDim.x, buf ^ 1);
+    float xs[3][8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const long long e = tile * 32 + 8 * g + q;
+      const bool ok = e < M;
+      xs[0][q] = ok ? xd[e] : 0.f; xs[1][q] = ok ? xa[e] : 0.f; xs[2][q] = ok ? xt[e] : 0.f;
+    }
+    ndfrag Bh[8], Bl[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      Bh[u] = *reinterpret_cast<const ndfrag*>(stage[buf] + (u * 2) * 1024 + lane * 16);
+      Bl[u] = *reinterpret_cast<const ndfrag*>(stage[buf] + (u * 2 + 1) * 1024 + lane * 16);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int f = (3 * wave + q) >> 3;                     // wave-uniform
+      float hv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float xx = f == 0 ? xs[0][k] : f == 1 ? xs[1][k] : xs[2][k];
+        const long long e = tile * 32 + 8 * g + k;
+        hv[k] = e < M ? fmaxf(fmaf(ua[q], xx, ub[q]), 0.f) : 0.f;
+      }
+      ndfrag Ah, Al;
+      nd_split8(hv, Ah, Al);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[q][u] = nd_mfma3(Ah, Al, Bh[u], Bl[u], acc[q][u]);
+    }
+    buf ^= 1;
+  }
+  // acc[q][u]: rows = units 16 (3 wave + q) + 4g + r, columns = z 16u + i
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (acc[q][u][r] != 0.f) atomicAdd(&dmcat[(size_t)(16 * u + i) * 384 + 16 * (3 * wave + q) + 4 * g + r], acc[q][u][r]);
+}
+
+// grads [ND_GRADS] and dmcat [128 * 384] must be zero-filled by the caller (the kernels add); dzf: M rounded up to 32, x 128 floats
 extern "C" int rr_nabdur_bwd(const NabDurBwdW* w, const float* xd, const float* xa, const float* xt, const float* gout, float* dzf,
                              float* grads, float* dmcat, long long M, hipStream_t st) {
   if (M <= 0) return RR_OK;
   if (w == nullptr || xd == nullptr || xa == nullptr || xt == nullptr || gout == nullptr || dzf == nullptr) return RR_EINVAL;
+  static const int f32only = getenv("RR_NABDUR_F32") ? atoi(getenv("RR_NABDUR_F32")) : 0;
+  if (w->mcat_s != nullptr && w->mcatT_s != nullptr && !f32only) {      // bf16 pipe, two-piece operands
+    const long long nt16 = ((M + 31) / 32) * 2, nt32 = (M + 31) / 32;
+    const int g1 = (int)((nt16 + 3) / 4 < 2048 ? (nt16 + 3) / 4 : 2048);
+    hipLaunchKernelGGL(k_nabdur_bwd_edges2, dim3(g1), dim3(256), 0, st, *w, xd, xa, xt, gout, (char*)dzf, grads, M);
+    const int g2 = (int)(nt32 < 512 ? nt32 : 512);
+    hipLaunchKernelGGL(k_nabdur_bwd_mcat2, dim3(g2), dim3(512), 0, st, *w, xd, xa, xt, (const char*)dzf, dmcat, M);
+    return rr_check(hipGetLastError());
+  }
   const long long ntile = (M + 15) / 16;
   const int g1 = (int)((ntile + 3) / 4 < 2048 ? (ntile + 3) / 4 : 2048);
   hipLaunchKernelGGL(k_nabdur_bwd_edges, dim3(g1), dim3(256), 0, st, *w, xd, xa, xt, gout, (float4*)dzf, grads, M);

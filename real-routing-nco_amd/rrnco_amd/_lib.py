@@ -92,7 +92,7 @@ class AftBwdIO(C.Structure):            # csrc/rr_train_enc.hip
 
 class NabDurBwdW(C.Structure):
     """csrc/rr_train_nabdur.hip: folded parameters of the duration NAB (models/grad_replay._nab_duration_params)."""
-    _fields_ = [(n, vp) for n in ("a", "b", "co", "cg", "wg2", "scal", "mcat", "mcatT")]
+    _fields_ = [(n, vp) for n in ("a", "b", "co", "cg", "wg2", "scal", "mcat", "mcatT", "mcat_s", "mcatT_s")]
 
 
 class DecBigIO(C.Structure):            # csrc/rr_bign.hip

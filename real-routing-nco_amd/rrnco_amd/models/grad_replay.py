@@ -188,7 +188,7 @@ def nab_duration_backward_hip(P, p, cost, theta, dur, alpha, gout):
     csrc/rr_train_nabdur.hip (fp32 MFMA; no [edges, 384] tensor ever exists), chained to the module parameters by autograd
     through the fold.  `cost`, `theta`, `dur` [Bp,N,N] contiguous (the col block passes the transposed matrices)."""
     from .. import _lib as L
-    from ..packing import pack_a
+    from ..packing import pack_a, pack_bf16x2
     with torch.enable_grad():
         fp = _nab_duration_params(P, p, alpha)
     a, b, Mcat, cg, co, ko, Wg2, bg2, inv_tau, bo, al = [t.detach().float().contiguous() for t in fp]
@@ -196,12 +196,14 @@ def nab_duration_backward_hip(P, p, cost, theta, dur, alpha, gout):
     w = L.NabDurBwdW()
     scal = torch.cat([bg2.reshape(3), ko.reshape(3), inv_tau.reshape(1), bo.reshape(1), al.reshape(1)]).contiguous()
     mc, mct = pack_a(Mcat), pack_a(Mcat.t().contiguous())
+    ms, mst = pack_bf16x2(Mcat), pack_bf16x2(Mcat.t().contiguous())      # bf16 pipe, two-piece operands (RR_NABDUR_F32=1: fp32 MFMA)
     w.a, w.b, w.co, w.cg, w.wg2, w.scal, w.mcat, w.mcatT = (L.ptr(a), L.ptr(b), L.ptr(co), L.ptr(cg), L.ptr(Wg2), L.ptr(scal),
                                                            L.ptr(mc), L.ptr(mct))
+    w.mcat_s, w.mcatT_s = L.ptr(ms), L.ptr(mst)
     M = cost.numel()
     grads = torch.zeros(1680, device=dev)
     dmcat = torch.zeros(128, 384, device=dev)
-    dzf = torch.empty(((M + 15) // 16) * 16 * 128, device=dev)
+    dzf = torch.empty(((M + 31) // 32) * 32 * 128, device=dev)
     L.check(L.lib().rr_nabdur_bwd(w, L.ptr(cost), L.ptr(theta), L.ptr(dur), L.ptr(gout.contiguous()), L.ptr(dzf), L.ptr(grads),
                                   L.ptr(dmcat), M, L.stream()), "rr_nabdur_bwd")
     g = grads

@@ -256,11 +256,12 @@ def test_nab_backward_from_segment_moments_matches_the_per_unit_kernel():
         assert torch.allclose(got[1024:1031], ref[1024:1031], rtol=2e-3, atol=1e-3), (got[1024:1032], ref[1024:1032])
 
 
-def test_duration_nab_backward_kernels_match_float64_autograd():
+@pytest.mark.parametrize("split", [False, True])
+def test_duration_nab_backward_kernels_match_float64_autograd(split):
     """csrc/rr_train_nabdur.hip against float64 autograd through the folded duration NAB (models/grad_replay._NabDurationFolded's
     own forward): every folded-parameter gradient, on edges that are not a multiple of the 16-edge tile."""
     from rrnco_amd import _lib as L
-    from rrnco_amd.packing import pack_a
+    from rrnco_amd.packing import pack_a, pack_bf16x2
     from rrnco_amd.models.grad_replay import _NabDurationFolded as F
     torch.manual_seed(3)
     dev = torch.device("cuda")
@@ -281,8 +282,11 @@ def test_duration_nab_backward_kernels_match_float64_autograd():
     scal = torch.cat([bg2, ko, inv_tau.reshape(1), bo.reshape(1), alpha.reshape(1)]).contiguous()
     mc, mct = pack_a(Mcat), pack_a(Mcat.t().contiguous())
     w.a, w.b, w.co, w.cg, w.wg2, w.scal, w.mcat, w.mcatT = (L.ptr(a), L.ptr(b), L.ptr(co), L.ptr(cg), L.ptr(Wg2), L.ptr(scal), L.ptr(mc), L.ptr(mct))
+    if split:          # bf16 pipe, two-piece operands
+        ms, mst = pack_bf16x2(Mcat), pack_bf16x2(Mcat.t().contiguous())
+        w.mcat_s, w.mcatT_s = L.ptr(ms), L.ptr(mst)
     grads, dmcat = torch.zeros(1680, device=dev), torch.zeros(128, 384, device=dev)
-    dzf = torch.empty(((M + 15) // 16) * 16 * 128, device=dev)
+    dzf = torch.full((((M + 31) // 32) * 32 * 128,), float("nan"), device=dev)        # the kernels must not depend on its contents
     xs = [x3[:, i].contiguous() for i in range(3)]
     L.check(L.lib().rr_nabdur_bwd(w, L.ptr(xs[0]), L.ptr(xs[1]), L.ptr(xs[2]), L.ptr(gout), L.ptr(dzf), L.ptr(grads), L.ptr(dmcat), M,
                                   L.stream()), "rr_nabdur_bwd")
@@ -292,4 +296,4 @@ def test_duration_nab_backward_kernels_match_float64_autograd():
     names = ["a", "b", "Mcat", "cg", "co", "ko", "Wg2", "bg2", "inv_tau", "bo", "alpha"]
     for n, x, r in zip(names, got, ref):
         err = (x.reshape(r.shape) - r).norm() / (r.norm() + 1e-12)
-        assert err < (5e-3 if n in ("a", "b") else 2e-4), (n, float(err))       # a / b: ReLU-kink flips of single units (see the MLP tests)
+        assert err < (5e-3 if n in ("a", "b") else 2e-4), (n, split, float(err))       # a / b: ReLU-kink flips of single units (see the MLP tests)
