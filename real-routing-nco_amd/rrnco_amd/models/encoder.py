@@ -190,8 +190,9 @@ class RRNetEncoder(nn.Module):
         bn = self.normalization == "batch"
         norm_mode = {"instance": 0, "batch": 1, "layer": 2, "rms": 3}[self.normalization]        # rr_enc_layer norm_affine_only
         if bn and self.training:
-            raise NotImplementedError("normalization='batch' is evaluated with running statistics (module.eval()); batch "
-                                      "statistics across instances (train mode) are not implemented")
+            raise NotImplementedError("the encoder kernels evaluate normalization='batch' with running statistics (module.eval()); "
+                                      "train mode (batch statistics across instances) goes through RRNetPolicy, which runs the "
+                                      "encoder with torch ops in that mode (models/grad_replay.encode_for_policy)")
         D = td["distance_matrix"].contiguous()
         L.require_gpu(D)
         if D.shape[-1] > 103:                 # more nodes than the on-chip kernels hold: row-parallel kernels (csrc/rr_bign.hip)

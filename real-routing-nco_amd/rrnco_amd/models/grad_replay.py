@@ -38,6 +38,14 @@ def _lin(P, name, x):
 def _inorm(P, p, x):
     """Normalization attn_freenet.py:101-111: 'instance' (:104-105); 'layer' (no parameters, unbiased variance over nodes x
     features); 'rms' (RMSNorm :13-26, weight only) — told apart by which parameters the module has."""
+    if (p + ".normalizer.running_mean") in P:
+        # 'batch' in TRAIN mode (:82-83, 102-103): BatchNorm1d over the flattened B*N rows with batch statistics.  `P` then carries
+        # the module's buffers too (params_and_buffers) and "__bn_momentum__": 0.1 for the training forward (updates the running
+        # statistics, like the reference's forward), 0 for the backward's recomputation (same batch statistics, no second update).
+        mom = float(P.get("__bn_momentum__", 0.0))
+        y = F.batch_norm(x.reshape(-1, x.shape[-1]), P[p + ".normalizer.running_mean"], P[p + ".normalizer.running_var"],
+                         P[p + ".normalizer.weight"], P[p + ".normalizer.bias"], True, mom, 1e-5)
+        return y.view_as(x)
     if (p + ".normalizer.weight") not in P:
         return (x - x.mean((1, 2)).view(-1, 1, 1)) / torch.sqrt(x.var((1, 2)).view(-1, 1, 1) + 1e-05)
     if (p + ".normalizer.bias") not in P:
@@ -539,13 +547,37 @@ def decode_log_likelihood_rcvrptw(P, row_emb, col_emb, D, Dur, demand_l, tw, ser
     return logp.sum(-1)
 
 
+def params_and_buffers(policy, bn_momentum=0.0):
+    """named_parameters, plus — for normalization='batch' in train mode — the BatchNorm buffers and the momentum `_inorm` applies."""
+    P = dict(policy.named_parameters())
+    if uses_batch_statistics(policy):
+        P.update({k: v for k, v in policy.named_buffers() if ".normalizer." in k})
+        P["__bn_momentum__"] = bn_momentum
+    return P
+
+
+def uses_batch_statistics(policy) -> bool:
+    return policy.training and any(k.endswith(".normalizer.running_mean") for k in policy.state_dict())
+
+
+def encode_for_policy(policy, td, sample_idx, bn_momentum=0.0):
+    """The encoder through torch ops (the model restated for autograd above), for the one mode the fused block kernel cannot
+    serve: batch statistics across instances (normalization='batch', module.train()).  -> row_emb, col_emb."""
+    P = params_and_buffers(policy, bn_momentum)
+    nl = 1 + max(int(n.split(".")[3]) for n in P if n.startswith("encoder.net.layers."))
+    vrp, vtw = policy.env_name == "rcvrp", policy.env_name == "rcvrptw"
+    demand, extra = (td["demand"].float() if vrp else None), None
+    if vtw:
+        demand = td["demand_linehaul"].float()[:, 1:]
+        extra = torch.cat([td["time_windows"].float(), td["service_time"].float()[..., None]], -1)
+    return encode(P, td["locs"].float(), td["distance_matrix"].float(), sample_idx, nl, use_checkpoint=False, demand=demand,
+                  extra=extra, dur=td["duration_matrix"].float() if vtw else None)
+
+
 def _check_replay_supported(policy):
-    """The encoder replay (_inorm) tells the normalisation apart by its parameters; BatchNorm1d has the same two as
-    InstanceNorm1d but batch statistics in train mode (attn_freenet.py:82-83, 102-103): refuse instead of returning the
-    gradient of a different network."""
-    if any(k.endswith(".normalizer.running_mean") for k in policy.state_dict()):
-        raise NotImplementedError("gradient replay: normalization='batch' (batch statistics in train mode) is not implemented; "
-                                  "the published configuration uses 'instance' (configs/experiment/rrnet.yaml)")
+    """(normalization='batch' in train mode is served since round 2: params_and_buffers / _inorm; the replay then runs on the
+    WHOLE shard at once — batch statistics do not split into chunks.)"""
+    return None
 
 
 def replay_backward(policy, td, actions, num_starts, grad_ll, sample_idx, enc_chunk=512, dec_chunk=None, tanh_clipping=None,
@@ -561,9 +593,11 @@ def replay_backward(policy, td, actions, num_starts, grad_ll, sample_idx, enc_ch
     vrp, vtw = policy.env_name == "rcvrp", policy.env_name == "rcvrptw"
     if dec_chunk is None:      # instances per teacher-forced decoder evaluation: measured optimum (tools/bench_train.py --dec-chunk);
         dec_chunk = 64 if vtw else 256      # RCVRPTW routes are ~1.8 N steps long: 4x the rows per instance
-    P = dict(policy.named_parameters())
+    P = params_and_buffers(policy, 0.0)
     nl = 1 + max(int(n.split(".")[3]) for n in P if n.startswith("encoder.net.layers."))
     D, locs = td["distance_matrix"].float(), td["locs"].float()
+    if uses_batch_statistics(policy):
+        enc_chunk = D.shape[0]          # batch statistics: the whole shard in one piece
     demand = td["demand"].float() if vrp else None
     if vtw:
         Dur, dl_full = td["duration_matrix"].float(), td["demand_linehaul"].float()      # [B,N+1] with the depot zero
@@ -630,9 +664,11 @@ def replay_backward_hip(policy, td, capture, num_starts, grad_ll, sample_idx, en
     env_name = policy.env_name
     _check_replay_supported(policy)
     atsp, vrp, vtw = env_name == "atsp", env_name == "rcvrp", env_name == "rcvrptw"
-    P = dict(policy.named_parameters())
+    P = params_and_buffers(policy, 0.0)
     nl = 1 + max(int(n.split(".")[3]) for n in P if n.startswith("encoder.net.layers."))
     D, locs = td["distance_matrix"].float().contiguous(), td["locs"].float()
+    if uses_batch_statistics(policy):
+        enc_chunk = D.shape[0]          # batch statistics: the whole shard in one piece
     Dur = td["duration_matrix"].float().contiguous() if vtw else None
     res = decoder_backward(policy, capture["cache"], capture["dump"], D, Dur, grad_ll)
 

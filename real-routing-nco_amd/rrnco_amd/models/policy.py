@@ -98,7 +98,19 @@ class RRNetPolicy(nn.Module):
         saves = None
         if capture is not None and self.encoder.supports_hip_backward(packed) and capture.get("enc_saves", True):
             saves = capture["enc"] = []          # training forward: the encoder keeps what its hand-written backward reads
-        row_emb, col_emb = self.encoder(td, phase=phase, packed=packed, train_saves=saves)
+        from . import grad_replay as GR
+        if GR.uses_batch_statistics(self):
+            # normalization='batch' in train mode: statistics over all instances of the call — the one configuration the fused
+            # block kernel (one instance per workgroup) does not serve; the encoder runs through torch ops on the device here
+            # (forward: running statistics updated once, momentum 0.1; its backward recomputes with the same batch statistics)
+            if td.get("sample_idx", None) is None:
+                from .encoder import ATSPInitEmbedding
+                td.set("sample_idx", ATSPInitEmbedding.sample_indices(td["distance_matrix"], self.encoder.init_embedding.sample_size))
+            row_emb, col_emb = GR.encode_for_policy(self, td, td["sample_idx"], bn_momentum=0.1)
+            row_emb, col_emb = row_emb.contiguous(), col_emb.contiguous()
+            self._pack_dirty = True
+        else:
+            row_emb, col_emb = self.encoder(td, phase=phase, packed=packed, train_saves=saves)
         if capture is not None:
             capture["emb"] = (row_emb, col_emb)
 

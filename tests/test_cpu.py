@@ -648,3 +648,24 @@ def test_rmtvrp_generator_presets_keep_exactly_their_features():
                 assert not bh.any()
         assert bool((td["service_time"][~tw] == 0).all()) and bool((td["demand_linehaul"] >= 0).all())
         assert bool(((td["demand_linehaul"] > 0) ^ (td["demand_backhaul"] > 0)).all())      # every customer is one or the other
+
+
+def test_batch_norm_train_branch_of_the_replay_matches_torch_batchnorm1d():
+    """models/grad_replay._inorm with BatchNorm buffers in `P` (normalization='batch', train mode; attn_freenet.py:82-83,
+    102-103): the same numbers and the same running-statistics update as nn.BatchNorm1d over the flattened B*N rows; momentum 0
+    (the backward's recomputation) leaves the running statistics alone."""
+    from rrnco_amd.models.grad_replay import _inorm
+    torch.manual_seed(0)
+    bn = torch.nn.BatchNorm1d(128).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+    x = torch.randn(5, 17, 128) * 2 + 0.3
+    P = {"n.normalizer.weight": bn.weight, "n.normalizer.bias": bn.bias,
+         "n.normalizer.running_mean": bn.running_mean.clone(), "n.normalizer.running_var": bn.running_var.clone(), "__bn_momentum__": 0.1}
+    ref = bn(x.view(-1, 128)).view_as(x)
+    got = _inorm(P, "n", x)
+    assert torch.allclose(got, ref, atol=1e-6)
+    assert torch.allclose(P["n.normalizer.running_mean"], bn.running_mean) and torch.allclose(P["n.normalizer.running_var"], bn.running_var)
+    P["__bn_momentum__"] = 0.0
+    rm = P["n.normalizer.running_mean"].clone()
+    assert torch.allclose(_inorm(P, "n", x), ref, atol=1e-6) and torch.equal(P["n.normalizer.running_mean"], rm)

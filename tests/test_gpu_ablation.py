@@ -59,9 +59,10 @@ def test_naive_nab_without_duration_matrix_is_rejected_like_the_reference():
         pol.packed(torch.device("cuda"))
 
 
-def test_batchnorm_eval_policy_matches_reference_and_train_mode_is_rejected():
+def test_batchnorm_eval_policy_matches_reference_and_train_mode_uses_batch_statistics():
     """normalization='batch' (the constructor default of RRNetPolicy, 3 layers): running statistics folded into per-feature
-    affine maps; golden vectors from the reference in eval mode.  Batch statistics (train mode) are not implemented."""
+    affine maps; golden vectors from the reference in eval mode.  Train mode: the encoder kernels refuse (one instance per
+    workgroup), the policy serves it with batch statistics through torch ops (tests/test_gpu_train.py)."""
     fx, w, pol, inst, env, td_in = _run_plain("atsp_n20_b4_pomo_batchnorm")
     assert pol.encoder.normalization == "batch" and len(pol.encoder.net.layers) == 3
     row, col = pol.encoder(env.reset(td_in), packed=pol.packed(torch.device("cuda")))
@@ -71,7 +72,9 @@ def test_batchnorm_eval_policy_matches_reference_and_train_mode_is_rejected():
     assert torch.allclose(out["reward"].cpu(), fx["reward"], atol=COST_ATOL)
     pol.train()
     with pytest.raises(NotImplementedError, match="running statistics"):
-        pol(env.reset(td_in), env, phase="train", num_starts=fx["S"])
+        pol.encoder(env.reset(td_in), packed=pol.packed(torch.device("cuda")))
+    out_t = pol(env.reset(td_in), env, phase="train", num_starts=fx["S"])           # batch statistics: a different network function
+    assert bool(torch.isfinite(out_t["reward"]).all()) and bool(torch.isfinite(out_t["log_likelihood"]).all())
 
 
 @pytest.mark.parametrize("name,kind", [("atsp_n20_b4_pomo_rmsnorm", "rms"), ("atsp_n20_b4_pomo_layernorm", "layer")])

@@ -244,3 +244,36 @@ def test_gradient_clipping_as_the_reference_trainer():
     out = model.training_step(td_in, seed=11, grad_clip=0.05)
     total = torch.linalg.vector_norm(torch.stack([p.grad.norm() for p in pol.parameters()]))
     assert float(out["grad_norm"]) > 0.05 and abs(float(total) - 0.05) < 1e-4
+
+
+def test_batch_norm_train_mode_step_runs_and_matches_the_torch_replay():
+    """normalization='batch' with module.train() (attn_freenet.py:82-83, 102-103; the constructor default of RRNetPolicy): batch
+    statistics across the instances of the call.  The encoder then runs through torch ops (models/grad_replay.encode_for_policy);
+    the step's gradients on the kernel decoder backward equal those of the all-torch teacher-forced replay, the running statistics
+    move once per step, and the eval-mode forward (kernels, folded running statistics) works afterwards."""
+    from rrnco_amd.envs import ATSPEnv
+    from rrnco_amd.models import RRNetPolicy
+    from rrnco_amd.models.rl import RRNet
+    dev = torch.device("cuda")
+    torch.manual_seed(5)
+    pol = RRNetPolicy(env_name="atsp", embed_dim=128, num_heads=8, num_encoder_layers=2, normalization="batch",
+                      use_graph_context=False, nab_type="gating", init_embedding_kwargs=dict(sample_size=10)).to(dev).train()
+    env = ATSPEnv(generator_params=dict(num_loc=20, device=dev), check_solution=False, device=dev)
+    model = RRNet(env, policy=pol)
+    batch = env.generator(6, generator=torch.Generator(device=dev).manual_seed(2))
+    batch["sample_idx"] = torch.stack([torch.stack([torch.randperm(20, device=dev)[:10] for _ in range(20)]) for _ in range(6)])
+    rm0 = pol.state_dict()["encoder.net.layers.0.row_encoding_block.norm1.normalizer.running_mean"].clone()
+    grads = {}
+    for replay in ("hip", "torch"):
+        pol.zero_grad(set_to_none=True)
+        out = model.training_step(batch, optimizer=None, seed=7, replay=replay)
+        assert torch.isfinite(out["loss"]) and torch.allclose(out["replay_log_likelihood"], out["log_likelihood"], atol=2e-3)
+        grads[replay] = {n: p.grad.clone() for n, p in pol.named_parameters() if p.grad is not None}
+    rm1 = pol.state_dict()["encoder.net.layers.0.row_encoding_block.norm1.normalizer.running_mean"]
+    assert not torch.equal(rm0, rm1)                                        # the forward updated the running statistics
+    num = sum(float((grads["hip"][n] - grads["torch"][n]).pow(2).sum()) for n in grads["torch"])
+    den = sum(float(grads["torch"][n].pow(2).sum()) for n in grads["torch"])
+    assert den > 0 and (num / den) ** 0.5 < 2e-3
+    pol.eval()
+    out = pol(env.reset(batch), env, phase="val", decode_type="multistart_greedy", num_starts=20, return_actions=True)
+    assert bool(torch.isfinite(out["reward"]).all())
