@@ -1,5 +1,5 @@
 """Host side of csrc/rr_bign.hip: encoder, decoder cache, decoder.forward and the selection for instances with 104 .. 208 nodes
-(ATSP, RCVRP; gating NAB without duration, instance norm).  The on-chip kernels (rr_enc_layer, rr_rollout) hold one instance's
+(ATSP, RCVRP, RCVRPTW / the multi-task variants; gating NAB without or with the duration matrix, instance norm).  The on-chip kernels (rr_enc_layer, rr_rollout) hold one instance's
 activations in registers / LDS and stop at 103 nodes; here the same operators (rrnco/models/nn/attn_freenet.py:417-441,
 rrnco/models/decoder.py:151-329) run as row-parallel kernels over HBM / L2-resident tensors and the decode loop runs step by step,
 as the reference's own policy loop does (rrnco/models/policy.py:210-228)."""
@@ -19,8 +19,8 @@ def _np(n: int) -> int:
 
 
 def supported(env_name: str, packed: dict, normalization: str) -> bool:
-    return (env_name in ("atsp", "rcvrp") and normalization == "instance" and packed.get("nab_kind", "gating") == "gating"
-            and len(packed["nabdur"]) == 0)
+    return (env_name in ("atsp", "rcvrp", "rcvrptw") and normalization == "instance" and packed.get("nab_kind", "gating") == "gating"
+            and (len(packed["nabdur"]) > 0) == (env_name == "rcvrptw"))
 
 
 def _ffn_packs(packed):
@@ -49,10 +49,16 @@ def encode(encoder, td, packed):
         from .encoder import ATSPInitEmbedding
         sidx = ATSPInitEmbedding.sample_indices(D, encoder.init_embedding.sample_size)
     P = packed["sd_ref"]
+    vtw = encoder.env_name == "rcvrptw"
     if encoder.env_name == "atsp":
         row, col = GR._init_embedding(P, locs, D, sidx)
+    elif vtw:
+        extra = torch.cat([td["time_windows"].float(), td["service_time"].float()[..., None]], -1)
+        row, col = GR._init_embedding_vrp(P, locs, td["demand_linehaul"].float()[:, 1:], D, sidx, extra, "init_embed")
     else:
         row, col = GR._init_embedding_vrp(P, locs, td["demand"].float(), D, sidx, None, "demand_init")
+    T = td["duration_matrix"].float().contiguous() if vtw else None
+    bias2 = torch.empty(Bp, 2, N * N, device=D.device) if vtw else None
     row, col = row.contiguous(), col.contiguous()
     theta = torch.empty(Bp, N, N, device=dev)
     L.check(lib.rr_edge_angles(L.ptr(locs), L.ptr(theta), Bp, N, st), "rr_edge_angles")
@@ -75,7 +81,13 @@ def encode(encoder, td, packed):
             norm(x, None, w.n1g, w.n1b, r)
             norm(y, None, w.n2g, w.n2b, c)
             lin(w.wq, w.bq, r, q); lin(w.wk, w.bk, c, k); lin(w.wv, w.bv, c, v)
-            L.check(lib.rr_nab_pwl_fwd(w.nab, L.ptr(D), L.ptr(theta), L.ptr(bias), Bp, N, si, st), "rr_nab_pwl_fwd")
+            if vtw:       # NAB with the duration matrix (attn_freenet.py:226-237): both sides of the layer by one rr_nab_dur launch
+                if si == 0:
+                    nr, nc = packed["nabdur"][l]
+                    L.check(lib.rr_nab_dur(nr, nc, L.ptr(D), L.ptr(T), L.ptr(locs), L.ptr(bias2), Bp, N, st), "rr_nab_dur")
+                bias.view(Bp, N * N).copy_(bias2[:, si])
+            else:
+                L.check(lib.rr_nab_pwl_fwd(w.nab, L.ptr(D), L.ptr(theta), L.ptr(bias), Bp, N, si, st), "rr_nab_pwl_fwd")
             L.check(lib.rr_colsoftmax_exp(L.ptr(k), L.ptr(v), L.ptr(ekT), L.ptr(kvT), Bp, N, NP, st), "rr_colsoftmax_exp")
             L.check(lib.rr_aft_mix_big(L.ptr(bias), L.ptr(q), L.ptr(ekT), L.ptr(kvT), L.ptr(yy), Bp, N, NP, st), "rr_aft_mix_big")
             lin(w.wp, w.bp, yy, o)                                     # project o multi_head_combine, folded (packing.py)
@@ -135,15 +147,28 @@ def decoder_forward(decoder, td, cache, packed):
         else:
             first = td["first_node"].reshape(-1).contiguous()
             keep.append(first)
-    scal = None
-    if not atsp:                              # VRPContext: vehicle_capacity - used_capacity
+    scal, nscal, Dur = None, 0, None
+    if decoder.env_name == "rcvrp":           # VRPContext: vehicle_capacity - used_capacity
         rem = (td["vehicle_capacity"].reshape(-1) - td["used_capacity"].reshape(-1)).float()
         scal = torch.zeros(R, 4, device=dev); scal[:, 0] = rem
+        nscal = 1
         keep.append(scal)
+    elif decoder.env_name == "rcvrptw":       # MTVRPContextEmbedding (env_embeddings/context.py:51-70)
+        b_of_r = torch.arange(R, device=dev) % Bp
+        cap = td["vehicle_capacity"].reshape(-1).float()
+        cap = cap if cap.shape[0] == R else cap[b_of_r]
+        ul, ub = td["used_capacity_linehaul"].reshape(-1).float(), td["used_capacity_backhaul"].reshape(-1).float()
+        ub = ub if ub.shape[0] == R else ub[b_of_r]
+        lim = td["distance_limit"].reshape(-1).float()[b_of_r]
+        rd = torch.nan_to_num(lim - td["current_route_length"].reshape(-1).float(), posinf=10.0)
+        scal = torch.stack([cap - torch.where(ub == 0, ul, ub), td["current_time"].reshape(-1).float(),
+                            td["open_route"].reshape(-1).float()[b_of_r], rd], 1).contiguous()
+        nscal, Dur = 4, td["duration_matrix"].float().contiguous()
+        keep += [scal, Dur]
     io.K, io.Vt, io.L, io.ctxA, io.ctxB = L.ptr(cache.glimpse_key), L.ptr(cache.glimpse_val_t), L.ptr(cache.logit_key), L.ptr(ctxA), L.ptr(ctxB)
-    io.D, io.Dur, io.cur, io.first, io.scal, io.wstate = L.ptr(D), None, L.ptr(cur), L.ptr(first), L.ptr(scal), (dw.wstate if not atsp else None)
+    io.D, io.Dur, io.cur, io.first, io.scal, io.wstate = L.ptr(D), L.ptr(Dur), L.ptr(cur), L.ptr(first), L.ptr(scal), (dw.wstate if not atsp else None)
     io.mask, io.w1, io.w2, io.b1, io.b2, io.logits = L.ptr(m8), dw.w1, dw.w2, dw.b1, dw.b2, L.ptr(logits)
-    io.Bp, io.N, io.NP, io.S, io.nscal = Bp, N, cache.glimpse_val_t.shape[-1], S, (0 if atsp else 1)
+    io.Bp, io.N, io.NP, io.S, io.nscal = Bp, N, cache.glimpse_val_t.shape[-1], S, nscal
     io.alpha, io.beta = dw.alpha, dw.beta
     L.check(L.lib().rr_dec_fwd_big(io, L.stream()), "rr_dec_fwd_big")
     return logits, mask

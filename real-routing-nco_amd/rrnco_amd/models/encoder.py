@@ -199,7 +199,7 @@ class RRNetEncoder(nn.Module):
             from . import bign
             if D.shape[-1] > bign.MAX_N_BIG or not bign.supported(self.env_name, packed, self.normalization) or train_saves is not None:
                 raise NotImplementedError(f"{D.shape[-1]} nodes: the encoder kernels cover N <= 103 for every configuration and "
-                                          f"N <= {bign.MAX_N_BIG} for ATSP / RCVRP with instance norm and the gating NAB (inference)")
+                                          f"N <= {bign.MAX_N_BIG} with instance norm and the gating NAB (inference)")
             return bign.encode(self, td, packed)
         locs = td["locs"].float().contiguous()
         Bp, N = D.shape[0], D.shape[-1]
