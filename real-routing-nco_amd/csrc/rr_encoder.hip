@@ -943,6 +943,11 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_init_embed(InitW w, const fl
     // comb[:, 0:E] = node embedding, comb[:, E:2E] = Lin(SS,E)(sorted)
     const float* wd = pass == 0 ? w.wr : w.wcl;
     const float* bd = pass == 0 ? w.br : w.bcl;
+    // a thread keeps its feature f = tid & 127 for every node it visits (ENC_THREADS is a multiple of 128): the SS weights of that
+    // feature are loaded once per pass instead of once per node, and the sorted samples of a node come as 16-byte LDS broadcasts
+    float wreg[MAXSS];
+#pragma unroll
+    for (int s = 0; s < MAXSS; ++s) wreg[s] = s < SS ? wd[s * RR_E + (tid & 127)] : 0.f;
     for (int e = tid; e < N * RR_E; e += ENC_THREADS) {
       int i = e >> 7, f = e & 127;
       if (KIND == 0) {
@@ -955,7 +960,14 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_init_embed(InitW w, const fl
         comb[i * 256 + f] = fmaf(w.wi[f * 3 + 2], ang, fmaf(w.wi[f * 3 + 1], y, w.wi[f * 3] * x)) + w.bi[f];
       }
       float acc = 0.f;
-      for (int s = 0; s < SS; ++s) acc = fmaf(wd[s * RR_E + f], scr[i * MAXSS + s], acc);   // weights stored [SS][E]
+#pragma unroll
+      for (int s4 = 0; s4 < MAXSS; s4 += 4) {                 // in the order s = 0, 1, 2, ...: the same sum as before
+        const float4 v = rr_ld4(scr + i * MAXSS + s4);
+        if (s4 < SS) acc = fmaf(wreg[s4], v.x, acc);
+        if (s4 + 1 < SS) acc = fmaf(wreg[s4 + 1], v.y, acc);
+        if (s4 + 2 < SS) acc = fmaf(wreg[s4 + 2], v.z, acc);
+        if (s4 + 3 < SS) acc = fmaf(wreg[s4 + 3], v.w, acc);
+      }
       comb[i * 256 + 128 + f] = acc + bd[f];
     }
     __syncthreads();
