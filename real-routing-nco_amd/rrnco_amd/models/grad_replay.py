@@ -44,8 +44,8 @@ def _inorm(P, p, x):
         # statistics, like the reference's forward), 0 for the backward's recomputation (same batch statistics, no second update).
         mom = float(P.get("__bn_momentum__", 0.0))
         y = F.batch_norm(x.reshape(-1, x.shape[-1]), P[p + ".normalizer.running_mean"], P[p + ".normalizer.running_var"],
-                         P[p + ".normalizer.weight"], P[p + ".normalizer.bias"], True, mom, 1e-5)
-        return y.view_as(x)
+                         P[p + ".normalizer.weight"], P[p + ".normalizer.bias"], bool(P.get("__bn_train__", True)), mom, 1e-5)
+        return y.view_as(x)      # (eval mode: the running statistics, as the kernels' folded affine maps)
     if (p + ".normalizer.weight") not in P:
         return (x - x.mean((1, 2)).view(-1, 1, 1)) / torch.sqrt(x.var((1, 2)).view(-1, 1, 1) + 1e-05)
     if (p + ".normalizer.bias") not in P:
@@ -550,9 +550,10 @@ def decode_log_likelihood_rcvrptw(P, row_emb, col_emb, D, Dur, demand_l, tw, ser
 def params_and_buffers(policy, bn_momentum=0.0):
     """named_parameters, plus — for normalization='batch' in train mode — the BatchNorm buffers and the momentum `_inorm` applies."""
     P = dict(policy.named_parameters())
-    if uses_batch_statistics(policy):
+    if any(k.endswith(".normalizer.running_mean") for k in policy.state_dict()):
         P.update({k: v for k, v in policy.named_buffers() if ".normalizer." in k})
-        P["__bn_momentum__"] = bn_momentum
+        P["__bn_momentum__"] = bn_momentum if policy.training else 0.0
+        P["__bn_train__"] = bool(policy.training)      # eval mode: gradients of the running-statistics network the kernels ran
     return P
 
 

@@ -277,3 +277,8 @@ def test_batch_norm_train_mode_step_runs_and_matches_the_torch_replay():
     pol.eval()
     out = pol(env.reset(batch), env, phase="val", decode_type="multistart_greedy", num_starts=20, return_actions=True)
     assert bool(torch.isfinite(out["reward"]).all())
+    # a step taken in EVAL mode differentiates the running-statistics network the kernels ran (not an instance-norm look-alike):
+    # the replayed log-likelihood must equal the rollout's
+    pol.zero_grad(set_to_none=True)
+    out = model.training_step(batch, optimizer=None, seed=8, replay="hip")
+    assert torch.allclose(out["replay_log_likelihood"], out["log_likelihood"], atol=2e-3)
