@@ -604,8 +604,10 @@ __global__ __launch_bounds__(256) void k_select16(const float* __restrict__ logi
       if (VEC) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < R && c < N) {
-          v = *reinterpret_cast<const float4*>(logits + off);
-          if (mask != nullptr) keep[i][q] = *reinterpret_cast<const uint32_t*>(mask + off);
+          // read once, never again: non-temporal loads keep the 210 MB stream from evicting what L2 holds for the next kernel
+          const f32x4 nv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(logits + off));
+          v = make_float4(nv[0], nv[1], nv[2], nv[3]);
+          if (mask != nullptr) keep[i][q] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(mask + off));
         }
         raw[i][4 * q] = v.x; raw[i][4 * q + 1] = v.y; raw[i][4 * q + 2] = v.z; raw[i][4 * q + 3] = v.w;
       } else {
