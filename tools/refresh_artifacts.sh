@@ -24,3 +24,10 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/proft_$TAG -o p -- python3 $R/tools/bench_train.py --steps 2 > /dev/null 2> /tmp/proft_err.log
 S=$(find /tmp/proft_$TAG -name "*kernel_stats.csv" | head -1)
 cp "$S" $R/gpurun_out/train_${TAG}_kernel_stats.csv
+# the other BASELINE configs (3, 4), RCVRP / RCVRPTW training, the reference-shaped step-wise loop
+cd $R
+python3 tools/bench_other.py 2>/dev/null | grep '^{' > gpurun_out/other_$TAG.jsonl
+python3 tools/bench_train.py --problem rcvrp --steps 3 2>/dev/null | tail -1 >> gpurun_out/other_$TAG.jsonl
+python3 tools/bench_train.py --problem rcvrptw --steps 2 --batch 512 2>/dev/null | tail -1 >> gpurun_out/other_$TAG.jsonl
+python3 tools/bench_stepwise.py 2>/dev/null | tail -2 >> gpurun_out/other_$TAG.jsonl
+python3 tools/stepkernels_time.py 2>/dev/null | tail -5 >> gpurun_out/other_$TAG.jsonl
