@@ -47,7 +47,10 @@ typedef struct {                /* folded DistAngleFusion(use_duration_matrix=Tr
   const float *pwl;             /* vector-valued piecewise-linear tables of the gate pre-activation (packing.fold_nab_dur_pwl) */
 } NabDurW;
 
-typedef struct { const void *wk, *wv, *wl, *wca, *wcb; } CacheW;   /* rrnco/models/decoder.py:214-232 + context */
+typedef struct {                /* rrnco/models/decoder.py:214-232 + the step-context tables */
+  const void *wk, *wv, *wl, *wca, *wcb;       /* pack_a fragments */
+  const void *wks, *wvs, *wls, *wcas, *wcbs;  /* optional: the same fragments as [hi | lo'] fp16 pairs (packing.f16x2_image): fp16 pipe */
+} CacheW;
 
 typedef struct {                /* pointer MLP + inductive-bias scalars: rrnco/models/decoder.py:186-198, 272-277 */
   const void *w1, *w2; const float *b1, *b2, *q0, *wstate; float alpha, beta;

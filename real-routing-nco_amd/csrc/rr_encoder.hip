@@ -4,6 +4,7 @@
 // the block live in three LDS buffers, GEMMs run on v_mfma_f32_16x16x4_f32 in the transposed-tile
 // convention of rr_common.h.  Reference: rrnco/models/nn/attn_freenet.py (cited per stage below).
 #include "rr_common.h"
+#include "rr_gemm_f16.h"
 
 #define ENC_THREADS 512
 #define ENC_WAVES 8
@@ -1050,9 +1051,12 @@ extern "C" int rr_init_embed(const InitW* w, int kind, const float* D, const flo
 //   ctxB = Wctx[:, E:2E] row_emb  (current-node half; for the VRP contexts ctxB = Wctx[:, 0:E] row_emb
 //                                   and ctxA is unused)
 // ------------------------------------------------------------------------------------------------
-struct CacheW { const float4 *wk, *wv, *wl, *wca, *wcb; };
+struct CacheW {
+  const float4 *wk, *wv, *wl, *wca, *wcb;
+  const float4 *wks, *wvs, *wls, *wcas, *wcbs;   // optional packing.f16x2_image of the same packs: the five products on the fp16 pipe (rr_gemm_f16.h)
+};
 
-template <int NT>
+template <int NT, bool SPLIT = false>
 __global__ __launch_bounds__(ENC_THREADS, 2) void k_dec_cache(CacheW w, const float* __restrict__ row_emb, const float* __restrict__ col_emb,
                                                               float* __restrict__ K, float* __restrict__ Vt, float* __restrict__ L,
                                                               float* __restrict__ ctxA, float* __restrict__ ctxB, int N) {
@@ -1062,20 +1066,32 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_dec_cache(CacheW w, const fl
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, g = lane >> 4, fb = 16 * wave;
   const size_t off = (size_t)b * N * RR_E;
-  for (int i = tid; i < N * (RR_E / 4); i += ENC_THREADS) {
-    rr_st4(R + i * 4, rr_ld4(row_emb + off + i * 4));
-    rr_st4(Cc + i * 4, rr_ld4(col_emb + off + i * 4));
+  for (int i = tid; i < N * (RR_E / 4); i += ENC_THREADS) {      // SPLIT: the LDS images in the [lo' | hi] form of rr_gemm_f16.h
+    const float4 rv = rr_ld4(row_emb + off + i * 4), cv = rr_ld4(col_emb + off + i * 4);
+    rr_st4(R + i * 4, SPLIT ? rr_to_lohi(rv) : rv);
+    rr_st4(Cc + i * 4, SPLIT ? rr_to_lohi(cv) : cv);
   }
   __syncthreads();
   f32x4 a[NT];
-  auto run = [&](const float4* wp, const float* X) {
+  auto run = [&](const float4* wp, const float4* wps, const float* X) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) a[nt] = rr_zero4();
-    rr_gemm_wx<NT>(a, wp + (size_t)wave * 8 * 64, 0, 8, X, LD, 0, N, lane);
+    if constexpr (SPLIT) {
+      f32x4 as[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) as[nt] = rr_zero4();
+      rr_gemm_wx_h<NT>(a, as, wps + (size_t)wave * 8 * 64, 0, 8, X, LD, 0, N, lane);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[nt][r] = fmaf(as[nt][r], RR_LO_INV, a[nt][r]);
+    } else {
+      rr_gemm_wx<NT>(a, wp + (size_t)wave * 8 * 64, 0, 8, X, LD, 0, N, lane);
+    }
   };
-  run(w.wk, Cc); rr_store_tiles<NT>(a, K + off, RR_E, fb, N, lane);
-  run(w.wl, Cc); rr_store_tiles<NT>(a, L + off, RR_E, fb, N, lane);
-  run(w.wv, Cc);
+  run(w.wk, w.wks, Cc); rr_store_tiles<NT>(a, K + off, RR_E, fb, N, lane);
+  run(w.wl, w.wls, Cc); rr_store_tiles<NT>(a, L + off, RR_E, fb, N, lane);
+  run(w.wv, w.wvs, Cc);
   {  // Vt[b][feature][key], keys padded to 112 with zeros
     float* vt = Vt + (size_t)b * RR_E * 112;
 #pragma unroll
@@ -1089,17 +1105,25 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_dec_cache(CacheW w, const fl
       }
     }
   }
-  if (w.wca) { run(w.wca, R); rr_store_tiles<NT>(a, ctxA + off, RR_E, fb, N, lane); }
-  run(w.wcb, R); rr_store_tiles<NT>(a, ctxB + off, RR_E, fb, N, lane);
+  if (w.wca) { run(w.wca, w.wcas, R); rr_store_tiles<NT>(a, ctxA + off, RR_E, fb, N, lane); }
+  run(w.wcb, w.wcbs, R); rr_store_tiles<NT>(a, ctxB + off, RR_E, fb, N, lane);
 }
 
 extern "C" int rr_dec_cache(const CacheW* w, const float* row_emb, const float* col_emb, float* K, float* Vt, float* L,
                             float* ctxA, float* ctxB, int Bp, int N, hipStream_t st) {
   if (Bp <= 0 || N < 2 || N > RR_MAXN || w == nullptr) return RR_EINVAL;
   dim3 grid(Bp), blk(ENC_THREADS);
-  if (N <= 32) hipLaunchKernelGGL(k_dec_cache<2>, grid, blk, 0, st, *w, row_emb, col_emb, K, Vt, L, ctxA, ctxB, N);
-  else if (N <= 64) hipLaunchKernelGGL(k_dec_cache<4>, grid, blk, 0, st, *w, row_emb, col_emb, K, Vt, L, ctxA, ctxB, N);
-  else hipLaunchKernelGGL(k_dec_cache<7>, grid, blk, 0, st, *w, row_emb, col_emb, K, Vt, L, ctxA, ctxB, N);
+  const char* es = getenv("RR_MLP_SPLIT");
+  const bool split = (es == nullptr || atoi(es) != 0) && w->wks && w->wvs && w->wls && w->wcbs && (w->wca == nullptr || w->wcas);
+#define RR_DC(NTV)                                                                                                        \
+  do {                                                                                                                    \
+    if (split) hipLaunchKernelGGL((k_dec_cache<NTV, true>), grid, blk, 0, st, *w, row_emb, col_emb, K, Vt, L, ctxA, ctxB, N); \
+    else hipLaunchKernelGGL((k_dec_cache<NTV, false>), grid, blk, 0, st, *w, row_emb, col_emb, K, Vt, L, ctxA, ctxB, N);   \
+  } while (0)
+  if (N <= 32) RR_DC(2);
+  else if (N <= 64) RR_DC(4);
+  else RR_DC(7);
+#undef RR_DC
   return rr_check(hipGetLastError());
 }
 

@@ -29,7 +29,7 @@ class InitW(C.Structure):
 
 
 class CacheW(C.Structure):
-    _fields_ = [(n, vp) for n in ("wk", "wv", "wl", "wca", "wcb")]
+    _fields_ = [(n, vp) for n in ("wk", "wv", "wl", "wca", "wcb", "wks", "wvs", "wls", "wcas", "wcbs")]
 
 
 class DecW(C.Structure):

@@ -84,6 +84,17 @@ def pack_a_f16x2(Wm: torch.Tensor) -> torch.Tensor:
     return x.reshape(*lead, M // 16, K // 32, 2, 64, 8).contiguous()                            # [t][s][piece][lane][8]
 
 
+def f16x2_image(t: torch.Tensor) -> torch.Tensor:
+    """fp32 tensor (numel % 4 == 0) -> same shape, every group of four values replaced by its four `hi` and four `lo'` fp16
+    halves (x = hi + 2^-11 lo', csrc/rr_common.h) — what csrc/rr_decode.hip:k_pack_f16x2 does on the device; applied to a pack_a
+    fragment array it yields the [hi | lo'] weight fragments of csrc/rr_gemm_f16.h."""
+    x = t.detach().float().contiguous()
+    g = x.view(-1, 4)
+    hi = g.to(torch.float16)
+    lo = ((g - hi.float()) * 2048.0).to(torch.float16)
+    return torch.cat((hi, lo), dim=1).contiguous().view(torch.float32).view(x.shape)
+
+
 def pack_bf16x2(Wm: torch.Tensor, k_major: bool = False) -> torch.Tensor:
     """[M,K] fp32 -> two-piece bf16 split (hi = bf16(W), lo = bf16(W - hi)) as A operands of v_mfma_f32_16x16x32_bf16 in the
     permuted k order of pack_a_bf16x3 (a lane's eight values = its four of two consecutive C-layout tiles): [M/16][K/32][2][64][8],
@@ -569,14 +580,20 @@ def _pack_policy(sd: dict, env_name: str, device) -> dict:
     wctx = sd["decoder.context_embedding.project_context.weight"].detach().float()
     cw = L.CacheW()
     cw.wk, cw.wv, cw.wl = ar.put(pack_a(wn[:E])), ar.put(pack_a(wn[E:2 * E])), ar.put(pack_a(wn[2 * E:]))
+    if split:      # the same five packs as [hi | lo'] fragments: decoder cache on the fp16 pipe (csrc/rr_gemm_f16.h)
+        cw.wks, cw.wvs, cw.wls = (ar.put(f16x2_image(pack_a(wn[i * E:(i + 1) * E]))) for i in range(3))
     dw = L.DecW()
     if env_name == "atsp":
         cw.wca, cw.wcb = ar.put(pack_a(wctx[:, :E])), ar.put(pack_a(wctx[:, E:2 * E]))
+        if split:
+            cw.wcas, cw.wcbs = ar.put(f16x2_image(pack_a(wctx[:, :E]))), ar.put(f16x2_image(pack_a(wctx[:, E:2 * E])))
         ph = sd["decoder.context_embedding.W_placeholder"].detach().float()
         dw.q0 = ar.put(wctx @ ph.to(wctx.device))
         dw.wstate = None
     else:
         cw.wca, cw.wcb = None, ar.put(pack_a(wctx[:, :E]))
+        if split:
+            cw.wcbs = ar.put(f16x2_image(pack_a(wctx[:, :E])))
         dw.q0 = None
         dw.wstate = ar.put(wctx[:, E:].t().contiguous())   # [nstate][E]
     dw.w1 = ar.put(pack_a(sd["decoder.pointer.ffn.lins.0.weight"].detach().float()))

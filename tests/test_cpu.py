@@ -226,7 +226,7 @@ def test_ctypes_struct_sizes_match_header_layout():
     from rrnco_amd import _lib
     import ctypes as C
     assert C.sizeof(_lib.EncBlockW) == 31 * 8 and C.sizeof(_lib.InitW) == 20 * 8 + 16
-    assert C.sizeof(_lib.CacheW) == 40 and C.sizeof(_lib.DecW) == 6 * 8 + 8 + 2 * 8
+    assert C.sizeof(_lib.CacheW) == 80 and C.sizeof(_lib.DecW) == 6 * 8 + 8 + 2 * 8
     assert C.sizeof(_lib.RolloutIO) == 24 * 8 + 12 * 4 + 2 * 4 + 8 + 5 * 8 + 4 * 8 + 8 + 3 * 8 and C.sizeof(_lib.NabDurW) == 4 * 8 + 9 * 4 + 4 + 8
     # the training-side descriptors (include/rrnco_hip.h: DecLogitIO, MlpRowsW, MlpWgradW, DecAttnIO, EncSave, AftBwdIO)
     assert C.sizeof(_lib.DecLogitIO) == 11 * 8 + 4 * 4 + 8 + 4 * 4 and C.sizeof(_lib.DecAttnIO) == 15 * 8 + 5 * 4 + 4 + 8
@@ -523,6 +523,17 @@ def test_pack_a_f16x2_is_a_two_piece_split_to_2pow23_in_kernel_order():
     f32 = torch.stack([torch.tensor(sum((float(x) * float(y) for x, y in zip(r.tolist(), b.tolist())), 0.0)) for r in a[:4]])
     scale = (a.double().abs() @ b.double().abs())
     assert ((got - ref).abs() / scale).max() < 2e-7
+
+
+def test_f16x2_image_reconstructs_to_2pow23():
+    """packing.f16x2_image (the host twin of k_pack_f16x2): per group of four values [hi x4 | lo' x4], hi + 2^-11 lo' = x to 2^-23."""
+    from rrnco_amd.packing import f16x2_image
+    x = torch.randn(8, 12) * torch.logspace(-5, 2, 12)[None, :]
+    im = f16x2_image(x)
+    assert im.shape == x.shape and im.dtype == torch.float32
+    h = im.contiguous().view(torch.float16).view(-1, 8)
+    rec = (h[:, :4].double() + h[:, 4:].double() / 2048.0).view(x.shape)
+    assert bool(((rec - x.double()).abs() <= torch.maximum(x.double().abs() * 2.0 ** -23, torch.tensor(2.0 ** -36, dtype=torch.float64))).all())
 
 
 def test_state_augmentation_matches_reference_functions():
