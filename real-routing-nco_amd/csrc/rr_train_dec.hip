@@ -509,17 +509,22 @@ struct MlpWgradW {
   const float* b1;
 };
 #define WG_RM 288     // bytes per row of the row-major bf16 images (128 values + 32 B: conflict-free ds_read_b128 by row)
-#define WG_TR 80      // bytes per feature of the transposed images (32 rows + 16 B; 96 would be conflict-free but two buffers must fit 160 KB)
+#define WG_TQ 36      // 16-byte slots per feature residue block of the transposed images (32 + 4: residue blocks 16 banks apart)
+#define WG_TG (4 * WG_TQ * 16)   // bytes per row-group block of a transposed image
 
 // dW1[hid][feat] += sum_m dH[m][hid] x[m][feat], db1 += sum_m dH, dW2[feat][hid] += sum_m dy[m][feat] H[m][hid], db2 += sum_m dy
 // with H = relu(W1 x + b1), dH = (W2^T dy) . 1(H > 0).  Workgroup (slab, split): hidden units [128 slab, +128), wave w the
 // tiles 2w, 2w+1 of them with their W1 / W2^T fragments resident in registers; rows in chunks of 32 through LDS: a row-major
 // image (A operand of the recomputation, k = feature) and a transposed one (A operand of the two outer products, k = row).
+// Transposed image: [row group gg][feature slot][8 rows = 16 B], row 16 rt + 4 gg + r at position 4 rt + r, feature f in slot
+// (f & 3) * WG_TQ + (f >> 2).  A staging thread owns rows 16 rt + 4 gg + (0..3) of four consecutive features: its 8-byte
+// writes run along the slots (lanes = consecutive slots, the two half-waves = the two halves of a slot) and the 16-byte
+// operand reads of a 16-feature tile hit 16 different bank quads: neither side conflicts.
 __global__ __launch_bounds__(256, 1) void k_mlp_wgrad(MlpWgradW w, const float* __restrict__ X, const float* __restrict__ dY,
                                                       float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2,
                                                       float* __restrict__ db2, RowSegs rs, int nsplit, const uint32_t* __restrict__ meta) {
   __shared__ __attribute__((aligned(16))) char rm[2][4][32 * WG_RM];     // [buffer][x hi, x lo, dy hi, dy lo]
-  __shared__ __attribute__((aligned(16))) char tr[2][4][RR_E * WG_TR];
+  __shared__ __attribute__((aligned(16))) char tr[2][4][4 * WG_TG];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, g = lane >> 4;
@@ -553,65 +558,71 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wgrad(MlpWgradW w, const float* 
     for (int tl = 0; tl < 2; ++tl) { aW2[u][tl] = rr_zero4(); aW1[u][tl] = rr_zero4(); }
   float ab1[2] = {0.f, 0.f};
   float4 sb2 = make_float4(0.f, 0.f, 0.f, 0.f);
-  // staging: thread -> column group c4 = tid & 31 (4 features), row pairs rp = (tid >> 5) and (tid >> 5) + 8
-  const int c4 = tid & 31, rp0 = tid >> 5;
-  float4 px[2][2], py[2][2], qx[2][2], qy[2][2];     // chunk being staged / chunk in flight
-  unsigned plv[2][2], qlv[2][2];
-  auto g_load = [&](long long c, bool real, float4 (&ox)[2][2], float4 (&oy)[2][2], unsigned (&olv)[2][2]) {      // !real: a chunk past the end (all rows zero)
+  // staging: thread -> column group c4 = tid & 31 (4 features), rows r0 + (0..3) with r0 = 16 rt + 4 gg, (gg, rt) = tid >> 5
+  const int c4 = tid & 31, srt = (tid >> 5) & 1, sgg = tid >> 6, r0 = 16 * srt + 4 * sgg;
+  float4 px[4], py[4], qx[4], qy[4];     // chunk being staged / chunk in flight
+  unsigned plv[4], qlv[4];
+  auto g_load = [&](long long c, bool real, float4 (&ox)[4], float4 (&oy)[4], unsigned (&olv)[4]) {      // !real: a chunk past the end (all rows zero)
     // every load unconditional (clamped row), zeroed by the flag in `stage`: no dependent loads
 #pragma unroll
-    for (int it = 0; it < 2; ++it)
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const long long i = c * 32 + 2 * (rp0 + 8 * it) + e;
-        const long long m = td_row(rs, i < total ? i : total - 1);
-        ox[it][e] = rr_ld4(X + m * RR_E + 4 * c4);
-        oy[it][e] = rr_ld4(dY + m * RR_E + 4 * c4);
-        olv[it][e] = (real && i < total) ? (meta == nullptr ? 1u : meta[m * 8 + 6]) : 0u;       // dead rows (finished routes) read as zero rows
-      }
+    for (int k = 0; k < 4; ++k) {
+      const long long i = c * 32 + r0 + k;
+      const long long m = td_row(rs, i < total ? i : total - 1);
+      ox[k] = rr_ld4(X + m * RR_E + 4 * c4);
+      oy[k] = rr_ld4(dY + m * RR_E + 4 * c4);
+      olv[k] = (real && i < total) ? (meta == nullptr ? 1u : meta[m * 8 + 6]) : 0u;       // dead rows (finished routes) read as zero rows
+    }
   };
-  auto put = [&](const float4 (&v)[2], int rp, char* rmh, char* rml, char* trh, char* trl) {
-    // rows 2rp, 2rp+1 of the chunk, features 4c4..4c4+3
-    uint16_t h[2][4], l[2][4];
+  uint32_t ch[4][2], cl[4][2];           // the operand being staged as packed bf16 pieces: [row][feature pair]
+  // rows r0 .. r0 + 3, features 4c4 .. 4c4 + 3 -> pieces, and the row-major images
+  auto put_rm = [&](const float4 (&v)[4], char* rmh, char* rml) {
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const float xs[4] = {v[e].x, v[e].y, v[e].z, v[e].w};
+    for (int k = 0; k < 4; ++k) {
+      const float xs[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+      uint16_t h[4], l[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const __bf16 hb = (__bf16)xs[q];
         const __bf16 lb = (__bf16)(xs[q] - (float)hb);
-        h[e][q] = __builtin_bit_cast(uint16_t, hb); l[e][q] = __builtin_bit_cast(uint16_t, lb);
+        h[q] = __builtin_bit_cast(uint16_t, hb); l[q] = __builtin_bit_cast(uint16_t, lb);
       }
-      const int row = 2 * rp + e;
-      *reinterpret_cast<uint2*>(rmh + row * WG_RM + c4 * 8) = make_uint2(h[e][0] | ((uint32_t)h[e][1] << 16), h[e][2] | ((uint32_t)h[e][3] << 16));
-      *reinterpret_cast<uint2*>(rml + row * WG_RM + c4 * 8) = make_uint2(l[e][0] | ((uint32_t)l[e][1] << 16), l[e][2] | ((uint32_t)l[e][3] << 16));
+      ch[k][0] = h[0] | ((uint32_t)h[1] << 16); ch[k][1] = h[2] | ((uint32_t)h[3] << 16);
+      cl[k][0] = l[0] | ((uint32_t)l[1] << 16); cl[k][1] = l[2] | ((uint32_t)l[3] << 16);
+      *reinterpret_cast<uint2*>(rmh + (r0 + k) * WG_RM + c4 * 8) = make_uint2(ch[k][0], ch[k][1]);
+      *reinterpret_cast<uint2*>(rml + (r0 + k) * WG_RM + c4 * 8) = make_uint2(cl[k][0], cl[k][1]);
     }
-    // transposed: row rho = 16 rt + 4 gg + r sits at position 8 gg + 4 rt + r (the order a lane of the recomputed C tiles owns them)
-    const int rho = 2 * rp, pos = 8 * ((rho & 15) >> 2) + 4 * (rho >> 4) + (rho & 3);
+  };
+  // the transposed images: per feature the four rows as one 8-byte write (positions 4 rt + 0..3 of row group gg)
+  auto put_tr = [&](char* trh, char* trl) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      *reinterpret_cast<uint32_t*>(trh + (4 * c4 + q) * WG_TR + pos * 2) = h[0][q] | ((uint32_t)h[1][q] << 16);
-      *reinterpret_cast<uint32_t*>(trl + (4 * c4 + q) * WG_TR + pos * 2) = l[0][q] | ((uint32_t)l[1][q] << 16);
+      const unsigned sel = (q & 1) ? 0x07060302u : 0x05040100u;       // the high / low halves of two packed pairs
+      const int off = sgg * WG_TG + (q * WG_TQ + c4) * 16 + 8 * srt;
+      *reinterpret_cast<uint2*>(trh + off) = make_uint2(__builtin_amdgcn_perm(ch[1][q >> 1], ch[0][q >> 1], sel), __builtin_amdgcn_perm(ch[3][q >> 1], ch[2][q >> 1], sel));
+      *reinterpret_cast<uint2*>(trl + off) = make_uint2(__builtin_amdgcn_perm(cl[1][q >> 1], cl[0][q >> 1], sel), __builtin_amdgcn_perm(cl[3][q >> 1], cl[2][q >> 1], sel));
     }
   };
   // Double-buffered images: chunk c is consumed from buffer c & 1 while chunk c + 1 (already in registers) is converted and
   // written to the other one BETWEEN the matrix instructions of chunk c (the conversions are VALU work the matrix pipe does not
   // wait for), and chunk c + 2 is requested from memory.  One barrier per chunk.
-  auto stage = [&](int it, int which, int buf) {      // which: 0 = the x rows, 1 = the dy rows of row pairs `it`
-    if (which == 0) {
+  auto stage = [&](int n, int buf) {      // n: 0 = x pieces + row-major, 1 = x transposed, 2 = dy pieces + row-major, 3 = dy transposed
+    if (n == 0) {
 #pragma unroll
-      for (int e = 0; e < 2; ++e)
-        {
-        const float k = plv[it][e] != 0u ? 1.0f : 0.f;      // (selects, not branches: NaN-safe zeroing of dead rows)
-        px[it][e] = make_float4(k != 0.f ? px[it][e].x : 0.f, k != 0.f ? px[it][e].y : 0.f, k != 0.f ? px[it][e].z : 0.f, k != 0.f ? px[it][e].w : 0.f);
-        py[it][e] = make_float4(k != 0.f ? py[it][e].x : 0.f, k != 0.f ? py[it][e].y : 0.f, k != 0.f ? py[it][e].z : 0.f, k != 0.f ? py[it][e].w : 0.f);
+      for (int k = 0; k < 4; ++k) {
+        const bool lv = plv[k] != 0u;                        // (selects, not branches: NaN-safe zeroing of dead rows)
+        px[k] = make_float4(lv ? px[k].x : 0.f, lv ? px[k].y : 0.f, lv ? px[k].z : 0.f, lv ? px[k].w : 0.f);
+        py[k] = make_float4(lv ? py[k].x : 0.f, lv ? py[k].y : 0.f, lv ? py[k].z : 0.f, lv ? py[k].w : 0.f);
       }
-      put(px[it], rp0 + 8 * it, rm[buf][0], rm[buf][1], tr[buf][0], tr[buf][1]);
-    } else {
-      put(py[it], rp0 + 8 * it, rm[buf][2], rm[buf][3], tr[buf][2], tr[buf][3]);
+      put_rm(px, rm[buf][0], rm[buf][1]);
+    } else if (n == 1) {
+      put_tr(tr[buf][0], tr[buf][1]);
+    } else if (n == 2) {
+      put_rm(py, rm[buf][2], rm[buf][3]);
       const float k0 = slab == 0 ? 1.0f : 0.f;        // branch-free: the staging must stay in the matrix instructions' basic block
 #pragma unroll
-      for (int e = 0; e < 2; ++e) { sb2.x = fmaf(k0, py[it][e].x, sb2.x); sb2.y = fmaf(k0, py[it][e].y, sb2.y); sb2.z = fmaf(k0, py[it][e].z, sb2.z); sb2.w = fmaf(k0, py[it][e].w, sb2.w); }
+      for (int k = 0; k < 4; ++k) { sb2.x = fmaf(k0, py[k].x, sb2.x); sb2.y = fmaf(k0, py[k].y, sb2.y); sb2.z = fmaf(k0, py[k].z, sb2.z); sb2.w = fmaf(k0, py[k].w, sb2.w); }
+    } else {
+      put_tr(tr[buf][2], tr[buf][3]);
     }
   };
   // scheduling hint for a region of 48 matrix instructions, 16 LDS reads and one `stage` (~50 VALU, 6 LDS writes): the
@@ -627,7 +638,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wgrad(MlpWgradW w, const float* 
   } while (0)
   if (c_lo < c_hi) {
     g_load(c_lo, true, px, py, plv);
-    stage(0, 0, 0); stage(0, 1, 0); stage(1, 0, 0); stage(1, 1, 0);
+    stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
     g_load(c_lo + 1 < c_hi ? c_lo + 1 : c_lo, c_lo + 1 < c_hi, px, py, plv);
   }
   __syncthreads();
@@ -637,12 +648,10 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wgrad(MlpWgradW w, const float* 
     // visible to the scheduler (values of a load are otherwise pushed behind every matrix instruction of the region)
     g_load(c + 2 < c_hi ? c + 2 : c, c + 2 < c_hi, qx, qy, qlv);
 #pragma unroll
-    for (int it = 0; it < 2; ++it)
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        asm volatile("" : "+v"(px[it][e].x), "+v"(px[it][e].y), "+v"(px[it][e].z), "+v"(px[it][e].w), "+v"(py[it][e].x), "+v"(py[it][e].y),
-                     "+v"(py[it][e].z), "+v"(py[it][e].w), "+v"(plv[it][e]));
-      }
+    for (int k = 0; k < 4; ++k) {
+      asm volatile("" : "+v"(px[k].x), "+v"(px[k].y), "+v"(px[k].z), "+v"(px[k].w), "+v"(py[k].x), "+v"(py[k].y),
+                   "+v"(py[k].z), "+v"(py[k].w), "+v"(plv[k]));
+    }
     // ---- recompute pre[row][hid] = x W1^T, dpre = dy W2 for this wave's two hidden tiles (A = activations, k = feature)
     f32x4 pre[2][2], dpre[2][2];
 #pragma unroll
@@ -662,7 +671,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wgrad(MlpWgradW w, const float* 
           dpre[rt][tl] = td_mfma3(yh, yl, W2h[tl][s], W2l[tl][s], dpre[rt][tl]);
         }
       }
-      if (s & 1) { stage(0, s >> 1, buf ^ 1); }      // (also for the last chunk: the rows past the end stage as zeros)
+      if (s & 1) { stage(s >> 1, buf ^ 1); }      // (also for the last chunk: the rows past the end stage as zeros)
       if (s & 1) { WG_INTERLEAVE(); __builtin_amdgcn_sched_barrier(0); }
     }
     // C layout here: lane (hid = j, g) holds rows 16 rt + 4g + r.  As the B operand of the outer products (k = row) a lane's
@@ -686,7 +695,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wgrad(MlpWgradW w, const float* 
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int off = (16 * u + j) * WG_TR + 16 * g;
+      const int off = g * WG_TG + ((j & 3) * WG_TQ + 4 * u + (j >> 2)) * 16;
       const bfrag xh = *reinterpret_cast<const bfrag*>(tr[buf][0] + off), xl = *reinterpret_cast<const bfrag*>(tr[buf][1] + off);
       const bfrag yh = *reinterpret_cast<const bfrag*>(tr[buf][2] + off), yl = *reinterpret_cast<const bfrag*>(tr[buf][3] + off);
 #pragma unroll
@@ -694,13 +703,11 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wgrad(MlpWgradW w, const float* 
         aW2[u][tl] = td_mfma3(yh, yl, Hh[tl], Hl[tl], aW2[u][tl]);      // [feat][hid] += dy^T H
         aW1[u][tl] = td_mfma3(xh, xl, Gh[tl], Gl[tl], aW1[u][tl]);      // [feat][hid] += x^T dH  (= dW1^T)
       }
-      if ((u & 3) == 3) { stage(1, u >> 2, buf ^ 1); }
+      if ((u & 3) == 3) { stage(2 + (u >> 2), buf ^ 1); }
       if ((u & 3) == 3) { WG_INTERLEAVE(); __builtin_amdgcn_sched_barrier(0); }
     }
 #pragma unroll
-    for (int it = 0; it < 2; ++it)
-#pragma unroll
-      for (int e = 0; e < 2; ++e) { px[it][e] = qx[it][e]; py[it][e] = qy[it][e]; plv[it][e] = qlv[it][e]; }
+    for (int k = 0; k < 4; ++k) { px[k] = qx[k]; py[k] = qy[k]; plv[k] = qlv[k]; }
     __syncthreads();                      // buffer buf is consumed by every wave, buffer buf ^ 1 is complete
   }
   // ---- epilogue: float atomics into the (zeroed) gradients
