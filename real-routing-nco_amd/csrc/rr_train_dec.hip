@@ -514,19 +514,19 @@ struct MlpWgradW {
 
 // dW1[hid][feat] += sum_m dH[m][hid] x[m][feat], db1 += sum_m dH, dW2[feat][hid] += sum_m dy[m][feat] H[m][hid], db2 += sum_m dy
 // with H = relu(W1 x + b1), dH = (W2^T dy) . 1(H > 0).  Workgroup (slab, split): hidden units [128 slab, +128), wave w the
-// tiles 2w, 2w+1 of them with their W1 / W2^T fragments resident in registers; rows in chunks of 32 through LDS: a row-major
+// tile w of them with its W1 / W2^T fragments resident in registers; rows in chunks of 32 through LDS: a row-major
 // image (A operand of the recomputation, k = feature) and a transposed one (A operand of the two outer products, k = row).
 // Transposed image: [row group gg][feature slot][8 rows = 16 B], row 16 rt + 4 gg + r at position 4 rt + r, feature f in slot
 // (f & 3) * WG_TQ + (f >> 2).  A staging thread owns rows 16 rt + 4 gg + (0..3) of four consecutive features: its 8-byte
 // writes run along the slots (lanes = consecutive slots, the two half-waves = the two halves of a slot) and the 16-byte
 // operand reads of a 16-feature tile hit 16 different bank quads: neither side conflicts.
-__global__ __launch_bounds__(256, 1) void k_mlp_wgrad(MlpWgradW w, const float* __restrict__ X, const float* __restrict__ dY,
+__global__ __launch_bounds__(512, 1) void k_mlp_wgrad(MlpWgradW w, const float* __restrict__ X, const float* __restrict__ dY,
                                                       float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2,
                                                       float* __restrict__ db2, RowSegs rs, int nsplit, const uint32_t* __restrict__ meta) {
   __shared__ __attribute__((aligned(16))) char rm[2][4][32 * WG_RM];     // [buffer][x hi, x lo, dy hi, dy lo]
   __shared__ __attribute__((aligned(16))) char tr[2][4][4 * WG_TG];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // eight waves: two per SIMD, one hidden tile each
   const int j = lane & 15, g = lane >> 4;
   // the four slabs of one row split share an XCD (blocks idx, idx+8, ...): its L2 serves the re-reads of the rows
   const int idx = blockIdx.x, xcd = idx & 7, kq = idx >> 3;
@@ -536,196 +536,165 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wgrad(MlpWgradW w, const float* 
   const long long chunks = (total + 31) / 32;
   const long long cper = (chunks + nsplit - 1) / nsplit;
   const long long c_lo = split * cper, c_hi = (c_lo + cper < chunks) ? c_lo + cper : chunks;
-  const int T0 = slab * 8 + wave * 2;                     // first of this wave's two hidden tiles
-  bfrag W1h[2][4], W1l[2][4], W2h[2][4], W2l[2][4];
-  float b1v[2];
+  const int T0 = slab * 8 + wave;                         // this wave's hidden tile
+  bfrag W1h[4], W1l[4], W2h[4], W2l[4];
+  const float b1v = w.b1[16 * T0 + j];
 #pragma unroll
-  for (int tl = 0; tl < 2; ++tl) {
-    b1v[tl] = w.b1[16 * (T0 + tl) + j];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const size_t f = ((size_t)(T0 + tl) * 4 + s) * 2;
-      W1h[tl][s] = *reinterpret_cast<const bfrag*>((const char*)w.w1n + f * 1024 + lane * 16);
-      W1l[tl][s] = *reinterpret_cast<const bfrag*>((const char*)w.w1n + (f + 1) * 1024 + lane * 16);
-      W2h[tl][s] = *reinterpret_cast<const bfrag*>((const char*)w.w2tn + f * 1024 + lane * 16);
-      W2l[tl][s] = *reinterpret_cast<const bfrag*>((const char*)w.w2tn + (f + 1) * 1024 + lane * 16);
-    }
+  for (int s = 0; s < 4; ++s) {
+    const size_t f = ((size_t)T0 * 4 + s) * 2;
+    W1h[s] = *reinterpret_cast<const bfrag*>((const char*)w.w1n + f * 1024 + lane * 16);
+    W1l[s] = *reinterpret_cast<const bfrag*>((const char*)w.w1n + (f + 1) * 1024 + lane * 16);
+    W2h[s] = *reinterpret_cast<const bfrag*>((const char*)w.w2tn + f * 1024 + lane * 16);
+    W2l[s] = *reinterpret_cast<const bfrag*>((const char*)w.w2tn + (f + 1) * 1024 + lane * 16);
   }
-  f32x4 aW2[8][2], aW1[8][2];
+  f32x4 aW2[8], aW1[8];
 #pragma unroll
-  for (int u = 0; u < 8; ++u)
-#pragma unroll
-    for (int tl = 0; tl < 2; ++tl) { aW2[u][tl] = rr_zero4(); aW1[u][tl] = rr_zero4(); }
-  float ab1[2] = {0.f, 0.f};
+  for (int u = 0; u < 8; ++u) { aW2[u] = rr_zero4(); aW1[u] = rr_zero4(); }
+  float ab1 = 0.f;
   float4 sb2 = make_float4(0.f, 0.f, 0.f, 0.f);
-  // staging: thread -> column group c4 = tid & 31 (4 features), rows r0 + (0..3) with r0 = 16 rt + 4 gg, (gg, rt) = tid >> 5
-  const int c4 = tid & 31, srt = (tid >> 5) & 1, sgg = tid >> 6, r0 = 16 * srt + 4 * sgg;
-  float4 px[4], py[4], qx[4], qy[4];     // chunk being staged / chunk in flight
-  unsigned plv[4], qlv[4];
-  auto g_load = [&](long long c, bool real, float4 (&ox)[4], float4 (&oy)[4], unsigned (&olv)[4]) {      // !real: a chunk past the end (all rows zero)
-    // every load unconditional (clamped row), zeroed by the flag in `stage`: no dependent loads
+  // staging: thread -> column group c4 = tid & 31 (4 features), rows r0, r0 + 1 with r0 = 16 rt + 4 gg + 2 sh, (gg, rt, sh) = tid >> 5
+  const int c4 = tid & 31, rg = tid >> 5;
+  const int sh = rg & 1, srt = (rg >> 1) & 1, sgg = rg >> 2, r0 = 16 * srt + 4 * sgg + 2 * sh;
+  float4 px[2], py[2];                   // the next chunk's rows of this thread (requested a chunk ahead)
+  unsigned plv[2];
+  // every load unconditional (clamped row), zeroed by the flag when staged: no dependent loads.  !real: a chunk past the end.
+  // Row -> address without a divide: segment = (i * magic) >> 40, magic = 2^40 / seg_rows + 1 (exact while i * seg_rows < 2^40:
+  // checked by the launcher); one segment: magic 0.
+  const unsigned long long magic = rs.nseg == 1 ? 0ull : (1ull << 40) / (unsigned)rs.seg_rows + 1ull;
+  long long mrow[2];
+  auto g_load_x = [&](long long c) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const long long i = c * 32 + r0 + k;
-      const long long m = td_row(rs, i < total ? i : total - 1);
-      ox[k] = rr_ld4(X + m * RR_E + 4 * c4);
-      oy[k] = rr_ld4(dY + m * RR_E + 4 * c4);
-      olv[k] = (real && i < total) ? (meta == nullptr ? 1u : meta[m * 8 + 6]) : 0u;       // dead rows (finished routes) read as zero rows
+    for (int k = 0; k < 2; ++k) {
+      const long long i0 = c * 32 + r0 + k, i = i0 < total ? i0 : total - 1;
+      const long long sg = (long long)(((unsigned long long)i * magic) >> 40);
+      mrow[k] = sg * rs.seg_stride + (i - sg * rs.seg_rows);
+      px[k] = rr_ld4(X + mrow[k] * RR_E + 4 * c4);
     }
   };
-  uint32_t ch[4][2], cl[4][2];           // the operand being staged as packed bf16 pieces: [row][feature pair]
-  // rows r0 .. r0 + 3, features 4c4 .. 4c4 + 3 -> pieces, and the row-major images
-  auto put_rm = [&](const float4 (&v)[4], char* rmh, char* rml) {
+  auto g_load_y = [&](long long c, bool real) {      // (after g_load_x of the same chunk)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float xs[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
-      uint16_t h[4], l[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const __bf16 hb = (__bf16)xs[q];
-        const __bf16 lb = (__bf16)(xs[q] - (float)hb);
-        h[q] = __builtin_bit_cast(uint16_t, hb); l[q] = __builtin_bit_cast(uint16_t, lb);
-      }
-      ch[k][0] = h[0] | ((uint32_t)h[1] << 16); ch[k][1] = h[2] | ((uint32_t)h[3] << 16);
-      cl[k][0] = l[0] | ((uint32_t)l[1] << 16); cl[k][1] = l[2] | ((uint32_t)l[3] << 16);
-      *reinterpret_cast<uint2*>(rmh + (r0 + k) * WG_RM + c4 * 8) = make_uint2(ch[k][0], ch[k][1]);
-      *reinterpret_cast<uint2*>(rml + (r0 + k) * WG_RM + c4 * 8) = make_uint2(cl[k][0], cl[k][1]);
+    for (int k = 0; k < 2; ++k) {
+      py[k] = rr_ld4(dY + mrow[k] * RR_E + 4 * c4);
+      plv[k] = (real && c * 32 + r0 + k < total) ? (meta == nullptr ? 1u : meta[mrow[k] * 8 + 6]) : 0u;       // dead rows (finished routes) read as zero rows
     }
   };
-  // the transposed images: per feature the four rows as one 8-byte write (positions 4 rt + 0..3 of row group gg)
-  auto put_tr = [&](char* trh, char* trl) {
+  uint32_t ch[2][2], cl[2][2];           // the operand being staged as packed bf16 pieces: [row][feature pair]
+  // row r0 + k, features 4c4 .. 4c4 + 3 -> pieces, and the row-major images (dead rows as zeros: selects, NaN-safe)
+  auto put_row = [&](float4 v, int k, char* rmh, char* rml) {
+    const bool lv = plv[k] != 0u;
+    const float xs[4] = {lv ? v.x : 0.f, lv ? v.y : 0.f, lv ? v.z : 0.f, lv ? v.w : 0.f};
+    uint16_t h[4], l[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const unsigned sel = (q & 1) ? 0x07060302u : 0x05040100u;       // the high / low halves of two packed pairs
-      const int off = sgg * WG_TG + (q * WG_TQ + c4) * 16 + 8 * srt;
-      *reinterpret_cast<uint2*>(trh + off) = make_uint2(__builtin_amdgcn_perm(ch[1][q >> 1], ch[0][q >> 1], sel), __builtin_amdgcn_perm(ch[3][q >> 1], ch[2][q >> 1], sel));
-      *reinterpret_cast<uint2*>(trl + off) = make_uint2(__builtin_amdgcn_perm(cl[1][q >> 1], cl[0][q >> 1], sel), __builtin_amdgcn_perm(cl[3][q >> 1], cl[2][q >> 1], sel));
+      const __bf16 hb = (__bf16)xs[q];
+      const __bf16 lb = (__bf16)(xs[q] - (float)hb);
+      h[q] = __builtin_bit_cast(uint16_t, hb); l[q] = __builtin_bit_cast(uint16_t, lb);
     }
+    ch[k][0] = h[0] | ((uint32_t)h[1] << 16); ch[k][1] = h[2] | ((uint32_t)h[3] << 16);
+    cl[k][0] = l[0] | ((uint32_t)l[1] << 16); cl[k][1] = l[2] | ((uint32_t)l[3] << 16);
+    *reinterpret_cast<uint2*>(rmh + (r0 + k) * WG_RM + c4 * 8) = make_uint2(ch[k][0], ch[k][1]);
+    *reinterpret_cast<uint2*>(rml + (r0 + k) * WG_RM + c4 * 8) = make_uint2(cl[k][0], cl[k][1]);
   };
-  // Double-buffered images: chunk c is consumed from buffer c & 1 while chunk c + 1 (already in registers) is converted and
-  // written to the other one BETWEEN the matrix instructions of chunk c (the conversions are VALU work the matrix pipe does not
-  // wait for), and chunk c + 2 is requested from memory.  One barrier per chunk.
-  auto stage = [&](int n, int buf) {      // n: 0 = x pieces + row-major, 1 = x transposed, 2 = dy pieces + row-major, 3 = dy transposed
-    if (n == 0) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const bool lv = plv[k] != 0u;                        // (selects, not branches: NaN-safe zeroing of dead rows)
-        px[k] = make_float4(lv ? px[k].x : 0.f, lv ? px[k].y : 0.f, lv ? px[k].z : 0.f, lv ? px[k].w : 0.f);
-        py[k] = make_float4(lv ? py[k].x : 0.f, lv ? py[k].y : 0.f, lv ? py[k].z : 0.f, lv ? py[k].w : 0.f);
-      }
-      put_rm(px, rm[buf][0], rm[buf][1]);
-    } else if (n == 1) {
-      put_tr(tr[buf][0], tr[buf][1]);
-    } else if (n == 2) {
-      put_rm(py, rm[buf][2], rm[buf][3]);
-      const float k0 = slab == 0 ? 1.0f : 0.f;        // branch-free: the staging must stay in the matrix instructions' basic block
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { sb2.x = fmaf(k0, py[k].x, sb2.x); sb2.y = fmaf(k0, py[k].y, sb2.y); sb2.z = fmaf(k0, py[k].z, sb2.z); sb2.w = fmaf(k0, py[k].w, sb2.w); }
-    } else {
-      put_tr(tr[buf][2], tr[buf][3]);
-    }
+  // the transposed images: per feature the two rows as one 4-byte write (positions 4 rt + 2 sh + 0..1 of row group gg)
+  auto put_tr = [&](int q, char* trh, char* trl) {
+    const unsigned sel = (q & 1) ? 0x07060302u : 0x05040100u;       // the high / low halves of two packed pairs
+    const int off = sgg * WG_TG + (q * WG_TQ + c4) * 16 + 8 * srt + 4 * sh;
+    *reinterpret_cast<uint32_t*>(trh + off) = __builtin_amdgcn_perm(ch[1][q >> 1], ch[0][q >> 1], sel);
+    *reinterpret_cast<uint32_t*>(trl + off) = __builtin_amdgcn_perm(cl[1][q >> 1], cl[0][q >> 1], sel);
   };
-  // scheduling hint for a region of 48 matrix instructions, 16 LDS reads and one `stage` (~50 VALU, 6 LDS writes): the
-  // conversions go between the matrix instructions instead of behind them
-#define WG_INTERLEAVE()                                                                        \
-  do {                                                                                         \
-    _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) {                                        \
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                       \
-      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                       \
-      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                       \
-    }                                                                                          \
-    __builtin_amdgcn_sched_group_barrier(0x200, 8, 0);                                         \
-  } while (0)
+  // Double-buffered images: chunk c is consumed from buffer c & 1 while chunk c + 1 (in registers since the previous chunk) is
+  // converted and written to the other one in eight slices placed between the matrix-instruction groups of chunk c (VALU work
+  // under the matrix pipe), and chunk c + 2 is requested as soon as a slice has freed its registers.  One barrier per chunk.
+  auto stage = [&](int n, int buf, long long cn, bool real) {      // slices 0-3: x, 4-7: dy; cn: the chunk to request
+    if (n == 0) put_row(px[0], 0, rm[buf][0], rm[buf][1]);
+    else if (n == 1) put_row(px[1], 1, rm[buf][0], rm[buf][1]);
+    else if (n == 2) { put_tr(0, tr[buf][0], tr[buf][1]); put_tr(1, tr[buf][0], tr[buf][1]); }
+    else if (n == 3) { put_tr(2, tr[buf][0], tr[buf][1]); put_tr(3, tr[buf][0], tr[buf][1]); g_load_x(cn); }
+    else if (n == 4 || n == 5) {
+      const int k = n - 4;
+      put_row(py[k], k, rm[buf][2], rm[buf][3]);
+      const float k0 = (slab == 0 && plv[k] != 0u) ? 1.0f : 0.f;       // branch-free: the staging stays in the matrix instructions' basic block
+      sb2.x = fmaf(k0, py[k].x, sb2.x); sb2.y = fmaf(k0, py[k].y, sb2.y); sb2.z = fmaf(k0, py[k].z, sb2.z); sb2.w = fmaf(k0, py[k].w, sb2.w);
+    } else if (n == 6) { put_tr(0, tr[buf][2], tr[buf][3]); put_tr(1, tr[buf][2], tr[buf][3]); }
+    else { put_tr(2, tr[buf][2], tr[buf][3]); put_tr(3, tr[buf][2], tr[buf][3]); g_load_y(cn, real); }
+  };
+  // operand fragments of one matrix-instruction group: [x hi, x lo, dy hi, dy lo]
+  auto ld_rm = [&](int buf, int s, int rt, bfrag (&f)[4]) {
+    const int off = (16 * rt + j) * WG_RM + (32 * s + 8 * g) * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = *reinterpret_cast<const bfrag*>(rm[buf][i] + off);
+  };
+  auto ld_tr = [&](int buf, int u, bfrag (&f)[4]) {
+    const int off = g * WG_TG + ((j & 3) * WG_TQ + 4 * u + (j >> 2)) * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = *reinterpret_cast<const bfrag*>(tr[buf][i] + off);
+  };
   if (c_lo < c_hi) {
-    g_load(c_lo, true, px, py, plv);
-    stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
-    g_load(c_lo + 1 < c_hi ? c_lo + 1 : c_lo, c_lo + 1 < c_hi, px, py, plv);
+    g_load_x(c_lo); g_load_y(c_lo, true);
+#pragma unroll
+    for (int n = 0; n < 8; ++n) stage(n, 0, c_lo + 1 < c_hi ? c_lo + 1 : c_lo, c_lo + 1 < c_hi);
   }
   __syncthreads();
   for (long long c = c_lo; c < c_hi; ++c) {
     const int buf = (int)((c - c_lo) & 1);
-    // chunk c + 2 goes into flight now; chunk c + 1 (requested an iteration ago) has landed: the opaque pass-through makes that
-    // visible to the scheduler (values of a load are otherwise pushed behind every matrix instruction of the region)
-    g_load(c + 2 < c_hi ? c + 2 : c, c + 2 < c_hi, qx, qy, qlv);
+    const long long cn = c + 2 < c_hi ? c + 2 : c;
+    const bool rn = c + 2 < c_hi;
+    bfrag fa[2][4];
+    ld_rm(buf, 0, 0, fa[0]);
+    // ---- recompute pre[row][hid] = x W1^T, dpre = dy W2 for this wave's hidden tile (A = activations, k = feature); the
+    // fragments of group i + 1 are requested before the matrix instructions of group i
+    f32x4 pre[2] = {rr_zero4(), rr_zero4()}, dpre[2] = {rr_zero4(), rr_zero4()};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      asm volatile("" : "+v"(px[k].x), "+v"(px[k].y), "+v"(px[k].z), "+v"(px[k].w), "+v"(py[k].x), "+v"(py[k].y),
-                   "+v"(py[k].z), "+v"(py[k].w), "+v"(plv[k]));
-    }
-    // ---- recompute pre[row][hid] = x W1^T, dpre = dy W2 for this wave's two hidden tiles (A = activations, k = feature)
-    f32x4 pre[2][2], dpre[2][2];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-      for (int tl = 0; tl < 2; ++tl) { pre[rt][tl] = rr_zero4(); dpre[rt][tl] = rr_zero4(); }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        const int off = (16 * rt + j) * WG_RM + (32 * s + 8 * g) * 2;
-        const bfrag xh = *reinterpret_cast<const bfrag*>(rm[buf][0] + off), xl = *reinterpret_cast<const bfrag*>(rm[buf][1] + off);
-        const bfrag yh = *reinterpret_cast<const bfrag*>(rm[buf][2] + off), yl = *reinterpret_cast<const bfrag*>(rm[buf][3] + off);
-#pragma unroll
-        for (int tl = 0; tl < 2; ++tl) {
-          pre[rt][tl] = td_mfma3(xh, xl, W1h[tl][s], W1l[tl][s], pre[rt][tl]);
-          dpre[rt][tl] = td_mfma3(yh, yl, W2h[tl][s], W2l[tl][s], dpre[rt][tl]);
-        }
-      }
-      if (s & 1) { stage(s >> 1, buf ^ 1); }      // (also for the last chunk: the rows past the end stage as zeros)
-      if (s & 1) { WG_INTERLEAVE(); __builtin_amdgcn_sched_barrier(0); }
+    for (int i = 0; i < 8; ++i) {                              // i = 2 s + rt
+      if (i + 1 < 8) ld_rm(buf, (i + 1) >> 1, (i + 1) & 1, fa[(i + 1) & 1]);
+      else ld_tr(buf, 0, fa[0]);
+      const int s = i >> 1, rt = i & 1;
+      pre[rt] = td_mfma3(fa[i & 1][0], fa[i & 1][1], W1h[s], W1l[s], pre[rt]);
+      dpre[rt] = td_mfma3(fa[i & 1][2], fa[i & 1][3], W2h[s], W2l[s], dpre[rt]);
+      if ((i & 1) == 0) stage(i >> 1, buf ^ 1, cn, rn);       // (also for the last chunk: the rows past the end stage as zeros)
+      __builtin_amdgcn_sched_barrier(0);
     }
     // C layout here: lane (hid = j, g) holds rows 16 rt + 4g + r.  As the B operand of the outer products (k = row) a lane's
-    // eight values are rows {4g + r} u {16 + 4g + r}: positions 8g + 4 rt + r of the transposed images.
-    bfrag Hh[2], Hl[2], Gh[2], Gl[2];
-#pragma unroll
-    for (int tl = 0; tl < 2; ++tl) {
+    // eight values are rows {4g + r} u {16 + 4g + r}: positions 4 rt + r of row group g in the transposed images.
+    bfrag Hh, Hl, Gh, Gl;
+    {
       float hx[8], gx[8];
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = pre[rt][tl][r] + b1v[tl];
+          const float pv = pre[rt][r] + b1v;
           hx[4 * rt + r] = fmaxf(pv, 0.f);
-          gx[4 * rt + r] = pv > 0.f ? dpre[rt][tl][r] : 0.f;
-          ab1[tl] += gx[4 * rt + r];
+          gx[4 * rt + r] = pv > 0.f ? dpre[rt][r] : 0.f;
+          ab1 += gx[4 * rt + r];
         }
-      td_split8(hx, Hh[tl], Hl[tl]);
-      td_split8(gx, Gh[tl], Gl[tl]);
+      td_split8(hx, Hh, Hl);
+      td_split8(gx, Gh, Gl);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int off = g * WG_TG + ((j & 3) * WG_TQ + 4 * u + (j >> 2)) * 16;
-      const bfrag xh = *reinterpret_cast<const bfrag*>(tr[buf][0] + off), xl = *reinterpret_cast<const bfrag*>(tr[buf][1] + off);
-      const bfrag yh = *reinterpret_cast<const bfrag*>(tr[buf][2] + off), yl = *reinterpret_cast<const bfrag*>(tr[buf][3] + off);
-#pragma unroll
-      for (int tl = 0; tl < 2; ++tl) {
-        aW2[u][tl] = td_mfma3(yh, yl, Hh[tl], Hl[tl], aW2[u][tl]);      // [feat][hid] += dy^T H
-        aW1[u][tl] = td_mfma3(xh, xl, Gh[tl], Gl[tl], aW1[u][tl]);      // [feat][hid] += x^T dH  (= dW1^T)
-      }
-      if ((u & 3) == 3) { stage(2 + (u >> 2), buf ^ 1); }
-      if ((u & 3) == 3) { WG_INTERLEAVE(); __builtin_amdgcn_sched_barrier(0); }
+      if (u + 1 < 8) ld_tr(buf, u + 1, fa[(u + 1) & 1]);
+      aW2[u] = td_mfma3(fa[u & 1][2], fa[u & 1][3], Hh, Hl, aW2[u]);      // [feat][hid] += dy^T H
+      aW1[u] = td_mfma3(fa[u & 1][0], fa[u & 1][1], Gh, Gl, aW1[u]);      // [feat][hid] += x^T dH  (= dW1^T)
+      if ((u & 1) == 0) stage(4 + (u >> 1), buf ^ 1, cn, rn);
+      __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { px[k] = qx[k]; py[k] = qy[k]; plv[k] = qlv[k]; }
     __syncthreads();                      // buffer buf is consumed by every wave, buffer buf ^ 1 is complete
   }
   // ---- epilogue: float atomics into the (zeroed) gradients
 #pragma unroll
   for (int u = 0; u < 8; ++u)
 #pragma unroll
-    for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int feat = 16 * u + 4 * g + r, hid = 16 * (T0 + tl) + j;
-        atomicAdd(dW2 + (size_t)feat * RR_FF + hid, aW2[u][tl][r]);
-        atomicAdd(dW1 + (size_t)hid * RR_E + feat, aW1[u][tl][r]);
-      }
-#pragma unroll
-  for (int tl = 0; tl < 2; ++tl) {
-    float v = ab1[tl];
+    for (int r = 0; r < 4; ++r) {
+      const int feat = 16 * u + 4 * g + r, hid = 16 * T0 + j;
+      atomicAdd(dW2 + (size_t)feat * RR_FF + hid, aW2[u][r]);
+      atomicAdd(dW1 + (size_t)hid * RR_E + feat, aW1[u][r]);
+    }
+  {
+    float v = ab1;
     v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-    if (g == 0) atomicAdd(db1 + 16 * (T0 + tl) + j, v);
+    if (g == 0) atomicAdd(db1 + 16 * T0 + j, v);
   }
   if (slab == 0 && db2 != nullptr) {
     atomicAdd(db2 + 4 * c4 + 0, sb2.x); atomicAdd(db2 + 4 * c4 + 1, sb2.y);
@@ -740,10 +709,11 @@ extern "C" int rr_mlp_wgrad(const MlpWgradW* w, const float* X, const float* dY,
       dW1 == nullptr || db1 == nullptr || dW2 == nullptr)
     return RR_EINVAL;
   if (nseg <= 0 || seg_rows <= 0 || seg_stride < seg_rows) return RR_EINVAL;
+  if (nseg > 1 && (long long)nseg * seg_rows >= (1ll << 40) / seg_rows) return RR_EINVAL;      // (the kernel's divide-free row map)
   RowSegs rs{nseg, seg_rows, seg_stride};
   const long long chunks = ((long long)nseg * seg_rows + 31) / 32;
   int nsplit = chunks >= 64 * 8 ? 64 : (chunks >= 64 ? 16 : 8);
-  hipLaunchKernelGGL(k_mlp_wgrad, dim3(4 * nsplit), dim3(256), 0, st, *w, X, dY, dW1, db1, dW2, db2, rs, nsplit, meta);
+  hipLaunchKernelGGL(k_mlp_wgrad, dim3(4 * nsplit), dim3(512), 0, st, *w, X, dY, dW1, db1, dW2, db2, rs, nsplit, meta);
   return rr_check(hipGetLastError());
 }
 
