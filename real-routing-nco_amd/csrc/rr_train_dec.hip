@@ -360,10 +360,11 @@ struct MlpRowsW {
 
 // MODE 0: out = x + W2 relu(W1 x + b1) + b2        (TransformerFFN / pointer MLP forward, decoder.py:296)
 // MODE 1: out = dy + W1^T [ (W2^T dy) . 1(W1 x + b1 > 0) ]   (its input gradient)
-// A workgroup = 4 waves x 32 rows; the weight fragments of one hidden pair (32 units) are one LDS stage, filled by LDS-DMA
-// one stage ahead, one barrier per stage.
+// A workgroup = 8 waves x 16 rows (two waves per SIMD); the weight fragments of one hidden pair (32 units) are one LDS stage,
+// filled by LDS-DMA one stage ahead, one barrier per stage.  The rows of the workgroup's next block are requested during the
+// first stage of the current one and converted when it is done.
 template <int MODE>
-__global__ __launch_bounds__(256, 1) void k_mlp_rows(MlpRowsW w, const float* __restrict__ X, const float* __restrict__ dY,
+__global__ __launch_bounds__(512, 1) void k_mlp_rows(MlpRowsW w, const float* __restrict__ X, const float* __restrict__ dY,
                                                      float* __restrict__ out, RowSegs rs, const uint32_t* __restrict__ meta) {
   constexpr int NF = MODE == 1 ? 48 : 32;                 // fragments (1 KB each) per stage
   extern __shared__ __attribute__((aligned(16))) char td_lds[];
@@ -372,13 +373,13 @@ __global__ __launch_bounds__(256, 1) void k_mlp_rows(MlpRowsW w, const float* __
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, g = lane >> 4;
-  for (int i = tid; i < RR_FF; i += 256) b1s[i] = w.b1[i];
+  for (int i = tid; i < RR_FF; i += 512) b1s[i] = w.b1[i];
   const long long total = (long long)rs.nseg * rs.seg_rows;
   const long long nblk = (total + 127) / 128;
   auto issue = [&](int p, int buf) {
 #pragma unroll
-    for (int q = 0; q < NF / 4; ++q) {
-      const int f = wave * (NF / 4) + q;
+    for (int q = 0; q < NF / 8; ++q) {
+      const int f = wave * (NF / 8) + q;
       const char* src;
       if (f < 16) src = (const char*)w.wa1 + ((size_t)p * 16 + f) * 1024;
       else if (MODE == 1 && f < 32) src = (const char*)w.wa2 + ((size_t)p * 16 + (f - 16)) * 1024;
@@ -387,41 +388,43 @@ __global__ __launch_bounds__(256, 1) void k_mlp_rows(MlpRowsW w, const float* __
     }
   };
   auto frag = [&](int buf, int f) { return *reinterpret_cast<const bfrag*>(stage + buf * (NF * 1024) + f * 1024 + lane * 16); };
+  // a lane's row of a block: 8 + 8 float4 in flight (every load unconditional, zeroed by the flag afterwards: no dependent loads)
+  long long nrow; bool nvr; unsigned nlv;
+  float4 xa4[4], xb4[4], ya4[4], yb4[4];
+  auto load_rows = [&](long long blk) {
+    long long i = blk * 128 + wave * 16 + j;
+    nvr = i < total;
+    i = nvr ? i : total - 1;
+    nrow = td_row(rs, i);
+    nlv = meta == nullptr ? 1u : meta[nrow * 8 + 6];      // rows the rollout never reached (finished routes) read as zero rows
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      xa4[s] = rr_ld4(X + nrow * RR_E + 32 * s + 4 * g); xb4[s] = rr_ld4(X + nrow * RR_E + 32 * s + 16 + 4 * g);
+      if (MODE == 1) { ya4[s] = rr_ld4(dY + nrow * RR_E + 32 * s + 4 * g); yb4[s] = rr_ld4(dY + nrow * RR_E + 32 * s + 16 + 4 * g); }
+    }
+  };
+  if ((long long)blockIdx.x < nblk) load_rows(blockIdx.x);
   for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-    long long mrow[2]; bool vr[2];
-    bfrag Xh[2][4], Xl[2][4], Yh[2][4], Yl[2][4];
-    f32x4 acc[2][8];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-      long long i = blk * 128 + wave * 32 + rt * 16 + j;
-      vr[rt] = i < total;
-      i = vr[rt] ? i : total - 1;
-      mrow[rt] = td_row(rs, i);
-      // rows the rollout never reached (finished routes) hold no data: they read as zero rows
-      // (every load is issued unconditionally and zeroed by the flag afterwards: no dependent-load chain)
-      const unsigned lvw = meta == nullptr ? 1u : meta[mrow[rt] * 8 + 6];
+    const long long mrow = nrow; const bool vr = nvr;
+    bfrag Xh[4], Xl[4], Yh[4], Yl[4];
+    f32x4 acc[8];
+    {
       const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      float4 xa4[4], xb4[4], ya4[4], yb4[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        xa4[s] = rr_ld4(X + mrow[rt] * RR_E + 32 * s + 4 * g); xb4[s] = rr_ld4(X + mrow[rt] * RR_E + 32 * s + 16 + 4 * g);
-        if (MODE == 1) { ya4[s] = rr_ld4(dY + mrow[rt] * RR_E + 32 * s + 4 * g); yb4[s] = rr_ld4(dY + mrow[rt] * RR_E + 32 * s + 16 + 4 * g); }
-      }
-      const bool lv = lvw != 0u;
+      const bool lv = nlv != 0u;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const float4 xa = lv ? xa4[s] : z4, xb = lv ? xb4[s] : z4;
         const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-        td_split8(xv, Xh[rt][s], Xl[rt][s]);
+        td_split8(xv, Xh[s], Xl[s]);
         if (MODE == 1) {
           const float4 ya = lv ? ya4[s] : z4, yb = lv ? yb4[s] : z4;
           const float yv[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
-          td_split8(yv, Yh[rt][s], Yl[rt][s]);
-          acc[rt][2 * s] = f32x4{ya.x, ya.y, ya.z, ya.w}; acc[rt][2 * s + 1] = f32x4{yb.x, yb.y, yb.z, yb.w};
+          td_split8(yv, Yh[s], Yl[s]);
+          acc[2 * s] = f32x4{ya.x, ya.y, ya.z, ya.w}; acc[2 * s + 1] = f32x4{yb.x, yb.y, yb.z, yb.w};
         } else {
           const float4 ba = rr_ld4(w.b2 + 32 * s + 4 * g), bb = rr_ld4(w.b2 + 32 * s + 16 + 4 * g);
-          acc[rt][2 * s] = f32x4{xa.x + ba.x, xa.y + ba.y, xa.z + ba.z, xa.w + ba.w};
-          acc[rt][2 * s + 1] = f32x4{xb.x + bb.x, xb.y + bb.y, xb.z + bb.z, xb.w + bb.w};
+          acc[2 * s] = f32x4{xa.x + ba.x, xa.y + ba.y, xa.z + ba.z, xa.w + ba.w};
+          acc[2 * s + 1] = f32x4{xb.x + bb.x, xb.y + bb.y, xb.z + bb.z, xb.w + bb.w};
         }
       }
     }
@@ -433,50 +436,44 @@ __global__ __launch_bounds__(256, 1) void k_mlp_rows(MlpRowsW w, const float* __
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                    // stage p landed (every wave's DMA) and stage p-1 is consumed by every wave
       if (p + 1 < RR_FF / 32) issue(p + 1, buf ^ 1);
-      f32x4 pre[2][2], dpre[2][2];
+      if (p == 0 && blk + gridDim.x < nblk) load_rows(blk + gridDim.x);      // (behind the DMA of stage 1: the wait of stage 1 covers both)
+      f32x4 pre[2], dpre[2];
 #pragma unroll
       for (int tl = 0; tl < 2; ++tl) {
         const float4 bv = rr_ld4(b1s + 32 * p + 16 * tl + 4 * g);
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) { pre[tl][rt] = f32x4{bv.x, bv.y, bv.z, bv.w}; dpre[tl][rt] = rr_zero4(); }
+        pre[tl] = f32x4{bv.x, bv.y, bv.z, bv.w}; dpre[tl] = rr_zero4();
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const bfrag ah = frag(buf, tl * 8 + s * 2), al = frag(buf, tl * 8 + s * 2 + 1);
-#pragma unroll
-          for (int rt = 0; rt < 2; ++rt) pre[tl][rt] = td_mfma3(ah, al, Xh[rt][s], Xl[rt][s], pre[tl][rt]);
+          pre[tl] = td_mfma3(ah, al, Xh[s], Xl[s], pre[tl]);
           if (MODE == 1) {
             const bfrag ch = frag(buf, 16 + tl * 8 + s * 2), cl = frag(buf, 16 + tl * 8 + s * 2 + 1);
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) dpre[tl][rt] = td_mfma3(ch, cl, Yh[rt][s], Yl[rt][s], dpre[tl][rt]);
+            dpre[tl] = td_mfma3(ch, cl, Yh[s], Yl[s], dpre[tl]);
           }
         }
       }
-      bfrag Hh[2], Hl[2];
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
+      bfrag Hh, Hl;
+      {
         float hx[8];
 #pragma unroll
         for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            hx[4 * tl + r] = MODE == 1 ? (pre[tl][rt][r] > 0.f ? dpre[tl][rt][r] : 0.f) : fmaxf(pre[tl][rt][r], 0.f);
-        td_split8(hx, Hh[rt], Hl[rt]);
+            hx[4 * tl + r] = MODE == 1 ? (pre[tl][r] > 0.f ? dpre[tl][r] : 0.f) : fmaxf(pre[tl][r], 0.f);
+        td_split8(hx, Hh, Hl);
       }
       constexpr int FB = MODE == 1 ? 32 : 16;
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const bfrag bh = frag(buf, FB + u * 2), bl = frag(buf, FB + u * 2 + 1);
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) acc[rt][u] = td_mfma3(bh, bl, Hh[rt], Hl[rt], acc[rt][u]);
+        acc[u] = td_mfma3(bh, bl, Hh, Hl, acc[u]);
       }
     }
+    if (vr) {
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-      if (vr[rt]) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          rr_st4(out + mrow[rt] * RR_E + 16 * u + 4 * g, make_float4(acc[rt][u][0], acc[rt][u][1], acc[rt][u][2], acc[rt][u][3]));
-      }
+      for (int u = 0; u < 8; ++u)
+        rr_st4(out + mrow * RR_E + 16 * u + 4 * g, make_float4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]));
+    }
     __syncthreads();                      // the next block's first stage overwrites buffer 0
   }
 }
@@ -493,11 +490,11 @@ extern "C" int rr_mlp_rows(const MlpRowsW* w, int mode, const float* X, const fl
   if (mode == 1) {
     const int shm = 2 * 48 * 1024 + RR_FF * 4;
     (void)hipFuncSetAttribute((const void*)k_mlp_rows<1>, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-    hipLaunchKernelGGL((k_mlp_rows<1>), dim3(grid), dim3(256), shm, st, *w, X, dY, out, rs, meta);
+    hipLaunchKernelGGL((k_mlp_rows<1>), dim3(grid), dim3(512), shm, st, *w, X, dY, out, rs, meta);
   } else {
     const int shm = 2 * 32 * 1024 + RR_FF * 4;
     (void)hipFuncSetAttribute((const void*)k_mlp_rows<0>, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-    hipLaunchKernelGGL((k_mlp_rows<0>), dim3(grid), dim3(256), shm, st, *w, X, dY, out, rs, meta);
+    hipLaunchKernelGGL((k_mlp_rows<0>), dim3(grid), dim3(512), shm, st, *w, X, dY, out, rs, meta);
   }
   return rr_check(hipGetLastError());
 }
