@@ -443,22 +443,13 @@ extern "C" int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStrea
     return rr_check(hipGetLastError());
   }
   // tail packing (rr_rollout_w.inc): the S % 16 left-over rollouts of 16 / (S % 16) consecutive instances share one tile
-  // A packed tile runs its attention and logits once per instance it spans: a workgroup of such tiles takes ~(1 + 0.73 (g - 1))
-  // ordinary workgroup times (measured: 3.2 at g = 4).  Over many rounds of workgroups that is hidden and the saved tiles count;
-  // in a launch of a few rounds those workgroups ARE the makespan (a 512-instance training rollout: 18.4 ms packed, 12.2 ms
-  // not).  So: pack only when the estimated makespan is shorter.  RR_TAIL_PACK=0 / 1 forces never / always.
-  static const int pack = getenv("RR_TAIL_PACK") ? atoi(getenv("RR_TAIL_PACK")) : -1;
-  static const int n_cu = [] { int d = 0, n = 0; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 0 ? n : 256; }();
+  // Off by default since the logit keys of ordinary tiles live in LDS: a packed tile runs its attention and logits once per
+  // instance it spans, with every operand from L2, and a workgroup of such tiles takes 3 (a 2-round launch) to ~6 (the 14-round
+  // headline launch) ordinary workgroup times for the work of 4 quarter-full tiles.  Measured: headline rollout 73.9 ms packed,
+  // 69.2 ms not (14 full rounds of 256 workgroups); 512-instance training rollout 18.4 / 12.2 ms.  RR_TAIL_PACK=1 turns it on.
+  static const int pack = getenv("RR_TAIL_PACK") ? atoi(getenv("RR_TAIL_PACK")) : 0;
   const int tail_m = S & 15;
-  int tail_g = (pack != 0 && S > 16 && tail_m > 0 && tail_m <= 8 && io->Bp > 1) ? 16 / tail_m : 0;
-  if (tail_g && pack < 0) {
-    auto est = [](double rounds) { return rounds <= 4.0 ? ceil(rounds - 1e-9) : rounds; };      // few rounds: whole rounds
-    const double c = 1.0 + 0.73 * (tail_g - 1);
-    const double n_ord = (double)io->Bp * (S / 16) / WWAVES, n_heavy = ceil((double)((io->Bp + tail_g - 1) / tail_g) / WWAVES);
-    const double t_pack = fmax(c, est((n_ord + n_heavy * c) / n_cu));
-    const double t_plain = est(ceil((double)io->Bp * ((S + 15) / 16) / WWAVES) / n_cu);
-    if (t_pack >= t_plain) tail_g = 0;
-  }
+  const int tail_g = (pack && S > 16 && tail_m > 0 && tail_m <= 8 && io->Bp > 1) ? 16 / tail_m : 0;
   const int ntask = tail_g ? (io->Bp + tail_g - 1) / tail_g + io->Bp * (S / 16) : io->Bp * ((S + 15) / 16);
   dim3 grid((ntask + WWAVES - 1) / WWAVES), blk(WTHREADS);
   // LDS-staged distance tiles: as many instances (<= 2) as leave room for 160 KB / WTHREADS-sized workgroups per CU

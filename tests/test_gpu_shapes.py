@@ -57,6 +57,17 @@ def test_atsp_other_shapes_match_oracle(N, B, S, ss):
     _run(N, B, S, ss, seed=100 + N + S)
 
 
+def test_tail_packed_rollout_still_matches_the_oracle():
+    """Tail packing (several instances' left-over rollouts in one tile) is off by default (csrc/rr_decode.hip); RR_TAIL_PACK=1 is
+    read once per process, so the packed shapes run in a child process with it set."""
+    import os, subprocess, sys
+    env = dict(os.environ, RR_TAIL_PACK="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "test_atsp_other_shapes_match_oracle and (20-9-20-15 or 24-20-17-15)"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_atsp_max_nodes_103_and_more_starts_than_a_workgroup_tile_set():
     _run(103, 2, 103, 25, seed=7)
 
