@@ -38,7 +38,8 @@ PEAK_F16_MFMA_TFLOPS = 2500.0            # ... dense fp16 / bf16 matrix peak (me
 # What the pipe executes per 16-rollout tile and decode step: 768 (MLP) + 3 x 112 (scores, P.V, logits: the k = 16 products ride
 # in k = 32 instructions as [hi | lo'] x [hi | 0] and [hi | lo'] x [lo' | hi]) = 1 104 v_mfma_f32_16x16x32_f16 of 16 384 flop.
 SPLIT_PRODUCTS = 3
-EXECUTED_F16_FLOP_PER_ROLLOUT_STEP = 1104 * 16384 // 16
+EXECUTED_F16_FLOP_PER_TILE_STEP = 1104 * 16384
+EXECUTED_F16_FLOP_PER_ROLLOUT_STEP = EXECUTED_F16_FLOP_PER_TILE_STEP // 16      # (a full tile; tools/bench_train.py)
 ROLLOUT_KERNEL = "k_rollout_w<7, 0, 0, true>"
 ROLLOUT_KERNEL_FP32 = "k_rollout_w<7, 0, 0, false>"
 # HBM-side traffic of ONE rollout launch at the default workload: rocprofv3 PMC, separate FETCH_SIZE / WRITE_SIZE passes,
@@ -185,7 +186,10 @@ def main():
         k_ms = sum(kern_ms) / max(len(kern_ms), 1)
         achieved = rollout_steps * FLOP_PER_ROLLOUT_STEP / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         peak_split = PEAK_F16_MFMA_TFLOPS / SPLIT_PRODUCTS
-        executed = rollout_steps * EXECUTED_F16_FLOP_PER_ROLLOUT_STEP / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        # executed work counts tiles: S = 100 starts are 6 full 16-rollout tiles and one quarter-full one per instance (tail tiles are
+        # not packed across instances: csrc/rr_decode.hip)
+        tile_steps = args.batch * AUG * ((STARTS + 15) // 16) * (N_NODES - 1)
+        executed = tile_steps * EXECUTED_F16_FLOP_PER_TILE_STEP / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         traffic, traffic_src = measured_rollout_traffic(args.batch)
         line = {
             "metric": "solved instances/sec (ATSP n=100, B=512, POMO greedy)", "value": total_inst / dt,
@@ -205,7 +209,7 @@ def main():
                          "peak_note": "fp32-equivalent flop/s of the fp16 matrix pipe at its dense peak with 3 partial products per product "
                                       "(2 500 / 3); round 1's all-fp32-MFMA kernel (peak 157.3) is under `variants`",
                          "executed_mfma": {"achieved": executed, "peak": PEAK_F16_MFMA_TFLOPS, "frac": executed / PEAK_F16_MFMA_TFLOPS,
-                                           "note": "1 104 v_mfma_f32_16x16x32_f16 per 16-rollout tile and decode step"},
+                                           "note": "1 104 v_mfma_f32_16x16x32_f16 per 16-rollout tile and decode step, 7 tiles per 100 starts"},
                          "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": k_ms,
                          "algorithmic_flop_per_launch": rollout_steps * FLOP_PER_ROLLOUT_STEP},
             "mean_best_cost": float(-best.mean().item()),
@@ -233,11 +237,11 @@ def main():
             os.environ["RR_MLP_SPLIT"] = "0"
             v32, k32 = timed("fp32")
             a32 = rollout_steps * FLOP_PER_ROLLOUT_STEP / (k32 * 1e-3) / 1e12
-            e32 = rollout_steps * EXECUTED_FLOP_PER_ROLLOUT_STEP / (k32 * 1e-3) / 1e12
+            e32 = tile_steps * 16 * EXECUTED_FLOP_PER_ROLLOUT_STEP / (k32 * 1e-3) / 1e12
             v32["roofline"] = {"bound": "mfma", "kernel": ROLLOUT_KERNEL_FP32, "achieved": a32, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": a32 / PEAK_F32_MFMA_TFLOPS,
                                "executed_mfma": {"achieved": e32, "frac": e32 / PEAK_F32_MFMA_TFLOPS,
-                                                 "note": "348 160 flop per rollout-step actually issued (no context GEMM, keys padded to 112)"}}
+                                                 "note": "348 160 flop per rollout-step actually issued (no context GEMM, keys padded to 112), 7 tiles of 16 per 100 starts"}}
             line["variants"]["all_fp32_mfma (RR_MLP_SPLIT=0)"] = v32
             R.SPLIT_MLP = True
             os.environ.pop("RR_MLP_SPLIT")
