@@ -466,6 +466,7 @@ extern "C" int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStrea
   const int per_x = nwg > theavy ? (nwg - theavy + 7) / 8 : 0;
   const dim3 grid_s(theavy + 8 * per_x), blk_s = blk;
   const int mode = io->logits_only ? 3 : io->mode;
+  static const bool inst_on = getenv("RR_ROLLOUT_INST") == nullptr || atoi(getenv("RR_ROLLOUT_INST")) != 0;
 #define RR_LAUNCHW4(NTV, P, M, SP)                                                                            \
   do {                                                                                                       \
     const int lds_inst_s = wstg + 2 * (size_t)(NTV) * 8192 <= per_wg ? 2 : 0;                               \
@@ -474,10 +475,21 @@ extern "C" int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStrea
     hipLaunchKernelGGL((k_rollout_w<NTV, P, M, SP>), (SP) ? grid_s : grid, (SP) ? blk_s : blk, shm, st, *w, *io, tail_g, \
                        (SP) ? lds_inst_s : lds_inst);                                                        \
   } while (0)
+  /* instance mode (rr_rollout_w.inc): one instance per workgroup, K + L in LDS, the eighth wave loads the weight ring: */ \
+  /* three 16 KB weight stage buffers + the L and K images = all 160 KB                                                 */
+#define RR_LAUNCHW4I(NTV, P, M)                                                                              \
+  do {                                                                                                       \
+    if constexpr ((NTV) == 7) {                                                                              \
+      const size_t shm_i = 3 * 16384 + 2 * (size_t)(NTV) * 8192;                                             \
+      (void)hipFuncSetAttribute((const void*)k_rollout_w<NTV, P, M, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_i); \
+      hipLaunchKernelGGL((k_rollout_w<NTV, P, M, true, true>), dim3(io->Bp), blk_s, shm_i, st, *w, *io, 0, 0); \
+    }                                                                                                        \
+  } while (0)
   // the split-bf16 pointer MLP is opt-in (RR_MLP_SPLIT=1), for the greedy / sampling rollouts of every problem
 #define RR_LAUNCHW3(NTV, P, M)                                                                               \
   do {                                                                                                       \
-    if ((M) <= 1 && mlp_split) RR_LAUNCHW4(NTV, P, ((M) <= 1 ? (M) : 0), true);                               \
+    if ((M) <= 1 && mlp_split && (NTV) == 7 && inst_on && tail_g == 0 && (S + 15) / 16 == WWAVES - 1) RR_LAUNCHW4I(NTV, P, ((M) <= 1 ? (M) : 0)); \
+    else if ((M) <= 1 && mlp_split) RR_LAUNCHW4(NTV, P, ((M) <= 1 ? (M) : 0), true);                          \
     else RR_LAUNCHW4(NTV, P, M, false);                                                                      \
   } while (0)
 #define RR_LAUNCHW2(NTV, P)                                                                                  \
