@@ -40,8 +40,8 @@ PEAK_F16_MFMA_TFLOPS = 2500.0            # ... dense fp16 / bf16 matrix peak (me
 SPLIT_PRODUCTS = 3
 EXECUTED_F16_FLOP_PER_TILE_STEP = 1104 * 16384
 EXECUTED_F16_FLOP_PER_ROLLOUT_STEP = EXECUTED_F16_FLOP_PER_TILE_STEP // 16      # (a full tile; tools/bench_train.py)
-ROLLOUT_KERNEL = "k_rollout_w<7, 0, 0, true>"
-ROLLOUT_KERNEL_FP32 = "k_rollout_w<7, 0, 0, false>"
+ROLLOUT_KERNEL = "k_rollout_w<7, 0, 0, true, true>"
+ROLLOUT_KERNEL_FP32 = "k_rollout_w<7, 0, 0, false, false>"
 # HBM-side traffic of ONE rollout launch at the default workload: rocprofv3 PMC, separate FETCH_SIZE / WRITE_SIZE passes,
 # (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B — FETCH_SIZE doubled for gfx950's 16-B/lane reads as MI355X_MICROARCH.md §HBM
 # prescribes; Infinity-Cache hits are included in the counter.  Read at run time from the committed summary
