@@ -68,6 +68,20 @@ def test_tail_packed_rollout_still_matches_the_oracle():
     assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_eight_tile_form_of_the_seven_tile_shapes_still_matches_the_oracle():
+    """Launches with 7 rollout tiles per instance run in instance mode (csrc/rr_rollout_w.inc: one instance per workgroup, K + L in
+    LDS, loader wave); RR_ROLLOUT_INST=0 (read once per process) sends the same shapes through the 8-tile form, which other
+    shapes still use: golden tours, log-likelihoods and determinism in a child process with it set."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RR_ROLLOUT_INST="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_atsp.py"),
+                        os.path.join(root, "tests", "test_gpu_rcvrptw.py"), os.path.join(root, "tests", "test_gpu_determinism.py"),
+                        "-k", "greedy_tours_match_reference or split_bf16_mlp or determin or repeat"],
+                       env=env, capture_output=True, text=True, timeout=1500, cwd=root)
+    assert r.returncode == 0 and " passed" in r.stdout and "no tests ran" not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_atsp_max_nodes_103_and_more_starts_than_a_workgroup_tile_set():
     _run(103, 2, 103, 25, seed=7)
 
