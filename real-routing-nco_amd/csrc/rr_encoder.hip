@@ -905,8 +905,47 @@ struct InitW {
 
 #define MAXSS 32
 
+// rr_gemm_wx (rr_common.h) for a 16-group K range with ALL sixteen weight fragments of the tile requested up front (64 VGPRs): the
+// one-group-ahead form waits on an L2 round trip per k-group when a group is only 28 matrix instructions long.
+template <int NT>
+__device__ __forceinline__ void ie_gemm_wx16(f32x4 (&acc)[NT], const float4* __restrict__ wp, const float* X, int ldx, int n_valid, int lane) {
+  const int j = lane & 15, g = lane >> 4;
+  float4 a[16];
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) a[kk] = wp[(size_t)kk * 64 + lane];
+  int rowoff[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    int node = nt * 16 + j;
+    node = node < n_valid ? node : n_valid - 1;
+    rowoff[nt] = node * ldx + 4 * g;
+  }
+  float4 b[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) b[nt] = rr_ld4(X + rowoff[nt]);
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+    float4 bn[NT];
+    const int kn = kk + 1 < 16 ? kk + 1 : kk;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bn[nt] = rr_ld4(X + rowoff[nt] + kn * 16);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = rr_mfma(a[kk].x, b[nt].x, acc[nt]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = rr_mfma(a[kk].y, b[nt].y, acc[nt]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = rr_mfma(a[kk].z, b[nt].z, acc[nt]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = rr_mfma(a[kk].w, b[nt].w, acc[nt]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = bn[nt];
+  }
+}
+
 template <int NT, int KIND>   // KIND 0 = ATSP, 1 = VRP (depot at node 0, extra node features `vfeat` [Bp][N][F])
-__global__ __launch_bounds__(ENC_THREADS, 2) void k_init_embed(InitW w, const float* __restrict__ D, const float* __restrict__ locs,
+__global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const float* __restrict__ D, const float* __restrict__ locs,
                                                                const int64_t* __restrict__ sidx, const float* __restrict__ vfeat,
                                                                float* __restrict__ row_out, float* __restrict__ col_out, int N, int SS) {
   __shared__ __attribute__((aligned(16))) float smem[3 * BUF_FLOATS];
@@ -981,7 +1020,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_init_embed(InitW w, const fl
       f32x4 h[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) h[nt] = rr_zero4();
-      rr_gemm_wx<NT>(h, g0 + (size_t)t * 16 * 64, 0, 16, comb, 256, 0, N, lane);
+      ie_gemm_wx16<NT>(h, g0 + (size_t)t * 16 * 64, comb, 256, N, lane);
       rr_add_bias<NT>(h, g0b, 16 * t, lane);
       float4 w2v = rr_ld4(g2 + 16 * t + 4 * g);
 #pragma unroll
