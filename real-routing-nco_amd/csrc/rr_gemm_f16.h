@@ -24,26 +24,39 @@ __device__ __forceinline__ void rr_gemm_wx_h(f32x4 (&acc)[NT], f32x4 (&accs)[NT]
     node = node < n_valid ? node : n_valid - 1;
     rowoff[nt] = node * ldx + 4 * g + xk0;
   }
-  float4 a = wp[(size_t)kk0 * 64 + lane];
+  // weight fragments up to eight k-groups ahead (a k-group is 2 NT matrix instructions: shorter than their L2 round trip)
+  constexpr int PF = 8;
+  float4 a[PF];
+#pragma unroll
+  for (int q = 0; q < PF; ++q) a[q] = wp[(size_t)(kk0 + (q < nkk ? q : nkk - 1)) * 64 + lane];
   float4 b[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) b[nt] = rr_ld4(X + rowoff[nt]);
-#pragma unroll 1
-  for (int kk = 0; kk < nkk; ++kk) {
-    float4 an = a, bn[NT];
-    const int kn = kk + 1 < nkk ? kk + 1 : kk;
-    an = wp[(size_t)(kk0 + kn) * 64 + lane];
+  for (int k0 = 0; k0 < nkk; k0 += PF) {
+    float4 an[PF];
+    const bool more = k0 + PF < nkk;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bn[nt] = rr_ld4(X + rowoff[nt] + kn * 16);
-    __builtin_amdgcn_sched_barrier(0);
-    const rr_f16x8 af = rr_as_f16x8(a);
+    for (int q = 0; q < PF; ++q) { const int kq = k0 + PF + q; an[q] = more ? wp[(size_t)(kk0 + (kq < nkk ? kq : nkk - 1)) * 64 + lane] : a[q]; }
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = rr_mfma_f16k16(rr_lo4(af), rr_hi4(rr_as_f16x8(b[nt])), acc[nt]);
+    for (int q = 0; q < PF; ++q) {
+      const int kk = k0 + q;
+      if (kk < nkk) {
+        float4 bn[NT];
+        const int kn = kk + 1 < nkk ? kk + 1 : kk;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) accs[nt] = rr_mfma_f16(af, rr_as_f16x8(b[nt]), accs[nt]);
-    __builtin_amdgcn_sched_barrier(0);
-    a = an;
+        for (int nt = 0; nt < NT; ++nt) bn[nt] = rr_ld4(X + rowoff[nt] + kn * 16);
+        __builtin_amdgcn_sched_barrier(0);
+        const rr_f16x8 af = rr_as_f16x8(a[q]);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) b[nt] = bn[nt];
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = rr_mfma_f16k16(rr_lo4(af), rr_hi4(rr_as_f16x8(b[nt])), acc[nt]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) accs[nt] = rr_mfma_f16(af, rr_as_f16x8(b[nt]), accs[nt]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt] = bn[nt];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < PF; ++q) a[q] = an[q];
   }
 }
