@@ -119,6 +119,15 @@ __device__ __forceinline__ f32x4 rr_mfma_f16(rr_f16x8 a, rr_f16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ void rr_split8h(const float (&x)[8], rr_f16x8& hi, rr_f16x8& lo) {
+#ifdef RR_KO_SPLIT   // diagnostic knock-out: the price of the split's vector instructions (results are wrong)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const rr_f32x2 v = {x[2 * q], x[2 * q + 1]};
+    const rr_f16x2 h = __builtin_convertvector(v, rr_f16x2);
+    hi[2 * q] = h[0]; hi[2 * q + 1] = h[1]; lo[2 * q] = h[0]; lo[2 * q + 1] = h[1];
+  }
+  return;
+#endif
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const rr_f32x2 v = {x[2 * q], x[2 * q + 1]};
@@ -130,6 +139,15 @@ __device__ __forceinline__ void rr_split8h(const float (&x)[8], rr_f16x8& hi, rr
 }
 typedef _Float16 rr_f16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void rr_split4h(const float (&x)[4], rr_f16x4& hi, rr_f16x4& lo) {
+#ifdef RR_KO_SPLIT
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const rr_f32x2 v = {x[2 * q], x[2 * q + 1]};
+    const rr_f16x2 h = __builtin_convertvector(v, rr_f16x2);
+    hi[2 * q] = h[0]; hi[2 * q + 1] = h[1]; lo[2 * q] = h[0]; lo[2 * q + 1] = h[1];
+  }
+  return;
+#endif
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const rr_f32x2 v = {x[2 * q], x[2 * q + 1]};

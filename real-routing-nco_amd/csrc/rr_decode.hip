@@ -506,9 +506,14 @@ extern "C" int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStrea
     else if (io->used_b == nullptr) RR_LAUNCHW2(NTV, 2);                                     \
     else RR_LAUNCHW2(NTV, 3);                                                                \
   } while (0)
+#ifdef RR_DEV_HEADLINE_ONLY   // diagnostic builds: only the headline instantiation (ATSP greedy, instance mode) is compiled
+  if (!(prob == 0 && mode == 0 && mlp_split && N > 64 && tail_g == 0 && (S + 15) / 16 == WWAVES - 1)) return RR_EINVAL;
+  RR_LAUNCHW4I(7, 0, 0);
+#else
   if (N <= 32) RR_LAUNCHW(2);
   else if (N <= 64) RR_LAUNCHW(4);
   else RR_LAUNCHW(7);
+#endif
 #undef RR_LAUNCHW2
 #undef RR_LAUNCHW3
 #undef RR_LAUNCHW4

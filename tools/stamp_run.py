@@ -22,13 +22,21 @@ lib.rr_debug_stamps(out, 1)
 lib.rr_debug_enc_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 eout = (ctypes.c_ulonglong * 8)()
 lib.rr_debug_enc_stamps(eout, 1)
-bench.hot_path_step(pol, env, inst); torch.cuda.synchronize()
+from rrnco_amd.models import rollout as _R
+_R.TIMING = []
+torch.manual_seed(7)
+_best, _out = bench.hot_path_step(pol, env, inst); torch.cuda.synchronize()
+_a = _out["actions"].long()
+print("checksum: best", float(_best.double().sum()), "actions", int((_a * torch.arange(1, _a.shape[1] + 1, device=_a.device)).sum() % 1000000007),
+      "ll", float(_out["log_likelihood"].double().sum()) if "log_likelihood" in _out else None)
+print("rollout kernel ms:", [round(a.elapsed_time(b), 2) for a, b in _R.TIMING]); _R.TIMING = None
 lib.rr_debug_stamps(out, 0)
 names = ["loop-top", "ctx gather", "attention", "MLP", "logits MFMA", "select+step"]
-waves = out[7]; tot = sum(out[i] for i in range(6))
+waves = max(out[7], 1); tot = max(sum(out[i] for i in range(6)), 1)
 print(f"waves={waves} total cycles/wave={tot/waves:.3e} per step={tot/waves/99:.0f}")
 for i, n in enumerate(names):
     print(f"  {n:12s} {out[i]/waves/99:10.0f} cycles/step  {100*out[i]/tot:5.1f}%")
+print(f"  (of the MLP: waiting at its stage barriers {out[6]/max(waves,1)/99:10.0f} cycles/step)")
 
 lib.rr_debug_enc_stamps(eout, 0)
 en = (["norm2,K,softmaxK,V", "NAB", "norm1,Q,mix", "P,M,norm3,normf1", "FFN+norm"] if os.environ.get("RR_ENC_VARIANT", "1") == "1"
