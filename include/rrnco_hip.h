@@ -54,7 +54,8 @@ typedef struct {                /* rrnco/models/decoder.py:214-232 + the step-co
 
 typedef struct {                /* pointer MLP + inductive-bias scalars: rrnco/models/decoder.py:186-198, 272-277 */
   const void *w1, *w2; const float *b1, *b2, *q0, *wstate; float alpha, beta;
-  const void *w1s, *w2s;        /* optional two-piece fp16 splits of w1 / w2 (packing.pack_a_f16x2) for the split rollout (RolloutIO.use_split) */
+  const void *w1s, *w2s;        /* optional two-piece fp16 images of 2^6 w1 / 2^6 w2 (packing.pack_a_f16u) for the split rollout (RolloutIO.use_split) */
+  const float* b1s;             /* 2^6 b1: the hidden layer of the split rollout lives at the scale of the w1s image */
 } DecW;
 
 typedef struct {                /* arguments of the persistent rollout: see csrc/rr_decode.hip */
@@ -75,10 +76,13 @@ typedef struct {                /* arguments of the persistent rollout: see csrc
    * output g [m][128], meta [m][8] = 4 action-mask words seen, node decided at, node chosen, live flag, 0; VRP state
    * scalars scal [m][4] (context.py:51-70).  Consumed by rr_dec_* below (the REINFORCE backward of decoder.py:151-329). */
   float *dump_g0, *dump_g; uint32_t *dump_meta; float *dump_scal; int dumpT;
-  int use_split;                /* 1: greedy / sampling launch on the fp16 matrix pipe with two-piece split fp32 operands (x = hi + 2^-11 lo',
+  int use_split;                /* 1: greedy / sampling launch on the fp16 matrix pipe with two-piece split fp32 operands (x~ = hi + lo,
                                  * three f16 MFMAs per product, error of a dot product 4e-8 of sum |a b|: csrc/rr_common.h); needs DecW.w1s /
                                  * w2s and the three images below, otherwise the fp32 MFMA kernel runs */
   const void *Ks, *Vts, *Ls;    /* rr_pack_f16x2 images of K / Vt / L (same shapes) */
+  int* status;                  /* optional device word: bit 2 is set when a split launch meets a non-finite log-probability — an
+                                 * operand left the fp16 range somewhere upstream (|x| >= 65504 after its image's scale); the caller
+                                 * then repeats the call on the fp32 kernels (use_split = 0) */
 } RolloutIO;
 
 /* Backward of the Neural Adaptive Bias with the duration matrix (rrnco/models/nn/attn_freenet.py:226-237, 265-286) in its folded
@@ -95,9 +99,11 @@ typedef struct {
 int rr_nabdur_bwd(const NabDurBwdW* w, const float* xd, const float* xa, const float* xt, const float* gout, float* dzf,
                   float* grads, float* dmcat, long long M, hipStream_t stream);
 
-/* fp32 -> two-piece fp16 image: every group of four values becomes its four hi and four lo' halves at the same byte offset
- * (n_floats % 4 == 0).  Used for the K / Vt / L operands of the split rollout (rrnco/models/decoder.py:214-232 products). */
-int rr_pack_f16x2(const float* src, void* dst, long long n_floats, hipStream_t stream);
+/* fp32 -> two-piece fp16 image of 2^4 x: every group of four values becomes the four hi = fp16(2^4 x) and the four
+ * lo = fp16(2^4 x - hi) halves at the same byte offset (n_floats % 4 == 0; csrc/rr_common.h, second form).  Used for the K / Vt / L
+ * operands of the split rollout (rrnco/models/decoder.py:214-232 products).  status (optional device word): bit 0 is set when a
+ * value is non-finite or leaves the fp16 range (|2^4 x| >= 65504). */
+int rr_pack_f16x2(const float* src, void* dst, long long n_floats, int* status, hipStream_t stream);
 
 /* ATSPEnv._reset / RCVRPEnv._reset / RMTVRPEnv._reset min-max normalisation
  * (rrnco/envs/atsp/env.py:113-120, rcvrp/env.py:137-146, rmtvrp/env.py:289-300): out = (in-min)/(max-min+1e-6)

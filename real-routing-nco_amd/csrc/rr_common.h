@@ -175,6 +175,64 @@ __device__ __forceinline__ rr_f16x8 rr_split4s(const float (&x)[4]) {
   rr_split4h(x, hi, lo);
   return rr_cat4(lo, hi);
 }
+// ---- Second form of the two-piece operands (the rollout kernel): NO scale between the pieces.  x~ = 2^s x (s = 0 for
+// activations, RR_WS for MLP weights, RR_KS for the K / V^T / L images: exact), hi = fp16(x~), lo = fp16(x~ - hi).  All three
+// partial products hi*hi + hi*lo + lo*hi then have the SAME scale 2^(sa + sb) and go into ONE fp32 accumulator: no second
+// accumulator, no 2^-11 recombination, and the scale folds into a constant the consumer multiplies by anyway.  x~ - hi is exact in
+// fp32 and lo keeps 11 of its bits as long as it is a normal fp16 number (|x~| >= 2^-3); below that lo is a subnormal with an
+// absolute error <= 2^-25 — which is why weights (|w| ~ 1e-2) are pre-scaled and O(1) activations need not be.  The split is
+// v_cvt_pk_f16_f32 for two hi halves + one v_fma_mixlo/hi_f16 per lo half (fp32 fma on the fp16 half, rounded into the half of
+// the destination): 1.5 instructions per value against 3 for the scaled form (cvt, cvt back, subtract, scale, cvt).
+// Measured (tools/clockprobe/mixsplit): |hi + lo - x| <= 2^-22 |x| for |x| >= 1/8, <= 2^-25 absolute below.
+#define RR_WS 6            // log2 scale of the MLP weight images W1s / W2s (packing.pack_a_f16u)
+#define RR_KS 4            // log2 scale of the K / V^T / L images (rr_pack_f16x2)
+#define RR_F16_LIMIT 65504.0f
+// The lo halves of 2 / 4 value pairs in ONE asm block.  hipcc cannot see that an asm statement is a VALU write, so it would not
+// keep the 2 wait states gfx950 needs between a VALU write of a register and a matrix instruction reading it as SrcA / SrcB
+// (it pads its own v_cvt_pk_f16_f32 -> v_mfma with s_nop 1); without them the MFMA reads the register's OLD contents — seen as
+// garbage attention outputs and run-to-run differences.  The block ends with that s_nop 1; the lo / hi writes of one
+// destination sit four (two) instructions apart.
+__device__ __forceinline__ void rr_ulo8(const rr_f16x2 (&h)[4], const float (&x)[8], rr_f16x2 (&l)[4]) {
+  asm("v_fma_mixlo_f16 %0, %4, -1.0, %8 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %1, %5, -1.0, %10 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %2, %6, -1.0, %12 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %3, %7, -1.0, %14 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %4, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %1, %5, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %2, %6, -1.0, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %3, %7, -1.0, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "s_nop 1"
+      : "=&v"(l[0]), "=&v"(l[1]), "=&v"(l[2]), "=&v"(l[3])
+      : "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
+}
+__device__ __forceinline__ void rr_ulo4(const rr_f16x2 (&h)[2], const float (&x)[4], rr_f16x2 (&l)[2]) {
+  asm("v_fma_mixlo_f16 %0, %2, -1.0, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %1, %3, -1.0, %6 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %2, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %1, %3, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "s_nop 1"
+      : "=&v"(l[0]), "=&v"(l[1])
+      : "v"(h[0]), "v"(h[1]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));
+}
+__device__ __forceinline__ void rr_usplit8(const float (&x)[8], rr_f16x8& hi, rr_f16x8& lo) {
+  rr_f16x2 h[4], l[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { const rr_f32x2 v = {x[2 * q], x[2 * q + 1]}; h[q] = __builtin_convertvector(v, rr_f16x2); }
+  rr_ulo8(h, x, l);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { hi[2 * q] = h[q][0]; hi[2 * q + 1] = h[q][1]; lo[2 * q] = l[q][0]; lo[2 * q + 1] = l[q][1]; }
+}
+// x[0..3] -> the tuple [lo | hi] (the register operand of a k = 16 product pair, see rr_split4s)
+__device__ __forceinline__ rr_f16x8 rr_usplit4s(const float (&x)[4]) {
+  rr_f16x2 h[2], l[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) { const rr_f32x2 v = {x[2 * q], x[2 * q + 1]}; h[q] = __builtin_convertvector(v, rr_f16x2); }
+  rr_ulo4(h, x, l);
+  rr_f16x8 r;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) { r[2 * q] = l[q][0]; r[2 * q + 1] = l[q][1]; r[4 + 2 * q] = h[q][0]; r[4 + 2 * q + 1] = h[q][1]; }
+  return r;
+}
 // MI355X, ROCm 7.2: a VALU write to a source register of a v_mfma_f32_16x16x32_f16 issued just before it can reach the
 // register file before the MFMA has read it when the other wave of the SIMD keeps the matrix pipe busy (seen as run-to-run
 // differences of the rollout's P.V, whose B operand is rebuilt for every key tile; hipcc inserts no wait states for this

@@ -25,7 +25,8 @@ struct DecW {
   const float* q0;             // project_context(W_placeholder) [E] (ATSP first step without multistart)
   const float* wstate;         // VRP: step-context state columns of project_context [nstate][E]
   float alpha, beta;
-  const void *w1s, *w2s;       // optional: the same two matrices as two-piece fp16 splits (packing.pack_a_f16x2) for the split rollout
+  const void *w1s, *w2s;       // optional: the same two matrices x 2^RR_WS as two-piece fp16 images (packing.pack_a_f16u) for the split rollout
+  const float* b1s;            // 2^RR_WS b1 (accumulator seeds of the split rollout's hidden tiles)
 };
 
 struct RolloutIO {
@@ -72,6 +73,7 @@ struct RolloutIO {
   int dumpT;
   int use_split;                         // 1: this launch runs on the fp16 matrix pipe with two-piece split operands (rr_common.h), if DecW has w1s / w2s and Ks / Vts / Ls are given
   const void *Ks, *Vts, *Ls;             // fp16 two-piece images of K / Vt / L (rr_pack_f16x2), same shapes and byte offsets
+  int* status;                           // optional: bit 2 <- a split launch met a non-finite log-probability (an operand left the fp16 range)
 };
 
 template <int NT, int PROB>  // PROB 0 = ATSP, 1 = RCVRP
@@ -390,23 +392,28 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_rollout(DecW w, RolloutIO io
 
 #include "rr_rollout_w.inc"
 
-// fp32 -> two-piece fp16 image (rr_common.h): every group of four values becomes its four hi and four lo' halves (16 bytes in,
-// 16 bytes out, same offset): K / Vt / L of the decoder cache for the split rollout's attention and logits
-__global__ __launch_bounds__(256) void k_pack_f16x2(const float4* __restrict__ src, float4* __restrict__ dst, long long n4) {
+// fp32 -> two-piece fp16 image of 2^RR_KS x (rr_common.h, second form): every group of four values becomes its four hi and four
+// lo halves (16 bytes in, 16 bytes out, same offset): K / Vt / L of the decoder cache for the split rollout's attention and
+// logits.  Range guard: a value that is not finite or leaves the fp16 range after the scale sets bit 0 of *status.
+__global__ __launch_bounds__(256) void k_pack_f16x2(const float4* __restrict__ src, float4* __restrict__ dst, long long n4, int* status) {
+  bool bad = false;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     const float4 v = src[i];
-    const float x[4] = {v.x, v.y, v.z, v.w};
-    rr_f16x4 hi, lo;
-    rr_split4h(x, hi, lo);
-    dst[i] = __builtin_bit_cast(float4, rr_cat4(hi, lo));
+    const float sc = (float)(1 << RR_KS);
+    const float x[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bad = bad || !(fabsf(x[q]) < RR_F16_LIMIT);
+    const rr_f16x8 s = rr_usplit4s(x);                          // [lo | hi]
+    dst[i] = __builtin_bit_cast(float4, rr_cat4(rr_hi4(s), rr_lo4(s)));
   }
+  if (status != nullptr && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(status, 1);
 }
-extern "C" int rr_pack_f16x2(const float* src, void* dst, long long n_floats, hipStream_t st) {
+extern "C" int rr_pack_f16x2(const float* src, void* dst, long long n_floats, int* status, hipStream_t st) {
   if (n_floats <= 0) return RR_OK;
   if (n_floats % 4 != 0) return RR_EINVAL;
   const long long n4 = n_floats / 4;
   const long long blocks = (n4 + 255) / 256;
-  hipLaunchKernelGGL(k_pack_f16x2, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st, (const float4*)src, (float4*)dst, n4);
+  hipLaunchKernelGGL(k_pack_f16x2, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st, (const float4*)src, (float4*)dst, n4, status);
   return rr_check(hipGetLastError());
 }
 
@@ -426,7 +433,7 @@ extern "C" int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStrea
   static const int variant = getenv("RR_ROLLOUT_VARIANT") ? atoi(getenv("RR_ROLLOUT_VARIANT")) : 1;
   const char* es = getenv("RR_MLP_SPLIT");
   // RolloutIO.use_split decides; the environment variable only forces it on for callers that leave the field 0
-  const bool mlp_split = (io->use_split != 0 || (es != nullptr && atoi(es) != 0 && io->use_split < 0)) && w->w1s != nullptr && w->w2s != nullptr &&
+  const bool mlp_split = (io->use_split != 0 || (es != nullptr && atoi(es) != 0 && io->use_split < 0)) && w->w1s != nullptr && w->w2s != nullptr && w->b1s != nullptr &&
                          io->Ks != nullptr && io->Vts != nullptr && io->Ls != nullptr;
   if (variant == 0 && prob < 2) {   // workgroup-per-instance variant (kept for A/B measurements; ATSP / RCVRP only)
     dim3 grid(io->Bp, (S + ROWS - 1) / ROWS), blk(DEC_THREADS);
@@ -522,6 +529,11 @@ extern "C" int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStrea
 }
 
 #ifdef RR_STAMP
+extern "C" int rr_debug_wave_cycles(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rr_wave_cycles), sizeof(unsigned long long) * 8) != hipSuccess) return RR_ELAUNCH;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rr_wave_cycles), z, sizeof(z)) != hipSuccess) return RR_ELAUNCH; }
+  return RR_OK;
+}
 extern "C" int rr_debug_stamps(unsigned long long* out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rr_stamps), sizeof(unsigned long long) * 8) != hipSuccess) return RR_ELAUNCH;
   if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rr_stamps), z, sizeof(z)) != hipSuccess) return RR_ELAUNCH; }

@@ -34,7 +34,7 @@ class CacheW(C.Structure):
 
 class DecW(C.Structure):
     _fields_ = [(n, vp) for n in ("w1", "w2", "b1", "b2", "q0", "wstate")] + [("alpha", f32), ("beta", f32)] + \
-        [("w1s", vp), ("w2s", vp)]
+        [("w1s", vp), ("w2s", vp), ("b1s", vp)]
 
 
 class NabDurW(C.Structure):
@@ -58,7 +58,7 @@ class RolloutIO(C.Structure):
         [(n, i32) for n in ("Bp", "N", "S", "T", "t0", "nsteps", "mode", "use_placeholder", "set_first",
                             "write_state", "logits_only", "stagger")] + \
         [("tanh_clip", f32), ("temperature", f32), ("seed", u64)] + [(n, vp) for n in ("used_b", "open_route", "dist_limit", "demand_b", "bclass")] + \
-        [(n, vp) for n in ("dump_g0", "dump_g", "dump_meta", "dump_scal")] + [("dumpT", i32), ("use_split", i32), ("Ks", vp), ("Vts", vp), ("Ls", vp)]
+        [(n, vp) for n in ("dump_g0", "dump_g", "dump_meta", "dump_scal")] + [("dumpT", i32), ("use_split", i32), ("Ks", vp), ("Vts", vp), ("Ls", vp), ("status", vp)]
 
 
 class DecLogitIO(C.Structure):          # csrc/rr_train_dec.hip
@@ -108,7 +108,7 @@ _SIGS = {
     "rr_minmax_normalize": [vp, vp, vp, vp, i32, i32, vp],
     "rr_atsp_step": [vp, vp, vp, vp, i32, i32, vp],
     "rr_sample_neighbors": [vp, vp, i32, i32, i32, u64, vp],
-    "rr_pack_f16x2": [vp, vp, C.c_longlong, vp],
+    "rr_pack_f16x2": [vp, vp, C.c_longlong, vp, vp],
     "rr_nabdur_bwd": [C.POINTER(NabDurBwdW), vp, vp, vp, vp, vp, vp, vp, C.c_longlong, vp],
     "rr_rcvrp_step": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "rr_tour_cost": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp],

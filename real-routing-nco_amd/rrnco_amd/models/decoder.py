@@ -20,13 +20,14 @@ class PrecomputedCache:              # decoder.py:25-44 plus the per-node step-c
     ctx_b: torch.Tensor              # Wctx[:, E:2E] row_emb (ATSP) / Wctx[:, :E] row_emb (VRP)
     split: tuple = None              # fp16 two-piece images of (glimpse_key, glimpse_val_t, logit_key) for the split rollout
 
-    def split_images(self):
-        """K / V^T / L as hi + 2^-11 lo' fp16 pairs (csrc/rr_common.h), built once per cache by rr_pack_f16x2."""
+    def split_images(self, status=None):
+        """K / V^T / L as two-piece fp16 images of 2^4 x (hi + lo, csrc/rr_common.h second form), built once per cache by
+        rr_pack_f16x2; `status` (int32 device word): bit 0 is set when a value is non-finite or leaves the fp16 range."""
         if self.split is None:
             out = []
             for t in (self.glimpse_key, self.glimpse_val_t, self.logit_key):
                 d = torch.empty_like(t)
-                L.check(L.lib().rr_pack_f16x2(L.ptr(t), L.ptr(d), t.numel(), L.stream()), "rr_pack_f16x2")
+                L.check(L.lib().rr_pack_f16x2(L.ptr(t), L.ptr(d), t.numel(), L.ptr(status), L.stream()), "rr_pack_f16x2")
                 out.append(d)
             self.split = tuple(out)
         return self.split

@@ -5,6 +5,7 @@ import torch
 import torch.nn as nn
 
 from .. import packing
+from ..tensordict_lite import TensorDict
 from ..ops import calculate_entropy, get_log_likelihood
 from .decoder import RRNetDecoder
 from .decoding import get_decoding_strategy
@@ -89,7 +90,37 @@ class RRNetPolicy(nn.Module):
         return out
 
     @torch.no_grad()
-    def _forward_impl(self, td, env=None, phase="train", calc_reward=True, return_actions=True, return_entropy=False,
+    def _forward_impl(self, td, env=None, *args, capture=None, **kwargs) -> dict:
+        """Range guard of the fp16 two-piece arithmetic (csrc/rr_common.h).  The default kernels convert fp32 operands to fp16
+        pairs: a weight, an embedding or an activation of magnitude >= 65 504 (after its image's scale) becomes inf and the
+        tours silently garbage.  One device word collects: bit 0 a K / V^T / L image out of range or non-finite (rr_pack_f16x2:
+        that includes anything non-finite the encoder produced), bit 1 a pointer-MLP weight image out of range
+        (packing.f16_range_status), bit 2 a non-finite log-probability in the fused rollout (RolloutIO::status).  It is read once
+        per call (for the VRPs together with the step count); a call that raised it is repeated on the fp32-MFMA kernels, which
+        have no such limit.  RR_RANGE_GUARD=0 switches the check (and its host read) off."""
+        import os
+        if not packing.mlp_split_enabled() or os.environ.get("RR_RANGE_GUARD", "1") == "0" or td.device.type != "cuda":
+            self._range_status = None
+            return self._forward_core(td, env, *args, capture=capture, **kwargs)
+        td_in = TensorDict(td, batch_size=td.batch_size)                                   # shallow copy: the second pass starts from the same state
+        self._range_status = self.packed(td.device)["range_status"].clone()
+        self.last_range_flags = 0
+        try:
+            return self._forward_core(td, env, *args, capture=capture, **kwargs)
+        except _RangeRetry as r:
+            import warnings
+            self.last_range_flags = r.flags
+            warnings.warn(f"rrnco_amd: an operand left the fp16 range of the split kernels (flags {r.flags:#x}: 1 = K/V/L image, "
+                          "2 = weight image, 4 = non-finite log-probability); repeating the call on the fp32 MFMA kernels")
+            if capture is not None:
+                capture.clear()
+            self._range_status = None
+            with packing.force_fp32():
+                return self._forward_core(td_in, env, *args, capture=capture, **kwargs)
+        finally:
+            self._range_status = None
+
+    def _forward_core(self, td, env=None, phase="train", calc_reward=True, return_actions=True, return_entropy=False,
                       return_hidden=False, return_init_embeds=False, return_sum_log_likelihood=True, actions=None,
                       max_steps=1_000_000, fused=True, capture=None, **decoding_kwargs) -> dict:
         if env is None or isinstance(env, str):
@@ -200,9 +231,14 @@ class RRNetPolicy(nn.Module):
         st = launch_rollout(self.env_name, packed, cache, td, strategy.num_starts, actions=acts, logp=logp, t0=t0,
                             nsteps=nsteps, mode=strategy.mode, actions_in=ain, write_state=True,
                             tanh_clip=strategy.tanh_clipping, temperature=strategy.temperature, seed=strategy.seed,
-                            steps_out=steps_out, dump=dump)
+                            steps_out=steps_out, dump=dump, status=getattr(self, "_range_status", None))
         if dump is not None:
             dump.update({"first": st["first"], "tanh_clip": strategy.tanh_clipping, "temperature": strategy.temperature})
+        status = getattr(self, "_range_status", None)
+        if status is not None:                          # the range guard's one host read (before anything looks at the tours)
+            flags = int(status.item())
+            if flags != 0:
+                raise _RangeRetry(flags)
         if self.env_name != "atsp":
             T_used = t0 + int(steps_out.item())
             if dump is not None:
@@ -213,6 +249,14 @@ class RRNetPolicy(nn.Module):
             td.set("first_node", st["first"])
         td.set("done", torch.ones(R, dtype=torch.bool, device=dev))
         return logp, acts, td
+
+
+class _RangeRetry(Exception):
+    """Raised inside a split-kernel forward whose range-guard word is set (RRNetPolicy._forward_impl repeats the call in fp32)."""
+
+    def __init__(self, flags):
+        super().__init__(f"fp16 range guard flags {flags:#x}")
+        self.flags = flags
 
 
 class _PolicyLogLikelihood(torch.autograd.Function):

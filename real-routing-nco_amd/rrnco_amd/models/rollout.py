@@ -13,14 +13,14 @@ import os
 # 1.1e-7: tools/clockprobe/f16probe.hip): attention scores, P.V, pointer MLP and logits.  The default since round 2 — tours
 # identical to the fp32-MFMA build on the golden fixtures and on >= 99.9 % of the full-size rollouts with every divergence at
 # a decision gap < 1e-3 (tests/test_gpu_fullsize.py).  RR_MLP_SPLIT=0 (or SPLIT_MLP = False) runs the fp32 MFMA kernel.
-SPLIT_MLP = os.environ.get("RR_MLP_SPLIT", "1") != "0"
+SPLIT_MLP = True      # False: the fp32 MFMA kernel whatever the pack holds (A/B measurements); packing.mlp_split_enabled() decides otherwise
 STAGGER = int(os.environ.get("RR_STAGGER", "0"))   # initial delay of the second wave of every SIMD (units of ~8k cycles)
 TIMING = None   # bench.py sets this to a list to collect (start, end) HIP events around each full rollout launch
 
 
 def launch_rollout(env_name, packed, cache, td, num_starts, *, actions=None, logp=None, t0=0, nsteps=1,
                    mode="greedy", actions_in=None, logits_out=None, logits_only=False, write_state=False,
-                   tanh_clip=10.0, temperature=1.0, seed=0, steps_out=None, state=None, dump=None):
+                   tanh_clip=10.0, temperature=1.0, seed=0, steps_out=None, state=None, dump=None, status=None):
     """Runs `nsteps` decode steps (nsteps <= 0: until every rollout is done) for all rollouts of `td`.
     `td` is the batchified rollout state (R = S*Bp rows, per-instance keys left at Bp rows)."""
     if env_name not in PROB_ID:
@@ -86,17 +86,20 @@ def launch_rollout(env_name, packed, cache, td, num_starts, *, actions=None, log
     io.set_first = int(env_name == "atsp" and td.meta.get("i", 1) == 0)
     io.write_state, io.logits_only = int(write_state), int(logits_only)
     io.stagger = STAGGER
-    io.use_split = int(SPLIT_MLP)
+    from .. import packing
+    split_on = SPLIT_MLP and packing.mlp_split_enabled()
+    io.use_split = int(split_on)
     if dump is not None:      # training: per decoder evaluation, what csrc/rr_train_dec.hip differentiates (see RolloutIO::dump_*)
         io.dump_g0, io.dump_g, io.dump_meta = L.ptr(dump["g0"]), L.ptr(dump["g"]), L.ptr(dump["meta"])
         io.dump_scal = L.ptr(dump.get("scal"))
         io.dumpT = int(dump["T"])
         # training rollouts run on the same split-operand kernel (fp32-level accuracy; the reference trains in 16-bit mixed
         # precision, configs/trainer/default.yaml:8)
-        io.use_split = int(os.environ.get("RR_TRAIN_SPLIT", "1") != "0" and SPLIT_MLP)
+        io.use_split = int(os.environ.get("RR_TRAIN_SPLIT", "1") != "0" and split_on)
     if io.use_split and not logits_only and mode != "evaluate":
-        ks, vts, ls = cache.split_images()
+        ks, vts, ls = cache.split_images(status)
         io.Ks, io.Vts, io.Ls = L.ptr(ks), L.ptr(vts), L.ptr(ls)
+        io.status = L.ptr(status)
     io.tanh_clip, io.temperature, io.seed = float(tanh_clip), float(temperature), int(seed)
     timed = TIMING is not None and not logits_only
     if timed:

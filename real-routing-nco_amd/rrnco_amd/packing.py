@@ -43,12 +43,33 @@ def pack_a(Wm: torch.Tensor) -> torch.Tensor:
     return x.view(*lead, Mp // 16, Kp // 16, 64, 4)
 
 
+_FORCE_FP32 = 0      # > 0 inside force_fp32(): the range guard's second pass (models/policy.py) runs every kernel on the fp32 MFMA
+
+
 def mlp_split_enabled() -> bool:
-    """Pointer MLP / encoder FFN on the bf16 matrix pipe with 3-way split fp32 operands: the default since round 2 (the whole
-    GPU suite — golden tours, embeddings to 2e-4, gradients — is green with it, and the full-size rollouts equal the
-    fp32-MFMA build's, tests/test_gpu_fullsize.py); RR_MLP_SPLIT=0 builds and runs the all-fp32-MFMA kernels."""
+    """Encoder GEMMs, decoder cache and the whole rollout on the fp16 matrix pipe with two-piece split fp32 operands: the default
+    since round 2 (the whole GPU suite — golden tours, embeddings to 2e-4, gradients — is green with it, and the full-size
+    rollouts equal the fp32-MFMA build's, tests/test_gpu_fullsize.py); RR_MLP_SPLIT=0 packs for and runs the all-fp32-MFMA kernels,
+    and so does a call whose operands left the fp16 range (force_fp32, the range guard of models/policy.py)."""
     import os
-    return os.environ.get("RR_MLP_SPLIT", "1") != "0"
+    return _FORCE_FP32 == 0 and os.environ.get("RR_MLP_SPLIT", "1") != "0"
+
+
+class force_fp32:
+    """Context: every kernel of the policy on the fp32 MFMA (the pack cache is keyed by mlp_split_enabled())."""
+
+    def __enter__(self):
+        global _FORCE_FP32
+        _FORCE_FP32 += 1
+
+    def __exit__(self, *exc):
+        global _FORCE_FP32
+        _FORCE_FP32 -= 1
+        return False
+
+
+F16U_WEIGHT_SCALE_LOG2 = 6      # csrc/rr_common.h RR_WS
+F16_LIMIT = 65504.0
 
 
 def pack_a_bf16x3(Wm: torch.Tensor) -> torch.Tensor:
@@ -82,6 +103,32 @@ def pack_a_f16x2(Wm: torch.Tensor) -> torch.Tensor:
     x = torch.stack((hi, lo), dim=n).reshape(*lead, 2, M // 16, 16, K // 32, 2, 4, 4)           # piece, t, i, s, half, g, e4
     x = x.permute(*range(n), n + 1, n + 3, n, n + 5, n + 2, n + 4, n + 6)                       # t, s, piece, g, i, half, e4
     return x.reshape(*lead, M // 16, K // 32, 2, 64, 8).contiguous()                            # [t][s][piece][lane][8]
+
+
+def pack_a_f16u(Wm: torch.Tensor, scale_log2: int = F16U_WEIGHT_SCALE_LOG2) -> torch.Tensor:
+    """[M,K] fp32 -> [M/16, K/32, 2, 64, 8] fp16: A operands of v_mfma_f32_16x16x32_f16 for the two pieces of the SECOND form
+    (csrc/rr_common.h): W~ = 2^scale_log2 W (exact), hi = fp16(W~), lo = fp16(W~ - hi) — no scale between the pieces, so all
+    three partial products of a split product share one accumulator; lane / k order of pack_a_bf16x3.  The rollout's pointer MLP."""
+    *lead, M, K = Wm.shape
+    assert M % 16 == 0 and K % 32 == 0
+    n = len(lead)
+    W = Wm.detach().float() * float(2 ** scale_log2)
+    hi = W.to(torch.float16)
+    lo = (W - hi.float()).to(torch.float16)
+    x = torch.stack((hi, lo), dim=n).reshape(*lead, 2, M // 16, 16, K // 32, 2, 4, 4)           # piece, t, i, s, half, g, e4
+    x = x.permute(*range(n), n + 1, n + 3, n, n + 5, n + 2, n + 4, n + 6)                       # t, s, piece, g, i, half, e4
+    return x.reshape(*lead, M // 16, K // 32, 2, 64, 8).contiguous()                            # [t][s][piece][lane][8]
+
+
+def f16_range_status(tensors, scale_log2: int = 0) -> torch.Tensor:
+    """int32[1] on the tensors' device: 2 if any value of any tensor is non-finite or leaves the fp16 range after the scale
+    (|2^s x| >= 65504), else 0 — bit 1 of the range guard's status word (models/policy.py); no host synchronisation."""
+    lim = F16_LIMIT / float(2 ** scale_log2)
+    bad = None
+    for t in tensors:
+        b = ~(t.detach().abs().max() < lim)          # NaN compares false: flagged
+        bad = b if bad is None else (bad | b)
+    return (bad.to(torch.int32) * 2).reshape(1)
 
 
 def f16x2_image(t: torch.Tensor) -> torch.Tensor:
@@ -600,9 +647,13 @@ def _pack_policy(sd: dict, env_name: str, device) -> dict:
     dw.w2 = ar.put(pack_a(sd["decoder.pointer.ffn.lins.1.weight"].detach().float()))
     # the same matrices as 3-way bf16 splits for the opt-in bf16-pipe MLP (RR_MLP_SPLIT=1); kept as raw 16-bit words
     # (always for the decoder: training rollouts use them, RolloutIO.use_split; two small device-side packs)
-    dw.w1s = ar.put_raw(pack_a_f16x2(sd["decoder.pointer.ffn.lins.0.weight"].to(device)))
-    dw.w2s = ar.put_raw(pack_a_f16x2(sd["decoder.pointer.ffn.lins.1.weight"].to(device)))
+    w1d, w2d = sd["decoder.pointer.ffn.lins.0.weight"].to(device), sd["decoder.pointer.ffn.lins.1.weight"].to(device)
+    dw.w1s = ar.put_raw(pack_a_f16u(w1d))
+    dw.w2s = ar.put_raw(pack_a_f16u(w2d))
     dw.b1, dw.b2 = ar.put(sd["decoder.pointer.ffn.lins.0.bias"]), ar.put(sd["decoder.pointer.ffn.lins.1.bias"])
+    dw.b1s = ar.put(sd["decoder.pointer.ffn.lins.0.bias"].detach().float() * float(2 ** F16U_WEIGHT_SCALE_LOG2))
+    # range guard, bit 1: a weight image that leaves the fp16 range (models/policy.py repeats such a call on the fp32 kernels)
+    out["range_status"] = f16_range_status([w1d, w2d], F16U_WEIGHT_SCALE_LOG2)
     dw.alpha = float(sd["decoder.alpha"].reshape(-1)[0])
     dw.beta = float(sd["decoder.beta"].reshape(-1)[0]) if "decoder.beta" in sd else 0.0
     out["cache"], out["dec"] = cw, dw

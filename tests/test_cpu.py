@@ -226,8 +226,8 @@ def test_ctypes_struct_sizes_match_header_layout():
     from rrnco_amd import _lib
     import ctypes as C
     assert C.sizeof(_lib.EncBlockW) == 31 * 8 and C.sizeof(_lib.InitW) == 20 * 8 + 16
-    assert C.sizeof(_lib.CacheW) == 80 and C.sizeof(_lib.DecW) == 6 * 8 + 8 + 2 * 8
-    assert C.sizeof(_lib.RolloutIO) == 24 * 8 + 12 * 4 + 2 * 4 + 8 + 5 * 8 + 4 * 8 + 8 + 3 * 8 and C.sizeof(_lib.NabDurW) == 4 * 8 + 9 * 4 + 4 + 8
+    assert C.sizeof(_lib.CacheW) == 80 and C.sizeof(_lib.DecW) == 6 * 8 + 8 + 3 * 8
+    assert C.sizeof(_lib.RolloutIO) == 24 * 8 + 12 * 4 + 2 * 4 + 8 + 5 * 8 + 4 * 8 + 8 + 4 * 8 and C.sizeof(_lib.NabDurW) == 4 * 8 + 9 * 4 + 4 + 8
     # the training-side descriptors (include/rrnco_hip.h: DecLogitIO, MlpRowsW, MlpWgradW, DecAttnIO, EncSave, AftBwdIO)
     assert C.sizeof(_lib.DecLogitIO) == 11 * 8 + 4 * 4 + 8 + 4 * 4 and C.sizeof(_lib.DecAttnIO) == 15 * 8 + 5 * 4 + 4 + 8
     assert C.sizeof(_lib.MlpRowsW) == 40 and C.sizeof(_lib.MlpWgradW) == 24
@@ -680,3 +680,28 @@ def test_batch_norm_train_branch_of_the_replay_matches_torch_batchnorm1d():
     P["__bn_momentum__"] = 0.0
     rm = P["n.normalizer.running_mean"].clone()
     assert torch.allclose(_inorm(P, "n", x), ref, atol=1e-6) and torch.equal(P["n.normalizer.running_mean"], rm)
+
+
+def test_second_form_weight_images_reproduce_the_scaled_weights_and_range_status_flags_overflow():
+    """packing.pack_a_f16u (csrc/rr_common.h, second form): hi + lo = 2^6 W to 2^-22, same fragment order as pack_a_f16x2;
+    f16_range_status: 2 when a scaled value leaves the fp16 range or is not finite, else 0."""
+    from rrnco_amd import packing
+    torch.manual_seed(3)
+    W = torch.randn(512, 128) * 0.09
+    img = packing.pack_a_f16u(W)
+    old = packing.pack_a_f16x2(W)
+    assert img.shape == old.shape == (32, 4, 2, 64, 8)
+    hi, lo = img[:, :, 0].float(), img[:, :, 1].float()
+    ohi = old[:, :, 0].float()
+    assert torch.equal(hi, (ohi * 64.0).half().float()) or (hi - ohi * 64.0).abs().max() <= 64.0 * 2 ** -11 * W.abs().max()
+    # undo the fragment permutation through pack_a_f16x2 of a marker matrix
+    mk = packing.pack_a_f16x2((torch.arange(512 * 128, dtype=torch.float32).reshape(512, 128) + 1.0) / 65536.0).float()
+    idx = (mk[:, :, 0] + mk[:, :, 1] / 2048.0) * 65536.0 - 1.0
+    rec = torch.empty(512 * 128)
+    rec[idx.round().long().flatten()] = (hi + lo).flatten()
+    err = (rec.view(512, 128) - W * 64.0).abs()
+    assert (err <= 2.0 ** -21 * (W * 64.0).abs() + 2.0 ** -25).all()
+    assert int(packing.f16_range_status([W], 6)) == 0
+    assert int(packing.f16_range_status([W * 1e4], 6)) == 2
+    Wn = W.clone(); Wn[3, 3] = float("nan")
+    assert int(packing.f16_range_status([W, Wn], 6)) == 2

@@ -1,0 +1,78 @@
+"""Range guard of the fp16 two-piece kernels (csrc/rr_common.h, models/policy.py:_forward_impl): operands that leave the fp16
+range must not turn into silent garbage — the status word is raised and the call is repeated on the fp32-MFMA kernels, whose
+result still equals the reference's.  The reference has no such limit (fp32 throughout: rrnco/models/decoder.py:281-323)."""
+import warnings
+
+import pytest
+import torch
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(pol, fx):
+    from rrnco_amd import TensorDict
+    from rrnco_amd.envs import ATSPEnv
+    env = ATSPEnv(generator_params=dict(num_loc=fx["N"]))
+    td = TensorDict({"locs": fx["locs"].cuda(), "distance_matrix": fx["distance_matrix"].cuda(),
+                     "sample_idx": fx["sample_idx"].cuda()}, batch_size=[fx["B"]])
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        out = pol(env.reset(td), env, phase="val", decode_type="multistart_greedy", num_starts=fx["S"], return_actions=True)
+    return out, [str(w.message) for w in rec]
+
+
+def _scaled_mlp(w, c):
+    """relu is positively homogeneous: (c W1, c b1, W2 / c) is the same pointer MLP; c a power of two keeps fp32 results bit-equal."""
+    w = dict(w)
+    w["decoder.pointer.ffn.lins.0.weight"] = w["decoder.pointer.ffn.lins.0.weight"] * c
+    w["decoder.pointer.ffn.lins.0.bias"] = w["decoder.pointer.ffn.lins.0.bias"] * c
+    w["decoder.pointer.ffn.lins.1.weight"] = w["decoder.pointer.ffn.lins.1.weight"] / c
+    return w
+
+
+@pytest.mark.parametrize("name", ["atsp_n20_b4_pomo", "atsp_n100_b2_pomo"])
+def test_in_range_call_raises_nothing_and_hidden_activations_beyond_fp16_fall_back_to_fp32(name):
+    fx = H.load_fixture(name)
+    w = H.atsp_weights(fx)
+    pol = H.make_policy(w, device="cuda:0")
+    out, msgs = _run(pol, fx)
+    assert pol.last_range_flags == 0 and not any("fp16 range" in m for m in msgs)
+    base = out["actions"].cpu()
+    # hidden pre-activations x 2^11: the weight images stay in range (|2^6 W1| < 65504), relu(H) does not -> inf -> NaN logits
+    pol2 = H.make_policy(_scaled_mlp(w, 2048.0), device="cuda:0")
+    out2, msgs2 = _run(pol2, fx)
+    assert pol2.last_range_flags & 4, f"guard did not fire: flags {pol2.last_range_flags}"
+    assert any("fp16 range" in m for m in msgs2)
+    a2 = out2["actions"].cpu()
+    assert torch.isfinite(out2["log_likelihood"]).all() and torch.isfinite(out2["reward"]).all()
+    same_ref = (a2 == fx["actions"]).all(1).float().mean().item()
+    same_base = (a2 == base).all(1).float().mean().item()
+    print(f"[{name}] scaled MLP: flags {pol2.last_range_flags:#x}; tours equal to the reference {same_ref:.4f}, to the unscaled split run {same_base:.4f}")
+    assert same_ref >= (1.0 if fx["N"] <= 20 else 0.99)
+    assert (out2["reward"].cpu() - fx["reward"]).abs().max().item() < 1e-4 or same_ref < 1.0
+
+
+def test_weight_image_out_of_range_is_caught_at_pack_time():
+    fx = H.load_fixture("atsp_n20_b4_pomo")
+    pol = H.make_policy(_scaled_mlp(H.atsp_weights(fx), 16384.0), device="cuda:0")      # |2^6 W1| ~ 1e5
+    out, msgs = _run(pol, fx)
+    assert pol.last_range_flags & 2 and any("fp16 range" in m for m in msgs)
+    assert (out["actions"].cpu() == fx["actions"]).all()
+
+
+def test_pack_kernel_flags_out_of_range_and_non_finite_values():
+    from rrnco_amd import _lib as L
+    for bad, expect in ((None, 0), (5000.0, 1), (float("nan"), 1), (float("inf"), 1), (-4095.0, 1), (4000.0, 0)):
+        x = torch.randn(2, 100, 128, device="cuda")
+        if bad is not None:
+            x[1, 37, 5] = bad
+        d = torch.empty_like(x)
+        st = torch.zeros(1, dtype=torch.int32, device="cuda")
+        L.check(L.lib().rr_pack_f16x2(L.ptr(x), L.ptr(d), x.numel(), L.ptr(st), L.stream()), "rr_pack_f16x2")
+        assert int(st.item()) == expect, (bad, int(st.item()))
+        if expect == 0:       # the image reproduces 2^4 x to 2^-22
+            h = d.view(torch.float16).view(-1, 8).float()
+            rec = (h[:, :4] + h[:, 4:]) / 16.0
+            assert ((rec - x.view(-1, 4)).abs() <= 2.0 ** -21 * x.view(-1, 4).abs() + 2.0 ** -28).all()

@@ -22,6 +22,9 @@ lib.rr_debug_stamps(out, 1)
 lib.rr_debug_enc_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 eout = (ctypes.c_ulonglong * 8)()
 lib.rr_debug_enc_stamps(eout, 1)
+wout = (ctypes.c_ulonglong * 8)()
+lib.rr_debug_wave_cycles.argtypes = [ctypes.c_void_p, ctypes.c_int]
+lib.rr_debug_wave_cycles(wout, 1)
 from rrnco_amd.models import rollout as _R
 _R.TIMING = []
 torch.manual_seed(7)
@@ -36,6 +39,8 @@ waves = max(out[7], 1); tot = max(sum(out[i] for i in range(6)), 1)
 print(f"waves={waves} total cycles/wave={tot/waves:.3e} per step={tot/waves/99:.0f}")
 for i, n in enumerate(names):
     print(f"  {n:12s} {out[i]/waves/99:10.0f} cycles/step  {100*out[i]/tot:5.1f}%")
+lib.rr_debug_wave_cycles(wout, 0)
+print("  per wave number, cycles/step:", [round(wout[i] / (B * 8) / 99) for i in range(8)])
 print(f"  (of the MLP: waiting at its stage barriers {out[6]/max(waves,1)/99:10.0f} cycles/step)")
 
 lib.rr_debug_enc_stamps(eout, 0)
