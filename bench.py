@@ -32,11 +32,12 @@ EXECUTED_FLOP_PER_ROLLOUT_STEP = 348_160
 PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: fp32 matrix peak
 PEAK_F16_MFMA_TFLOPS = 2500.0            # ... dense fp16 / bf16 matrix peak (measured 2 360-2 380 on both: tools/clockprobe/f16probe.hip)
 # The default rollout runs every product of a rollout-step (attention scores, P.V, pointer MLP, logits) on the fp16 matrix pipe
-# with each fp32 operand split in two fp16 pieces x = hi + 2^-11 lo' and three partial products kept (hi*hi, hi*lo', lo'*hi; fp32
-# accumulate; measured error 4e-8 of sum |a b|, below the fp32 MFMA's own): 3 x 404 480 fp16 flop per rollout-step.  Its MFMA
-# roofline is the time the fp16 pipe needs for that at its dense peak: 2 500 / 3 = 833 TFLOP/s of fp32-equivalent work.
-# What the pipe executes per 16-rollout tile and decode step: 768 (MLP) + 3 x 112 (scores, P.V, logits: the k = 16 products ride
-# in k = 32 instructions as [hi | lo'] x [hi | 0] and [hi | lo'] x [lo' | hi]) = 1 104 v_mfma_f32_16x16x32_f16 of 16 384 flop.
+# with each fp32 operand split in two fp16 pieces x~ = hi + lo (csrc/rr_common.h, second form) and three partial products kept
+# (hi*hi, hi*lo, lo*hi; fp32 accumulate; measured error of a dot product 8e-8 of sum |a b|, at the fp32 MFMA's own level): 3 x
+# 404 480 fp16 flop per rollout-step.  Its MFMA roofline is the time the fp16 pipe needs for that at its dense peak: 2 500 / 3 =
+# 833 TFLOP/s of fp32-equivalent work.  What the pipe executes per 16-rollout tile and decode step: 768 (MLP) + 3 x 112 (scores,
+# P.V, logits: a k = 16 product is one k = 16 instruction on the hi halves + one k = 32 instruction [hi | lo] x [lo | hi], both
+# 16 cycles) = 1 104 matrix instructions of 16 384 flop-slots.
 SPLIT_PRODUCTS = 3
 EXECUTED_F16_FLOP_PER_TILE_STEP = 1104 * 16384
 EXECUTED_F16_FLOP_PER_ROLLOUT_STEP = EXECUTED_F16_FLOP_PER_TILE_STEP // 16      # (a full tile; tools/bench_train.py)
@@ -46,7 +47,7 @@ ROLLOUT_KERNEL_FP32 = "k_rollout_w<7, 0, 0, false, false>"
 # (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B — FETCH_SIZE doubled for gfx950's 16-B/lane reads as MI355X_MICROARCH.md §HBM
 # prescribes; Infinity-Cache hits are included in the counter.  Read at run time from the committed summary
 # (tools/pmc_traffic.sh writes it together with a hash of the rollout's sources): a summary of other sources -> null.
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02", "bench_pmc_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03", "bench_pmc_hbm_traffic.json")
 ROLLOUT_SOURCES = ("rr_decode.hip", "rr_rollout_w.inc", "rr_common.h")
 
 
@@ -106,7 +107,8 @@ def cpu_baseline(w, seed=4321, budget_s=20.0, max_inst=8):
     sample of the same workload: instances x 8 augmentations x 100 starts, one instance (8 instance-augs)
     per micro-batch, as many instances as fit in ~budget_s."""
     from oracle import restate
-    threads = min(os.cpu_count() or 1, 32)     # torch-CPU scales poorly past a few dozen threads on these ops
+    host_cores = os.cpu_count() or 1
+    threads = min(host_cores, 32)              # torch-CPU scales poorly past a few dozen threads on these ops
     torch.set_num_threads(threads)
     done, spent = 0, 0.0
     while done < max_inst and (done == 0 or spent + spent / done < budget_s):
@@ -118,17 +120,184 @@ def cpu_baseline(w, seed=4321, budget_s=20.0, max_inst=8):
             restate.atsp_policy(w, st, sidx, STARTS, "greedy")
         spent += time.perf_counter() - t0
         done += 1
-    return {"value": done / spent, "unit": "instances/s", "cores": threads, "kind": "port",
+    return {"value": done / spent, "unit": "instances/s", "cores": threads, "threads": threads, "host_cores": host_cores, "kind": "port",
             "sample": f"{done} ATSP n=100 instance(s) x8 aug x100 starts greedy, torch-CPU fp32 oracle, {spent:.1f} s"}
+
+
+ENC_BLOCK_FLOP = 48e6                    # GEMM flop of one AttnFree_Block per instance, two blocks per layer
+ENC_KERNEL = "k_enc_block_w<7, true>"
+
+
+class kernel_timers:
+    """HIP events around the named C-ABI launchers (on torch's current stream, the stream they launch on): the launchers are
+    one kernel each, so the event pair times that kernel.  with kernel_timers("rr_enc_layer", ...) as t: ...; t.ms("rr_enc_layer")."""
+
+    def __init__(self, *names):
+        self.names, self.ev, self.saved = names, {n: [] for n in names}, {}
+
+    def __enter__(self):
+        from rrnco_amd import _lib as L
+        lib = L.lib()
+        for n in self.names:
+            fn = getattr(lib, n)
+            self.saved[n] = fn
+
+            def wrap(*a, _fn=fn, _n=n):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = _fn(*a)
+                e1.record()
+                self.ev[_n].append((e0, e1))
+                return r
+            setattr(lib, n, wrap)
+        return self
+
+    def __exit__(self, *exc):
+        from rrnco_amd import _lib as L
+        for n, fn in self.saved.items():
+            setattr(L.lib(), n, fn)
+        return False
+
+    def ms(self, name):
+        """(mean ms per call, calls)"""
+        v = [a.elapsed_time(b) for a, b in self.ev[name]]
+        return (sum(v) / len(v), len(v)) if v else (0.0, 0)
+
+    def reset(self):
+        for n in self.ev:
+            self.ev[n] = []
+
+
+def timed_loop(step, min_seconds=1.0, min_steps=2, max_steps=200):
+    """Runs step() until at least min_seconds have passed; -> (seconds per step, steps)."""
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        step()
+        n += 1
+        if n >= min_steps and (n >= max_steps or (n % 2 == 0 and (torch.cuda.synchronize() or True) and time.perf_counter() - t0 >= min_seconds)):
+            break
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n, n
+
+
+def other_configs(dev):
+    """BASELINE.json configs[2], [3] and one configs[4] shard on this GPU, each timed for >= 1 s: instances/s, ms per step, the
+    rollout kernel's time (HIP events) and a roofline block (C5: the backward's dominant kernel)."""
+    from rrnco_amd import TensorDict
+    from rrnco_amd.envs import ATSPEnv, RCVRPEnv, RMTVRPEnv
+    from rrnco_amd.models import RRNetPolicy, rollout as R
+    from rrnco_amd.models.encoder import ATSPInitEmbedding
+    from rrnco_amd.models.rl import RRNet
+    from rrnco_amd.models.transforms import StateAugmentation
+    out = {}
+    peak_split = PEAK_F16_MFMA_TFLOPS / SPLIT_PRODUCTS
+
+    def vrp_policy(env_name):
+        torch.manual_seed(1234)
+        return RRNetPolicy(env_name=env_name, embed_dim=128, num_heads=8, num_encoder_layers=6, normalization="instance",
+                           use_graph_context=False, nab_type="gating", init_embedding_kwargs=dict(sample_size=25)).to(dev).eval()
+
+    def inference(label, env, pol, B, S, aug, decode, kernel):
+        inst = env.generator(B, generator=torch.Generator(device=dev).manual_seed(5))
+        sidx = ATSPInitEmbedding.sample_indices(env.reset(inst)["distance_matrix"], 25)
+        if aug:
+            sidx = sidx.repeat(8, 1, 1).contiguous()
+        res = {}
+
+        def step():
+            td = TensorDict(dict(inst.items()), batch_size=[B])
+            if aug:
+                td = StateAugmentation(augment_fn="dihedral8", no_aug_coords=False)(td)
+            td["sample_idx"] = sidx
+            res["out"] = pol(env.reset(td), env, phase="val", decode_type=decode, num_starts=S, seed=1)
+        step()
+        R.TIMING = []
+        sec, n = timed_loop(step)
+        ks = [a.elapsed_time(b) for a, b in R.TIMING]
+        R.TIMING = None
+        k_ms = sum(ks) / max(len(ks), 1)
+        o = res["out"]
+        T, Rr = int(o["actions"].shape[1]), int(o["actions"].shape[0])
+        # executed decoder evaluations: every rollout of a tile runs until the instance's longest route ends (T - 1 evaluated steps)
+        ach = Rr * (T - 1) * FLOP_PER_ROLLOUT_STEP / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        out[label] = {"value": B / sec, "unit": "instances/s", "ms_per_step": sec * 1e3, "steps": n, "kernel_ms": k_ms,
+                      "rollouts": Rr, "decode_steps": T,
+                      "mean_best_cost": float(-o["reward"].view(S, -1).max(0).values.mean()),
+                      "roofline": {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": peak_split, "unit": "TFLOP/s",
+                                   "frac": ach / peak_split, "traffic": None,
+                                   "note": "404 480 flop per rollout and decode step x rollouts x (decode steps of the longest route - 1); "
+                                           "fp32-equivalent peak of the fp16 pipe with 3 partial products"}}
+
+    env = RCVRPEnv(generator_params=dict(num_loc=N_NODES, device=dev), check_solution=False, device=dev)
+    inference("C3 RCVRP n=100 B=512 POMO S=101 greedy (configs[2])", env, vrp_policy("rcvrp"), 512, 101, False, "multistart_greedy",
+              "k_rollout_w<7, 1, 0, true, true>")
+    env = RMTVRPEnv(generator_params=dict(num_loc=N_NODES, device=dev), device=dev)
+    inference("C4 RCVRPTW n=100 B=256 x8 aug S=100 sampling (configs[3])", env, vrp_policy("rcvrptw"), 256, 100, True, "multistart_sampling",
+              "k_rollout_w<7, 2, 1, true, true>")
+    torch.cuda.empty_cache()
+
+    # configs[4], one rank's shard: REINFORCE step on 512 ATSP instances (sampling rollout with the training dump, hand-written
+    # backward, clip, fused Adam; the flat RCCL all-reduce is a no-op at one rank)
+    pol, _ = make_policy(dev)
+    pol.train()
+    env = ATSPEnv(generator_params=dict(num_loc=N_NODES, device=dev), check_solution=False, device=dev)
+    model = RRNet(env, policy=pol)
+    opt = torch.optim.Adam(pol.parameters(), lr=1e-4, fused=True)
+    gen = torch.Generator(device=dev).manual_seed(77)
+    batches = [env.generator(512, generator=gen) for _ in range(3)]
+    state = {"i": 0}
+
+    def train_step():
+        state["out"] = model.training_step(batches[state["i"] % 3], optimizer=opt, world=1, seed=2 + state["i"], grad_clip=1.0)
+        state["i"] += 1
+    train_step()
+    bw = ("rr_dec_attn_bwd", "rr_mlp_wgrad", "rr_mlp_rows", "rr_dec_logit_bwd", "rr_gemm_tn", "rr_linear_rows", "rr_aft_bwd",
+          "rr_inorm_bwd", "rr_nab_hist_bwd", "rr_enc_layer_train")
+    with kernel_timers(*bw) as kt:
+        R.TIMING = []
+        sec, n = timed_loop(train_step)
+        ks = [a.elapsed_time(b) for a, b in R.TIMING]
+        R.TIMING = None
+        per_step = {k: kt.ms(k)[0] * kt.ms(k)[1] / n for k in bw}
+    dom = max(per_step, key=per_step.get)
+    rows = 512 * STARTS * (N_NODES - 2)                  # decoder evaluations of the step (the forced last move is not evaluated)
+    roof = {"bound": "mfma", "kernel": dom, "kernel_ms_per_step": per_step[dom], "calls_per_step": kt.ms(dom)[1] / n, "traffic": None}
+    if dom == "rr_dec_attn_bwd":
+        # masked 8-head glimpse backward per decoder evaluation: recomputed scores, dP, dQ, dK, dV = 5 products of 2 N E flop, fp32 MFMA
+        fl = rows * 5 * 2 * N_NODES * 128
+        roof.update({"achieved": fl / (per_step[dom] * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "note": "5 x 2 N E flop per decoder evaluation (scores recomputed, dP, dQ, dK, dV) on the fp32 MFMA"})
+    elif dom == "rr_mlp_wgrad":
+        # pointer MLP + 12 encoder FFNs: per row the hidden layer recomputed, dH, dW1, dW2 = 4 products of 2 x 128 x 512 flop, bf16 two-piece
+        fl = (rows + 12 * 512 * N_NODES) * 4 * 2 * 128 * 512
+        roof.update({"achieved": fl / (per_step[dom] * 1e-3) / 1e12, "peak": peak_split, "unit": "TFLOP/s",
+                     "note": "4 x 2 x 128 x 512 flop per row (hidden recomputed, dH, dW1, dW2), two-piece bf16 operands: 2 500 / 3"})
+    if "achieved" in roof:
+        roof["frac"] = roof["achieved"] / roof["peak"]
+    o = state["out"]
+    out["C5 ATSP n=100 REINFORCE step, 512 instances (one rank's shard of configs[4])"] = {
+        "value": 512 / sec, "unit": "trained instances/s", "ms_per_step": sec * 1e3, "steps": n,
+        "kernel_ms": sum(ks) / max(len(ks), 1), "kernel": "k_rollout_w<7, 0, 1, true, true> (sampling rollout with the training dump)",
+        "backward_kernels_ms_per_step": {k: round(v, 3) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
+        "loss": float(o["loss"]), "grad_norm": float(o["grad_norm"]), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+        "roofline": roof}
+    del model, opt, pol, batches, state
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=15)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --batch instances per GPU (the default); strong: --batch instances in all, parallel.shard_range per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs[2..4] (timed on one GPU after the headline)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -149,11 +318,19 @@ def main():
 
     from rrnco_amd.envs import ATSPEnv, ATSPGenerator
     from rrnco_amd.models import rollout as R
+    from rrnco_amd.parallel import aggregate_throughput, shard_range
     pol, w = make_policy(dev)
     env = ATSPEnv(generator_params=dict(num_loc=N_NODES, device=dev), check_solution=False, device=dev)
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    inst_td = ATSPGenerator(num_loc=N_NODES, device=dev)(args.batch, generator=gen)
-    inst = {"locs": inst_td["locs"], "distance_matrix": inst_td["distance_matrix"]}
+    if args.scaling == "strong":       # the B instances of ONE batch partitioned over the ranks
+        lo, hi = shard_range(args.batch, rank, world)
+        gen = torch.Generator(device=dev).manual_seed(1234)
+        inst_td = ATSPGenerator(num_loc=N_NODES, device=dev)(args.batch, generator=gen)
+        inst = {"locs": inst_td["locs"][lo:hi].contiguous(), "distance_matrix": inst_td["distance_matrix"][lo:hi].contiguous()}
+    else:
+        gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+        inst_td = ATSPGenerator(num_loc=N_NODES, device=dev)(args.batch, generator=gen)
+        inst = {"locs": inst_td["locs"], "distance_matrix": inst_td["distance_matrix"]}
+    local_batch = int(inst["locs"].shape[0])
     torch.manual_seed(4242 + rank)           # the neighbour samples of the timed steps come from this stream
 
     def sync_all():
@@ -162,56 +339,73 @@ def main():
             td_.barrier()
             torch.cuda.synchronize()
 
-    # headline = the default build (rollout pointer MLP and encoder FFN on split-bf16 operands, everything else fp32 MFMA);
+    # headline = the default build (every GEMM of the encoder, the decoder cache and the whole rollout on two-piece fp16 operands);
     # the all-fp32-MFMA build is measured separately below
     os.environ.pop("RR_MLP_SPLIT", None)
     R.SPLIT_MLP = True
     for _ in range(args.warmup):
         hot_path_step(pol, env, inst)
-    R.TIMING = []
-    sync_all()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        torch.manual_seed(4242 + rank + 1000 * k)      # the step's neighbour sample (the variant below replays the same draws)
-        best, out = hot_path_step(pol, env, inst)
-    sync_all()
-    dt = time.perf_counter() - t0
-    kern_ms = [a.elapsed_time(b) for a, b in R.TIMING]
-    R.TIMING = None
-    from rrnco_amd.parallel import aggregate_throughput
-    total_inst, dt = aggregate_throughput(args.batch * args.steps, dt, dist, dev if backend == "nccl" else torch.device("cpu"))
+    with kernel_timers("rr_enc_layer", "rr_init_embed", "rr_dec_cache") as kt:
+        R.TIMING = []
+        sync_all()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            torch.manual_seed(4242 + rank + 1000 * k)      # the step's neighbour sample (the variant below replays the same draws)
+            best, out = hot_path_step(pol, env, inst)
+        sync_all()
+        dt = time.perf_counter() - t0
+        pol.check_range()                  # the range guard's deferred word (models/policy.py): a raised one fails the run loudly
+        kern_ms = [a.elapsed_time(b) for a, b in R.TIMING]
+        R.TIMING = None
+        enc_ms, enc_calls = kt.ms("rr_enc_layer")
+        init_ms, _ = kt.ms("rr_init_embed")
+        cache_ms, _ = kt.ms("rr_dec_cache")
+    total_inst, dt = aggregate_throughput(local_batch * args.steps, dt, dist, dev if backend == "nccl" else torch.device("cpu"))
+    devices = [f"cuda:{local}"]
+    if dist:
+        names = [None] * world
+        td_.all_gather_object(names, f"rank {rank}: cuda:{local} ({torch.cuda.get_device_name(local)})")
+        devices = names
 
     if rank == 0:
-        rollout_steps = args.batch * AUG * STARTS * (N_NODES - 1)
+        rollout_steps = local_batch * AUG * STARTS * (N_NODES - 1)
         k_ms = sum(kern_ms) / max(len(kern_ms), 1)
         achieved = rollout_steps * FLOP_PER_ROLLOUT_STEP / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         peak_split = PEAK_F16_MFMA_TFLOPS / SPLIT_PRODUCTS
         # executed work counts tiles: S = 100 starts are 6 full 16-rollout tiles and one quarter-full one per instance (tail tiles are
         # not packed across instances: csrc/rr_decode.hip)
-        tile_steps = args.batch * AUG * ((STARTS + 15) // 16) * (N_NODES - 1)
+        tile_steps = local_batch * AUG * ((STARTS + 15) // 16) * (N_NODES - 1)
         executed = tile_steps * EXECUTED_F16_FLOP_PER_TILE_STEP / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-        traffic, traffic_src = measured_rollout_traffic(args.batch)
+        traffic, traffic_src = measured_rollout_traffic(local_batch)
+        enc_ach = 2 * ENC_BLOCK_FLOP * local_batch * AUG / (enc_ms * 1e-3) / 1e12 if enc_ms > 0 else 0.0
         line = {
             "metric": "solved instances/sec (ATSP n=100, B=512, POMO greedy)", "value": total_inst / dt,
             "unit": "instances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "arithmetic": "fp32 operands and fp32 accumulation throughout; the rollout's products (scores, P.V, pointer MLP, logits) "
-                          "multiply two-piece fp16 splits x = hi + 2^-11 lo' on the fp16 matrix pipe (3 partial products; error of a dot "
-                          "product 4e-8 of sum|ab| against 1.1e-7 for the fp32 MFMA, tools/clockprobe/f16probe.hip), the encoder FFN "
-                          "3-way bf16 splits (6 products); tours equal to the all-fp32-MFMA build's (tests/test_gpu_fullsize.py), which "
-                          "is timed under `variants`",
-            "config": {"workload": f"ATSP n={N_NODES}, batch={args.batch}/GPU, POMO S={STARTS} starts x {AUG} dihedral aug, greedy "
-                                   "(BASELINE.json configs[1]); random-init RRNet E=128 L=6",
-                       "rollouts_per_gpu": args.batch * AUG * STARTS, "sharding": f"instances over {world} rank(s), no collective"},
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic", "devices": devices,
+            "arithmetic": "fp32 operands and fp32 accumulation throughout; the products of the rollout (scores, P.V, pointer MLP, logits), "
+                          "of the encoder (projections, AFT mixing, FFN) and of the decoder cache multiply two-piece fp16 splits of the fp32 "
+                          "operands on the fp16 matrix pipe (3 partial products: hi*hi, hi*lo, lo*hi; error of a dot product 4e-8 .. 8e-8 of "
+                          "sum|ab| against 1.1e-7 for the fp32 MFMA: tools/clockprobe/f16probe.hip, usplitprobe.hip); operands that leave the "
+                          "fp16 range raise a status word and the call repeats on the fp32-MFMA kernels (models/policy.py); tours equal to "
+                          "the all-fp32-MFMA build's (tests/test_gpu_fullsize.py), which is timed under `variants`",
+            "config": {"workload": f"ATSP n={N_NODES}, batch={args.batch}{'/GPU' if args.scaling == 'weak' else ' in all'}, POMO S={STARTS} starts x "
+                                   f"{AUG} dihedral aug, greedy (BASELINE.json configs[1]); random-init RRNet E=128 L=6",
+                       "rollouts_per_gpu": local_batch * AUG * STARTS,
+                       "sharding": f"instances over {world} rank(s), no collective ({args.scaling} scaling: {local_batch} instances on rank 0)"},
             "roofline": {"bound": "mfma", "kernel": ROLLOUT_KERNEL + " (persistent wave-autonomous POMO decode)", "achieved": achieved,
                          "peak": peak_split, "unit": "TFLOP/s", "frac": achieved / peak_split,
                          "peak_note": "fp32-equivalent flop/s of the fp16 matrix pipe at its dense peak with 3 partial products per product "
                                       "(2 500 / 3); round 1's all-fp32-MFMA kernel (peak 157.3) is under `variants`",
                          "executed_mfma": {"achieved": executed, "peak": PEAK_F16_MFMA_TFLOPS, "frac": executed / PEAK_F16_MFMA_TFLOPS,
-                                           "note": "1 104 v_mfma_f32_16x16x32_f16 per 16-rollout tile and decode step, 7 tiles per 100 starts"},
+                                           "note": "1 104 matrix instructions (16 384 flop-slots each) per 16-rollout tile and decode step, 7 tiles per 100 starts"},
                          "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": k_ms,
                          "algorithmic_flop_per_launch": rollout_steps * FLOP_PER_ROLLOUT_STEP},
+            "roofline_encoder": {"bound": "mfma", "kernel": ENC_KERNEL + " (one launch = the row and the column AttnFree_Block of a layer)",
+                                 "achieved": enc_ach, "peak": peak_split, "unit": "TFLOP/s", "frac": enc_ach / peak_split if peak_split else 0.0,
+                                 "kernel_ms": enc_ms, "launches_per_step": enc_calls / max(args.steps, 1), "traffic": None,
+                                 "algorithmic_flop_per_launch": 2 * ENC_BLOCK_FLOP * local_batch * AUG,
+                                 "init_embed_ms": init_ms, "dec_cache_ms": cache_ms},
             "mean_best_cost": float(-best.mean().item()),
         }
         if world == 1:
@@ -220,7 +414,8 @@ def main():
                 R.TIMING = []
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                for k in range(args.steps):
+                nv = max(min(args.steps, 8), 1)
+                for k in range(nv):
                     torch.manual_seed(4242 + rank + 1000 * k)
                     best_v, _ = hot_path_step(pol, env, inst)
                 torch.cuda.synchronize()
@@ -228,9 +423,10 @@ def main():
                 ks = [a.elapsed_time(b) for a, b in R.TIMING]
                 R.TIMING = None
                 kv = sum(ks) / max(len(ks), 1)
-                return {"value": args.batch * args.steps / dtv, "unit": "instances/s", "ms_per_step": dtv / args.steps * 1e3,
+                return {"value": local_batch * nv / dtv, "unit": "instances/s", "ms_per_step": dtv / nv * 1e3, "steps": nv,
                         "kernel_ms": kv, "mean_best_cost": float(-best_v.mean().item()),
-                        "instances_with_identical_best_cost": float((best_v == best).float().mean().item())}, kv
+                        "instances_with_identical_best_cost": float((best_v == best).float().mean().item())
+                        if nv == args.steps else None}, kv
             line["variants"] = {}
             # the all-fp32-MFMA build (round 1's default): priced against the fp32 matrix peak, algorithmic and executed flop
             R.SPLIT_MLP = False
@@ -245,6 +441,11 @@ def main():
             line["variants"]["all_fp32_mfma (RR_MLP_SPLIT=0)"] = v32
             R.SPLIT_MLP = True
             os.environ.pop("RR_MLP_SPLIT")
+            pol.invalidate_pack()
+        if world == 1 and not args.no_other_configs:
+            del pol
+            torch.cuda.empty_cache()
+            line["configs"] = other_configs(dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(line))

@@ -50,7 +50,8 @@ def evaluate_dataset(path, problem, policy, env, batch_size, n_aug, n_start, dev
         td = env.reset(batch)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        out = policy(td, env, phase="val", return_actions=True, num_starts=n_start)       # test.py:192-207 (reward inside)
+        out = policy(td, env, phase="val", return_actions=True, num_starts=n_start,       # test.py:192-207 (reward inside)
+                     range_guard="sync")      # the timing brackets synchronise anyway: out-of-range calls repeat on the fp32 kernels
         reward = out["reward"]
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)

@@ -90,21 +90,41 @@ class RRNetPolicy(nn.Module):
         return out
 
     @torch.no_grad()
-    def _forward_impl(self, td, env=None, *args, capture=None, **kwargs) -> dict:
+    def _forward_impl(self, td, env=None, *args, capture=None, range_guard=None, **kwargs) -> dict:
         """Range guard of the fp16 two-piece arithmetic (csrc/rr_common.h).  The default kernels convert fp32 operands to fp16
-        pairs: a weight, an embedding or an activation of magnitude >= 65 504 (after its image's scale) becomes inf and the
-        tours silently garbage.  One device word collects: bit 0 a K / V^T / L image out of range or non-finite (rr_pack_f16x2:
-        that includes anything non-finite the encoder produced), bit 1 a pointer-MLP weight image out of range
-        (packing.f16_range_status), bit 2 a non-finite log-probability in the fused rollout (RolloutIO::status).  It is read once
-        per call (for the VRPs together with the step count); a call that raised it is repeated on the fp32-MFMA kernels, which
-        have no such limit.  RR_RANGE_GUARD=0 switches the check (and its host read) off."""
+        pairs: a weight, an embedding or an activation of magnitude >= 65 504 (after its image's scale) becomes inf.  One device
+        word collects: bit 0 a K / V^T / L image out of range or non-finite (rr_pack_f16x2: that includes anything non-finite the
+        encoder produced), bit 1 a pointer-MLP weight image out of range (packing.f16_range_status), bit 2 a non-finite
+        log-probability in the fused rollout (RolloutIO::status; the kernel also writes NaN into that rollout's log-probability,
+        so the call's log-likelihood is NaN, never a plausible number).  Modes (`range_guard=` or RR_RANGE_GUARD):
+          "sync"     the word is read once per call, before anything looks at the tours; a call that raised it is repeated on the
+                     fp32-MFMA kernels, which have no such limit — costs one host synchronisation per call (~2 ms of pipeline bubble
+                     on the 80 ms headline step);
+          "deferred" no host read in the call: the word of call k is read at the start of call k + 1 and by check_range(); a raised
+                     word then raises FloatingPointError (call k's outputs were NaN-marked) and every later call runs in fp32;
+          "auto"     (default) "sync" where the call synchronises anyway (the VRPs read their step count; training steps),
+                     "deferred" otherwise (ATSP inference);  "off": no guard."""
         import os
-        if not packing.mlp_split_enabled() or os.environ.get("RR_RANGE_GUARD", "1") == "0" or td.device.type != "cuda":
+        mode = range_guard or os.environ.get("RR_RANGE_GUARD", "auto")
+        mode = {"1": "sync", "0": "off"}.get(mode, mode)
+        self.check_range()                                       # a deferred word of the previous call
+        if getattr(self, "_range_sticky_fp32", False):
+            with packing.force_fp32():
+                return self._forward_core(td, env, *args, capture=capture, **kwargs)
+        if not packing.mlp_split_enabled() or mode == "off" or td.device.type != "cuda":
             self._range_status = None
             return self._forward_core(td, env, *args, capture=capture, **kwargs)
-        td_in = TensorDict(td, batch_size=td.batch_size)                                   # shallow copy: the second pass starts from the same state
+        if mode == "auto":
+            mode = "sync" if (self.env_name != "atsp" or capture is not None) else "deferred"
         self._range_status = self.packed(td.device)["range_status"].clone()
+        self._range_sync = mode == "sync"
         self.last_range_flags = 0
+        if mode == "deferred":
+            try:
+                return self._forward_core(td, env, *args, capture=capture, **kwargs)
+            finally:
+                self._range_pending, self._range_status = self._range_status, None
+        td_in = TensorDict(td, batch_size=td.batch_size)         # shallow copy: the second pass starts from the same state
         try:
             return self._forward_core(td, env, *args, capture=capture, **kwargs)
         except _RangeRetry as r:
@@ -119,6 +139,23 @@ class RRNetPolicy(nn.Module):
                 return self._forward_core(td_in, env, *args, capture=capture, **kwargs)
         finally:
             self._range_status = None
+
+    def check_range(self) -> None:
+        """Reads the range-guard word a "deferred" call left behind (one host read of a finished call).  If it is raised:
+        FloatingPointError — that call's log-likelihoods were NaN-marked and its tours are not to be trusted — and the policy
+        runs on the fp32-MFMA kernels from now on."""
+        pend = getattr(self, "_range_pending", None)
+        if pend is None:
+            return
+        self._range_pending = None
+        flags = int(pend.item())
+        self.last_range_flags = flags
+        if flags != 0:
+            self._range_sticky_fp32 = True
+            raise FloatingPointError(
+                f"rrnco_amd: the previous policy call left the fp16 range of the split kernels (flags {flags:#x}: 1 = K/V/L image, 2 = weight "
+                "image, 4 = non-finite log-probability); its outputs are invalid (log-likelihood NaN).  This policy now runs on the fp32 "
+                "MFMA kernels: repeat the call (range_guard='sync' repeats such calls by itself).")
 
     def _forward_core(self, td, env=None, phase="train", calc_reward=True, return_actions=True, return_entropy=False,
                       return_hidden=False, return_init_embeds=False, return_sum_log_likelihood=True, actions=None,
@@ -235,7 +272,7 @@ class RRNetPolicy(nn.Module):
         if dump is not None:
             dump.update({"first": st["first"], "tanh_clip": strategy.tanh_clipping, "temperature": strategy.temperature})
         status = getattr(self, "_range_status", None)
-        if status is not None:                          # the range guard's one host read (before anything looks at the tours)
+        if status is not None and getattr(self, "_range_sync", True):      # the range guard's one host read (before anything looks at the tours)
             flags = int(status.item())
             if flags != 0:
                 raise _RangeRetry(flags)

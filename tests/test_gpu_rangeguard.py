@@ -11,7 +11,7 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-def _run(pol, fx):
+def _run(pol, fx, mode="sync"):
     from rrnco_amd import TensorDict
     from rrnco_amd.envs import ATSPEnv
     env = ATSPEnv(generator_params=dict(num_loc=fx["N"]))
@@ -19,7 +19,8 @@ def _run(pol, fx):
                      "sample_idx": fx["sample_idx"].cuda()}, batch_size=[fx["B"]])
     with warnings.catch_warnings(record=True) as rec:
         warnings.simplefilter("always")
-        out = pol(env.reset(td), env, phase="val", decode_type="multistart_greedy", num_starts=fx["S"], return_actions=True)
+        out = pol(env.reset(td), env, phase="val", decode_type="multistart_greedy", num_starts=fx["S"], return_actions=True,
+                  range_guard=mode)
     return out, [str(w.message) for w in rec]
 
 
@@ -76,3 +77,29 @@ def test_pack_kernel_flags_out_of_range_and_non_finite_values():
             h = d.view(torch.float16).view(-1, 8).float()
             rec = (h[:, :4] + h[:, 4:]) / 16.0
             assert ((rec - x.view(-1, 4)).abs() <= 2.0 ** -21 * x.view(-1, 4).abs() + 2.0 ** -28).all()
+
+
+def test_deferred_mode_marks_the_log_likelihood_and_raises_at_the_next_call_then_runs_fp32():
+    """The default for ATSP inference: no host read in the call; the offending call's log-likelihood is NaN, the next call (or
+    check_range) raises, later calls run on the fp32 kernels and match the reference."""
+    from rrnco_amd import TensorDict
+    from rrnco_amd.envs import ATSPEnv
+    fx = H.load_fixture("atsp_n20_b4_pomo")
+    pol = H.make_policy(_scaled_mlp(H.atsp_weights(fx), 2048.0), device="cuda:0")
+    env = ATSPEnv(generator_params=dict(num_loc=fx["N"]), check_solution=False)
+
+    def call():
+        td = TensorDict({"locs": fx["locs"].cuda(), "distance_matrix": fx["distance_matrix"].cuda(),
+                         "sample_idx": fx["sample_idx"].cuda()}, batch_size=[fx["B"]])
+        return pol(env.reset(td), env, phase="val", decode_type="multistart_greedy", num_starts=fx["S"], return_actions=True)
+    out = call()                                               # auto -> deferred: returns without a host read
+    assert torch.isnan(out["log_likelihood"]).any()
+    with pytest.raises(FloatingPointError):
+        pol.check_range()
+    out2 = call()                                              # sticky fp32 from now on
+    assert (out2["actions"].cpu() == fx["actions"]).all() and torch.isfinite(out2["log_likelihood"]).all()
+    pol3 = H.make_policy(_scaled_mlp(H.atsp_weights(fx), 2048.0), device="cuda:0")
+    pol, pol_old = pol3, pol
+    call()
+    with pytest.raises(FloatingPointError):
+        call()                                                 # ... or the next call raises
