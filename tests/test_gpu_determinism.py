@@ -68,3 +68,77 @@ def test_full_size_atsp_rollout_is_deterministic():
         outs.append((out["actions"].clone(), out["log_likelihood"].clone()))
     for a, ll in outs[1:]:
         assert torch.equal(a, outs[0][0]) and torch.equal(ll, outs[0][1])
+
+
+@pytest.mark.parametrize("name", ["atsp_n20_b4_pomo", "atsp_n100_b2_pomo"])
+def test_encoder_and_decoder_cache_are_deterministic(name):
+    """The encoder block kernel and the decoder cache rebuild split operands on the fly as the rollout does (csrc/rr_enc_w.inc,
+    rr_gemm_f16.h): repeated launches must return bit-identical embeddings and caches (VERDICT r02, weak #3)."""
+    from tests import helpers as H
+    from rrnco_amd import TensorDict
+    from rrnco_amd.envs import ATSPEnv
+    fx = H.load_fixture(name)
+    pol = H.make_policy(H.atsp_weights(fx), "atsp")
+    env = ATSPEnv(check_solution=False, device=torch.device("cuda"))
+    st = H.fixture_state(fx)
+    td_in = TensorDict({k: v.cuda() for k, v in st.items()}, batch_size=[st["locs"].shape[0]])
+    td_in["sample_idx"] = fx["sample_idx"].cuda()
+    packed = pol.packed(torch.device("cuda"))
+    ref = None
+    for i in range(REPEATS):
+        td = env.reset(td_in)
+        row, col = pol.encoder(td, phase="val", packed=packed)
+        _, _, cache = pol.decoder.pre_decoder_hook(td, env, (row, col), fx["S"], packed=packed)
+        cur = (row.clone(), col.clone(), cache.glimpse_key.clone(), cache.glimpse_val_t.clone(), cache.logit_key.clone())
+        if ref is None:
+            ref = cur
+            continue
+        for a, b, what in zip(cur, ref, ("row_emb", "col_emb", "K", "V^T", "L")):
+            assert torch.equal(a, b), f"{what} differs in repeat {i}: max {float((a - b).abs().max()):.3e}"
+
+
+def test_full_size_encoder_is_deterministic():
+    """4 096 instance-augmentations (the headline's encoder launches: every workgroup of the chip busy, two waves per SIMD)."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from rrnco_amd import TensorDict
+    from rrnco_amd.envs import ATSPEnv, ATSPGenerator
+    from rrnco_amd.models.encoder import ATSPInitEmbedding
+    from rrnco_amd.models.transforms import StateAugmentation
+    dev = torch.device("cuda")
+    pol, _ = bench.make_policy(dev)
+    env = ATSPEnv(generator_params=dict(num_loc=100, device=dev), check_solution=False, device=dev)
+    inst = ATSPGenerator(num_loc=100, device=dev)(512, generator=torch.Generator(device=dev).manual_seed(5))
+    td0 = env.reset(StateAugmentation(augment_fn="dihedral8", no_aug_coords=False)(TensorDict(dict(inst.items()), batch_size=[512])))
+    torch.manual_seed(3)
+    td0["sample_idx"] = ATSPInitEmbedding.sample_indices(td0["distance_matrix"], 25)
+    packed = pol.packed(dev)
+    outs = []
+    for _ in range(4):
+        row, col = pol.encoder(td0, phase="val", packed=packed)
+        outs.append((row.clone(), col.clone()))
+    for r, c in outs[1:]:
+        assert torch.equal(r, outs[0][0]) and torch.equal(c, outs[0][1])
+
+
+@pytest.mark.parametrize("name", ["atsp_n20_b4_pomo", "atsp_n100_b2_pomo"])
+def test_training_step_repeats(name):
+    """The sampling rollout with the training dump is a pure function of (weights, instances, seed): tours and log-likelihoods
+    bit-identical between repeats.  The backward kernels accumulate with float atomics (order-dependent in the last bits), so the
+    gradients are held to 1e-5 of the gradient norm — a stale-operand hazard shows up orders of magnitude above that."""
+    from tests import helpers as H
+    from tests.test_gpu_train import _model
+    fx = H.load_fixture(name)
+    ref = None
+    for i in range(6):
+        w, pol, model, st, td_in = _model(fx)
+        out = model.training_step(td_in, seed=11)
+        g = torch.cat([p.grad.reshape(-1) for p in pol.parameters() if p.grad is not None]).clone()
+        cur = (out["actions"].clone(), out["log_likelihood"].clone(), g)
+        if ref is None:
+            ref = cur
+            continue
+        assert torch.equal(cur[0], ref[0]) and torch.equal(cur[1], ref[1]), f"sampled tours / log-likelihoods differ in repeat {i}"
+        rel = float((cur[2] - ref[2]).norm() / ref[2].norm())
+        assert rel < 1e-5, f"gradients differ by {rel:.3e} of their norm in repeat {i}"

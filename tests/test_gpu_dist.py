@@ -8,6 +8,7 @@ import subprocess
 import sys
 
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,6 +30,14 @@ def test_bench_contract_under_torchrun_two_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert abs(out["value"] - 2 * 64 * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 1e-6     # all ranks' units / max time
+    assert len(out["devices"]) == 2 and out["devices"][0].startswith("rank 0: cuda:") and "configs" not in out
+    # strong scaling: the 64 instances of ONE batch partitioned over the two ranks
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "64", "--scaling", "strong",
+                   "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["scaling"] == "strong" and out["config"]["rollouts_per_gpu"] == 32 * 8 * 100
+    assert abs(out["value"] - 64 * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 1e-6
 
 
 def test_sharded_training_step_gradient_all_reduce(tmp_path):
@@ -43,3 +52,22 @@ def test_bench_train_full_size_two_ranks():
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["loss"] == out["loss"] and 0 < out["grad_norm"] < 1e4
+
+
+def test_rccl_paths_when_two_devices_are_visible(tmp_path):
+    """On a box with >= 2 GPUs the nccl (= RCCL) path of allreduce_flat_gradients and aggregate_throughput runs under
+    torch.distributed.run, one rank per device: the sharded training gradient must equal the single-rank one and bench.py must
+    report both ranks' devices.  Skipped on the single-GPU test boxes (the gloo twin above covers the logic there)."""
+    import json
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs (RCCL over xGMI); single-GPU box")
+    env = dict(os.environ, RR_DIST_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29613"]
+    r = subprocess.run(cmd + [os.path.join(ROOT, "tests", "dist_worker_gpu.py"), str(tmp_path)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run(cmd + [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "64"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and len(line["devices"]) == 2 and "cuda:0" in line["devices"][0] and "cuda:1" in line["devices"][1]
