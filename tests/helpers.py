@@ -21,6 +21,9 @@ def load_fixture(name):
 
 
 def atsp_weights(fx_or_ss, layers=6, seed=None):
+    if isinstance(fx_or_ss, dict) and "weights_file" in fx_or_ss:      # a trained state_dict stored beside the fixtures
+        z = np.load(os.path.join(GOLD, str(fx_or_ss["weights_file"])))
+        return {k: torch.from_numpy(z[k]).float() for k in z.files}
     if isinstance(fx_or_ss, dict):
         ss, layers, seed = fx_or_ss["sample_size"], fx_or_ss["layers"], fx_or_ss["seed"]
     else:

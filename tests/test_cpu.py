@@ -14,7 +14,8 @@ from tests import helpers as H
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ATSP_FIXTURES = ["atsp_n20_b4_greedy", "atsp_n20_b4_pomo", "atsp_n20_b2_pomo_aug8", "atsp_n100_b2_pomo", "atsp_n20_b4_pomo_heuristic",
-                 "atsp_n20_b4_pomo_batchnorm", "atsp_n20_b4_pomo_rmsnorm", "atsp_n20_b4_pomo_layernorm"]
+                 "atsp_n20_b4_pomo_batchnorm", "atsp_n20_b4_pomo_rmsnorm", "atsp_n20_b4_pomo_layernorm",
+                 "atsp_n100_b2_pomo_trained", "atsp_n50_b3_pomo_trained", "atsp_n100_b2_pomo_aug8_trained"]
 
 
 # ---------------------------------------------------------------- oracle vs golden (reference outputs)

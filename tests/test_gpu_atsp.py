@@ -18,7 +18,10 @@ LL_ATOL = 1e-3
 COST_ATOL = 2e-5       # tour cost
 GAP_TOL = 1e-3         # decision gap below which a greedy flip is attributed to fp32 noise
 
-FIXTURES = ["atsp_n20_b4_greedy", "atsp_n20_b4_pomo", "atsp_n20_b2_pomo_aug8", "atsp_n100_b2_pomo"]
+# *_trained: the weights of a policy trained for 1 600 REINFORCE steps on the engine (tests/golden/atsp_trained_weights.npz; the chosen
+# action's probability is 0.83 on average against ~0.05 at initialisation), run through the real reference by oracle/gen_golden.py
+TRAINED = ["atsp_n100_b2_pomo_trained", "atsp_n50_b3_pomo_trained", "atsp_n100_b2_pomo_aug8_trained"]
+FIXTURES = ["atsp_n20_b4_greedy", "atsp_n20_b4_pomo", "atsp_n20_b2_pomo_aug8", "atsp_n100_b2_pomo"] + TRAINED
 
 
 def _setup(name):
@@ -94,7 +97,10 @@ def test_select_kernel_argmax_takes_first_index_on_exact_ties():
 def test_encoder_matches_reference_embeddings(name):
     fx, w, pol, st, env, td_in = _setup(name)
     row, col = pol.encoder(env.reset(td_in), packed=pol.packed(torch.device("cuda")))
-    assert torch.allclose(row.cpu(), fx["row_emb"], atol=ENC_ATOL) and torch.allclose(col.cpu(), fx["col_emb"], atol=ENC_ATOL)
+    # trained weights amplify the rounding differences of BOTH builds about twofold (measured on MI355X: default-init <= 7.6e-5 split
+    # / 7.5e-5 fp32 MFMA; trained <= 2.3e-4 split / 1.8e-4 fp32 MFMA, embeddings of magnitude <= 5.1): 2e-4 and 4e-4 absolute
+    tol = 2 * ENC_ATOL if name in TRAINED else ENC_ATOL
+    assert torch.allclose(row.cpu(), fx["row_emb"], atol=tol) and torch.allclose(col.cpu(), fx["col_emb"], atol=tol)
 
 
 def test_decoder_forward_logits_match_golden_trace_given_reference_embeddings():
@@ -145,7 +151,7 @@ def test_policy_greedy_tours_match_reference(name, fused):
     assert torch.allclose(out["log_likelihood"].cpu()[same], fx["log_likelihood"][same], rtol=LL_RTOL, atol=LL_ATOL)
 
 
-@pytest.mark.parametrize("name", ["atsp_n20_b4_pomo", "atsp_n20_b2_pomo_aug8", "atsp_n100_b2_pomo"])
+@pytest.mark.parametrize("name", ["atsp_n20_b4_pomo", "atsp_n20_b2_pomo_aug8", "atsp_n100_b2_pomo"] + TRAINED)
 def test_split_bf16_mlp_rollout_meets_the_fp32_contract(name, monkeypatch, capsys):
     """RR_MLP_SPLIT=1 runs the pointer MLP of the fused rollout on the bf16 matrix pipe with 3-way split fp32 operands
     (six partial products, fp32 accumulate; dropped terms <= 2^-23 of a product).  It has to meet the same contract as the
