@@ -193,7 +193,8 @@ __device__ __forceinline__ rr_f16x8 rr_split4s(const float (&x)[4]) {
 // garbage attention outputs and run-to-run differences.  The block ends with that s_nop 1; the lo / hi writes of one
 // destination sit four (two) instructions apart.
 __device__ __forceinline__ void rr_ulo8(const rr_f16x2 (&h)[4], const float (&x)[8], rr_f16x2 (&l)[4]) {
-  asm("v_fma_mixlo_f16 %0, %4, -1.0, %8 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+  asm("s_nop 0\n\t"                     // (the hi halves come from a v_cvt_pk right before: hipcc pads its own VALU pairs where gfx950 needs it, not ours)
+      "v_fma_mixlo_f16 %0, %4, -1.0, %8 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
       "v_fma_mixlo_f16 %1, %5, -1.0, %10 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
       "v_fma_mixlo_f16 %2, %6, -1.0, %12 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
       "v_fma_mixlo_f16 %3, %7, -1.0, %14 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
@@ -206,7 +207,8 @@ __device__ __forceinline__ void rr_ulo8(const rr_f16x2 (&h)[4], const float (&x)
       : "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
 }
 __device__ __forceinline__ void rr_ulo4(const rr_f16x2 (&h)[2], const float (&x)[4], rr_f16x2 (&l)[2]) {
-  asm("v_fma_mixlo_f16 %0, %2, -1.0, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+  asm("s_nop 0\n\t"
+      "v_fma_mixlo_f16 %0, %2, -1.0, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
       "v_fma_mixlo_f16 %1, %3, -1.0, %6 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
       "v_fma_mixhi_f16 %0, %2, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
       "v_fma_mixhi_f16 %1, %3, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
@@ -238,12 +240,16 @@ __device__ __forceinline__ rr_f16x8 rr_usplit4s(const float (&x)[4]) {
 // differences of the rollout's P.V, whose B operand is rebuilt for every key tile; hipcc inserts no wait states for this
 // write-after-read).  Operands that are rebuilt within a few instructions of their use are fenced: nothing is scheduled
 // across, and the MFMA has a full instruction time before the next write.
+#ifdef RR_KO_FENCE
+#define RR_MFMA_SRC_FENCE()
+#else
 #define RR_MFMA_SRC_FENCE()                      \
   do {                                           \
     __builtin_amdgcn_sched_barrier(0);           \
     asm volatile("s_nop 15");                    \
     __builtin_amdgcn_sched_barrier(0);           \
   } while (0)
+#endif
 // LDS-DMA: 16 bytes per lane from global memory straight into LDS at ldst + 16 * lane (ldst wave-uniform); completes on vmcnt
 __device__ __forceinline__ void rr_glds16(const void* gsrc, void* ldst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,

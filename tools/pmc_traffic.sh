@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d $R/gpurun_out/pmc_$C -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/pmc_$C.log 2>&1
+  rocprofv3 --pmc $C --output-format csv -d $R/gpurun_out/pmc_$C -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-configs > $R/gpurun_out/pmc_$C.log 2>&1
   python3 $R/tools/pmc_summary.py $R/gpurun_out/pmc_$C > $R/gpurun_out/pmc_$C.txt
   rm -rf $R/gpurun_out/pmc_$C
 done
