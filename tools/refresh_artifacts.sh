@@ -1,6 +1,7 @@
 #!/bin/bash
-# Round artefacts: bench line (with cpu_baseline), rocprofv3 kernel stats of the same command, HBM-side PMC traffic,
-# training-step bench + profile.  Run on the GPU box through gpurun; copy gpurun_out/<TAG>_* into profiles/rNN/.
+# Round artefacts in one GPU call: the bench line (headline + BASELINE configs[2..4] + cpu_baseline), rocprofv3 kernel stats of the
+# same command, HBM-side PMC traffic of the rollout, MFMA / VALU / LDS counters, training-step profile.  Run through gpurun; copy
+# gpurun_out/<TAG>_* into profiles/rNN/ (bench.py reads profiles/r03/bench_pmc_hbm_traffic.json).
 TAG=${1:-v1}
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -9,25 +10,23 @@ cd $R
 python3 bench.py > gpurun_out/bench_$TAG.jsonl 2> gpurun_out/bench_$TAG.err
 tail -1 gpurun_out/bench_$TAG.jsonl | cut -c1-300
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o p -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/bench_${TAG}_prof.jsonl 2> /tmp/prof_err.log
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o p -- python3 $R/bench.py --no-cpu-baseline --no-other-configs > $R/gpurun_out/bench_${TAG}_prof.jsonl 2> /tmp/prof_err.log
 S=$(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1)
 cp "$S" $R/gpurun_out/bench_${TAG}_kernel_stats.csv
-head -12 $R/gpurun_out/bench_${TAG}_kernel_stats.csv | cut -c1-160
+head -14 $R/gpurun_out/bench_${TAG}_kernel_stats.csv | cut -c1-160
 bash $R/tools/pmc_traffic.sh
 cp $R/gpurun_out/bench_pmc_hbm_traffic.json $R/gpurun_out/bench_${TAG}_pmc_hbm_traffic.json
 cat $R/gpurun_out/pmc_FETCH_SIZE.txt $R/gpurun_out/pmc_WRITE_SIZE.txt > $R/gpurun_out/bench_${TAG}_pmc_hbm_traffic.txt
+bash $R/tools/pmc_mfma.sh > /dev/null
+cp $R/gpurun_out/pmc_mfma.txt $R/gpurun_out/bench_${TAG}_pmc_counters.txt
 cd $R
-python3 tools/bench_train.py --steps 4 > gpurun_out/train_$TAG.jsonl 2> gpurun_out/train_$TAG.err
-tail -1 gpurun_out/train_$TAG.jsonl | cut -c1-300
 python3 tools/profile_train_step.py 2>&1 | grep -v Warning > gpurun_out/train_${TAG}_profile.txt
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/proft_$TAG -o p -- python3 $R/tools/bench_train.py --steps 2 > /dev/null 2> /tmp/proft_err.log
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/proft_$TAG -o p -- python3 $R/tools/bench_train.py --steps 2 > $R/gpurun_out/train_${TAG}.jsonl 2> /tmp/proft_err.log
 S=$(find /tmp/proft_$TAG -name "*kernel_stats.csv" | head -1)
 cp "$S" $R/gpurun_out/train_${TAG}_kernel_stats.csv
-# the other BASELINE configs (3, 4), RCVRP / RCVRPTW training, the reference-shaped step-wise loop
 cd $R
-python3 tools/bench_other.py 2>/dev/null | grep '^{' > gpurun_out/other_$TAG.jsonl
+python3 tools/bench_stepwise.py 2>/dev/null | tail -2 > gpurun_out/other_$TAG.jsonl
+python3 tools/stepkernels_time.py 2>/dev/null | tail -5 >> gpurun_out/other_$TAG.jsonl
 python3 tools/bench_train.py --problem rcvrp --steps 3 2>/dev/null | tail -1 >> gpurun_out/other_$TAG.jsonl
 python3 tools/bench_train.py --problem rcvrptw --steps 2 --batch 512 2>/dev/null | tail -1 >> gpurun_out/other_$TAG.jsonl
-python3 tools/bench_stepwise.py 2>/dev/null | tail -2 >> gpurun_out/other_$TAG.jsonl
-python3 tools/stepkernels_time.py 2>/dev/null | tail -5 >> gpurun_out/other_$TAG.jsonl
