@@ -434,6 +434,7 @@ static int rr_enc_layer_impl(const EncBlockW* wrow, const EncBlockW* wcol, const
   static const int variant = [] { const char* e = getenv("RR_ENC_VARIANT"); return e ? atoi(e) : 1; }();
   if ((variant == 1 || norm_affine_only) && dbg == nullptr && (theta != nullptr || bias_pre != nullptr)) {
     EncBlockW2 ws; ws.blk[0] = *wrow; ws.blk[1] = *wcol;   // wave = node tile, register-resident (rr_enc_w.inc); stage dumps use the LDS-staged kernel
+    static const bool ffn_kernel = [] { const char* e = getenv("RR_ENC_FFN_KERNEL"); return e == nullptr || atoi(e) != 0; }();
     const char* es = getenv("RR_MLP_SPLIT");
     // FFN on 3-way bf16-split operands whenever the packs carry them (packing.mlp_split_enabled: default on; RR_MLP_SPLIT=0 off)
     const bool split = (es == nullptr || atoi(es) != 0) && wrow->w1s && wrow->w2s && wcol->w1s && wcol->w2s &&
@@ -441,6 +442,11 @@ static int rr_enc_layer_impl(const EncBlockW* wrow, const EncBlockW* wcol, const
 #define RR_ENCW(NTV, SP) hipLaunchKernelGGL((k_enc_block_w<NTV, SP>), grid, dim3(64 * NTV), 0, st, ws, row_in, col_in, row_out, col_out, D, theta, bias_pre, N, norm_affine_only, svs)
     if (N <= 32) { if (split) RR_ENCW(2, true); else RR_ENCW(2, false); }
     else if (N <= 64) { if (split) RR_ENCW(4, true); else RR_ENCW(4, false); }
+    else if (split && svs.s[0].r == nullptr && ffn_kernel) {
+      // headline shape, inference: the block up to ffn.norm1, then the FFN + ffn.norm2 as a kernel with a loader wave (rr_enc_w.inc: k_enc_ffn)
+      hipLaunchKernelGGL((k_enc_block_w<7, true, false>), grid, dim3(64 * 7), 0, st, ws, row_in, col_in, row_out, col_out, D, theta, bias_pre, N, norm_affine_only, svs);
+      hipLaunchKernelGGL((k_enc_ffn<7>), grid, dim3(64 * 8), 0, st, ws, row_out, col_out, N, norm_affine_only);
+    }
     else { if (split) RR_ENCW(7, true); else RR_ENCW(7, false); }
 #undef RR_ENCW
     return rr_check(hipGetLastError());

@@ -522,7 +522,7 @@ def _pack_policy(sd: dict, env_name: str, device) -> dict:
     bpc = (torch.bmm(Wc64, stk("attn_free.project.bias").double()[:, :, None])[:, :, 0] + stk("multi_head_combine.bias").double()).float().contiguous()
     ar.keep += [sq, p1, p2, ppc, bpc]
     if split:      # FFN weights again as 3-way bf16 splits for the bf16-pipe FFN
-        p1s, p2s = pack_a_f16x2(W1s), pack_a_f16x2(W2s)
+        p1s, p2s = pack_a_f16u(W1s), pack_a_f16u(W2s)          # second-form images (x 2^6, csrc/rr_common.h): encoder FFN
         sqs = pack_a_f16x2(torch.stack([stk("attn_free.to_q.weight"), stk("attn_free.to_k.weight"), stk("attn_free.to_v.weight"),
                                         torch.bmm(Wc64, Wp64).float()]))                       # [4][nb][8][4][2][64][8]
         ar.keep += [p1s, p2s, sqs]
