@@ -25,7 +25,10 @@ def mlp_train_pack(policy):
              "decoder.pointer.ffn.lins.1.weight", "decoder.pointer.ffn.lins.1.bias"]
     P = dict(policy.named_parameters())
     ts = [P[n] for n in names]
-    key = tuple((t._version, t.data_ptr()) for t in ts) + tuple(torch.stack(torch._foreach_norm([t.detach() for t in ts])).tolist())
+    # keyed like enc_backward.train_packs: the policy's own pack key (versions, pointers and — while training — the norm
+    # fingerprint policy.packed() has already read this step) instead of a second blocking norm read in front of the backward
+    pk = getattr(policy, "_pack_cache", None)
+    key = tuple((t._version, t.data_ptr()) for t in ts) + ((pk[0],) if pk is not None else ())
     cached = getattr(policy, "_mlp_train_pack", None)
     if cached is None or cached[0] != key:
         with torch.no_grad():

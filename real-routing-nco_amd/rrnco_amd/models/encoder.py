@@ -144,6 +144,9 @@ class ATSPInitEmbedding(nn.Module):   # env_embeddings/atsp.py:5-35
             # counter-based noise; the seed advances torch's CPU generator like any draw would (csrc/rr_sample.hip)
             out = torch.empty(B, N, sample_size, dtype=torch.int64, device=distance.device)
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            # data-parallel ranks share torch.manual_seed (same initial weights): every rank its own noise field
+            import os
+            seed = (seed + 0x9E3779B97F4A7C15 * int(os.environ.get("RANK", "0"))) % (2 ** 62)
             L.check(L.lib().rr_sample_neighbors(L.ptr(distance.float().contiguous()), L.ptr(out), B, N, int(sample_size), seed,
                                                 L.stream()), "rr_sample_neighbors")
             return out

@@ -40,6 +40,7 @@ class RRNetPolicy(nn.Module):
     # ---- packed (MFMA-ordered / folded) weights, rebuilt when any parameter changes (versions + packing.weights_fingerprint)
     def invalidate_pack(self) -> None:
         self._pack_cache = None
+        self._mlp_train_pack = None          # (models/dec_backward.py: the pointer MLP's training packs follow the same rule)
 
     def train(self, mode: bool = True):
         self._pack_dirty = True          # any train() / eval() switch: re-check the weights' fingerprint once (see packed())

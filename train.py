@@ -72,6 +72,8 @@ def main(argv=None):
         if isinstance(blob, dict) and "optimizer_states" in blob and "rrnco_amd" in blob:
             opt.load_state_dict(blob["optimizer_states"][0]); sched.load_state_dict(blob["lr_schedulers"][0])
             start_epoch = int(blob["epoch"]) + 1
+            if "cpu_rng_state" in blob:              # the encoder's neighbour-sample seeds come from torch's CPU generator
+                torch.set_rng_state(blob["cpu_rng_state"])
     # a resumed run continues the instance stream instead of replaying epoch 0's data: the stream is keyed by the epoch it starts at
     gen = torch.Generator(device=dev).manual_seed(o.seed + 1000 * rank + 1_000_003 * start_epoch)
     val_gen = torch.Generator(device=dev).manual_seed(o.seed + 7)     # same validation set every epoch, on every rank
@@ -100,7 +102,8 @@ def main(argv=None):
             os.makedirs(os.path.join(o.checkpoint_dir, o.problem), exist_ok=True)
             ck = {"rrnco_amd": 1, "epoch": epoch, "state_dict": {"policy." + k: v.detach().cpu() for k, v in policy.state_dict().items()},
                   "optimizer_states": [opt.state_dict()], "lr_schedulers": [sched.state_dict()],
-                  "hyper_parameters": {k: v for k, v in vars(o).items()}, "val_reward": val_reward}
+                  "hyper_parameters": {k: v for k, v in vars(o).items()}, "val_reward": val_reward,
+                  "cpu_rng_state": torch.get_rng_state()}
             torch.save(ck, os.path.join(o.checkpoint_dir, o.problem, f"epoch_{epoch:03d}.ckpt"))
             torch.save(ck, os.path.join(o.checkpoint_dir, o.problem, "last.ckpt"))
     if world > 1:
