@@ -404,13 +404,24 @@ __device__ __forceinline__ float rr_sigmoid(float x) { return __builtin_amdgcn_r
 __device__ __forceinline__ uint32_t rr_hash32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x;
 }
-__device__ __forceinline__ float rr_uniform(uint64_t seed, uint32_t r, uint32_t step, uint32_t key) {
-  uint32_t h = rr_hash32((uint32_t)seed ^ rr_hash32(r + 0x9e3779b9U * (uint32_t)(seed >> 32)));
-  h = rr_hash32(h ^ rr_hash32(step * 131u + key + 0x85ebca6bU));
+// (seed, rollout) part of the noise key: constant over a rollout's keys and decode steps — kernels hoist it out of their loops
+__device__ __forceinline__ uint32_t rr_noise_key(uint64_t seed, uint32_t r) {
+  return rr_hash32((uint32_t)seed ^ rr_hash32(r + 0x9e3779b9U * (uint32_t)(seed >> 32)));
+}
+__device__ __forceinline__ float rr_uniform_k(uint32_t h1, uint32_t step, uint32_t key) {
+  const uint32_t h = rr_hash32(h1 ^ ((step * 131u + key + 0x85ebca6bU) * 0x9E3779B1u));   // one multiply mixes (step, key) in, one full hash finishes
   return ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0,1)
 }
+__device__ __forceinline__ float rr_gumbel_k(uint32_t h1, uint32_t step, uint32_t key) {
+  // -ln(-ln u) on the hardware base-2 logarithms (1 ulp each; noise needs no correction term): 2 transcendentals + 2 multiplies
+  const float LN2 = 0.693147180559945309f;
+  return -LN2 * __builtin_amdgcn_logf(-LN2 * __builtin_amdgcn_logf(rr_uniform_k(h1, step, key)));
+}
+__device__ __forceinline__ float rr_uniform(uint64_t seed, uint32_t r, uint32_t step, uint32_t key) {
+  return rr_uniform_k(rr_noise_key(seed, r), step, key);
+}
 __device__ __forceinline__ float rr_gumbel(uint64_t seed, uint32_t r, uint32_t step, uint32_t key) {
-  return -rr_log(-rr_log(rr_uniform(seed, r, step, key)));
+  return rr_gumbel_k(rr_noise_key(seed, r), step, key);
 }
 
 static inline int rr_check(hipError_t e) { return e == hipSuccess ? RR_OK : RR_ELAUNCH; }
