@@ -236,20 +236,10 @@ __device__ __forceinline__ rr_f16x8 rr_usplit4s(const float (&x)[4]) {
   return r;
 }
 // MI355X, ROCm 7.2: a VALU write to a source register of a v_mfma_f32_16x16x32_f16 issued just before it can reach the
-// register file before the MFMA has read it when the other wave of the SIMD keeps the matrix pipe busy (seen as run-to-run
-// differences of the rollout's P.V, whose B operand is rebuilt for every key tile; hipcc inserts no wait states for this
-// write-after-read).  Operands that are rebuilt within a few instructions of their use are fenced: nothing is scheduled
-// across, and the MFMA has a full instruction time before the next write.
-#ifdef RR_KO_FENCE
-#define RR_MFMA_SRC_FENCE()
-#else
-#define RR_MFMA_SRC_FENCE()                      \
-  do {                                           \
-    __builtin_amdgcn_sched_barrier(0);           \
-    asm volatile("s_nop 15");                    \
-    __builtin_amdgcn_sched_barrier(0);           \
-  } while (0)
-#endif
+// register file before the MFMA has read it when the other wave of the SIMD keeps the matrix pipe busy (seen in round 2 as
+// run-to-run differences of the rollout's P.V, whose B operand is rebuilt for every key tile; hipcc inserts no wait states for
+// this write-after-read).  The rollout keeps a rebuilt operand's registers allocated until the NEXT pair has issued
+// (rr_rollout_w.inc, P.V: software-pipelined tuples) instead of idling an instruction time behind every pair.
 // LDS-DMA: 16 bytes per lane from global memory straight into LDS at ldst + 16 * lane (ldst wave-uniform); completes on vmcnt
 __device__ __forceinline__ void rr_glds16(const void* gsrc, void* ldst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
