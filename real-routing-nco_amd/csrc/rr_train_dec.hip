@@ -24,6 +24,7 @@
 
 #define TD_NT 7
 #define TD_LDK 112          // padded key count: dlg rows, K^T / L^T rows
+#define TD_AS 20           // row stride (floats) of k_dec_attn_bwd's d query accumulators in LDS
 
 // rows of one launch: nseg segments (instances) of seg_rows live rows each, seg_stride rows apart
 struct RowSegs { int nseg; int seg_rows; long long seg_stride; };
@@ -750,9 +751,83 @@ __device__ __forceinline__ f32x4 td_xpose(f32x4 v, const float (&sel)[4]) {
   return d;
 }
 
-__global__ __launch_bounds__(256, 1) void k_dec_attn_bwd(DecAttnIO io) {
-  __shared__ float accA[TD_LDK * 16], accB[TD_LDK * 16];
-  __shared__ __attribute__((aligned(16))) float red[4][2 * TD_NT][64 * 4];
+// The same on the bf16 matrix pipe (BF = true, the default): every fp32 operand as two bf16 pieces (td_split4: x = hi + lo to 2^-17,
+// a product keeps hi*hi + hi*lo + lo*hi like the pointer-MLP kernels above), one v_mfma_f32_16x16x16_bf16 per partial product:
+// 24 matrix-pipe cycles per 16x16x16 product against 128 on the fp32 MFMA.  A piece is transposed exactly by ONE product with the
+// identity (a bf16 value times 1.0 accumulates exactly in fp32 and converts back exactly).
+typedef __bf16 rr_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 td_mfma16(rr_bf16x4 a, rr_bf16x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+// (one asm block: hipcc scalarises the two-wide conversion — a convert per value plus packing, 22 instructions for four values
+// against these 12.  Leading s_nop: an operand may come straight from a transcendental; trailing s_nop 1: the pieces feed a
+// matrix instruction, and hipcc does not see the vector writes inside the block — profiles/r03/NOTES.md §2.)
+__device__ __forceinline__ void td_split4(const float (&x)[4], rr_bf16x4& hi, rr_bf16x4& lo) {
+#ifdef TD_SPLIT_C
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const rr_f32x2 v = {x[2 * q], x[2 * q + 1]};
+    const rr_bf16x2 h = __builtin_convertvector(v, rr_bf16x2);
+    const rr_f32x2 r1 = v - __builtin_convertvector(h, rr_f32x2);
+    const rr_bf16x2 l = __builtin_convertvector(r1, rr_bf16x2);
+    hi[2 * q] = h[0]; hi[2 * q + 1] = h[1]; lo[2 * q] = l[0]; lo[2 * q + 1] = l[1];
+  }
+  return;
+#endif
+  uint32_t h01, h23, l01, l23;
+  float t0, t1, t2, t3;
+#ifndef TD_NOP
+#define TD_NOP "0"
+#endif
+  asm("s_nop " TD_NOP "\n\t"
+      "v_cvt_pk_bf16_f32 %0, %8, %9\n\t"
+      "v_cvt_pk_bf16_f32 %1, %10, %11\n\t"
+      "v_lshlrev_b32 %4, 16, %0\n\t"
+      "v_and_b32 %5, 0xffff0000, %0\n\t"
+      "v_lshlrev_b32 %6, 16, %1\n\t"
+      "v_and_b32 %7, 0xffff0000, %1\n\t"
+      "v_sub_f32 %4, %8, %4\n\t"
+      "v_sub_f32 %5, %9, %5\n\t"
+      "v_sub_f32 %6, %10, %6\n\t"
+      "v_sub_f32 %7, %11, %7\n\t"
+      "v_cvt_pk_bf16_f32 %2, %4, %5\n\t"
+      "v_cvt_pk_bf16_f32 %3, %6, %7\n\t"
+      "s_nop 1"
+      : "=&v"(h01), "=&v"(h23), "=&v"(l01), "=&v"(l23), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));
+  const uint2 hv = make_uint2(h01, h23), lv = make_uint2(l01, l23);
+  hi = __builtin_bit_cast(rr_bf16x4, hv); lo = __builtin_bit_cast(rr_bf16x4, lv);
+}
+__device__ __forceinline__ f32x4 td_mfma16x3(rr_bf16x4 ah, rr_bf16x4 al, rr_bf16x4 bh, rr_bf16x4 bl, f32x4 c) {
+  c = td_mfma16(ah, bl, c);
+  c = td_mfma16(al, bh, c);
+  return td_mfma16(ah, bh, c);
+}
+// piece at lane (a = j, g), element m = X[a][4g + m]  ->  lane (c = j, g), element r = X[4g + r][c]
+__device__ __forceinline__ rr_bf16x4 td_xpose16(rr_bf16x4 p, rr_bf16x4 ident) {
+  const f32x4 d = td_mfma16(p, ident, rr_zero4());            // every element IS a bf16 value: packing = taking the high halves
+  const float d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3];     // (__builtin_bit_cast on a vector ELEMENT reads element 0 every time: hipcc 7.2)
+  const uint2 o = make_uint2(__builtin_amdgcn_perm(__float_as_uint(d1), __float_as_uint(d0), 0x07060302u),
+                             __builtin_amdgcn_perm(__float_as_uint(d3), __float_as_uint(d2), 0x07060302u));
+  return __builtin_bit_cast(rr_bf16x4, o);
+}
+
+template <bool BF>
+__global__ __launch_bounds__(256, BF ? 2 : 1) void k_dec_attn_bwd(DecAttnIO io) {
+  // d query accumulators [node][16 dims of this head] (row stride TD_AS floats: 16-byte rows, banks spread): accA for ctxA[first]
+  // shared by the waves (float atomics), accB for ctxB[current] ONE PER WAVE.  LDS float atomics retire ~0.7 lanes per cycle and CU
+  // (they were 3.2 of this kernel's 7.6 ms), so the rows are tiled to need almost none: a tile = 16 consecutive decode steps of ONE
+  // rollout, whose current nodes are all different (a node is visited once; the VRPs' depot is the exception and keeps its
+  // atomic) — every lane adds its four values to its own 16 bytes of the wave's table with a plain read-modify-write, and the
+  // rollout's first node is common to the tile: one 16-lane sum, four lanes' atomics.  The T % 16 left-over steps of the rollouts
+  // are packed 16 / (T % 16) rollouts to a tile and take the atomic path.
+  __shared__ __attribute__((aligned(16))) float accA[TD_LDK * TD_AS], accB[4][TD_LDK * TD_AS];
+  // fp32: the four waves' dK / dV partials.  BF: during the loop the head's K / V / K^T tiles as [hi | lo] bf16 operands (21 KB, one
+  // 16-byte entry per (operand, key tile, lane): two workgroups per CU need them out of the registers), afterwards two partial
+  // images (the fold runs in two rounds).
+  constexpr int RED_W = BF ? 2 : 4;
+  __shared__ __attribute__((aligned(16))) float red[RED_W][2 * TD_NT][64 * 4];
+  char* opnd = reinterpret_cast<char*>(&red[0][0][0]);      // BF: entry (o, kt, lane) at ((o * TD_NT + kt) * 64 + lane) * 16
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, g = lane >> 4;
@@ -760,20 +835,50 @@ __global__ __launch_bounds__(256, 1) void k_dec_attn_bwd(DecAttnIO io) {
   const int h = kq & 7, b = (kq >> 3) * 8 + xcd;          // the eight heads of an instance share an XCD (its L2 holds the rows)
   if (b >= io.Bp) return;
   const int N = io.N, S = io.S, rows_b = io.T * S;
-  for (int i = tid; i < TD_LDK * 16; i += 256) { accA[i] = 0.f; accB[i] = 0.f; }
+  for (int i = tid; i < TD_LDK * TD_AS; i += 256) { accA[i] = 0.f; accB[0][i] = 0.f; accB[1][i] = 0.f; accB[2][i] = 0.f; accB[3][i] = 0.f; }
   __syncthreads();
   float sel[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) sel[r] = (j == 4 * g + r) ? 1.0f : 0.f;
   // per-head operands, resident for the whole instance
-  float4 kf[TD_NT], vf[TD_NT], ktf[TD_NT];
+  float4 kf[TD_NT], vf[TD_NT], ktf[TD_NT];                 // fp32: resident in registers
+  rr_bf16x4 ident;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ident[r] = (__bf16)sel[r];
+  uint32_t nmw = 0;                         // nibble kt: which of this lane's four keys of key tile kt exist (key < N)
 #pragma unroll
   for (int kt = 0; kt < TD_NT; ++kt) {
-    int key = kt * 16 + j; key = key < N ? key : N - 1;
-    kf[kt] = rr_ld4(io.K + ((size_t)b * N + key) * RR_E + 16 * h + 4 * g);       // A[i = key][k = dim 4g+m]
-    vf[kt] = rr_ld4(io.V + ((size_t)b * N + key) * RR_E + 16 * h + 4 * g);
-    ktf[kt] = rr_ld4(io.Kt + ((size_t)b * RR_E + 16 * h + j) * TD_LDK + 16 * kt + 4 * g);   // A[i = dim j][k = key 16kt+4g+m]
+    const int left = N - (16 * kt + 4 * g);
+    nmw |= (left >= 4 ? 15u : left <= 0 ? 0u : ((1u << left) - 1u)) << (4 * kt);
   }
+  auto ld_opnd = [&](int kt, float4& kq4, float4& vq4, float4& tq4) {
+    int key = kt * 16 + j; key = key < N ? key : N - 1;
+    kq4 = rr_ld4(io.K + ((size_t)b * N + key) * RR_E + 16 * h + 4 * g);       // A[i = key][k = dim 4g+m]
+    vq4 = rr_ld4(io.V + ((size_t)b * N + key) * RR_E + 16 * h + 4 * g);
+    tq4 = rr_ld4(io.Kt + ((size_t)b * RR_E + 16 * h + j) * TD_LDK + 16 * kt + 4 * g);   // A[i = dim j][k = key 16kt+4g+m]
+  };
+  if constexpr (BF) {
+    for (int kt = wave; kt < TD_NT; kt += 4) {
+      float4 q3[3];
+      ld_opnd(kt, q3[0], q3[1], q3[2]);
+#pragma unroll
+      for (int o = 0; o < 3; ++o) {
+        const float x4[4] = {q3[o].x, q3[o].y, q3[o].z, q3[o].w};
+        rr_bf16x4 hi, lo;
+        td_split4(x4, hi, lo);
+        const rr_bf16x8 e = {hi[0], hi[1], hi[2], hi[3], lo[0], lo[1], lo[2], lo[3]};
+        *reinterpret_cast<rr_bf16x8*>(opnd + ((o * TD_NT + kt) * 64 + lane) * 16) = e;
+      }
+    }
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int kt = 0; kt < TD_NT; ++kt) ld_opnd(kt, kf[kt], vf[kt], ktf[kt]);
+  }
+  auto opnd_hi = [&](int o, int kt, rr_bf16x4& hi, rr_bf16x4& lo) {
+    const rr_bf16x8 e = *reinterpret_cast<const rr_bf16x8*>(opnd + ((o * TD_NT + kt) * 64 + lane) * 16);
+    hi = rr_bf16x4{e[0], e[1], e[2], e[3]}; lo = rr_bf16x4{e[4], e[5], e[6], e[7]};
+  };
   f32x4 aK[TD_NT], aV[TD_NT];
 #pragma unroll
   for (int kt = 0; kt < TD_NT; ++kt) { aK[kt] = rr_zero4(); aV[kt] = rr_zero4(); }
@@ -782,19 +887,31 @@ __global__ __launch_bounds__(256, 1) void k_dec_attn_bwd(DecAttnIO io) {
   for (int k = 0; k < 4; ++k)
 #pragma unroll
     for (int r = 0; r < 4; ++r) dws[k][r] = 0.f;
-  const int ntile = (rows_b + 15) / 16;
+  const int nfull = io.T >> 4, rem = io.T & 15;          // per rollout: full 16-step tiles, left-over steps
+  const int nft = S * nfull;                               // tile < nft: rollout tile % S, steps 16 (tile / S) + j
+  const int lper = rem ? 16 / rem : 1;                     // rollouts per left-over tile
+  const int ntile = nft + (rem ? (S + lper - 1) / lper : 0);
+  const int lr = rem ? j / rem : 0, lst = rem ? j - lr * rem : 0;       // this lane's (rollout, step) slot in a left-over tile
   // Inputs of a tile are two dependent global round trips (meta -> gathers of the context rows): they are requested two /
   // one tiles ahead, so that a tile's arithmetic runs under the next tiles' loads.
-  struct TMeta { uint4 m0, m1; size_t m; int s; bool vrow; };
+  struct TMeta { uint4 m0, m1; size_t m; int fst; bool vrow; };      // (the rollout's first node rides with the meta words: its context row is a dependent gather)
   struct TVals { float4 qb, qa, dh, sv; int fst; };
   auto ld_meta = [&](int tile) {
     TMeta r;
-    int q = tile * 16 + j;
-    r.vrow = q < rows_b;
-    q = q < rows_b ? q : rows_b - 1;
+    int q, sr;
+    if (tile < nft) {                                      // (wave-uniform)
+      const int tb = tile / S;
+      sr = tile - tb * S;
+      q = (16 * tb + j) * S + sr;
+      r.vrow = true;
+    } else {
+      sr = (tile - nft) * lper + lr;
+      r.vrow = lr < lper && sr < S;
+      sr = sr < S ? sr : S - 1;
+      q = (16 * nfull + lst) * S + sr;
+    }
     r.m = (size_t)b * (size_t)io.seg_stride + (size_t)q;
-    const int t = q / S;
-    r.s = q - t * S;
+    r.fst = io.first ? (int)io.first[(size_t)sr * io.Bp + b] : 0;
     r.m0 = *reinterpret_cast<const uint4*>(io.meta + r.m * 8);
     r.m1 = *reinterpret_cast<const uint4*>(io.meta + r.m * 8 + 4);
     return r;
@@ -806,12 +923,42 @@ __global__ __launch_bounds__(256, 1) void k_dec_attn_bwd(DecAttnIO io) {
     v.fst = 0;
     v.qa = make_float4(0.f, 0.f, 0.f, 0.f);
     if (io.first) {
-      v.fst = min((int)io.first[(size_t)tm.s * io.Bp + b], N - 1);
+      v.fst = min(tm.fst, N - 1);
       v.qa = rr_ld4(io.ctxA + ((size_t)b * N + v.fst) * RR_E + 16 * h + 4 * g);
     }
     v.sv = io.nscal > 0 ? rr_ld4(io.scal + tm.m * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     v.dh = rr_ld4(io.dg0 + tm.m * RR_E + 16 * h + 4 * g);
     return v;
+  };
+  float4 wst[4];                            // state columns of project_context for this head (VRPs)
+#pragma unroll
+  for (int k = 0; k < 4; ++k) wst[k] = k < io.nscal ? rr_ld4(io.wstate + k * RR_E + 16 * h + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float* myB = &accB[wave][0];
+  auto scatter_dq = [&](const float (&dq)[4], bool live, int prev, int fst, bool fulltile) {
+    if (fulltile) {
+      if (live && prev != 0) {                             // distinct nodes within the tile: plain read-modify-write
+        float4 v = rr_ld4(myB + prev * TD_AS + 4 * g);
+        v.x += dq[0]; v.y += dq[1]; v.z += dq[2]; v.w += dq[3];
+        rr_st4(myB + prev * TD_AS + 4 * g, v);
+      } else if (live) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(myB + prev * TD_AS + 4 * g + r, dq[r]);
+      }
+      if (io.first) {                                      // one rollout: one first node
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = live ? dq[r] : 0.f;
+          v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+          if (j == 0) atomicAdd(&accA[fst * TD_AS + 4 * g + r], v);
+        }
+      }
+    } else if (live) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        atomicAdd(myB + prev * TD_AS + 4 * g + r, dq[r]);
+        if (io.first) atomicAdd(&accA[fst * TD_AS + 4 * g + r], dq[r]);
+      }
+    }
   };
   TMeta mA = ld_meta(wave < ntile ? wave : 0), mB = ld_meta(wave + 4 < ntile ? wave + 4 : 0);
   TVals vA = ld_vals(mA);
@@ -840,106 +987,202 @@ __global__ __launch_bounds__(256, 1) void k_dec_attn_bwd(DecAttnIO io) {
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (k < io.nscal) {
-          const float4 wv = rr_ld4(io.wstate + k * RR_E + 16 * h + 4 * g);
+          const float4 wv = wst[k];
           qv.x = fmaf(wv.x, sc4[k], qv.x); qv.y = fmaf(wv.y, sc4[k], qv.y); qv.z = fmaf(wv.z, sc4[k], qv.z); qv.w = fmaf(wv.w, sc4[k], qv.w);
         }
     }
     float4 dh = tv.dh;
     if (!live) dh = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float qs[4] = {qv.x * 0.25f, qv.y * 0.25f, qv.z * 0.25f, qv.w * 0.25f};          // 1/sqrt(head_dim)
-    const float dhv[4] = {dh.x, dh.y, dh.z, dh.w};
-    // ---- scores, masked softmax (decoder.py:308-323), d weights = V dhv
-    f32x4 a[TD_NT], ds[TD_NT];
-    float mx = -INFINITY;
+    if constexpr (BF) {
+      const float LOG2E = 1.44269504088896341f;
+      // scores in base 2: the query carries log2(e) / sqrt(head_dim); dK is scaled back by ln 2 when it is stored
+      const float qs[4] = {qv.x * (0.25f * LOG2E), qv.y * (0.25f * LOG2E), qv.z * (0.25f * LOG2E), qv.w * (0.25f * LOG2E)};
+      const float dhv[4] = {dh.x, dh.y, dh.z, dh.w};
+      rr_bf16x4 qh, ql, hh, hl;
+      td_split4(qs, qh, ql); td_split4(dhv, hh, hl);
+      const uint32_t mwg[4] = {mw[0] >> (4 * g), mw[1] >> (4 * g), mw[2] >> (4 * g), mw[3] >> (4 * g)};
+      // ---- scores, masked softmax (decoder.py:308-323), d weights = V dhv
+      f32x4 a[TD_NT], ds[TD_NT];
+      float mx = -INFINITY;
 #pragma unroll
-    for (int kt = 0; kt < TD_NT; ++kt) {
-      f32x4 c = rr_zero4(), d = rr_zero4();
-      c = rr_mfma(kf[kt].x, qs[0], c); c = rr_mfma(kf[kt].y, qs[1], c); c = rr_mfma(kf[kt].z, qs[2], c); c = rr_mfma(kf[kt].w, qs[3], c);
-      d = rr_mfma(vf[kt].x, dhv[0], d); d = rr_mfma(vf[kt].y, dhv[1], d); d = rr_mfma(vf[kt].z, dhv[2], d); d = rr_mfma(vf[kt].w, dhv[3], d);
+      for (int kt = 0; kt < TD_NT; ++kt) {
+        rr_bf16x4 Kh, Kl, Vh, Vl;
+        opnd_hi(0, kt, Kh, Kl); opnd_hi(1, kt, Vh, Vl);
+        f32x4 c = td_mfma16x3(Kh, Kl, qh, ql, rr_zero4());
+        ds[kt] = td_mfma16x3(Vh, Vl, hh, hl, rr_zero4());
+        const uint32_t bits = (mwg[kt >> 1] >> (16 * (kt & 1))) & (nmw >> (4 * kt));       // this lane's four keys of the tile
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + 4 * g + r;
-        const bool ok = key < N && ((mw[kt >> 1] >> (16 * (kt & 1) + 4 * g + r)) & 1u);
-        c[r] = ok ? c[r] : -INFINITY;
-        mx = fmaxf(mx, c[r]);
+        for (int r = 0; r < 4; ++r) {
+          c[r] = (bits & (1u << r)) ? c[r] : -INFINITY;
+          mx = fmaxf(mx, c[r]);
+        }
+        a[kt] = c;
       }
-      a[kt] = c; ds[kt] = d;
-    }
-    mx = rr_max_g(mx);
-    if (mx == -INFINITY) mx = 0.f;
-    float sum = 0.f;
+      mx = rr_max_g(mx);
+      if (mx == -INFINITY) mx = 0.f;
+      float sum = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < TD_NT; ++kt)
+      for (int kt = 0; kt < TD_NT; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { a[kt][r] = rr_exp(a[kt][r] - mx); sum += a[kt][r]; }
-    sum = rr_sum_g(sum);
-    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
-    float dot = 0.f;
+        for (int r = 0; r < 4; ++r) { a[kt][r] = __builtin_amdgcn_exp2f(a[kt][r] - mx); sum += a[kt][r]; }
+      sum = rr_sum_g(sum);
+      const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+      float dot = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < TD_NT; ++kt)
+      for (int kt = 0; kt < TD_NT; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { a[kt][r] *= inv; dot = fmaf(a[kt][r], ds[kt][r], dot); }
-    dot = rr_sum_g(dot);
+        for (int r = 0; r < 4; ++r) { a[kt][r] *= inv; dot = fmaf(a[kt][r], ds[kt][r], dot); }
+      dot = rr_sum_g(dot);
+      // ---- d scores (softmax backward) as pieces; d query = dhv (residual, decoder.py:294) + K^T ds / sqrt(d)
+      rr_bf16x4 sh[TD_NT], sl[TD_NT];
+      f32x4 dq0 = rr_zero4();
 #pragma unroll
-    for (int kt = 0; kt < TD_NT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ds[kt][r] = a[kt][r] * (ds[kt][r] - dot);          // d scores (softmax backward)
-    // ---- d query = dhv (residual, decoder.py:294) + K^T ds / sqrt(d)
-    f32x4 dq0 = rr_zero4(), dq1 = rr_zero4();
-#pragma unroll
-    for (int kt = 0; kt < TD_NT; ++kt) {
-      dq0 = rr_mfma(ktf[kt].x, ds[kt][0], dq0); dq1 = rr_mfma(ktf[kt].y, ds[kt][1], dq1);
-      dq0 = rr_mfma(ktf[kt].z, ds[kt][2], dq0); dq1 = rr_mfma(ktf[kt].w, ds[kt][3], dq1);
-    }
-    float dq[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) dq[r] = fmaf(dq0[r] + dq1[r], 0.25f, dhv[r]);
-    if (live) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        atomicAdd(&accB[prev * 16 + 4 * g + r], dq[r]);
-        if (io.first) atomicAdd(&accA[fst * 16 + 4 * g + r], dq[r]);
+      for (int kt = 0; kt < TD_NT; ++kt) {
+        const float d4[4] = {a[kt][0] * (ds[kt][0] - dot), a[kt][1] * (ds[kt][1] - dot), a[kt][2] * (ds[kt][2] - dot),
+                             a[kt][3] * (ds[kt][3] - dot)};
+        td_split4(d4, sh[kt], sl[kt]);
+        rr_bf16x4 Th, Tl;
+        opnd_hi(2, kt, Th, Tl);
+        dq0 = td_mfma16x3(Th, Tl, sh[kt], sl[kt], dq0);
       }
+      float dq[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
+      for (int r = 0; r < 4; ++r) dq[r] = fmaf(dq0[r], 0.25f, dhv[r]);
+      scatter_dq(dq, live, prev, fst, tile < nft);
+      if (live) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dws[k][r] = fmaf(dq[r], sc4[k], dws[k][r]);
-    }
-    // ---- dK_h[key][dim] += ds[row][key] q[row][dim] / sqrt(d),  dV_h[key][dim] += a[row][key] dhv[row][dim]  (k = row)
-    const f32x4 qT = td_xpose(f32x4{qs[0], qs[1], qs[2], qs[3]}, sel);
-    const f32x4 hT = td_xpose(f32x4{dhv[0], dhv[1], dhv[2], dhv[3]}, sel);
+        for (int k = 0; k < 4; ++k)
 #pragma unroll
-    for (int kt = 0; kt < TD_NT; ++kt) {
-      const f32x4 dT = td_xpose(ds[kt], sel);
-      const f32x4 pT = td_xpose(a[kt], sel);
-      aK[kt] = rr_mfma(qT[0], dT[0], aK[kt]); aV[kt] = rr_mfma(hT[0], pT[0], aV[kt]);
-      aK[kt] = rr_mfma(qT[1], dT[1], aK[kt]); aV[kt] = rr_mfma(hT[1], pT[1], aV[kt]);
-      aK[kt] = rr_mfma(qT[2], dT[2], aK[kt]); aV[kt] = rr_mfma(hT[2], pT[2], aV[kt]);
-      aK[kt] = rr_mfma(qT[3], dT[3], aK[kt]); aV[kt] = rr_mfma(hT[3], pT[3], aV[kt]);
+          for (int r = 0; r < 4; ++r) dws[k][r] = fmaf(dq[r], sc4[k], dws[k][r]);
+      }
+      // ---- dK_h[key][dim] += ds[row][key] q[row][dim] / sqrt(d),  dV_h[key][dim] += a[row][key] dhv[row][dim]  (k = row)
+      const rr_bf16x4 qTh = td_xpose16(qh, ident), qTl = td_xpose16(ql, ident);
+      const rr_bf16x4 hTh = td_xpose16(hh, ident), hTl = td_xpose16(hl, ident);
+#pragma unroll
+      for (int kt = 0; kt < TD_NT; ++kt) {
+        const float p4[4] = {a[kt][0], a[kt][1], a[kt][2], a[kt][3]};
+        rr_bf16x4 ph, pl;
+        td_split4(p4, ph, pl);
+        const rr_bf16x4 dTh = td_xpose16(sh[kt], ident), dTl = td_xpose16(sl[kt], ident);
+        const rr_bf16x4 pTh = td_xpose16(ph, ident), pTl = td_xpose16(pl, ident);
+        aK[kt] = td_mfma16x3(qTh, qTl, dTh, dTl, aK[kt]);
+        aV[kt] = td_mfma16x3(hTh, hTl, pTh, pTl, aV[kt]);
+      }
+    } else {
+      const float qs[4] = {qv.x * 0.25f, qv.y * 0.25f, qv.z * 0.25f, qv.w * 0.25f};          // 1/sqrt(head_dim)
+      const float dhv[4] = {dh.x, dh.y, dh.z, dh.w};
+      // ---- scores, masked softmax (decoder.py:308-323), d weights = V dhv
+      f32x4 a[TD_NT], ds[TD_NT];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < TD_NT; ++kt) {
+        f32x4 c = rr_zero4(), d = rr_zero4();
+        c = rr_mfma(kf[kt].x, qs[0], c); c = rr_mfma(kf[kt].y, qs[1], c); c = rr_mfma(kf[kt].z, qs[2], c); c = rr_mfma(kf[kt].w, qs[3], c);
+        d = rr_mfma(vf[kt].x, dhv[0], d); d = rr_mfma(vf[kt].y, dhv[1], d); d = rr_mfma(vf[kt].z, dhv[2], d); d = rr_mfma(vf[kt].w, dhv[3], d);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 16 + 4 * g + r;
+          const bool ok = key < N && ((mw[kt >> 1] >> (16 * (kt & 1) + 4 * g + r)) & 1u);
+          c[r] = ok ? c[r] : -INFINITY;
+          mx = fmaxf(mx, c[r]);
+        }
+        a[kt] = c; ds[kt] = d;
+      }
+      mx = rr_max_g(mx);
+      if (mx == -INFINITY) mx = 0.f;
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < TD_NT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { a[kt][r] = rr_exp(a[kt][r] - mx); sum += a[kt][r]; }
+      sum = rr_sum_g(sum);
+      const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+      float dot = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < TD_NT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { a[kt][r] *= inv; dot = fmaf(a[kt][r], ds[kt][r], dot); }
+      dot = rr_sum_g(dot);
+#pragma unroll
+      for (int kt = 0; kt < TD_NT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ds[kt][r] = a[kt][r] * (ds[kt][r] - dot);          // d scores (softmax backward)
+      // ---- d query = dhv (residual, decoder.py:294) + K^T ds / sqrt(d)
+      f32x4 dq0 = rr_zero4(), dq1 = rr_zero4();
+#pragma unroll
+      for (int kt = 0; kt < TD_NT; ++kt) {
+        dq0 = rr_mfma(ktf[kt].x, ds[kt][0], dq0); dq1 = rr_mfma(ktf[kt].y, ds[kt][1], dq1);
+        dq0 = rr_mfma(ktf[kt].z, ds[kt][2], dq0); dq1 = rr_mfma(ktf[kt].w, ds[kt][3], dq1);
+      }
+      float dq[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dq[r] = fmaf(dq0[r] + dq1[r], 0.25f, dhv[r]);
+      scatter_dq(dq, live, prev, fst, tile < nft);
+      if (live) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dws[k][r] = fmaf(dq[r], sc4[k], dws[k][r]);
+      }
+      // ---- dK_h[key][dim] += ds[row][key] q[row][dim] / sqrt(d),  dV_h[key][dim] += a[row][key] dhv[row][dim]  (k = row)
+      const f32x4 qT = td_xpose(f32x4{qs[0], qs[1], qs[2], qs[3]}, sel);
+      const f32x4 hT = td_xpose(f32x4{dhv[0], dhv[1], dhv[2], dhv[3]}, sel);
+#pragma unroll
+      for (int kt = 0; kt < TD_NT; ++kt) {
+        const f32x4 dT = td_xpose(ds[kt], sel);
+        const f32x4 pT = td_xpose(a[kt], sel);
+        aK[kt] = rr_mfma(qT[0], dT[0], aK[kt]); aV[kt] = rr_mfma(hT[0], pT[0], aV[kt]);
+        aK[kt] = rr_mfma(qT[1], dT[1], aK[kt]); aV[kt] = rr_mfma(hT[1], pT[1], aV[kt]);
+        aK[kt] = rr_mfma(qT[2], dT[2], aK[kt]); aV[kt] = rr_mfma(hT[2], pT[2], aV[kt]);
+        aK[kt] = rr_mfma(qT[3], dT[3], aK[kt]); aV[kt] = rr_mfma(hT[3], pT[3], aV[kt]);
+      }
+  
     }
   }
   // ---- fold the four waves' dK_h / dV_h (fixed order), write the head's slice of every table
+  if constexpr (BF) {
+    __syncthreads();                      // every wave is done with the operand entries
+    if (wave >= 2) {
 #pragma unroll
-  for (int kt = 0; kt < TD_NT; ++kt) {
-    rr_st4(&red[wave][kt][lane * 4], make_float4(aK[kt][0], aK[kt][1], aK[kt][2], aK[kt][3]));
-    rr_st4(&red[wave][TD_NT + kt][lane * 4], make_float4(aV[kt][0], aV[kt][1], aV[kt][2], aV[kt][3]));
+      for (int kt = 0; kt < TD_NT; ++kt) {
+        rr_st4(&red[wave - 2][kt][lane * 4], make_float4(aK[kt][0], aK[kt][1], aK[kt][2], aK[kt][3]));
+        rr_st4(&red[wave - 2][TD_NT + kt][lane * 4], make_float4(aV[kt][0], aV[kt][1], aV[kt][2], aV[kt][3]));
+      }
+    }
+    __syncthreads();
+    if (wave < 2) {                       // (w0 + w2), (w1 + w3): a lane rewrites the 16 bytes it read
+#pragma unroll
+      for (int kt = 0; kt < TD_NT; ++kt) {
+        const float4 o = rr_ld4(&red[wave][kt][lane * 4]), p = rr_ld4(&red[wave][TD_NT + kt][lane * 4]);
+        rr_st4(&red[wave][kt][lane * 4], make_float4(aK[kt][0] + o.x, aK[kt][1] + o.y, aK[kt][2] + o.z, aK[kt][3] + o.w));
+        rr_st4(&red[wave][TD_NT + kt][lane * 4], make_float4(aV[kt][0] + p.x, aV[kt][1] + p.y, aV[kt][2] + p.z, aV[kt][3] + p.w));
+      }
+    }
+  } else {
+#pragma unroll
+    for (int kt = 0; kt < TD_NT; ++kt) {
+      rr_st4(&red[wave][kt][lane * 4], make_float4(aK[kt][0], aK[kt][1], aK[kt][2], aK[kt][3]));
+      rr_st4(&red[wave][TD_NT + kt][lane * 4], make_float4(aV[kt][0], aV[kt][1], aV[kt][2], aV[kt][3]));
+    }
   }
   __syncthreads();
   for (int e = tid; e < 2 * TD_NT * 64; e += 256) {
     const int ti = e >> 6, ln = e & 63;
     float4 sacc = rr_ld4(&red[0][ti][ln * 4]);
 #pragma unroll
-    for (int wv = 1; wv < 4; ++wv) {
+    for (int wv = 1; wv < RED_W; ++wv) {
       const float4 o = rr_ld4(&red[wv][ti][ln * 4]);
       sacc.x += o.x; sacc.y += o.y; sacc.z += o.z; sacc.w += o.w;
     }
     const int kt = ti % TD_NT, key = 16 * kt + (ln & 15), gg = ln >> 4;
+    if (BF && ti < TD_NT) { sacc.x *= 0.693147180559945309f; sacc.y *= 0.693147180559945309f; sacc.z *= 0.693147180559945309f; sacc.w *= 0.693147180559945309f; }
     if (key < N) rr_st4((ti < TD_NT ? io.dK : io.dV) + ((size_t)b * N + key) * RR_E + 16 * h + 4 * gg, sacc);
   }
   for (int e = tid; e < N * 16; e += 256) {
     const int n = e >> 4, d = e & 15;
-    io.dctxB[((size_t)b * N + n) * RR_E + 16 * h + d] = accB[e];
-    if (io.dctxA) io.dctxA[((size_t)b * N + n) * RR_E + 16 * h + d] = accA[e];
+    io.dctxB[((size_t)b * N + n) * RR_E + 16 * h + d] =
+        (accB[0][n * TD_AS + d] + accB[1][n * TD_AS + d]) + (accB[2][n * TD_AS + d] + accB[3][n * TD_AS + d]);
+    if (io.dctxA) io.dctxA[((size_t)b * N + n) * RR_E + 16 * h + d] = accA[n * TD_AS + d];
   }
   if (io.nscal > 0) {
 #pragma unroll
@@ -961,6 +1204,9 @@ extern "C" int rr_dec_attn_bwd(const DecAttnIO* io, hipStream_t st) {
   if (io->nscal < 0 || io->nscal > 4 || (io->nscal > 0 && (io->scal == nullptr || io->wstate == nullptr || io->dwstate == nullptr))) return RR_EINVAL;
   if (io->Bp <= 0 || io->N < 2 || io->N > TD_LDK || io->S < 1 || io->T < 1) return RR_EINVAL;
   const unsigned grid = (unsigned)((io->Bp + 7) / 8) * 64u;
-  hipLaunchKernelGGL(k_dec_attn_bwd, dim3(grid), dim3(256), 0, st, *io);
+  const char* ev = getenv("RR_ATTN_BWD_F32");                    // diagnostic: the fp32-MFMA kernel (read per call: tests switch it)
+  const int f32only = ev ? atoi(ev) : 0;
+  if (f32only) hipLaunchKernelGGL(k_dec_attn_bwd<false>, dim3(grid), dim3(256), 0, st, *io);
+  else hipLaunchKernelGGL(k_dec_attn_bwd<true>, dim3(grid), dim3(256), 0, st, *io);
   return rr_check(hipGetLastError());
 }
