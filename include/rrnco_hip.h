@@ -220,9 +220,11 @@ typedef struct {
   float *dlg, *dg, *logp, *dscal;     /* dlg [rows][112], dg [rows][128], logp [rows], dscal[2] += d alpha, d beta */
   int Bp, N, S, T; long long seg_stride;
   float alpha, beta, tanh_clip, temperature;
+  const void* Ls;                     /* rr_pack_f16x2 image of L [Bp][N][128] or NULL */
 } DecLogitIO;
 /* logits = g L^T / sqrt(E), inductive bias, log(exp + 1e-6), 10 tanh, mask, log-softmax (decoder.py:186-198, 300-302;
- * decoding.py:341-361): the chosen node's log-probability per row, d logits and d g. */
+ * decoding.py:341-361): the chosen node's log-probability per row, d logits and d g.  With Ls the products run on the fp16 /
+ * bf16 matrix pipe from LDS-resident operands (the logits exactly as the split rollout computed them), without it on the fp32 MFMA. */
 int rr_dec_logit_bwd(const DecLogitIO* io, hipStream_t stream);
 
 /* C[b][p][q] (+)= sum_m A[b][m][p] B[b][m][q], q < 128: d logit keys (dlg^T g per instance) and the weight gradient of a

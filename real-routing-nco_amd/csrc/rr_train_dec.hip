@@ -48,6 +48,7 @@ struct DecLogitIO {
   int Bp, N, S, T;            // T = decode steps that ran; rows of instance b: b*seg_stride + t*S + s
   long long seg_stride;
   float alpha, beta, tanh_clip, temperature;
+  const void* Ls;             // fp16 two-piece image of L (PrecomputedCache.split_images / rr_pack_f16x2) or NULL: fp32-MFMA kernel
 };
 
 __global__ __launch_bounds__(256, 2) void k_dec_logit_bwd(DecLogitIO io, int tiles_per_inst, int wgs_per_inst) {
@@ -210,12 +211,14 @@ __global__ __launch_bounds__(256, 2) void k_dec_logit_bwd(DecLogitIO io, int til
   }
 }
 
+static int rr_dec_logit_bwd_split(const DecLogitIO* io, int tiles, hipStream_t st);      // (k_dec_logit_bwd_s, below)
 extern "C" int rr_dec_logit_bwd(const DecLogitIO* io, hipStream_t st) {
   if (io == nullptr || io->g == nullptr || io->meta == nullptr || io->L == nullptr || io->Lt == nullptr || io->D == nullptr ||
       io->gll == nullptr || io->dlg == nullptr || io->dg == nullptr || io->logp == nullptr || io->dscal == nullptr)
     return RR_EINVAL;
   if (io->Bp <= 0 || io->N < 2 || io->N > TD_LDK || io->S < 1 || io->T < 1) return RR_EINVAL;
   const int tiles = (io->T * io->S + 15) / 16, wgs = (tiles + 3) / 4;
+  if (io->Ls != nullptr) return rr_dec_logit_bwd_split(io, tiles, st);
   hipLaunchKernelGGL(k_dec_logit_bwd, dim3((unsigned)io->Bp * wgs), dim3(256), 0, st, *io, tiles, wgs);
   return rr_check(hipGetLastError());
 }
@@ -810,6 +813,221 @@ __device__ __forceinline__ rr_bf16x4 td_xpose16(rr_bf16x4 p, rr_bf16x4 ident) {
   const uint2 o = make_uint2(__builtin_amdgcn_perm(__float_as_uint(d1), __float_as_uint(d0), 0x07060302u),
                              __builtin_amdgcn_perm(__float_as_uint(d3), __float_as_uint(d2), 0x07060302u));
   return __builtin_bit_cast(rr_bf16x4, o);
+}
+
+// ------------------------------------------------------------------------------------------------ logits backward, split operands
+// k_dec_logit_bwd on the fp16 / bf16 matrix pipe.  The fp32-MFMA kernel above spends its time on 448 matrix instructions of 32 cycles
+// per tile and on 112 KB of L / L^T fragments every wave fetches from L2 for its ONE tile.  Here a workgroup (8 waves) keeps one
+// instance's operands in LDS for all the tiles it runs: the rollout's own two-piece fp16 image of L (same products, same order
+// as rr_rollout_w.inc's logits phase: the replayed logits are the rollout's) and L^T as [hi | lo] bf16 pieces for d g = d logits L
+// (gradients leave the fp16 range; error 2^-16 of a product like the pointer-MLP kernels).  Per tile 112 + 112 matrix
+// instructions of 8 / 16 cycles; what is left is the row traffic (g in, d g and d logits out).
+__device__ __forceinline__ rr_bf16x4 td_lo4(rr_bf16x8 v) { return __builtin_shufflevector(v, v, 0, 1, 2, 3); }
+__device__ __forceinline__ rr_bf16x4 td_hi4(rr_bf16x8 v) { return __builtin_shufflevector(v, v, 4, 5, 6, 7); }
+
+template <bool DUR>
+__global__ __launch_bounds__(512, 1) void k_dec_logit_bwd_s(DecLogitIO io, int tiles_per_inst, int chunks) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* limg = lds;                                  // fragment (kt, kk): A = [L~ hi | L~ lo] of keys 16kt + j, features 16kk + 4g ..
+  char* timg = lds + TD_NT * 8 * 1024;               // fragment (u, kt):  A = [L^T hi | L^T lo] of features 16u + j, keys 16kt + 4g ..
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / chunks, ch = blockIdx.x - b * chunks;
+  const int N = io.N, S = io.S, rows_b = io.T * S;
+  for (int f = wave; f < TD_NT * 8; f += 8) {
+    const int kt = f >> 3, kk = f & 7;
+    int key = kt * 16 + j; key = key < N ? key : N - 1;
+    rr_glds16((const char*)io.Ls + ((size_t)b * N + key) * (RR_E * 4) + (size_t)(16 * kk + 4 * g) * 4, limg + f * 1024);
+    const int u = f / TD_NT, kq = f - u * TD_NT;
+    const float4 v = rr_ld4(io.Lt + ((size_t)b * RR_E + 16 * u + j) * TD_LDK + 16 * kq + 4 * g);
+    const float x4[4] = {v.x, v.y, v.z, v.w};
+    rr_bf16x4 hi, lo;
+    td_split4(x4, hi, lo);
+    *reinterpret_cast<rr_bf16x8*>(timg + (f * 64 + lane) * 16) = rr_bf16x8{hi[0], hi[1], hi[2], hi[3], lo[0], lo[1], lo[2], lo[3]};
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int per = (tiles_per_inst + chunks - 1) / chunks;
+  const int t_lo = ch * per, t_hi = min(t_lo + per, tiles_per_inst);
+  const float inv_sqe = 1.0f / ((float)(1 << RR_KS) * sqrtf((float)RR_E)), inv_temp = 1.0f / io.temperature;     // (the L image carries 2^RR_KS)
+  const float inv_sqg = 1.0f / sqrtf((float)RR_E);
+  const bool clip = io.tanh_clip > 0.f;
+  float da_acc = 0.f, db_acc = 0.f;
+  uint32_t nmw = 0;                         // nibble kt: which of this lane's four keys of key tile kt exist (key < N)
+#pragma unroll
+  for (int kt = 0; kt < TD_NT; ++kt) {
+    const int left = N - (16 * kt + 4 * g);
+    nmw |= (left >= 4 ? 15u : left <= 0 ? 0u : ((1u << left) - 1u)) << (4 * kt);
+  }
+  const __amdgpu_buffer_rsrc_t rD = rr_make_buf(io.D + (size_t)b * N * N, (unsigned)(N * N) * 4u);
+  const __amdgpu_buffer_rsrc_t rT = rr_make_buf((DUR ? io.Dur : io.D) + (size_t)b * N * N, (unsigned)(N * N) * 4u);
+  struct In { uint4 m0, m1; float4 f[8]; float gl; size_t m; bool vrow; };
+  auto ld_in = [&](int tile) {
+    In r;
+    int q = tile * 16 + j;
+    r.vrow = q < rows_b;
+    q = r.vrow ? q : rows_b - 1;
+    r.m = (size_t)b * (size_t)io.seg_stride + (size_t)q;
+    const int t = q / S;
+    r.m0 = *reinterpret_cast<const uint4*>(io.meta + r.m * 8);
+    r.m1 = *reinterpret_cast<const uint4*>(io.meta + r.m * 8 + 4);
+    r.gl = io.gll[(size_t)(q - t * S) * io.Bp + b];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) r.f[kk] = rr_ld4(io.g + r.m * RR_E + 16 * kk + 4 * g);
+    return r;
+  };
+  In nx = ld_in(t_lo + wave < t_hi ? t_lo + wave : t_lo);
+#pragma unroll 1
+  for (int tile = t_lo + wave; tile < t_hi; tile += 8) {
+    const In in = nx;
+    const size_t m = in.m;
+    const bool vrow = in.vrow;
+    const int prev = min((int)in.m1.x, N - 1), target = (int)in.m1.y;
+    const bool live = vrow && in.m1.z != 0u;
+    const float gl = live ? in.gl : 0.f;
+    // the bias rows of this tile, then the next tile's inputs: both land under the matrix instructions
+    // (buffer loads: one 32-bit offset for the 28 values; keys past N read a neighbour row or, past the matrix, zero: they are masked)
+    const unsigned drow = (unsigned)(prev * N + 4 * g) * 4u;
+    float dd[TD_NT][4], tt[TD_NT][4];
+#pragma unroll
+    for (int kt = 0; kt < TD_NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dd[kt][r] = rr_bld1(rD, drow, (unsigned)(16 * kt + r) * 4u);
+        tt[kt][r] = DUR ? rr_bld1(rT, drow, (unsigned)(16 * kt + r) * 4u) : 0.f;
+      }
+    rr_f16x8 FS[8];                                   // [g lo | g hi] per feature group (dead rows: zeros, and zeroed in place)
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const float fx[4] = {live ? in.f[kk].x : 0.f, live ? in.f[kk].y : 0.f, live ? in.f[kk].z : 0.f, live ? in.f[kk].w : 0.f};
+      FS[kk] = rr_usplit4s(fx);
+      if (vrow && !live) rr_st4(io.g + m * RR_E + 16 * kk + 4 * g, make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+    // ---- logits^T[key][row] = L g^T (decoder.py:300-302): two chains per key tile (k = 16: hi hi; k = 32: hi lo + lo hi)
+    f32x4 la[TD_NT];
+    {
+      const char* lb = limg + lane * 16;
+      rr_f16x8 A[2][4];                              // half a key tile ahead
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) A[0][kk] = *reinterpret_cast<const rr_f16x8*>(lb + kk * 1024);
+#pragma unroll
+      for (int kt = 0; kt < TD_NT; ++kt) {
+        f32x4 lt = rr_zero4(), ls = rr_zero4();
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const int nxt = 2 * kt + hf + 1;
+          if (nxt < 2 * TD_NT) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) A[nxt & 1][kk] = *reinterpret_cast<const rr_f16x8*>(lb + (nxt * 4 + kk) * 1024);
+          }
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            lt = rr_mfma_f16k16(rr_lo4(A[hf][kk]), rr_hi4(FS[4 * hf + kk]), lt);
+            ls = rr_mfma_f16(A[hf][kk], FS[4 * hf + kk], ls);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) la[kt][q] = lt[q] + ls[q];
+      }
+    }
+    nx = ld_in(tile + 8 < t_hi ? tile + 8 : tile);      // the next tile's rows land under the epilogue and the d g products
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- bias, log(exp(.) + 1e-6) (decoder.py:187-198), 10 tanh, mask, temperature, log-softmax (decoding.py:341-361)
+    const uint32_t mw[4] = {in.m0.x >> (4 * g), in.m0.y >> (4 * g), in.m0.z >> (4 * g), in.m0.w >> (4 * g)};
+    float uu[TD_NT][4], vv[TD_NT][4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < TD_NT; ++kt) {
+      const uint32_t bits = (mw[kt >> 1] >> (16 * (kt & 1))) & (nmw >> (4 * kt));      // this lane's four keys of the tile
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float x = la[kt][r] * inv_sqe - (io.alpha * dd[kt][r] + io.beta * tt[kt][r]);
+        const float u = rr_exp(x) + 1e-6f;
+        uu[kt][r] = u;
+        float v;
+        if (clip) v = (1.0f - 2.0f / fmaf(u, u, 1.0f)) * io.tanh_clip * inv_temp;      // tanh(log u) = (u^2-1)/(u^2+1)
+        else v = rr_log(u) * inv_temp;
+        v = (bits & (1u << r)) ? v : -INFINITY;
+        vv[kt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    }
+    mx = rr_max_g(mx);
+    if (mx == -INFINITY) mx = 0.f;
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < TD_NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sum += rr_exp(vv[kt][r] - mx);
+    sum = rr_sum_g(sum);
+    const float lse = rr_log(sum);
+    float lpt = 0.f, da = 0.f, db = 0.f;
+    rr_bf16x8 DT[TD_NT];                              // d logits / sqrt(E) as [lo | hi] bf16 pieces
+#pragma unroll
+    for (int kt = 0; kt < TD_NT; ++kt) {
+      float dl4[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + 4 * g + r;
+        const float v = vv[kt][r];
+        const bool ok = v > -INFINITY;
+        const float lp = v - mx - lse;
+        if (key == target) lpt += ok ? lp : 0.f;
+        const float p = ok ? rr_exp(lp) : 0.f;
+        float dv = gl * ((key == target ? 1.0f : 0.f) - p);          // d loss / d v (log-softmax picked at the target)
+        dv = (ok && live) ? dv : 0.f;
+        const float u = uu[kt][r];
+        float dx;                                                    // through v(u), u = exp(x) + 1e-6
+        if (clip) { const float w = fmaf(u, u, 1.0f); dx = dv * io.tanh_clip * inv_temp * (4.0f * u / (w * w)) * (u - 1e-6f); }
+        else dx = dv * inv_temp * (u - 1e-6f) / u;
+        dl4[r] = dx * inv_sqg;
+        da -= dx * dd[kt][r];
+        db -= dx * tt[kt][r];
+      }
+      if (vrow) rr_st4(io.dlg + m * TD_LDK + 16 * kt + 4 * g, make_float4(dl4[0], dl4[1], dl4[2], dl4[3]));
+      rr_bf16x4 hi, lo;
+      td_split4(dl4, hi, lo);
+      DT[kt] = rr_bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+    lpt = rr_sum_g(lpt);
+    if (vrow && g == 0) io.logp[m] = live ? lpt : 0.f;
+    da_acc += vrow ? da : 0.f; db_acc += vrow ? db : 0.f;
+    // ---- dg^T[feat][row] = L^T dla  (A = [L^T hi | L^T lo], k = key): two chains per feature tile
+    {
+      const char* tb = timg + lane * 16;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        f32x4 c0 = rr_zero4(), c1 = rr_zero4();
+#pragma unroll
+        for (int kt = 0; kt < TD_NT; ++kt) {
+          const rr_bf16x8 A = *reinterpret_cast<const rr_bf16x8*>(tb + (u * TD_NT + kt) * 1024);
+          c0 = td_mfma16(td_lo4(A), td_hi4(DT[kt]), c0);
+          c1 = rr_mfma_bf16(A, DT[kt], c1);
+        }
+        if (vrow) rr_st4(io.dg + m * RR_E + 16 * u + 4 * g, make_float4(c0[0] + c1[0], c0[1] + c1[1], c0[2] + c1[2], c0[3] + c1[3]));
+      }
+    }
+  }
+  da_acc = rr_wave_sum(da_acc); db_acc = rr_wave_sum(db_acc);
+  if (lane == 0) { atomicAdd(io.dscal, da_acc); if (DUR) atomicAdd(io.dscal + 1, db_acc); }
+}
+
+static int rr_dec_logit_bwd_split(const DecLogitIO* io, int tiles, hipStream_t st) {
+  // one workgroup per instance when there are enough instances to fill the chip twice over; otherwise an instance's tiles are cut
+  // into chunks (each pays the 112 KB of operand staging again)
+  int chunks = io->Bp >= 512 ? 1 : (512 + io->Bp - 1) / io->Bp;
+  chunks = chunks < 1 ? 1 : chunks;
+  if (chunks > (tiles + 7) / 8) chunks = (tiles + 7) / 8;
+  const size_t shm = (size_t)2 * TD_NT * 8 * 1024;
+  if (io->Dur) {
+    (void)hipFuncSetAttribute((const void*)k_dec_logit_bwd_s<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipLaunchKernelGGL(k_dec_logit_bwd_s<true>, dim3((unsigned)io->Bp * chunks), dim3(512), shm, st, *io, tiles, chunks);
+  } else {
+    (void)hipFuncSetAttribute((const void*)k_dec_logit_bwd_s<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipLaunchKernelGGL(k_dec_logit_bwd_s<false>, dim3((unsigned)io->Bp * chunks), dim3(512), shm, st, *io, tiles, chunks);
+  }
+  return rr_check(hipGetLastError());
 }
 
 template <bool BF>

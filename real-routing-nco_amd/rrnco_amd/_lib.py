@@ -64,7 +64,7 @@ class RolloutIO(C.Structure):
 class DecLogitIO(C.Structure):          # csrc/rr_train_dec.hip
     _fields_ = [(n, vp) for n in ("g", "meta", "L", "Lt", "D", "Dur", "gll", "dlg", "dg", "logp", "dscal")] + \
         [(n, i32) for n in ("Bp", "N", "S", "T")] + [("seg_stride", C.c_longlong)] + \
-        [(n, f32) for n in ("alpha", "beta", "tanh_clip", "temperature")]
+        [(n, f32) for n in ("alpha", "beta", "tanh_clip", "temperature")] + [("Ls", vp)]
 
 
 class MlpRowsW(C.Structure):

@@ -11,6 +11,8 @@ five kernels turn d loss / d log-likelihood into
 Problem independent: ATSP (first-node table), RCVRP (1 state scalar), RCVRPTW / RMTVRP (4 state scalars, duration bias)."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .. import _lib as L
@@ -70,6 +72,8 @@ def decoder_backward(policy, cache, dump, D, Dur, grad_ll) -> dict:
     io.gll, io.dlg, io.dg, io.logp, io.dscal = L.ptr(gll), L.ptr(dlg), L.ptr(dg), L.ptr(logp), L.ptr(dscal)
     io.Bp, io.N, io.S, io.T, io.seg_stride = Bp, N, S, T, seg
     io.alpha, io.beta, io.tanh_clip, io.temperature = alpha, beta, float(dump["tanh_clip"]), float(dump["temperature"])
+    # the split rollout's own fp16 image of L (the replay then repeats its products); a forward on the fp32 kernels left none
+    io.Ls = L.ptr(cache.split[2]) if (cache.split is not None and os.environ.get("RR_LOGIT_BWD_F32", "0") != "1") else None
     L.check(lib.rr_dec_logit_bwd(io, st), "rr_dec_logit_bwd")
     # ---- d logit keys: dL[b] = dlg_b^T g_b (rows on the MFMA k axis)
     dL = torch.empty(Bp, N, E, device=dev)
