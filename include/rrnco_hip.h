@@ -38,6 +38,7 @@ typedef struct {                /* ATSPInitEmbedding (rrnco/models/env_embedding
   const float *cmrb, *cmcb;
   float g2rb, g2cb;
   int nfeat;
+  const void *g0rs, *g0cs;      /* gating_fc.0 as two-piece fp16 images of 2^6 W [16][8][2][64][8] (fp16 matrix pipe) or NULL (fp32 MFMA) */
 } InitW;
 
 typedef struct {                /* folded DistAngleFusion(use_duration_matrix=True): attn_freenet.py:226-237, 265-286 */

@@ -907,6 +907,7 @@ struct InitW {
   const float *cmrb, *cmcb;
   float g2rb, g2cb;                // gating_fc.2 bias
   int nfeat;                       // F: 1 (demand) or 4 (demand, tw0, tw1, service)
+  const void *g0rs, *g0cs;         // gating_fc.0 as second-form fp16 images of 2^6 W [16 t][8 s][2 pieces][64][8] (packing.pack_a_f16u) or NULL
 };
 
 #define MAXSS 32
@@ -947,6 +948,47 @@ __device__ __forceinline__ void ie_gemm_wx16(f32x4 (&acc)[NT], const float4* __r
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) b[nt] = bn[nt];
+  }
+}
+
+// The gate's first layer (Linear(2E,2E) on [node | distance embedding]) is 0.83 of k_init_embed's 1.71 ms on the fp32 MFMA (7 168
+// instructions of 32 cycles per pass and instance).  Second-form fp16 operands (rr_common.h): hidden tiles t0 and t1 of this wave
+// for all node tiles at once, the rows of X split once per (node tile, 32-feature slice) and used for both; accumulators seeded
+// with 2^6 bias, results x 2^6.
+template <int NT>
+__device__ __forceinline__ void ie_gemm_split2(f32x4 (&h0)[NT], f32x4 (&h1)[NT], const void* ws, int t0, int t1, const float* X, int ldx,
+                                               int n_valid, int lane) {
+  const int j = lane & 15, g = lane >> 4;
+  int rowoff[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    int node = nt * 16 + j;
+    node = node < n_valid ? node : n_valid - 1;
+    rowoff[nt] = node * ldx + 4 * g;
+  }
+  const char* a0 = (const char*)ws + (size_t)t0 * (16 * 1024) + lane * 16;      // fragment ((t * 8 + s) * 2 + piece)
+  const char* a1 = (const char*)ws + (size_t)t1 * (16 * 1024) + lane * 16;
+  rr_f16x8 A[2][4];
+  A[0][0] = *reinterpret_cast<const rr_f16x8*>(a0); A[0][1] = *reinterpret_cast<const rr_f16x8*>(a0 + 1024);
+  A[0][2] = *reinterpret_cast<const rr_f16x8*>(a1); A[0][3] = *reinterpret_cast<const rr_f16x8*>(a1 + 1024);
+#pragma unroll
+  for (int sl = 0; sl < 8; ++sl) {
+    if (sl + 1 < 8) {
+      A[(sl + 1) & 1][0] = *reinterpret_cast<const rr_f16x8*>(a0 + (sl + 1) * 2048);
+      A[(sl + 1) & 1][1] = *reinterpret_cast<const rr_f16x8*>(a0 + (sl + 1) * 2048 + 1024);
+      A[(sl + 1) & 1][2] = *reinterpret_cast<const rr_f16x8*>(a1 + (sl + 1) * 2048);
+      A[(sl + 1) & 1][3] = *reinterpret_cast<const rr_f16x8*>(a1 + (sl + 1) * 2048 + 1024);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float4 xa = rr_ld4(X + rowoff[nt] + 32 * sl), xb = rr_ld4(X + rowoff[nt] + 32 * sl + 16);
+      const float xx[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+      rr_f16x8 xh, xl;
+      rr_usplit8(xx, xh, xl);
+      h0[nt] = rr_mfma_f16(A[sl & 1][0], xl, h0[nt]); h1[nt] = rr_mfma_f16(A[sl & 1][2], xl, h1[nt]);
+      h0[nt] = rr_mfma_f16(A[sl & 1][1], xh, h0[nt]); h1[nt] = rr_mfma_f16(A[sl & 1][3], xh, h1[nt]);
+      h0[nt] = rr_mfma_f16(A[sl & 1][0], xh, h0[nt]); h1[nt] = rr_mfma_f16(A[sl & 1][2], xh, h1[nt]);
+    }
   }
 }
 
@@ -1021,6 +1063,25 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
     const float4* g0 = pass == 0 ? w.g0r : w.g0c;
     const float* g0b = pass == 0 ? w.g0rb : w.g0cb;
     const float* g2 = pass == 0 ? w.g2r : w.g2c;
+    const void* g0s = pass == 0 ? w.g0rs : w.g0cs;
+    if (g0s != nullptr) {                  // (kernel argument: uniform)
+      f32x4 h0[NT], h1[NT];
+      const float4 ba = rr_ld4(g0b + 16 * wave + 4 * g), bb = rr_ld4(g0b + 16 * (wave + 8) + 4 * g);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        h0[nt] = f32x4{64.f * ba.x, 64.f * ba.y, 64.f * ba.z, 64.f * ba.w};
+        h1[nt] = f32x4{64.f * bb.x, 64.f * bb.y, 64.f * bb.z, 64.f * bb.w};
+      }
+      ie_gemm_split2<NT>(h0, h1, g0s, wave, wave + 8, comb, 256, N, lane);
+      const float4 wa = rr_ld4(g2 + 16 * wave + 4 * g), wb = rr_ld4(g2 + 16 * (wave + 8) + 4 * g);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        float p0 = fmaxf(h0[nt][0], 0.f) * wa.x + fmaxf(h0[nt][1], 0.f) * wa.y + fmaxf(h0[nt][2], 0.f) * wa.z + fmaxf(h0[nt][3], 0.f) * wa.w;
+        float p1 = fmaxf(h1[nt][0], 0.f) * wb.x + fmaxf(h1[nt][1], 0.f) * wb.y + fmaxf(h1[nt][2], 0.f) * wb.z + fmaxf(h1[nt][3], 0.f) * wb.w;
+        p0 = rr_sum_g(p0) * (1.0f / 64.0f); p1 = rr_sum_g(p1) * (1.0f / 64.0f);
+        if (g == 0) { gpart[wave * 112 + nt * 16 + j] = p0; gpart[(wave + 8) * 112 + nt * 16 + j] = p1; }
+      }
+    } else
     for (int tt = 0; tt < 2; ++tt) {
       int t = wave + 8 * tt;
       f32x4 h[NT];

@@ -589,6 +589,7 @@ def _pack_policy(sd: dict, env_name: str, device) -> dict:
     out = {"arena": ar, "sd_ref": sd, "blocks": blocks, "num_layers": nl, "nabdur": [tuple(nabdur[l]) for l in sorted(nabdur)],
            "nab_kind": nab_kind, "nabsimple": [tuple(nabsimple[l]) for l in sorted(nabsimple)]}
     p = "encoder.init_embedding"
+    gate_w = []            # weights with fp16 images beside the pointer MLP's: they join the range guard's bit 1
     if env_name == "atsp":
         iw = L.InitW()
         iw.wi, iw.bi = ar.put(sd[p + ".init_embed.weight"]), ar.put(sd[p + ".init_embed.bias"])
@@ -597,6 +598,9 @@ def _pack_policy(sd: dict, env_name: str, device) -> dict:
         for rc, s in (("row", "r"), ("col", "c")):
             q = f"{p}.gating_network_{rc}.gating_fc"
             setattr(iw, "g0" + s, ar.put(pack_a(sd[q + ".0.weight"].detach().float())))
+            if split:       # the gate's first layer on the fp16 pipe (csrc/rr_encoder.hip: ie_gemm_split2)
+                setattr(iw, "g0" + s + "s", ar.put_raw(pack_a_f16u(sd[q + ".0.weight"].to(device))))
+                gate_w.append(sd[q + ".0.weight"].to(device))
             setattr(iw, "g0" + s + "b", ar.put(sd[q + ".0.bias"]))
             setattr(iw, "g2" + s, ar.put(sd[q + ".2.weight"].reshape(-1)))
             setattr(iw, "g2" + s + "b", float(sd[q + ".2.bias"].reshape(-1)[0]))
@@ -615,6 +619,9 @@ def _pack_policy(sd: dict, env_name: str, device) -> dict:
         for rc, s in (("row", "r"), ("col", "c")):
             q = f"{p}.gating_network_{rc}.gating_fc"
             setattr(iw, "g0" + s, ar.put(pack_a(sd[q + ".0.weight"].detach().float())))
+            if split:       # the gate's first layer on the fp16 pipe (csrc/rr_encoder.hip: ie_gemm_split2)
+                setattr(iw, "g0" + s + "s", ar.put_raw(pack_a_f16u(sd[q + ".0.weight"].to(device))))
+                gate_w.append(sd[q + ".0.weight"].to(device))
             setattr(iw, "g0" + s + "b", ar.put(sd[q + ".0.bias"]))
             setattr(iw, "g2" + s, ar.put(sd[q + ".2.weight"].reshape(-1)))
             setattr(iw, "g2" + s + "b", float(sd[q + ".2.bias"].reshape(-1)[0]))
@@ -653,7 +660,7 @@ def _pack_policy(sd: dict, env_name: str, device) -> dict:
     dw.b1, dw.b2 = ar.put(sd["decoder.pointer.ffn.lins.0.bias"]), ar.put(sd["decoder.pointer.ffn.lins.1.bias"])
     dw.b1s = ar.put(sd["decoder.pointer.ffn.lins.0.bias"].detach().float() * float(2 ** F16U_WEIGHT_SCALE_LOG2))
     # range guard, bit 1: a weight image that leaves the fp16 range (models/policy.py repeats such a call on the fp32 kernels)
-    out["range_status"] = f16_range_status([w1d, w2d], F16U_WEIGHT_SCALE_LOG2)
+    out["range_status"] = f16_range_status([w1d, w2d] + gate_w, F16U_WEIGHT_SCALE_LOG2)
     dw.alpha = float(sd["decoder.alpha"].reshape(-1)[0])
     dw.beta = float(sd["decoder.beta"].reshape(-1)[0]) if "decoder.beta" in sd else 0.0
     out["cache"], out["dec"] = cw, dw
