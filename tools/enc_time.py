@@ -3,6 +3,9 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "real-routing-nco_amd"))
 import torch
+from rrnco_amd import _lib
+if os.environ.get("RR_LIB"):
+    _lib.LIB_PATH = _lib.LIB_PATH.replace("librrnco_hip.so", os.environ["RR_LIB"])
 import bench
 from rrnco_amd.envs import ATSPEnv, ATSPGenerator
 from rrnco_amd.models.encoder import ATSPInitEmbedding
