@@ -265,10 +265,10 @@ def other_configs(dev):
     rows = 512 * STARTS * (N_NODES - 2)                  # decoder evaluations of the step (the forced last move is not evaluated)
     roof = {"bound": "mfma", "kernel": dom, "kernel_ms_per_step": per_step[dom], "calls_per_step": kt.ms(dom)[1] / n, "traffic": None}
     if dom == "rr_dec_attn_bwd":
-        # masked 8-head glimpse backward per decoder evaluation: recomputed scores, dP, dQ, dK, dV = 5 products of 2 N E flop, fp32 MFMA
+        # masked 8-head glimpse backward per decoder evaluation: recomputed scores, dP, dQ, dK, dV = 5 products of 2 N E flop
         fl = rows * 5 * 2 * N_NODES * 128
-        roof.update({"achieved": fl / (per_step[dom] * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "note": "5 x 2 N E flop per decoder evaluation (scores recomputed, dP, dQ, dK, dV) on the fp32 MFMA"})
+        roof.update({"achieved": fl / (per_step[dom] * 1e-3) / 1e12, "peak": peak_split, "unit": "TFLOP/s",
+                     "note": "5 x 2 N E flop per decoder evaluation (scores recomputed, dP, dQ, dK, dV), two-piece bf16 operands: 2 500 / 3"})
     elif dom == "rr_mlp_wgrad":
         # pointer MLP + 12 encoder FFNs: per row the hidden layer recomputed, dH, dW1, dW2 = 4 products of 2 x 128 x 512 flop, bf16 two-piece
         fl = (rows + 12 * 512 * N_NODES) * 4 * 2 * 128 * 512

@@ -30,3 +30,9 @@ python3 tools/bench_stepwise.py 2>/dev/null | tail -2 > gpurun_out/other_$TAG.js
 python3 tools/stepkernels_time.py 2>/dev/null | tail -5 >> gpurun_out/other_$TAG.jsonl
 python3 tools/bench_train.py --problem rcvrp --steps 3 2>/dev/null | tail -1 >> gpurun_out/other_$TAG.jsonl
 python3 tools/bench_train.py --problem rcvrptw --steps 2 --batch 512 2>/dev/null | tail -1 >> gpurun_out/other_$TAG.jsonl
+python3 tools/profile_c4.py 2>&1 | grep -v Warning | tail -23 > gpurun_out/c4_${TAG}_profile.txt
+PROBLEM=rcvrp python3 tools/profile_c4.py 2>&1 | grep -v Warning | tail -23 > gpurun_out/c3_${TAG}_profile.txt
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profs_$TAG -o p -- python3 $R/tools/bench_stepwise.py > /dev/null 2> /tmp/profs_err.log
+S=$(find /tmp/profs_$TAG -name "*kernel_stats.csv" | head -1)
+cp "$S" $R/gpurun_out/stepwise_${TAG}_kernel_stats.csv
