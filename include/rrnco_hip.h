@@ -229,9 +229,10 @@ typedef struct {
 int rr_dec_logit_bwd(const DecLogitIO* io, hipStream_t stream);
 
 /* C[b][p][q] (+)= sum_m A[b][m][p] B[b][m][q], q < 128: d logit keys (dlg^T g per instance) and the weight gradient of a
- * Linear layer (dY^T X).  msplit > 1 or accumulate != 0: float atomics into C (caller zeroes it). */
+ * Linear layer (dY^T X).  msplit > 1 or accumulate != 0 adds into C: through per-split partials in `ws` (batch * msplit * P * 128
+ * floats) and a fixed-order reduction, or, ws == NULL, with float atomics (caller zeroes C). */
 int rr_gemm_tn(const float* A, const float* B, float* C, int batch, int Mb, int P, int lda, int ldb, int ldc,
-               long long strideA, long long strideB, long long strideC, int msplit, int accumulate, hipStream_t stream);
+               long long strideA, long long strideB, long long strideC, int msplit, int accumulate, float* ws, hipStream_t stream);
 
 typedef struct { const void *wa1, *wa2, *wb; const float *b1, *b2; } MlpRowsW;   /* packing.pack_mlp_train */
 typedef struct { const void *w1n, *w2tn; const float *b1; } MlpWgradW;
@@ -242,9 +243,10 @@ typedef struct { const void *w1n, *w2tn; const float *b1; } MlpWgradW;
  * live flag meta[m][6] is 0 hold no data and are read as zero rows. */
 int rr_mlp_rows(const MlpRowsW* w, int mode, const float* X, const float* dY, float* out, const uint32_t* meta,
                 int nseg, int seg_rows, long long seg_stride, hipStream_t stream);
-/* dW1 [512][128], db1 [512], dW2 [128][512], db2 [128] of that MLP from (x, dy); ADDED to (caller zeroes). */
+/* dW1 [512][128], db1 [512], dW2 [128][512], db2 [128] of that MLP from (x, dy); ADDED to (caller zeroes).  ws: NULL (float atomics)
+ * or 64 * 2 * 512 * 128 floats: the row splits' partials of dW1 / dW2, added up in a fixed order. */
 int rr_mlp_wgrad(const MlpWgradW* w, const float* X, const float* dY, float* dW1, float* db1, float* dW2, float* db2,
-                 const uint32_t* meta, int nseg, int seg_rows, long long seg_stride, hipStream_t stream);
+                 const uint32_t* meta, int nseg, int seg_rows, long long seg_stride, float* ws, hipStream_t stream);
 
 typedef struct {
   const float *dg0; const uint32_t *meta; const float *scal; const int64_t *first;

@@ -231,7 +231,7 @@ extern "C" int rr_dec_logit_bwd(const DecLogitIO* io, hipStream_t st) {
 template <int PT>
 __global__ __launch_bounds__(256, 2) void k_gemm_tn(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
                                                     int Mb, int lda, int ldb, int ldc, int P, long long sA, long long sB, long long sC,
-                                                    int msplit, int accumulate) {
+                                                    int msplit, int accumulate, float* __restrict__ ws) {
   constexpr int LA = PT * 16 + ((PT * 16) % 32 == 16 ? 0 : 16), LB = 144;
   __shared__ __attribute__((aligned(16))) float As[32 * LA];
   __shared__ __attribute__((aligned(16))) float Bs[32 * LB];
@@ -309,25 +309,49 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const float* __restrict__ A,
         const int p = p0 + 16 * pt + 4 * g + r, qq = 32 * wave + 16 * qt + j;
         if (p < P) {
           float* dst = Cb + (size_t)p * ldc + qq;
-          if (msplit > 1 || accumulate) atomicAdd(dst, acc[pt][qt][r]);
+          if (ws != nullptr) ws[(((size_t)b * msplit + ms) * P + p) * 128 + qq] = acc[pt][qt][r];      // this split's partial: k_split_reduce adds them up
+          else if (msplit > 1 || accumulate) atomicAdd(dst, acc[pt][qt][r]);
           else *dst = acc[pt][qt][r];
         }
       }
 }
 
-// C[b] = A[b]^T B[b] with B 128 columns wide.  msplit > 1 (or accumulate) adds into C with float atomics: the caller zeroes C.
+// C[b][p][q] = (accumulate ? C : 0) + sum over the msplit partials, in a fixed order.  The chip retires ~1e11 global float atomics
+// per second: 256 row splits of a 128 x 128 block are 4.2 M of them, 42 of the 50 us such a product took with the atomic epilogue.
+__global__ __launch_bounds__(256) void k_split_reduce(const float* __restrict__ ws, float* __restrict__ C, int P, int ldc, long long sC,
+                                                      int msplit, int accumulate) {
+  const int e = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (e >= P * 128) return;
+  const int p = e >> 7, q = e & 127;
+  const float* src = ws + (size_t)b * msplit * P * 128 + e;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int m = 0;
+  for (; m + 4 <= msplit; m += 4) {
+    s0 += src[(size_t)m * P * 128]; s1 += src[(size_t)(m + 1) * P * 128]; s2 += src[(size_t)(m + 2) * P * 128]; s3 += src[(size_t)(m + 3) * P * 128];
+  }
+  for (; m < msplit; ++m) s0 += src[(size_t)m * P * 128];
+  float* dst = C + (size_t)b * sC + (size_t)p * ldc + q;
+  const float tot = (s0 + s1) + (s2 + s3);
+  *dst = accumulate ? *dst + tot : tot;
+}
+
+// C[b] = A[b]^T B[b] with B 128 columns wide.  msplit > 1 (or accumulate) adds into C: with a workspace `ws` of batch * msplit * P * 128
+// floats through per-split partials and a fixed-order reduction (deterministic), without one with float atomics (the caller zeroes C).
 extern "C" int rr_gemm_tn(const float* A, const float* B, float* C, int batch, int Mb, int P, int lda, int ldb, int ldc,
-                          long long strideA, long long strideB, long long strideC, int msplit, int accumulate, hipStream_t st) {
+                          long long strideA, long long strideB, long long strideC, int msplit, int accumulate, float* ws, hipStream_t st) {
   if (A == nullptr || B == nullptr || C == nullptr || batch <= 0 || Mb <= 0 || P <= 0 || msplit < 1) return RR_EINVAL;
   if ((lda & 3) || (ldb & 3) || ldb < 128 || lda < P) return RR_EINVAL;
+  if (msplit == 1 && !accumulate) ws = nullptr;             // plain stores already
   if (P <= 112 || (P % 128) != 0) {
     if (P > 112 && (P % 112) != 0) return RR_EINVAL;
     hipLaunchKernelGGL((k_gemm_tn<7>), dim3((P + 111) / 112, msplit, batch), dim3(256), 0, st, A, B, C, Mb, lda, ldb, ldc, P,
-                       strideA, strideB, strideC, msplit, accumulate);
+                       strideA, strideB, strideC, msplit, accumulate, ws);
   } else {
     hipLaunchKernelGGL((k_gemm_tn<8>), dim3(P / 128, msplit, batch), dim3(256), 0, st, A, B, C, Mb, lda, ldb, ldc, P,
-                       strideA, strideB, strideC, msplit, accumulate);
+                       strideA, strideB, strideC, msplit, accumulate, ws);
   }
+  if (ws != nullptr)
+    hipLaunchKernelGGL(k_split_reduce, dim3((P * 128 + 255) / 256, batch), dim3(256), 0, st, ws, C, P, ldc, strideC, msplit, accumulate);
   return rr_check(hipGetLastError());
 }
 
@@ -523,7 +547,8 @@ struct MlpWgradW {
 // operand reads of a 16-feature tile hit 16 different bank quads: neither side conflicts.
 __global__ __launch_bounds__(512, 1) void k_mlp_wgrad(MlpWgradW w, const float* __restrict__ X, const float* __restrict__ dY,
                                                       float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2,
-                                                      float* __restrict__ db2, RowSegs rs, int nsplit, const uint32_t* __restrict__ meta) {
+                                                      float* __restrict__ db2, RowSegs rs, int nsplit, const uint32_t* __restrict__ meta,
+                                                      float* __restrict__ ws) {
   __shared__ __attribute__((aligned(16))) char rm[2][4][32 * WG_RM];     // [buffer][x hi, x lo, dy hi, dy lo]
   __shared__ __attribute__((aligned(16))) char tr[2][4][4 * WG_TG];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -533,6 +558,9 @@ __global__ __launch_bounds__(512, 1) void k_mlp_wgrad(MlpWgradW w, const float* 
   const int idx = blockIdx.x, xcd = idx & 7, kq = idx >> 3;
   const int slab = kq & 3, split = (kq >> 2) * 8 + xcd;
   if (split >= nsplit) return;
+  // with a workspace the (slab, split) block of dW1 / dW2 is STORED to the split's partial image [dW1 512 x 128 | dW2 128 x 512] and
+  // k_wgrad_reduce adds the splits up in a fixed order (64 splits x 4 slabs x 32 K float atomics were 84 of the 240 us of an encoder FFN's call)
+  float* wsp = ws ? ws + (size_t)split * (2 * RR_FF * RR_E) : nullptr;
   const long long total = (long long)rs.nseg * rs.seg_rows;
   const long long chunks = (total + 31) / 32;
   const long long cper = (chunks + nsplit - 1) / nsplit;
@@ -696,13 +724,20 @@ __global__ __launch_bounds__(512, 1) void k_mlp_wgrad(MlpWgradW w, const float* 
 #pragma unroll
     for (int h = 0; h < 16; ++h)
 #pragma unroll
-      for (int half = 0; half < 2; ++half)
-        atomicAdd(dW1 + (size_t)(16 * T0 + h) * RR_E + 64 * half + lane, ep[h * 132 + 64 * half + lane]);
+      for (int half = 0; half < 2; ++half) {
+        const size_t o = (size_t)(16 * T0 + h) * RR_E + 64 * half + lane;
+        if (wsp) wsp[o] = ep[h * 132 + 64 * half + lane];
+        else atomicAdd(dW1 + o, ep[h * 132 + 64 * half + lane]);
+      }
   }
 #pragma unroll
   for (int u = 0; u < 8; ++u)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(dW2 + (size_t)(16 * u + 4 * g + r) * RR_FF + 16 * T0 + j, aW2[u][r]);
+    for (int r = 0; r < 4; ++r) {
+      const size_t o = (size_t)(16 * u + 4 * g + r) * RR_FF + 16 * T0 + j;
+      if (wsp) wsp[RR_FF * RR_E + o] = aW2[u][r];
+      else atomicAdd(dW2 + o, aW2[u][r]);
+    }
   {
     float v = ab1;
     v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
@@ -714,9 +749,24 @@ __global__ __launch_bounds__(512, 1) void k_mlp_wgrad(MlpWgradW w, const float* 
   }
 }
 
-// dW1 [512][128], db1 [512], dW2 [128][512], db2 [128]: ADDED to (caller zeroes them).
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ ws, float* __restrict__ dW1, float* __restrict__ dW2, int nsplit) {
+  const int e = blockIdx.x * 256 + threadIdx.x;           // < 2 * 512 * 128
+  const float* src = ws + e;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int m = 0;
+  for (; m + 4 <= nsplit; m += 4) {
+    s0 += src[(size_t)m * (2 * RR_FF * RR_E)]; s1 += src[(size_t)(m + 1) * (2 * RR_FF * RR_E)];
+    s2 += src[(size_t)(m + 2) * (2 * RR_FF * RR_E)]; s3 += src[(size_t)(m + 3) * (2 * RR_FF * RR_E)];
+  }
+  for (; m < nsplit; ++m) s0 += src[(size_t)m * (2 * RR_FF * RR_E)];
+  float* dst = e < RR_FF * RR_E ? dW1 + e : dW2 + (e - RR_FF * RR_E);
+  *dst += (s0 + s1) + (s2 + s3);
+}
+
+// dW1 [512][128], db1 [512], dW2 [128][512], db2 [128]: ADDED to (caller zeroes them).  ws: NULL (float atomics) or 64 * 2 * 512 * 128
+// floats for the row splits' partials of dW1 / dW2 (added up in a fixed order).
 extern "C" int rr_mlp_wgrad(const MlpWgradW* w, const float* X, const float* dY, float* dW1, float* db1, float* dW2, float* db2,
-                            const uint32_t* meta, int nseg, int seg_rows, long long seg_stride, hipStream_t st) {
+                            const uint32_t* meta, int nseg, int seg_rows, long long seg_stride, float* ws, hipStream_t st) {
   if (w == nullptr || w->w1n == nullptr || w->w2tn == nullptr || w->b1 == nullptr || X == nullptr || dY == nullptr ||
       dW1 == nullptr || db1 == nullptr || dW2 == nullptr)
     return RR_EINVAL;
@@ -725,7 +775,8 @@ extern "C" int rr_mlp_wgrad(const MlpWgradW* w, const float* X, const float* dY,
   RowSegs rs{nseg, seg_rows, seg_stride};
   const long long chunks = ((long long)nseg * seg_rows + 31) / 32;
   int nsplit = chunks >= 64 * 8 ? 64 : (chunks >= 64 ? 16 : 8);
-  hipLaunchKernelGGL(k_mlp_wgrad, dim3(4 * nsplit), dim3(512), 0, st, *w, X, dY, dW1, db1, dW2, db2, rs, nsplit, meta);
+  hipLaunchKernelGGL(k_mlp_wgrad, dim3(4 * nsplit), dim3(512), 0, st, *w, X, dY, dW1, db1, dW2, db2, rs, nsplit, meta, ws);
+  if (ws != nullptr) hipLaunchKernelGGL(k_wgrad_reduce, dim3(2 * RR_FF * RR_E / 256), dim3(256), 0, st, ws, dW1, dW2, nsplit);
   return rr_check(hipGetLastError());
 }
 

@@ -143,9 +143,9 @@ _SIGS = {
     "rr_dec_fwd_big": [C.POINTER(DecBigIO), vp],
     "rr_select_big": [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, u64, u32, vp],
     "rr_dec_logit_bwd": [C.POINTER(DecLogitIO), vp],
-    "rr_gemm_tn": [vp, vp, vp, i32, i32, i32, i32, i32, i32, C.c_longlong, C.c_longlong, C.c_longlong, i32, i32, vp],
+    "rr_gemm_tn": [vp, vp, vp, i32, i32, i32, i32, i32, i32, C.c_longlong, C.c_longlong, C.c_longlong, i32, i32, vp, vp],
     "rr_mlp_rows": [C.POINTER(MlpRowsW), i32, vp, vp, vp, vp, i32, i32, C.c_longlong, vp],
-    "rr_mlp_wgrad": [C.POINTER(MlpWgradW), vp, vp, vp, vp, vp, vp, vp, i32, i32, C.c_longlong, vp],
+    "rr_mlp_wgrad": [C.POINTER(MlpWgradW), vp, vp, vp, vp, vp, vp, vp, i32, i32, C.c_longlong, vp, vp],
     "rr_dec_attn_bwd": [C.POINTER(DecAttnIO), vp],
 }
 

@@ -39,6 +39,19 @@ def mlp_train_pack(policy):
     return cached[1]
 
 
+_WGRAD_WS = {}
+
+
+def wgrad_workspace(dev) -> torch.Tensor:
+    """64 x (dW1 | dW2) partials of rr_mlp_wgrad's row splits (33.5 MB, one per device, reused by every call on the stream)."""
+    if os.environ.get("RR_TRAIN_WS", "1") == "0":          # diagnostic: float atomics instead of partials + reduction
+        return None
+    key = str(dev)
+    if key not in _WGRAD_WS:
+        _WGRAD_WS[key] = torch.empty(64 * 2 * 4 * E * E, device=dev)
+    return _WGRAD_WS[key]
+
+
 @torch.no_grad()
 def decoder_backward(policy, cache, dump, D, Dur, grad_ll) -> dict:
     """cache: PrecomputedCache of the forward; dump: what the rollout left (policy._fused_rollout); D / Dur: the normalised
@@ -77,7 +90,7 @@ def decoder_backward(policy, cache, dump, D, Dur, grad_ll) -> dict:
     L.check(lib.rr_dec_logit_bwd(io, st), "rr_dec_logit_bwd")
     # ---- d logit keys: dL[b] = dlg_b^T g_b (rows on the MFMA k axis)
     dL = torch.empty(Bp, N, E, device=dev)
-    L.check(lib.rr_gemm_tn(L.ptr(dlg), L.ptr(dump["g"]), L.ptr(dL), Bp, T * S, N, LDK, E, E, seg * LDK, seg * E, N * E, 1, 0, st),
+    L.check(lib.rr_gemm_tn(L.ptr(dlg), L.ptr(dump["g"]), L.ptr(dL), Bp, T * S, N, LDK, E, E, seg * LDK, seg * E, N * E, 1, 0, None, st),
             "rr_gemm_tn")
     del dlg
     # ---- pointer MLP: input gradient and weight gradients
@@ -89,7 +102,7 @@ def decoder_backward(policy, cache, dump, D, Dur, grad_ll) -> dict:
     dW1, db1 = torch.zeros(4 * E, E, device=dev), torch.zeros(4 * E, device=dev)
     dW2, db2 = torch.zeros(E, 4 * E, device=dev), torch.zeros(E, device=dev)
     L.check(lib.rr_mlp_wgrad(mp["wgrad"], L.ptr(dump["g0"]), L.ptr(dg), L.ptr(dW1), L.ptr(db1), L.ptr(dW2), L.ptr(db2),
-                             L.ptr(live), Bp, T * S, seg, st), "rr_mlp_wgrad")
+                             L.ptr(live), Bp, T * S, seg, L.ptr(wgrad_workspace(dev)), st), "rr_mlp_wgrad")
     del dg
     # ---- masked multi-head attention: d keys, d values, d query -> the step-context tables
     atsp = env_name == "atsp"

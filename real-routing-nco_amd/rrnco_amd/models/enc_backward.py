@@ -134,13 +134,16 @@ def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
     G = _Grads(P)
     new = lambda: torch.empty(Bp, N, E, device=dev)                                         # noqa: E731
     MS = 256                                                                                 # row splits of the weight-gradient products
+    from .dec_backward import wgrad_workspace
+    ws_wg = wgrad_workspace(dev)
+    ws_tn = torch.empty(MS * E * E, device=dev) if ws_wg is not None else None                                              # their partials (rr_gemm_tn reduces them in a fixed order)
 
     def lin(wp, x, out, acc=0, colsum=None):
         L.check(lib.rr_linear_rows(L.ptr(wp), None, L.ptr(x), L.ptr(out), M, acc, L.ptr(colsum), st), "rr_linear_rows")
 
     def wgrad(dy, x, gbuf, off=0, ldc=E):
         """gbuf (+ off floats) [128][ldc] += dy^T x"""
-        L.check(lib.rr_gemm_tn(L.ptr(dy), L.ptr(x), gbuf.data_ptr() + 4 * off, 1, M, E, E, E, ldc, 0, 0, 0, MS, 1, st), "rr_gemm_tn")
+        L.check(lib.rr_gemm_tn(L.ptr(dy), L.ptr(x), gbuf.data_ptr() + 4 * off, 1, M, E, E, E, ldc, 0, 0, 0, MS, 1, L.ptr(ws_tn), st), "rr_gemm_tn")
 
     def inorm(x, dy1, dy2, pname, dx, acc=0):
         L.check(lib.rr_inorm_bwd(L.ptr(x), L.ptr(dy1), L.ptr(dy2), L.ptr(P[pname + ".normalizer.weight"].detach()), L.ptr(dx),
@@ -187,7 +190,7 @@ def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
                 L.check(lib.rr_mlp_rows(mlp["bwd"], 1, L.ptr(S["x1"]), L.ptr(dF), L.ptr(dx1), None, 1, M, M, st), "rr_mlp_rows")
                 f = b + ".feed_forward.ops.ffn"
                 L.check(lib.rr_mlp_wgrad(mlp["wgrad"], L.ptr(S["x1"]), L.ptr(dF), L.ptr(G.buf(f + ".W1.weight")), L.ptr(G.buf(f + ".W1.bias")),
-                                         L.ptr(G.buf(f + ".W2.weight")), L.ptr(G.buf(f + ".W2.bias")), None, 1, M, M, st), "rr_mlp_wgrad")
+                                         L.ptr(G.buf(f + ".W2.weight")), L.ptr(G.buf(f + ".W2.bias")), None, 1, M, M, L.ptr(ws_wg), st), "rr_mlp_wgrad")
                 # x1 = ffn.norm1(r + norm3(o)) (:355, 436)
                 dU1 = dF                                                                  # reuse
                 inorm(S["u1"], dx1, None, b + ".feed_forward.ops.norm1", dU1)

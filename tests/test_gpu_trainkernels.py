@@ -66,8 +66,9 @@ def test_mlp_rows_forward_and_input_gradient(nseg, seg_rows, stride):
         assert bool((dX[gap] == 7.0).all()) and bool((out[gap] == 7.0).all())
 
 
+@pytest.mark.parametrize("use_ws", [False, True])
 @pytest.mark.parametrize("nseg,seg_rows,stride", [(1, 1000, 1000), (3, 300, 350), (4, 5000, 5000)])
-def test_mlp_weight_gradients(nseg, seg_rows, stride):
+def test_mlp_weight_gradients(nseg, seg_rows, stride, use_ws):
     from rrnco_amd import _lib as L, packing
     W1, b1, W2, b2 = _mlp_weights(3)
     mp = packing.pack_mlp_train(W1, b1, W2, b2)
@@ -76,8 +77,9 @@ def test_mlp_weight_gradients(nseg, seg_rows, stride):
     dY, _ = _seg_rows(nseg, seg_rows, stride, E, gen)
     dW1, db1 = torch.zeros(512, E, device="cuda"), torch.zeros(512, device="cuda")
     dW2, db2 = torch.zeros(E, 512, device="cuda"), torch.zeros(E, device="cuda")
+    ws = torch.empty(64 * 2 * 512 * E, device="cuda") if use_ws else None       # row splits' partials, reduced in a fixed order
     L.check(L.lib().rr_mlp_wgrad(mp["wgrad"], L.ptr(X), L.ptr(dY), L.ptr(dW1), L.ptr(db1), L.ptr(dW2), L.ptr(db2),
-                                 None, nseg, seg_rows, stride, L.stream()), "wgrad")
+                                 None, nseg, seg_rows, stride, L.ptr(ws), L.stream()), "wgrad")
     P = [t.double().requires_grad_() for t in (W1, b1, W2, b2)]
     y = F.linear(F.relu(F.linear(X[idx].double(), P[0], P[1])), P[2], P[3])
     y.backward(dY[idx].double())
@@ -85,8 +87,11 @@ def test_mlp_weight_gradients(nseg, seg_rows, stride):
         assert _rel(got, ref.grad) < 1e-4, (nm, _rel(got, ref.grad))
 
 
-@pytest.mark.parametrize("batch,M,P,msplit", [(3, 333, 100, 1), (2, 1000, 101, 1), (1, 5000, 384, 4), (1, 700, 512, 2), (1, 257, 128, 1)])
-def test_gemm_tn(batch, M, P, msplit):
+@pytest.mark.parametrize("use_ws", [False, True])
+@pytest.mark.parametrize("batch,M,P,msplit", [(3, 333, 100, 1), (2, 1000, 101, 1), (1, 5000, 384, 4), (1, 700, 512, 2), (1, 257, 128, 1),
+                                              (2, 3000, 128, 16)])
+def test_gemm_tn(batch, M, P, msplit, use_ws):
+    """msplit > 1: float atomics into C, or (use_ws) per-split partials reduced in a fixed order — then bit-reproducible."""
     from rrnco_amd import _lib as L
     gen = torch.Generator().manual_seed(5)
     lda = 112 if P <= 112 else P
@@ -94,9 +99,14 @@ def test_gemm_tn(batch, M, P, msplit):
     B = torch.randn(batch, M, E, generator=gen)
     A, B = A.cuda(), B.cuda()
     C = torch.zeros(batch, P, E, device="cuda")
-    L.check(L.lib().rr_gemm_tn(L.ptr(A), L.ptr(B), L.ptr(C), batch, M, P, lda, E, E, M * lda, M * E, P * E, msplit, 0, L.stream()), "gemm_tn")
+    ws = torch.empty(batch * msplit * P * 128, device="cuda") if use_ws else None
+    L.check(L.lib().rr_gemm_tn(L.ptr(A), L.ptr(B), L.ptr(C), batch, M, P, lda, E, E, M * lda, M * E, P * E, msplit, 0, L.ptr(ws), L.stream()), "gemm_tn")
     ref = torch.einsum("bmp,bmq->bpq", A[:, :, :P].double(), B.double())
     assert _rel(C, ref) < 2e-6
+    if use_ws and msplit > 1:
+        C2 = torch.full_like(C, 7.0)          # (accumulate = 0: the reduction overwrites)
+        L.check(L.lib().rr_gemm_tn(L.ptr(A), L.ptr(B), L.ptr(C2), batch, M, P, lda, E, E, M * lda, M * E, P * E, msplit, 0, L.ptr(ws), L.stream()), "gemm_tn")
+        assert torch.equal(C, C2)
 
 
 def _ref_decoder_ll(K, V, Lk, ctxA, ctxB, W1, b1, W2, b2, alpha, D, actions, tanh_clip=10.0, temp=1.0):
