@@ -147,7 +147,8 @@ class RMTVRPEnv(EnvBase):
         limit = torch.full_like(ones, float("inf")) if limit is None else limit.float().reshape(-1, 1)
         open_route = td.get("open_route", None)
         open_route = torch.zeros_like(ones, dtype=torch.bool) if open_route is None else open_route.bool().reshape(-1, 1)
-        variant = bool((db != 0).any() or open_route.any() or torch.isfinite(limit).any() or (bclass != 1).any())
+        # (one host read instead of four: the rollout's instantiation is chosen from the instance data)
+        variant = bool(torch.stack([(db != 0).any(), open_route.any(), torch.isfinite(limit).any(), (bclass != 1).any()]).any())
         tw = td.get("time_windows", None)
         if tw is None:
             tw = torch.zeros_like(td["locs"]); tw[..., 1] = float("inf")
