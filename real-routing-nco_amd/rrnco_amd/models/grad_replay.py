@@ -550,15 +550,25 @@ def decode_log_likelihood_rcvrptw(P, row_emb, col_emb, D, Dur, demand_l, tw, ser
 def params_and_buffers(policy, bn_momentum=0.0):
     """named_parameters, plus — for normalization='batch' in train mode — the BatchNorm buffers and the momentum `_inorm` applies."""
     P = dict(policy.named_parameters())
-    if any(k.endswith(".normalizer.running_mean") for k in policy.state_dict()):
+    if _has_running_stats(policy):
         P.update({k: v for k, v in policy.named_buffers() if ".normalizer." in k})
         P["__bn_momentum__"] = bn_momentum if policy.training else 0.0
         P["__bn_train__"] = bool(policy.training)      # eval mode: gradients of the running-statistics network the kernels ran
     return P
 
 
+def _has_running_stats(policy) -> bool:
+    """normalization='batch' modules carry running statistics; a structural fact, looked up once per policy (state_dict() detaches
+    every parameter: ~470 views per call, several calls per training step)."""
+    flag = getattr(policy, "_has_bn_buffers", None)
+    if flag is None:
+        flag = any(k.endswith(".normalizer.running_mean") for k, _ in policy.named_buffers())
+        policy._has_bn_buffers = flag
+    return flag
+
+
 def uses_batch_statistics(policy) -> bool:
-    return policy.training and any(k.endswith(".normalizer.running_mean") for k in policy.state_dict())
+    return policy.training and _has_running_stats(policy)
 
 
 def encode_for_policy(policy, td, sample_idx, bn_momentum=0.0):

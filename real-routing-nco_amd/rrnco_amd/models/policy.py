@@ -40,13 +40,35 @@ class RRNetPolicy(nn.Module):
     # ---- packed (MFMA-ordered / folded) weights, rebuilt when any parameter changes (versions + packing.weights_fingerprint)
     def invalidate_pack(self) -> None:
         self._pack_cache = None
+        self._pack_verified = False
         self._mlp_train_pack = None          # (models/dec_backward.py: the pointer MLP's training packs follow the same rule)
+
+    def pack_scope(self):
+        """Context: the weights do not change inside (one training step up to its optimizer step) — packed() verifies once."""
+        pol = self
+
+        class _Scope:
+            def __enter__(self_):
+                pol._pack_scope, pol._pack_verified = True, False
+
+            def __exit__(self_, *exc):
+                pol._pack_scope, pol._pack_verified = False, False
+                return False
+        return _Scope()
 
     def train(self, mode: bool = True):
         self._pack_dirty = True          # any train() / eval() switch: re-check the weights' fingerprint once (see packed())
+        self._pack_verified = False
         return super().train(mode)
 
     def packed(self, device):
+        # Inside RRNet.training_step (pack_scope) the pack is checked ONCE per step: the first packed() verifies (fingerprint: one host
+        # read, ~470 detached views) or rebuilds, the others — the encoder, the decoder backward, the encoder backward — take the
+        # cache.  Outside such a scope every call verifies, as before.
+        if getattr(self, "_pack_scope", False) and getattr(self, "_pack_verified", False) and self._pack_cache is not None \
+                and self._pack_cache[0][0] == str(device) \
+                and self._pack_cache[0][1] == packing.mlp_split_enabled():
+            return self._pack_cache[1]
         # buffers too: BatchNorm running statistics are folded into the pack (packing.py), and a buffer-only load must repack
         ts = list(self.parameters()) + list(self.buffers())
         key = (str(device), packing.mlp_split_enabled(), tuple(p._version for p in ts), tuple(p.data_ptr() for p in ts))
@@ -63,6 +85,7 @@ class RRNetPolicy(nn.Module):
             if not dirty:
                 key = key[:4] + (packing.weights_fingerprint(self),)
             self._pack_cache = (key, packing.pack_policy(self.state_dict(), self.env_name, device))
+        self._pack_verified = True
         return self._pack_cache[1]
 
     def forward(self, td, env=None, phase="train", *args, capture=None, **kwargs) -> dict:
@@ -178,6 +201,7 @@ class RRNetPolicy(nn.Module):
             row_emb, col_emb = GR.encode_for_policy(self, td, td["sample_idx"], bn_momentum=0.1)
             row_emb, col_emb = row_emb.contiguous(), col_emb.contiguous()
             self._pack_dirty = True
+            self._pack_verified = False      # (the running statistics just moved)
         else:
             row_emb, col_emb = self.encoder(td, phase=phase, packed=packed, train_saves=saves)
         if capture is not None:

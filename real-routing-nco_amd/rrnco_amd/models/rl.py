@@ -69,6 +69,10 @@ class RRNet:
         sidx = td["sample_idx"]
         n_start = self.env.get_num_starts(td) if self.num_starts is None else self.num_starts
         cap = {} if replay == "hip" else None
+        with self.policy.pack_scope():      # forward and backward of this step see the same weights: one pack verification
+            return self._training_step_body(td, state, sidx, n_start, cap, optimizer, world, enc_chunk, dec_chunk, grad_clip, policy_kw)
+
+    def _training_step_body(self, td, state, sidx, n_start, cap, optimizer, world, enc_chunk, dec_chunk, grad_clip, policy_kw) -> dict:
         out = self.policy(td, self.env, phase="train", num_starts=n_start, capture=cap, **policy_kw)
         r = out["normalized_reward"] if self.env.normalize else out["reward"]
         out.update(reinforce_loss(r, out["log_likelihood"], n_start))

@@ -31,6 +31,8 @@ def allreduce_flat_gradients(grads, world: int):
     without a gradient (decoder.pointer.project_out, decoder.project_fixed_context, W_placeholder under multistart:
     SURVEY App. D-9) take part as zeros so that every rank reduces the same layout."""
     import torch.distributed as dist
+    if world <= 1:          # nothing to combine: no flat copy, no ~1 400 view / slice ops on the host
+        return list(grads)
     flat = torch.cat([g.reshape(-1).float() for g in grads])
     if world > 1:
         if flat.is_cuda and dist.get_backend() != "nccl":      # gloo (ranks sharing a GPU in the tests): through the host
