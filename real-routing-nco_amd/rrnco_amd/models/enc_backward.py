@@ -26,7 +26,7 @@ def train_packs(policy) -> dict:
     cached = getattr(policy, "_enc_train_pack", None)
     if cached is not None and cached[0] == key:
         return cached[1]
-    sd = {k: v.detach() for k, v in policy.named_parameters()}
+    sd = dict(policy.named_parameters())          # (used under no_grad below: no ~470 detached views per step)
     nl = 1 + max(int(n.split(".")[3]) for n in sd if n.startswith("encoder.net.layers."))
     keep, blocks = [], []
     with torch.no_grad():
@@ -95,16 +95,15 @@ class _Grads:
 
     def __init__(self, P):
         self.P, self.g = P, {}
-        self.off, n = {}, 0
-        for k, p in P.items():                      # one zero-filled flat buffer (one memset), views per parameter
-            self.off[k] = n
-            n += (p.numel() + 3) // 4 * 4           # 16-byte aligned views (float4 stores / atomics on rows)
-        self.flat = torch.zeros(n, dtype=torch.float32, device=next(iter(P.values())).device)
+        sizes = [(p.numel() + 3) // 4 * 4 for p in P.values()]      # 16-byte aligned views (float4 stores / atomics on rows)
+        self.flat = torch.zeros(sum(sizes), dtype=torch.float32, device=next(iter(P.values())).device)   # one memset
+        self.chunks = dict(zip(P.keys(), self.flat.split(sizes)))   # one op for all the views
 
     def buf(self, name):
         if name not in self.g:
             p = self.P[name]
-            self.g[name] = self.flat[self.off[name]:self.off[name] + p.numel()].view(p.shape)
+            c = self.chunks[name]
+            self.g[name] = (c if c.numel() == p.numel() else c[:p.numel()]).view(p.shape)
         return self.g[name]
 
     def flush(self):

@@ -84,7 +84,10 @@ class RRNetPolicy(nn.Module):
         if self._pack_cache is None or self._pack_cache[0] != key:
             if not dirty:
                 key = key[:4] + (packing.weights_fingerprint(self),)
-            self._pack_cache = (key, packing.pack_policy(self.state_dict(), self.env_name, device))
+            # (names -> tensors like state_dict(), without its ~470 detached views: this runs once per training step)
+            sd = dict(self.named_parameters())
+            sd.update(self.named_buffers())
+            self._pack_cache = (key, packing.pack_policy(sd, self.env_name, device))
         self._pack_verified = True
         return self._pack_cache[1]
 

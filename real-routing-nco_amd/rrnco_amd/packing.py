@@ -495,7 +495,7 @@ class _Arena:
 
 
 def pack_policy(sd: dict, env_name: str, device) -> dict:
-    with _few_threads():
+    with _few_threads(), torch.no_grad():          # (sd may hold the Parameters themselves: no graph is wanted here)
         return _pack_policy(sd, env_name, device)
 
 
