@@ -19,81 +19,57 @@
 // y = gamma * (x - mean) * rstd + beta over the node axis, per instance and feature (biased variance, eps 1e-5).
 // dx = gamma rstd (dy - mean_n(dy) - xhat mean_n(dy xhat)); dgamma += sum dy xhat; dbeta += sum dy.
 // dy = dy1 (+ dy2).  `accumulate`: dx is added to what dx_out holds.
-// One workgroup per instance; thread = (feature group of 4, node residue mod 8): 16-byte loads (a wave-instruction moves 1 KB;
-// with 4-byte loads it moved 256 B and the kernel ran at 1.6 TB/s), the instance's values stay in registers between the passes.
 __global__ __launch_bounds__(256) void k_inorm_bwd(const float* __restrict__ x, const float* __restrict__ dy1, const float* __restrict__ dy2,
                                                    const float* __restrict__ gamma, float* __restrict__ dx_out,
                                                    float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int accumulate) {
-  __shared__ __attribute__((aligned(16))) float red[3][8][RR_E];
-  const int b = blockIdx.x, tid = threadIdx.x, fg = tid & 31, ng = tid >> 5;      // features 4 fg .. 4 fg + 3, nodes ng, ng + 8, ...
-  const size_t base = (size_t)b * N * RR_E + 4 * fg;
-  constexpr int MAXR = 14;               // nodes per thread (N <= 112)
-  float4 xv[MAXR], dv[MAXR];
-  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  __shared__ float red[3][256];
+  const int b = blockIdx.x, tid = threadIdx.x, f = tid & 127, half = tid >> 7;
+  const size_t base = (size_t)b * N * RR_E + f;
+  constexpr int MAXR = 56;               // nodes per thread (N <= 112)
+  float xv[MAXR], dv[MAXR];
+  float s0 = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXR; ++i) {
-    const int n = 8 * i + ng;
+    const int n = 2 * i + half;
     if (n < N) {
-      xv[i] = rr_ld4(x + base + (size_t)n * RR_E);
-      float4 d = rr_ld4(dy1 + base + (size_t)n * RR_E);
-      if (dy2) { const float4 e = rr_ld4(dy2 + base + (size_t)n * RR_E); d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w; }
-      dv[i] = d;
-      s0.x += xv[i].x; s0.y += xv[i].y; s0.z += xv[i].z; s0.w += xv[i].w;
-    } else { xv[i] = z4; dv[i] = z4; }
+      xv[i] = x[base + (size_t)n * RR_E];
+      dv[i] = dy1[base + (size_t)n * RR_E] + (dy2 ? dy2[base + (size_t)n * RR_E] : 0.f);
+      s0 += xv[i];
+    } else { xv[i] = 0.f; dv[i] = 0.f; }
   }
-  rr_st4(&red[0][ng][4 * fg], s0);
+  red[0][tid] = s0;
   __syncthreads();
   const float inv_n = 1.0f / (float)N;
-  auto fold = [&](int k) {               // the eight node residues in a fixed order
-    float4 a = rr_ld4(&red[k][0][4 * fg]);
-#pragma unroll
-    for (int r = 1; r < 8; ++r) { const float4 o = rr_ld4(&red[k][r][4 * fg]); a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
-    return a;
-  };
-  float4 mean = fold(0);
-  mean.x *= inv_n; mean.y *= inv_n; mean.z *= inv_n; mean.w *= inv_n;
-  float4 q = z4, s1 = z4, s2 = z4;
+  const float mean = (red[0][f] + red[0][128 + f]) * inv_n;
+  float q = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXR; ++i) {
-    const bool ok = 8 * i + ng < N;
-    float4 d = make_float4(xv[i].x - mean.x, xv[i].y - mean.y, xv[i].z - mean.z, xv[i].w - mean.w);
-    if (!ok) d = z4;
+    const int n = 2 * i + half;
+    const float d = n < N ? xv[i] - mean : 0.f;
     xv[i] = d;
-    q.x = fmaf(d.x, d.x, q.x); q.y = fmaf(d.y, d.y, q.y); q.z = fmaf(d.z, d.z, q.z); q.w = fmaf(d.w, d.w, q.w);
-    s1.x += dv[i].x; s1.y += dv[i].y; s1.z += dv[i].z; s1.w += dv[i].w;
-    s2.x = fmaf(dv[i].x, d.x, s2.x); s2.y = fmaf(dv[i].y, d.y, s2.y); s2.z = fmaf(dv[i].z, d.z, s2.z); s2.w = fmaf(dv[i].w, d.w, s2.w);
+    q = fmaf(d, d, q); s1 += dv[i]; s2 = fmaf(dv[i], d, s2);
   }
   __syncthreads();
-  rr_st4(&red[0][ng][4 * fg], q); rr_st4(&red[1][ng][4 * fg], s1); rr_st4(&red[2][ng][4 * fg], s2);
+  red[0][tid] = q; red[1][tid] = s1; red[2][tid] = s2;
   __syncthreads();
-  const float4 var = fold(0), t1 = fold(1), t2r = fold(2);
-  const float4 gm = rr_ld4(gamma + 4 * fg);
-  const float rs[4] = {1.0f / sqrtf(var.x * inv_n + 1e-5f), 1.0f / sqrtf(var.y * inv_n + 1e-5f), 1.0f / sqrtf(var.z * inv_n + 1e-5f),
-                       1.0f / sqrtf(var.w * inv_n + 1e-5f)};
-  const float t2[4] = {t2r.x * rs[0], t2r.y * rs[1], t2r.z * rs[2], t2r.w * rs[3]};        // sum dy xhat
-  const float m1[4] = {t1.x * inv_n, t1.y * inv_n, t1.z * inv_n, t1.w * inv_n};
-  const float m2[4] = {t2[0] * inv_n, t2[1] * inv_n, t2[2] * inv_n, t2[3] * inv_n};
-  const float gv[4] = {gm.x * rs[0], gm.y * rs[1], gm.z * rs[2], gm.w * rs[3]};
+  const float var = (red[0][f] + red[0][128 + f]) * inv_n;
+  const float rstd = 1.0f / sqrtf(var + 1e-5f);
+  const float t1 = (red[1][f] + red[1][128 + f]);
+  const float t2 = (red[2][f] + red[2][128 + f]) * rstd;             // sum dy xhat
+  const float gm = gamma[f];
+  const float m1 = t1 * inv_n, m2 = t2 * inv_n;
 #pragma unroll
   for (int i = 0; i < MAXR; ++i) {
-    const int n = 8 * i + ng;
+    const int n = 2 * i + half;
     if (n < N) {
-      float4 v;
-      v.x = gv[0] * (dv[i].x - m1[0] - xv[i].x * rs[0] * m2[0]);
-      v.y = gv[1] * (dv[i].y - m1[1] - xv[i].y * rs[1] * m2[1]);
-      v.z = gv[2] * (dv[i].z - m1[2] - xv[i].z * rs[2] * m2[2]);
-      v.w = gv[3] * (dv[i].w - m1[3] - xv[i].w * rs[3] * m2[3]);
+      const float xh = xv[i] * rstd;
+      float v = gm * rstd * (dv[i] - m1 - xh * m2);
       float* dst = dx_out + base + (size_t)n * RR_E;
-      if (accumulate) { const float4 o = rr_ld4(dst); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-      rr_st4(dst, v);
+      if (accumulate) v += *dst;
+      *dst = v;
     }
   }
-  if (ng == 0) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { atomicAdd(dgamma + 4 * fg + r, t2[r]); }
-    atomicAdd(dbeta + 4 * fg + 0, t1.x); atomicAdd(dbeta + 4 * fg + 1, t1.y); atomicAdd(dbeta + 4 * fg + 2, t1.z); atomicAdd(dbeta + 4 * fg + 3, t1.w);
-  }
+  if (half == 0) { atomicAdd(dgamma + f, t2); atomicAdd(dbeta + f, t1); }
 }
 
 extern "C" int rr_inorm_bwd(const float* x, const float* dy1, const float* dy2, const float* gamma, float* dx, float* dgamma,
