@@ -107,6 +107,35 @@ def test_fused_optimizer_updates_are_seen_by_the_pack_cache():
     assert float(same.float().mean()) > 0.9
 
 
+def test_pack_scope_verifies_once_per_step_and_expires():
+    """RRNet.training_step checks the weight pack once (RRNetPolicy.pack_scope: forward and backward of one step see the same
+    weights); outside a scope every packed() call verifies again, so an in-place update that bumps no version counter is seen."""
+    from rrnco_amd import packing
+    fx = H.load_fixture("atsp_n20_b4_pomo")
+    w, pol, model, st, td_in = _model(fx)
+    dev = torch.device("cuda")
+    calls = {"n": 0}
+    real = packing.weights_fingerprint
+
+    def counting(module):
+        calls["n"] += 1
+        return real(module)
+    packing.weights_fingerprint = counting
+    try:
+        model.training_step(td_in, seed=3)                 # forward + decoder backward + encoder backward: several packed() calls
+        assert calls["n"] == 1
+        p0 = pol.packed(dev)
+        assert calls["n"] == 2 and getattr(pol, "_pack_scope", False) is False
+        with torch.no_grad():                              # what a fused optimizer does: new values, same version counter
+            q = pol.decoder.pointer.ffn.lins[0].weight
+            v = q._version
+            q.data.mul_(1.5)
+            assert q._version == v
+        assert pol.packed(dev) is not p0                   # outside a scope: verified, rebuilt
+    finally:
+        packing.weights_fingerprint = real
+
+
 def test_nab_training_kernels_match_the_torch_formula():
     """csrc/rr_train.hip: forward value and d loss / d (folded table) of the gating NAB against the same formula in torch ops."""
     from rrnco_amd import _lib as L
