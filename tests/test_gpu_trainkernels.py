@@ -175,6 +175,40 @@ def test_decoder_backward_matches_autograd_on_the_rollouts_own_cache(name):
         assert _rel(got, ref) < tol, (nm, _rel(got, ref))
 
 
+@pytest.mark.parametrize("B,N,S", [(3, 5, 5), (2, 17, 17), (2, 33, 20), (1, 18, 3)])
+def test_decoder_backward_on_odd_shapes(B, N, S):
+    """The row tilings of the backward kernels at their edges: fewer decode steps than a tile (N = 5: only left-over tiles), exactly
+    one full tile per rollout (N = 17: T = 16, nothing left over), fewer rollouts than a tile, a ragged last tile."""
+    from rrnco_amd import TensorDict
+    from rrnco_amd.envs import ATSPEnv
+    from rrnco_amd.models import RRNetPolicy, dec_backward
+    torch.manual_seed(100 + N)
+    pol = RRNetPolicy(env_name="atsp", embed_dim=128, num_heads=8, num_encoder_layers=2, normalization="instance",
+                      use_graph_context=False, nab_type="gating", init_embedding_kwargs=dict(sample_size=min(25, N - 1))).cuda().train()
+    env = ATSPEnv(generator_params=dict(num_loc=N, device="cuda"), check_solution=True, device="cuda")
+    td = env.reset(env.generator(B, generator=torch.Generator(device="cuda").manual_seed(N)))
+    D = td["distance_matrix"].contiguous()
+    cap = {}
+    with torch.no_grad():
+        out = pol(td, env, phase="train", decode_type="multistart_sampling", num_starts=S, seed=5, capture=cap)
+    cache, dump = cap["cache"], cap["dump"]
+    gll = torch.randn(S * B, generator=torch.Generator().manual_seed(3)).cuda() / (S * B)
+    res = dec_backward.decoder_backward(pol, cache, dump, D, None, gll)
+    assert torch.allclose(res["log_likelihood"], out["log_likelihood"], rtol=1e-5, atol=2e-4)
+    P = dict(pol.named_parameters())
+    leaves = [cache.glimpse_key, cache.glimpse_val, cache.logit_key, cache.ctx_a, cache.ctx_b,
+              P["decoder.pointer.ffn.lins.0.weight"], P["decoder.pointer.ffn.lins.0.bias"],
+              P["decoder.pointer.ffn.lins.1.weight"], P["decoder.pointer.ffn.lins.1.bias"], P["decoder.alpha"]]
+    leaves = [t.detach().double().contiguous().requires_grad_() for t in leaves]
+    acts = out["actions"].view(S, B, N).transpose(0, 1)
+    ll = _ref_decoder_ll(*leaves, D.double(), acts)
+    ll.backward(gll.double().view(S, B).t())
+    for nm, leaf in zip(["dK", "dV", "dL", "dctxA", "dctxB", "dW1", "db1", "dW2", "db2", "dalpha"], leaves):
+        got, ref = res[nm].reshape(leaf.grad.shape), leaf.grad
+        tol = 1e-2 if nm in ("dW1", "db1") else 2e-3
+        assert _rel(got, ref) < tol, (nm, _rel(got, ref))
+
+
 # ---------------------------------------------------------------- encoder block backward (csrc/rr_train_enc.hip)
 @pytest.mark.parametrize("B,N", [(3, 20), (2, 100), (2, 101)])
 def test_instance_norm_backward(B, N):
