@@ -174,6 +174,8 @@ class RRNetPolicy(nn.Module):
         pend = getattr(self, "_range_pending", None)
         if pend is None:
             return
+        if pend.is_cuda and torch.cuda.is_current_stream_capturing():
+            return          # inside a hipGraph capture nothing may be read back: the word stays pending (the captured calls still NaN-mark)
         self._range_pending = None
         flags = int(pend.item())
         self.last_range_flags = flags
