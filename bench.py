@@ -60,6 +60,31 @@ def rollout_source_hash():
     return h.hexdigest()[:16]
 
 
+ENCODER_SOURCES = ("rr_encoder.hip", "rr_enc_w.inc", "rr_common.h", "rr_gemm_f16.h")
+ENCODER_LAYER_KERNELS = ("k_enc_block_w<7, true, false>", "k_enc_ffn<7>")      # one encoder layer at the headline shape = these two launches
+
+
+def encoder_source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for f in ENCODER_SOURCES:
+        with open(os.path.join(ROOT, "real-routing-nco_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def measured_encoder_traffic(batch):
+    """HBM-side bytes of one encoder layer (block kernel + FFN kernel) from the same PMC summary, or None."""
+    try:
+        with open(TRAFFIC_FILE) as fh:
+            rec = json.load(fh).get("encoder")
+    except (OSError, ValueError):
+        return None
+    if not rec or rec.get("source_hash") != encoder_source_hash() or rec.get("batch") != batch:
+        return None
+    return sum((2 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0 for k in rec["kernels"].values())
+
+
 def measured_rollout_traffic(batch):
     """-> (bytes per launch or None, provenance string)."""
     try:
@@ -403,7 +428,10 @@ def main():
                          "algorithmic_flop_per_launch": rollout_steps * FLOP_PER_ROLLOUT_STEP},
             "roofline_encoder": {"bound": "mfma", "kernel": ENC_KERNEL + " (one launch = the row and the column AttnFree_Block of a layer)",
                                  "achieved": enc_ach, "peak": peak_split, "unit": "TFLOP/s", "frac": enc_ach / peak_split if peak_split else 0.0,
-                                 "kernel_ms": enc_ms, "launches_per_step": enc_calls / max(args.steps, 1), "traffic": None,
+                                 "kernel_ms": enc_ms, "launches_per_step": enc_calls / max(args.steps, 1),
+                                 "traffic": measured_encoder_traffic(local_batch),
+                                 "traffic_note": "HBM-side bytes of one layer (block kernel + FFN kernel), same PMC passes as the rollout's; "
+                                                 "null: the committed summary is of other encoder sources",
                                  "algorithmic_flop_per_launch": 2 * ENC_BLOCK_FLOP * local_batch * AUG,
                                  "init_embed_ms": init_ms, "dec_cache_ms": cache_ms},
             "mean_best_cost": float(-best.mean().item()),
