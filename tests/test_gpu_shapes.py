@@ -240,19 +240,21 @@ def _run_vrp(problem, N, B, S, ss, seed, layers=2):
     td = TensorDict({k: v.cuda() for k, v in inst.items()}, batch_size=[B])
     td["sample_idx"] = sidx.cuda()
     outs = [pol(env.reset(td), env, phase="val", decode_type="multistart_greedy", num_starts=S, fused=f) for f in (True, False)]
-    T2 = min(outs[0]["actions"].shape[1], outs[1]["actions"].shape[1])            # fused ~ step-wise (see _run)
-    assert float((outs[0]["actions"][:, :T2] == outs[1]["actions"][:, :T2]).all(1).float().mean()) >= 0.98
-    acts = outs[0]["actions"].cpu()
-    assert bool((acts.sort(1).values[:, -N:] == torch.arange(1, N + 1)).all())     # every customer exactly once
-    T = min(acts.shape[1], ref["actions"].shape[1])
-    frac, first = H.tour_agreement(acts[:, :T], ref["actions"][:, :T])
-    if frac < 1.0:
-        lp = torch.nan_to_num(torch.stack(tr["logp"], 1), neginf=-1e9).topk(2, -1).values
-        gap = lp[..., 0] - lp[..., 1]
+    # fused ~ step-wise (see _run): the two paths round differently, so a near-tie of the oracle may fall either way in each — both
+    # are held to the oracle below (a fuzzed case had five rollouts of one instance share a 1.3e-5 tie: 96 % between the paths)
+    T2 = min(outs[0]["actions"].shape[1], outs[1]["actions"].shape[1])
+    assert float((outs[0]["actions"][:, :T2] == outs[1]["actions"][:, :T2]).all(1).float().mean()) >= 0.9
+    lp = torch.nan_to_num(torch.stack(tr["logp"], 1), neginf=-1e9).topk(2, -1).values
+    gap = lp[..., 0] - lp[..., 1]
+    for o in reversed(outs):                                                       # (ends on the fused call: `first` is used below)
+        acts = o["actions"].cpu()
+        assert bool((acts.sort(1).values[:, -N:] == torch.arange(1, N + 1)).all())     # every customer exactly once
+        T = min(acts.shape[1], ref["actions"].shape[1])
+        frac, first = H.tour_agreement(acts[:, :T], ref["actions"][:, :T])
         for r in torch.nonzero(first >= 0).flatten().tolist():
             t = int(first[r]) - 1
             assert t >= gap.shape[1] or gap[r, t] < 1e-3
-    assert frac >= 0.95
+        assert frac >= 0.95
     same = first < 0
     assert torch.allclose(outs[0]["reward"].cpu()[same], ref["reward"][same], atol=1e-4)
     assert torch.allclose(outs[0]["log_likelihood"].cpu()[same], ref["log_likelihood"][same], rtol=2e-5, atol=4e-3)
