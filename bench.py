@@ -194,15 +194,17 @@ class kernel_timers:
 
 
 def timed_loop(step, min_seconds=1.0, min_steps=2, max_steps=200):
-    """Runs step() until at least min_seconds have passed; -> (seconds per step, steps)."""
+    """Times step() over >= min_seconds WITHOUT a synchronisation between the steps (two probing steps size the loop; the host
+    runs ahead of the device exactly as in the headline loop); -> (seconds per step, steps)."""
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n = 0
-    while True:
+    step(); step()
+    torch.cuda.synchronize()
+    est = max((time.perf_counter() - t0) / 2, 1e-4)
+    n = int(min(max_steps, max(min_steps, -(-min_seconds // est))))
+    t0 = time.perf_counter()
+    for _ in range(n):
         step()
-        n += 1
-        if n >= min_steps and (n >= max_steps or (n % 2 == 0 and (torch.cuda.synchronize() or True) and time.perf_counter() - t0 >= min_seconds)):
-            break
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n, n
 
@@ -280,15 +282,19 @@ def other_configs(dev):
     train_step()
     bw = ("rr_dec_attn_bwd", "rr_mlp_wgrad", "rr_mlp_rows", "rr_dec_logit_bwd", "rr_gemm_tn", "rr_linear_rows", "rr_aft_bwd",
           "rr_inorm_bwd", "rr_nab_hist_bwd", "rr_enc_layer_train")
-    with kernel_timers(*bw) as kt:
+    sec, n = timed_loop(train_step)                     # the step's wall clock, nothing wrapped around its launchers
+    with kernel_timers(*bw) as kt:                      # then a few steps with HIP events around the backward's launchers (~3 ms per step of host work)
         R.TIMING = []
-        sec, n = timed_loop(train_step)
+        nk = 4
+        for _ in range(nk):
+            train_step()
+        torch.cuda.synchronize()
         ks = [a.elapsed_time(b) for a, b in R.TIMING]
         R.TIMING = None
-        per_step = {k: kt.ms(k)[0] * kt.ms(k)[1] / n for k in bw}
+        per_step = {k: kt.ms(k)[0] * kt.ms(k)[1] / nk for k in bw}
     dom = max(per_step, key=per_step.get)
     rows = 512 * STARTS * (N_NODES - 2)                  # decoder evaluations of the step (the forced last move is not evaluated)
-    roof = {"bound": "mfma", "kernel": dom, "kernel_ms_per_step": per_step[dom], "calls_per_step": kt.ms(dom)[1] / n, "traffic": None}
+    roof = {"bound": "mfma", "kernel": dom, "kernel_ms_per_step": per_step[dom], "calls_per_step": kt.ms(dom)[1] / nk, "traffic": None}
     if dom == "rr_dec_attn_bwd":
         # masked 8-head glimpse backward per decoder evaluation: recomputed scores, dP, dQ, dK, dV = 5 products of 2 N E flop
         fl = rows * 5 * 2 * N_NODES * 128
