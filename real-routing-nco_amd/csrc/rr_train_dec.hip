@@ -817,23 +817,9 @@ __device__ __forceinline__ f32x4 td_mfma16(rr_bf16x4 a, rr_bf16x4 b, f32x4 c) {
 // against these 12.  Leading s_nop: an operand may come straight from a transcendental; trailing s_nop 1: the pieces feed a
 // matrix instruction, and hipcc does not see the vector writes inside the block — profiles/r03/NOTES.md §2.)
 __device__ __forceinline__ void td_split4(const float (&x)[4], rr_bf16x4& hi, rr_bf16x4& lo) {
-#ifdef TD_SPLIT_C
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const rr_f32x2 v = {x[2 * q], x[2 * q + 1]};
-    const rr_bf16x2 h = __builtin_convertvector(v, rr_bf16x2);
-    const rr_f32x2 r1 = v - __builtin_convertvector(h, rr_f32x2);
-    const rr_bf16x2 l = __builtin_convertvector(r1, rr_bf16x2);
-    hi[2 * q] = h[0]; hi[2 * q + 1] = h[1]; lo[2 * q] = l[0]; lo[2 * q + 1] = l[1];
-  }
-  return;
-#endif
   uint32_t h01, h23, l01, l23;
   float t0, t1, t2, t3;
-#ifndef TD_NOP
-#define TD_NOP "0"
-#endif
-  asm("s_nop " TD_NOP "\n\t"
+  asm("s_nop 0\n\t"
       "v_cvt_pk_bf16_f32 %0, %8, %9\n\t"
       "v_cvt_pk_bf16_f32 %1, %10, %11\n\t"
       "v_lshlrev_b32 %4, 16, %0\n\t"
