@@ -318,21 +318,30 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const float* __restrict__ A,
 
 // C[b][p][q] = (accumulate ? C : 0) + sum over the msplit partials, in a fixed order.  The chip retires ~1e11 global float atomics
 // per second: 256 row splits of a 128 x 128 block are 4.2 M of them, 42 of the 50 us such a product took with the atomic epilogue.
-__global__ __launch_bounds__(256) void k_split_reduce(const float* __restrict__ ws, float* __restrict__ C, int P, int ldc, long long sC,
-                                                      int msplit, int accumulate) {
-  const int e = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-  if (e >= P * 128) return;
-  const int p = e >> 7, q = e & 127;
-  const float* src = ws + (size_t)b * msplit * P * 128 + e;
+__global__ __launch_bounds__(1024) void k_split_reduce(const float* __restrict__ ws, float* __restrict__ C, int P, int ldc, long long sC,
+                                                       int msplit, int accumulate) {
+  // 256 elements per workgroup, FOUR threads per element (a quarter of the splits each, then a fixed-order sum through LDS): with one
+  // thread per element the 64 workgroups of a 128 x 128 block had too few loads in flight (16 MB in 19 us)
+  __shared__ float part[4][256];
+  const int el = threadIdx.x & 255, qd = threadIdx.x >> 8;
+  const int e = blockIdx.x * 256 + el, b = blockIdx.y;
+  const bool ok = e < P * 128;
+  const int per = (msplit + 3) >> 2, m0 = qd * per, m1 = min(m0 + per, msplit);
+  const float* src = ws + (size_t)b * msplit * P * 128 + (ok ? e : 0);
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int m = 0;
-  for (; m + 4 <= msplit; m += 4) {
+  int m = m0;
+  for (; m + 4 <= m1; m += 4) {
     s0 += src[(size_t)m * P * 128]; s1 += src[(size_t)(m + 1) * P * 128]; s2 += src[(size_t)(m + 2) * P * 128]; s3 += src[(size_t)(m + 3) * P * 128];
   }
-  for (; m < msplit; ++m) s0 += src[(size_t)m * P * 128];
-  float* dst = C + (size_t)b * sC + (size_t)p * ldc + q;
-  const float tot = (s0 + s1) + (s2 + s3);
-  *dst = accumulate ? *dst + tot : tot;
+  for (; m < m1; ++m) s0 += src[(size_t)m * P * 128];
+  part[qd][el] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (qd == 0 && ok) {
+    const int p = e >> 7, q = e & 127;
+    float* dst = C + (size_t)b * sC + (size_t)p * ldc + q;
+    const float tot = (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
+    *dst = accumulate ? *dst + tot : tot;
+  }
 }
 
 // C[b] = A[b]^T B[b] with B 128 columns wide.  msplit > 1 (or accumulate) adds into C: with a workspace `ws` of batch * msplit * P * 128
@@ -351,7 +360,7 @@ extern "C" int rr_gemm_tn(const float* A, const float* B, float* C, int batch, i
                        strideA, strideB, strideC, msplit, accumulate, ws);
   }
   if (ws != nullptr)
-    hipLaunchKernelGGL(k_split_reduce, dim3((P * 128 + 255) / 256, batch), dim3(256), 0, st, ws, C, P, ldc, strideC, msplit, accumulate);
+    hipLaunchKernelGGL(k_split_reduce, dim3((P * 128 + 255) / 256, batch), dim3(1024), 0, st, ws, C, P, ldc, strideC, msplit, accumulate);
   return rr_check(hipGetLastError());
 }
 
