@@ -76,7 +76,13 @@ class RRNetPolicy(nn.Module):
         # counters (fused optimizers).  Those only happen around training-mode calls: an eval-mode module that has not been in
         # training mode since its last pack is checked by versions and pointers alone — no host synchronisation per inference call.
         dirty = self.training or getattr(self, "_pack_dirty", True)
-        if dirty:
+        if getattr(self, "_pack_scope", False) and self._pack_cache is None:
+            # a training step right after invalidate_pack(): there is nothing to compare a fingerprint with (one host read saved: the
+            # host may run ahead into this step while the device finishes the last optimizer step); the key without it never
+            # matches a later out-of-scope key, so the next unscoped call verifies from scratch
+            key = key + ("in-scope",)
+            self._pack_dirty = True
+        elif dirty:
             key = key + (packing.weights_fingerprint(self),)
             self._pack_dirty = self.training
         elif self._pack_cache is not None:

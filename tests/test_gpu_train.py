@@ -122,10 +122,16 @@ def test_pack_scope_verifies_once_per_step_and_expires():
         return real(module)
     packing.weights_fingerprint = counting
     try:
+        pol.packed(dev)                                    # (a cached pack: the step below has something to verify)
+        n0 = calls["n"]
         model.training_step(td_in, seed=3)                 # forward + decoder backward + encoder backward: several packed() calls
-        assert calls["n"] == 1
-        p0 = pol.packed(dev)
-        assert calls["n"] == 2 and getattr(pol, "_pack_scope", False) is False
+        assert calls["n"] == n0 + 1
+        pol.invalidate_pack()                              # what an optimizer step is followed by: nothing to compare with,
+        model.training_step(td_in, seed=3)                 # so the next step packs without reading a fingerprint back
+        assert calls["n"] == n0 + 1
+        p0 = pol.packed(dev)                               # outside a scope: verified (and rebuilt: the in-scope key carries no fingerprint)
+        assert calls["n"] == n0 + 2 and getattr(pol, "_pack_scope", False) is False
+        assert pol.packed(dev) is p0
         with torch.no_grad():                              # what a fused optimizer does: new values, same version counter
             q = pol.decoder.pointer.ffn.lins[0].weight
             v = q._version
