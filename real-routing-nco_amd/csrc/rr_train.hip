@@ -170,7 +170,8 @@ extern "C" int rr_nab_hist_bwd(const float* pwl, const float* xd, const float* x
                                hipStream_t st) {
   if (pwl == nullptr || xd == nullptr || xa == nullptr || gout == nullptr || hist == nullptr || M <= 0) return RR_EINVAL;
   const long want = (M + 255) / 256;
-  hipLaunchKernelGGL(k_nab_hist_bwd, dim3((unsigned)(want < 512 ? want : 512)), dim3(256), 0, st, pwl, xd, xa, gout, hist, M);
+  // (1 024 workgroups: 295 -> 258 us at 5 M edges against 512; 4 096 pay for their histograms' global atomics: 375 us)
+  hipLaunchKernelGGL(k_nab_hist_bwd, dim3((unsigned)(want < 1024 ? want : 1024)), dim3(256), 0, st, pwl, xd, xa, gout, hist, M);
   return rr_check(hipGetLastError());
 }
 
