@@ -442,8 +442,10 @@ static int rr_enc_layer_impl(const EncBlockW* wrow, const EncBlockW* wcol, const
 #define RR_ENCW(NTV, SP) hipLaunchKernelGGL((k_enc_block_w<NTV, SP>), grid, dim3(64 * NTV), 0, st, ws, row_in, col_in, row_out, col_out, D, theta, bias_pre, N, norm_affine_only, svs)
     if (N <= 32) { if (split) RR_ENCW(2, true); else RR_ENCW(2, false); }
     else if (N <= 64) { if (split) RR_ENCW(4, true); else RR_ENCW(4, false); }
-    else if (split && svs.s[0].r == nullptr && ffn_kernel) {
-      // headline shape, inference: the block up to ffn.norm1, then the FFN + ffn.norm2 as a kernel with a loader wave (rr_enc_w.inc: k_enc_ffn)
+    else if (split && ffn_kernel) {
+      // headline shape: the block up to ffn.norm1, then the FFN + ffn.norm2 as a kernel with a loader wave (rr_enc_w.inc: k_enc_ffn).
+      // (Also the training forward: everything the backward reads — _lib.EncSave — is produced in front of the FFN, whose input x1
+      // the block kernel stores anyway; its output is recomputed by the backward.)
       hipLaunchKernelGGL((k_enc_block_w<7, true, false>), grid, dim3(64 * 7), 0, st, ws, row_in, col_in, row_out, col_out, D, theta, bias_pre, N, norm_affine_only, svs);
       hipLaunchKernelGGL((k_enc_ffn<7>), grid, dim3(64 * 8), 0, st, ws, row_out, col_out, N, norm_affine_only);
     }
