@@ -245,6 +245,23 @@ __device__ __forceinline__ void rr_glds16(const void* gsrc, void* ldst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
 }
+// One 16 KB weight stage = 16 LDS-DMA requests of 1 KB to consecutive LDS slots.  What a request costs its wave is what its
+// instructions cost: with per-fragment pointer arithmetic (a 64-bit vector add and a dozen scalar instructions, as the builtin form
+// compiles) 68 cycles; with the lane offsets of the fragments precomputed in registers (`vo`), the stage's global base in a scalar
+// pair and M0 stepped by 1 KB, 25 cycles (tools/clockprobe/dmaprobe2.hip; bare requests without an M0 write issue every 17).
+__device__ __forceinline__ void rr_dma_stage16(unsigned lds_base, const void* gbase, const unsigned (&vo)[16]) {
+#define RR_DMA_NEXT(K) "s_add_i32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %" #K ", %1\n\t"
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
+               RR_DMA_NEXT(3) RR_DMA_NEXT(4) RR_DMA_NEXT(5) RR_DMA_NEXT(6) RR_DMA_NEXT(7) RR_DMA_NEXT(8) RR_DMA_NEXT(9) RR_DMA_NEXT(10)
+               RR_DMA_NEXT(11) RR_DMA_NEXT(12) RR_DMA_NEXT(13) RR_DMA_NEXT(14) RR_DMA_NEXT(15) RR_DMA_NEXT(16) RR_DMA_NEXT(17)
+               ::"s"(lds_base), "s"(gbase), "v"(vo[0]), "v"(vo[1]), "v"(vo[2]), "v"(vo[3]), "v"(vo[4]), "v"(vo[5]), "v"(vo[6]), "v"(vo[7]),
+               "v"(vo[8]), "v"(vo[9]), "v"(vo[10]), "v"(vo[11]), "v"(vo[12]), "v"(vo[13]), "v"(vo[14]), "v"(vo[15])
+               : "memory", "scc", "m0");
+#undef RR_DMA_NEXT
+}
+__device__ __forceinline__ unsigned rr_lds_offset(const void* p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
 // x[0..7] -> hi + mid + lo, each bf16 with round-to-nearest (v_cvt_pk_bf16_f32): x - hi and (x - hi) - mid are exact in fp32
 __device__ __forceinline__ void rr_split8(const float (&x)[8], rr_bf16x8& hi, rr_bf16x8& mid, rr_bf16x8& lo) {
 #pragma unroll
