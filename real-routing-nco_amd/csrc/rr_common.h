@@ -245,6 +245,14 @@ __device__ __forceinline__ void rr_glds16(const void* gsrc, void* ldst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
 }
+// max(x, 0) as ONE instruction: fmaxf() on a matrix-instruction result costs two (hipcc canonicalises the operand first:
+// v_max_f32 x, x).  The integer maximum of the bit pattern with 0 is the same function for every non-NaN float (negative floats
+// and -0 are negative integers) and stays visible to the hazard recognizer — an `asm("v_max_f32")` here is not: it read matrix
+// results before they were written (tours changing from call to call, test_full_size_properties_n100_b64_aug8).
+__device__ __forceinline__ float rr_relu(float x) {
+  const int i = __float_as_int(x);
+  return __int_as_float(i > 0 ? i : 0);
+}
 // One 16 KB weight stage = 16 LDS-DMA requests of 1 KB to consecutive LDS slots.  What a request costs its wave is what its
 // instructions cost: with per-fragment pointer arithmetic (a 64-bit vector add and a dozen scalar instructions, as the builtin form
 // compiles) 68 cycles; with the lane offsets of the fragments precomputed in registers (`vo`), the stage's global base in a scalar
