@@ -250,6 +250,9 @@ __device__ __forceinline__ void rr_glds16(const void* gsrc, void* ldst) {
 // and -0 are negative integers) and stays visible to the hazard recognizer — an `asm("v_max_f32")` here is not: it read matrix
 // results before they were written (tours changing from call to call, test_full_size_properties_n100_b64_aug8).
 __device__ __forceinline__ float rr_relu(float x) {
+#ifdef RR_RELU_FMAXF
+  return fmaxf(x, 0.f);
+#endif
   const int i = __float_as_int(x);
   return __int_as_float(i > 0 ? i : 0);
 }
