@@ -8,6 +8,8 @@ second MLP layers: tiny tensors) and the init embedding (atsp.py:69-121 / rcvrp.
 Covers instance norm + gating NAB without duration (ATSP, RCVRP: RRNetEncoder.supports_hip_backward)."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .. import _lib as L
@@ -64,6 +66,24 @@ def _nab_tab(P, p, alpha):
     rows, ks, bg, bo = _nab_table(P, p)
     z = torch.zeros((), device=alpha.device, dtype=alpha.dtype)
     return torch.cat([torch.cat(rows), torch.stack([ks[0], ks[1], ks[2], ks[3], bg, bo, alpha.reshape(()), z])]).float()
+
+
+def _nab_tabs_batched(P, prefixes, alphas):
+    """_nab_tab for several blocks in one torch expression ([nb, 8*128+8]): stacked parameters and two batched contractions per
+    family instead of a dozen tiny ops per block (the step is launch-bound on them); autograd unstacks the gradient."""
+    st = lambda k: torch.stack([P[p + k] for p in prefixes])           # noqa: E731
+    wo, bo = st(".out_lin.weight")[:, 0], st(".out_lin.bias")[:, 0]     # [nb,E], [nb]
+    wg, bg = st(".gate.0.weight")[:, 0], st(".gate.0.bias")[:, 0]       # [nb,2E], [nb]
+    rows, ks = [], []
+    for f, nm in enumerate(("dist_emb", "angle_emb")):
+        wgh = wg[:, f * E:(f + 1) * E]
+        W2, b2 = st(f".{nm}.2.weight"), st(f".{nm}.2.bias")             # [nb,E,E], [nb,E]
+        rows += [st(f".{nm}.0.weight")[:, :, 0], st(f".{nm}.0.bias"),
+                 torch.einsum("bji,bj->bi", W2, wo), torch.einsum("bji,bj->bi", W2, wgh)]
+        ks += [(wo * b2).sum(1), (wgh * b2).sum(1)]
+    alpha = torch.stack([a.reshape(()) for a in alphas])
+    scal = torch.stack([ks[0], ks[1], ks[2], ks[3], bg, bo, alpha, torch.zeros_like(alpha)], dim=1)
+    return torch.cat(rows + [scal], dim=1).float()
 
 
 def nab_grad_from_hist(tabs: torch.Tensor, hist: torch.Tensor) -> torch.Tensor:
@@ -169,6 +189,11 @@ def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
         small = []            # (torch expression of parameters, its gradient): chained through autograd at the end
         packed = policy.packed(dev)
         nab_tabs, nab_hists = [], torch.zeros(2 * packs["num_layers"], 2 * 129 * 4 + 1, device=dev)
+        tabs_all = None       # the folded NAB tables of all blocks in processing order as ONE expression (RR_NAB_TAB_PERBLOCK=1: one per block)
+        if not vtw and os.environ.get("RR_NAB_TAB_PERBLOCK", "0") != "1":
+            order = [f"encoder.net.layers.{l}.{side}_encoding_block" for l in reversed(range(packs["num_layers"])) for side in ("row", "col")]
+            with torch.enable_grad():
+                tabs_all = _nab_tabs_batched(P, [b + ".angle_distance_fusion" for b in order], [P[b + ".alpha"] for b in order])
         # ---- the blocks, last layer first
         for l in reversed(range(packs["num_layers"])):
             sv = layers[l]
@@ -216,8 +241,11 @@ def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
                     dur_todo.append((b, si, dbias))
                 else:
                     # alpha * NAB (:427-429): the folded-table backward of csrc/rr_train.hip, chained to the module parameters by autograd
-                    with torch.enable_grad():
-                        tab = _nab_tab(P, b + ".angle_distance_fusion", P[b + ".alpha"])
+                    if tabs_all is None:
+                        with torch.enable_grad():
+                            tab = _nab_tab(P, b + ".angle_distance_fusion", P[b + ".alpha"])
+                    else:
+                        tab = None
                     xd = D if side == "row" else Dt
                     hist = nab_hists[len(nab_tabs)]
                     L.check(lib.rr_nab_hist_bwd(packed["blocks"][l][si].nab, L.ptr(xd), L.ptr(theta), L.ptr(dbias), L.ptr(hist),
@@ -237,8 +265,11 @@ def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
                 inorm(y_in, dc, None, b + ".norm2", dy_out, acc=si)
             d_row, d_col = n_row, n_col
         if nab_tabs:          # the NAB moments of all blocks -> d (folded tables), one batched prefix-sum pass
-            gtabs = nab_grad_from_hist(torch.stack([t.detach() for t in nab_tabs]), nab_hists)
-            small += [(t, gtabs[i]) for i, t in enumerate(nab_tabs)]
+            if tabs_all is None:
+                gtabs = nab_grad_from_hist(torch.stack([t.detach() for t in nab_tabs]), nab_hists)
+                small += [(t, gtabs[i]) for i, t in enumerate(nab_tabs)]
+            else:
+                small.append((tabs_all, nab_grad_from_hist(tabs_all.detach(), nab_hists)))
     G.flush()
     # ---- chain rule through the folds and the init embedding (autograd on tiny / [Bp*N,128] tensors)
     vrp = policy.env_name == "rcvrp"

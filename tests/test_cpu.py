@@ -706,3 +706,28 @@ def test_second_form_weight_images_reproduce_the_scaled_weights_and_range_status
     assert int(packing.f16_range_status([W * 1e4], 6)) == 2
     Wn = W.clone(); Wn[3, 3] = float("nan")
     assert int(packing.f16_range_status([W, Wn], 6)) == 2
+
+
+def test_batched_nab_tables_equal_the_per_block_expression_and_its_gradients():
+    """models/enc_backward._nab_tabs_batched: the folded NAB tables of several blocks as one torch expression (the training step's
+    launch count) against one _nab_tab per block — values and parameter gradients."""
+    from rrnco_amd.models import enc_backward as EB
+    E = 128
+    g = torch.Generator().manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, generator=g).requires_grad_()   # noqa: E731
+    P, prefixes = {}, [f"b{i}.adf" for i in range(3)]
+    for p in prefixes:
+        P[p + ".out_lin.weight"], P[p + ".out_lin.bias"] = rnd(1, E), rnd(1)
+        P[p + ".gate.0.weight"], P[p + ".gate.0.bias"] = rnd(1, 2 * E), rnd(1)
+        for nm in ("dist_emb", "angle_emb"):
+            P[f"{p}.{nm}.0.weight"], P[f"{p}.{nm}.0.bias"] = rnd(E, 1), rnd(E)
+            P[f"{p}.{nm}.2.weight"], P[f"{p}.{nm}.2.bias"] = rnd(E, E), rnd(E)
+    alphas = [rnd(()) for _ in prefixes]
+    one = torch.stack([EB._nab_tab(P, p, a) for p, a in zip(prefixes, alphas)])
+    bat = EB._nab_tabs_batched(P, prefixes, alphas)
+    assert bat.shape == one.shape == (3, 8 * E + 8)
+    assert torch.allclose(bat, one, rtol=1e-5, atol=1e-4)
+    w = torch.randn(one.shape, generator=g)
+    wrt = [P[prefixes[1] + ".dist_emb.2.weight"], alphas[2], P[prefixes[0] + ".gate.0.weight"], P[prefixes[2] + ".angle_emb.0.bias"]]
+    for a, b in zip(torch.autograd.grad(one, wrt, w, retain_graph=True), torch.autograd.grad(bat, wrt, w)):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-4)
