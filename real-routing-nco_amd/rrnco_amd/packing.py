@@ -285,7 +285,7 @@ def fold_nab_pwl_batched(sd, prefixes, alphas) -> torch.Tensor:
     float32 cast).  -> [len(prefixes), NAB_TAB2_FLOATS] float32."""
     dev = sd[prefixes[0] + ".out_lin.weight"].device
     nb = len(prefixes)
-    st = lambda k: torch.stack([sd[p + k].detach().double() for p in prefixes])           # noqa: E731
+    st = lambda k: torch.stack([sd[p + k].detach() for p in prefixes]).double()           # noqa: E731  (one conversion per stack, not per block)
     wo, bo = st(".out_lin.weight")[:, 0], st(".out_lin.bias")[:, 0]                        # [nb,E], [nb]
     wg, bg = st(".gate.0.weight")[:, 0], st(".gate.0.bias")[:, 0]                          # [nb,2E], [nb]
     ts, segs, cells = [], [], []
