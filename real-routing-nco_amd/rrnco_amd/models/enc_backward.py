@@ -189,6 +189,15 @@ def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
         small = []            # (torch expression of parameters, its gradient): chained through autograd at the end
         packed = policy.packed(dev)
         nab_tabs, nab_hists = [], torch.zeros(2 * packs["num_layers"], 2 * 129 * 4 + 1, device=dev)
+        # the folded project + combine Linear of every block (Wpc = Wc Wp, bpc = Wc bp + bc) as ONE expression of the parameters, its
+        # gradients in one buffer each: the kernels fill the per-block views, autograd unstacks at the end (a dozen launches, not 12 x 8)
+        order_all = [f"encoder.net.layers.{l}.{side}_encoding_block" for l in reversed(range(packs["num_layers"])) for side in ("row", "col")]
+        dWpc_all, dbpc_all, bidx = torch.zeros(len(order_all), E, E, device=dev), torch.zeros(len(order_all), E, device=dev), 0
+        with torch.enable_grad():
+            Wc_all = torch.stack([P[b + ".multi_head_combine.weight"] for b in order_all])
+            Wpc_all = torch.bmm(Wc_all, torch.stack([P[b + ".attn_free.project.weight"] for b in order_all]))
+            bpc_all = (torch.bmm(Wc_all, torch.stack([P[b + ".attn_free.project.bias"] for b in order_all])[:, :, None])[:, :, 0]
+                       + torch.stack([P[b + ".multi_head_combine.bias"] for b in order_all]))
         tabs_all = None       # the folded NAB tables of all blocks in processing order as ONE expression (RR_NAB_TAB_PERBLOCK=1: one per block)
         if not vtw and os.environ.get("RR_NAB_TAB_PERBLOCK", "0") != "1":
             order = [f"encoder.net.layers.{l}.{side}_encoding_block" for l in reversed(range(packs["num_layers"])) for side in ("row", "col")]
@@ -221,14 +230,11 @@ def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
                 dO = dx1
                 inorm(S["o"], dU1, None, b + ".norm3", dO)
                 # o = combine(project(y)) (:325, 435): one folded Linear Wpc = Wc Wp
-                dbpc = torch.zeros(E, device=dev)
+                dbpc, dWpc = dbpc_all[bidx], dWpc_all[bidx]                               # (zero-filled views of one buffer each)
+                bidx += 1
                 dY = new()
                 lin(pk["wpcT"], dO, dY, 0, dbpc)
-                dWpc = torch.zeros(E, E, device=dev)
                 wgrad(dO, S["y"], dWpc)
-                with torch.enable_grad():
-                    Wc_, Wp_ = P[b + ".multi_head_combine.weight"], P[b + ".attn_free.project.weight"]
-                    small += [(Wc_ @ Wp_, dWpc), (Wc_ @ P[b + ".attn_free.project.bias"] + P[b + ".multi_head_combine.bias"], dbpc)]
                 # AFTFull (:309-324)
                 dq, dk, dv = new(), new(), new()
                 dbias = torch.empty(Bp, N, N, device=dev)
@@ -264,6 +270,7 @@ def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
                 inorm(x_in, dU1, dr, b + ".norm1", dx_out, acc=si)           # the col block adds to what the row block wrote
                 inorm(y_in, dc, None, b + ".norm2", dy_out, acc=si)
             d_row, d_col = n_row, n_col
+        small += [(Wpc_all, dWpc_all), (bpc_all, dbpc_all)]
         if nab_tabs:          # the NAB moments of all blocks -> d (folded tables), one batched prefix-sum pass
             if tabs_all is None:
                 gtabs = nab_grad_from_hist(torch.stack([t.detach() for t in nab_tabs]), nab_hists)
