@@ -27,8 +27,10 @@ B = int(os.environ.get("PB", "512"))
 for i in range(2):
     model.training_step(env.generator(B, generator=gen), optimizer=opt, seed=i)
 torch.cuda.synchronize()
+batch = env.generator(B, generator=gen)          # outside the profile: the generator's 100 closure passes are not the step's
+torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
-    model.training_step(env.generator(B, generator=gen), optimizer=opt, seed=9)
+    model.training_step(batch, optimizer=opt, seed=9)
     torch.cuda.synchronize()
 cpu = sorted([e for e in prof.key_averages() if e.key.startswith("aten::") or e.key.startswith("hip")], key=lambda e: -e.count)
 if os.environ.get("PROFILE_HOST"):
