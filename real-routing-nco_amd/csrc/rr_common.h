@@ -270,6 +270,10 @@ __device__ __forceinline__ void rr_dma_stage16(unsigned lds_base, const void* gb
                : "memory", "scc", "m0");
 #undef RR_DMA_NEXT
 }
+// one LDS-DMA request of 1 KB in the cheap form: LDS byte address in a scalar, global base in a scalar pair, lane offset in a register
+__device__ __forceinline__ void rr_dma1(unsigned lds_addr, const void* gbase, unsigned voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(gbase) : "memory", "m0");
+}
 __device__ __forceinline__ unsigned rr_lds_offset(const void* p) {
   return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
 }

@@ -413,16 +413,23 @@ __global__ __launch_bounds__(512, 1) void k_mlp_rows(MlpRowsW w, const float* __
   for (int i = tid; i < RR_FF; i += 512) b1s[i] = w.b1[i];
   const long long total = (long long)rs.nseg * rs.seg_rows;
   const long long nblk = (total + 127) / 128;
-  auto issue = [&](int p, int buf) {
+  // this wave's NF / 8 fragments of a stage: global base and LDS slot of each as scalars, computed once; a request is then
+  // s_mov m0 / global_load_lds (rr_dma1: 25 instead of 68 cycles of the wave's issue time, tools/clockprobe/dmaprobe2.hip)
+  const char* fsrc[NF / 8];
+  unsigned fdst[NF / 8];
 #pragma unroll
-    for (int q = 0; q < NF / 8; ++q) {
-      const int f = wave * (NF / 8) + q;
-      const char* src;
-      if (f < 16) src = (const char*)w.wa1 + ((size_t)p * 16 + f) * 1024;
-      else if (MODE == 1 && f < 32) src = (const char*)w.wa2 + ((size_t)p * 16 + (f - 16)) * 1024;
-      else src = (const char*)w.wb + ((size_t)p * 16 + (f - (MODE == 1 ? 32 : 16))) * 1024;
-      td_glds16(src + lane * 16, stage + buf * (NF * 1024) + f * 1024);
-    }
+  for (int q = 0; q < NF / 8; ++q) {
+    const int f = wave * (NF / 8) + q;
+    if (f < 16) fsrc[q] = (const char*)w.wa1 + (size_t)f * 1024;
+    else if (MODE == 1 && f < 32) fsrc[q] = (const char*)w.wa2 + (size_t)(f - 16) * 1024;
+    else fsrc[q] = (const char*)w.wb + (size_t)(f - (MODE == 1 ? 32 : 16)) * 1024;
+    fdst[q] = rr_lds_offset(stage) + (unsigned)f * 1024u;
+  }
+  const unsigned lane16 = (unsigned)lane * 16u;
+  auto issue = [&](int p, int buf) {
+    const unsigned vo = lane16 + (unsigned)p * 16384u;
+#pragma unroll
+    for (int q = 0; q < NF / 8; ++q) rr_dma1(fdst[q] + (unsigned)buf * (unsigned)(NF * 1024), fsrc[q], vo);
   };
   auto frag = [&](int buf, int f) { return *reinterpret_cast<const bfrag*>(stage + buf * (NF * 1024) + f * 1024 + lane * 16); };
   // a lane's row of a block: 8 + 8 float4 in flight (every load unconditional, zeroed by the flag afterwards: no dependent loads)

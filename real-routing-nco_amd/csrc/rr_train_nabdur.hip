@@ -482,12 +482,12 @@ __global__ __launch_bounds__(512, 2) void k_nabdur_bwd_mcat2(NabDurBwdW w, const
 #pragma unroll
     for (int u = 0; u < 8; ++u) acc[q][u] = rr_zero4();
   const long long ntile = (M + 31) / 32;
+  // this wave's two fragments of a tile (rr_dma1: the tile's base in scalars, lane offsets and LDS slots computed once)
+  const unsigned fvo0 = (unsigned)lane * 16u + (unsigned)(2 * wave) * 1024u, fdst0 = rr_lds_offset(&stage[0][0]) + (unsigned)(2 * wave) * 1024u;
   auto issue = [&](long long tile, int buf) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int f = 2 * wave + q;
-      rr_glds16(dzf + (size_t)tile * 16 * 1024 + f * 1024 + lane * 16, stage[buf] + f * 1024);
-    }
+    const char* gb = dzf + (size_t)tile * 16 * 1024;
+    rr_dma1(fdst0 + (unsigned)buf * 16384u, gb, fvo0);
+    rr_dma1(fdst0 + (unsigned)buf * 16384u + 1024u, gb, fvo0 + 1024u);
   };
   int buf = 0;
   if ((long long)blockIdx.x < ntile) issue(blockIdx.x, 0);
