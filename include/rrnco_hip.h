@@ -229,8 +229,10 @@ typedef struct {
 int rr_dec_logit_bwd(const DecLogitIO* io, hipStream_t stream);
 
 /* C[b][p][q] (+)= sum_m A[b][m][p] B[b][m][q], q < 128: d logit keys (dlg^T g per instance) and the weight gradient of a
- * Linear layer (dY^T X).  msplit > 1 or accumulate != 0 adds into C: through per-split partials in `ws` (batch * msplit * P * 128
- * floats) and a fixed-order reduction, or, ws == NULL, with float atomics (caller zeroes C). */
+ * Linear layer (dY^T X).  msplit == 1, accumulate == 0: plain stores, C is overwritten (ws ignored).  Otherwise, with `ws`
+ * (batch * msplit * P * 128 floats, owned by this call until the stream has passed it): the row splits' partials go through ws and
+ * one fixed-order reduction that OVERWRITES C when accumulate == 0 and ADDS to C when accumulate != 0 (bit-reproducible); with
+ * ws == NULL: float atomics into C for either value of accumulate (caller zeroes C when it wants a plain product). */
 int rr_gemm_tn(const float* A, const float* B, float* C, int batch, int Mb, int P, int lda, int ldb, int ldc,
                long long strideA, long long strideB, long long strideC, int msplit, int accumulate, float* ws, hipStream_t stream);
 

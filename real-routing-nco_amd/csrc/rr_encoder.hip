@@ -1097,8 +1097,11 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
       const float4 wa = rr_ld4(g2 + 16 * wave + 4 * g), wb = rr_ld4(g2 + 16 * (wave + 8) + 4 * g);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        float p0 = fmaxf(h0[nt][0], 0.f) * wa.x + fmaxf(h0[nt][1], 0.f) * wa.y + fmaxf(h0[nt][2], 0.f) * wa.z + fmaxf(h0[nt][3], 0.f) * wa.w;
-        float p1 = fmaxf(h1[nt][0], 0.f) * wb.x + fmaxf(h1[nt][1], 0.f) * wb.y + fmaxf(h1[nt][2], 0.f) * wb.z + fmaxf(h1[nt][3], 0.f) * wb.w;
+        // NaN-preserving relu (x < 0 ? 0 : x): fmaxf(NaN, 0) = 0 would hide an fp16 overflow of the gate's split operands from the
+        // range guard — a NaN here reaches the embeddings and raises bit 0 in rr_pack_f16x2
+        auto rl = [](float x) { return x < 0.f ? 0.f : x; };
+        float p0 = rl(h0[nt][0]) * wa.x + rl(h0[nt][1]) * wa.y + rl(h0[nt][2]) * wa.z + rl(h0[nt][3]) * wa.w;
+        float p1 = rl(h1[nt][0]) * wb.x + rl(h1[nt][1]) * wb.y + rl(h1[nt][2]) * wb.z + rl(h1[nt][3]) * wb.w;
         p0 = rr_sum_g(p0) * (1.0f / 64.0f); p1 = rr_sum_g(p1) * (1.0f / 64.0f);
         if (g == 0) { gpart[wave * 112 + nt * 16 + j] = p0; gpart[(wave + 8) * 112 + nt * 16 + j] = p1; }
       }

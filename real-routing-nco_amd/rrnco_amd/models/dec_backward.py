@@ -46,7 +46,11 @@ def wgrad_workspace(dev) -> torch.Tensor:
     """64 x (dW1 | dW2) partials of rr_mlp_wgrad's row splits (33.5 MB, one per device, reused by every call on the stream)."""
     if os.environ.get("RR_TRAIN_WS", "1") == "0":          # diagnostic: float atomics instead of partials + reduction
         return None
-    key = str(dev)
+    # one buffer per (device, stream): two backward passes on different HIP streams must not share partials ("cuda" and "cuda:0"
+    # are the same device)
+    d = torch.device(dev)
+    idx = d.index if d.index is not None else torch.cuda.current_device()
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
     if key not in _WGRAD_WS:
         _WGRAD_WS[key] = torch.empty(64 * 2 * 4 * E * E, device=dev)
     return _WGRAD_WS[key]

@@ -42,6 +42,17 @@ class RRNetPolicy(nn.Module):
         self._pack_cache = None
         self._pack_verified = False
         self._mlp_train_pack = None          # (models/dec_backward.py: the pointer MLP's training packs follow the same rule)
+        self._enc_train_pack = None          # (models/enc_backward.py: transposed projections, FFN packs of the encoder backward)
+        # Generation counter: part of the "in-scope" pack key below.  A fused optimizer updates in place without bumping the version
+        # counters, so (device, versions, pointers) repeat step after step; without the counter a pack derived from the policy's key
+        # (the encoder's training packs) would be taken for current after every optimizer step but the first.
+        self._pack_gen = getattr(self, "_pack_gen", 0) + 1
+        self._range_sticky_fp32 = False      # new weights: the split kernels get another chance (a raised word sets it again)
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_pack()               # new weights: every derived pack is stale; the fp32 exile of the range guard ends
+        return out
 
     def pack_scope(self):
         """Context: the weights do not change inside (one training step up to its optimizer step) — packed() verifies once."""
@@ -80,7 +91,7 @@ class RRNetPolicy(nn.Module):
             # a training step right after invalidate_pack(): there is nothing to compare a fingerprint with (one host read saved: the
             # host may run ahead into this step while the device finishes the last optimizer step); the key without it never
             # matches a later out-of-scope key, so the next unscoped call verifies from scratch
-            key = key + ("in-scope",)
+            key = key + (("in-scope", getattr(self, "_pack_gen", 0)),)
             self._pack_dirty = True
         elif dirty:
             key = key + (packing.weights_fingerprint(self),)
@@ -133,10 +144,15 @@ class RRNetPolicy(nn.Module):
           "sync"     the word is read once per call, before anything looks at the tours; a call that raised it is repeated on the
                      fp32-MFMA kernels, which have no such limit — costs one host synchronisation per call (~2 ms of pipeline bubble
                      on the 80 ms headline step);
-          "deferred" no host read in the call: the word of call k is read at the start of call k + 1 and by check_range(); a raised
-                     word then raises FloatingPointError (call k's outputs were NaN-marked) and every later call runs in fp32;
+          "deferred" no host read in the call: every float output of a flagged call (reward, normalized_reward, log_likelihood) is
+                     NaN-marked ON THE DEVICE (one scalar `where` + three adds, no synchronisation), so a caller that only reads the
+                     rewards (test.py:204-213) cannot consume a bad batch as a plausible number; the word itself joins a list that is
+                     read at the start of the next call and by check_range(): a raised word raises FloatingPointError there and the
+                     policy runs in fp32 until its weights change (invalidate_pack / load_state_dict);
           "auto"     (default) "sync" where the call synchronises anyway (the VRPs read their step count; training steps),
-                     "deferred" otherwise (ATSP inference);  "off": no guard."""
+                     "deferred" otherwise (ATSP inference);  "off": no guard.
+        The step-wise decode paths (fused=False, N > 103, top-k / top-p, beam search) run the same split encoder / cache kernels: "sync"
+        reads the word after their loop as well, "deferred" NaN-marks their outputs the same way."""
         import os
         mode = range_guard or os.environ.get("RR_RANGE_GUARD", "auto")
         mode = {"1": "sync", "0": "off"}.get(mode, mode)
@@ -153,13 +169,30 @@ class RRNetPolicy(nn.Module):
         self._range_sync = mode == "sync"
         self.last_range_flags = 0
         if mode == "deferred":
+            status = self._range_status
             try:
-                return self._forward_core(td, env, *args, capture=capture, **kwargs)
+                out = self._forward_core(td, env, *args, capture=capture, **kwargs)
             finally:
-                self._range_pending, self._range_status = self._range_status, None
+                self._range_status = None
+                pend = getattr(self, "_range_pending", None) or []
+                pend.append(status)
+                self._range_pending = pend[-64:]                 # (a caller that never checks: bounded)
+            # device-side poison: 0 for a clean word, NaN for a raised one — added to every float output of the call
+            poison = torch.where(status != 0, torch.full((), float("nan"), device=status.device), torch.zeros((), device=status.device))
+            for k in ("reward", "normalized_reward", "log_likelihood"):
+                v = out.get(k, None)
+                if torch.is_tensor(v) and v.is_floating_point():
+                    out[k] = v + poison.to(v.dtype)
+            return out
         td_in = TensorDict(td, batch_size=td.batch_size)         # shallow copy: the second pass starts from the same state
         try:
-            return self._forward_core(td, env, *args, capture=capture, **kwargs)
+            self._range_read = False
+            out = self._forward_core(td, env, *args, capture=capture, **kwargs)
+            if not self._range_read:                             # step-wise decode path: nobody has read the word yet
+                flags = int(self._range_status.item())
+                if flags != 0:
+                    raise _RangeRetry(flags)
+            return out
         except _RangeRetry as r:
             import warnings
             self.last_range_flags = r.flags
@@ -178,19 +211,21 @@ class RRNetPolicy(nn.Module):
         FloatingPointError — that call's log-likelihoods were NaN-marked and its tours are not to be trusted — and the policy
         runs on the fp32-MFMA kernels from now on."""
         pend = getattr(self, "_range_pending", None)
-        if pend is None:
+        if not pend:
             return
-        if pend.is_cuda and torch.cuda.is_current_stream_capturing():
-            return          # inside a hipGraph capture nothing may be read back: the word stays pending (the captured calls still NaN-mark)
+        if pend[0].is_cuda and torch.cuda.is_current_stream_capturing():
+            return          # inside a hipGraph capture nothing may be read back: the words stay pending (the captured calls still NaN-mark)
         self._range_pending = None
-        flags = int(pend.item())
+        flags = 0
+        for f in torch.stack([p.reshape(()) for p in pend]).tolist():      # ONE host read for every pending call
+            flags |= int(f)
         self.last_range_flags = flags
         if flags != 0:
             self._range_sticky_fp32 = True
             raise FloatingPointError(
-                f"rrnco_amd: the previous policy call left the fp16 range of the split kernels (flags {flags:#x}: 1 = K/V/L image, 2 = weight "
-                "image, 4 = non-finite log-probability); its outputs are invalid (log-likelihood NaN).  This policy now runs on the fp32 "
-                "MFMA kernels: repeat the call (range_guard='sync' repeats such calls by itself).")
+                f"rrnco_amd: an earlier policy call left the fp16 range of the split kernels (flags {flags:#x}: 1 = K/V/L image, 2 = weight "
+                "image, 4 = non-finite log-probability); its outputs were NaN-marked (reward, log-likelihood).  This policy now runs on the "
+                "fp32 MFMA kernels until its weights change: repeat the call (range_guard='sync' repeats such calls by itself).")
 
     def _forward_core(self, td, env=None, phase="train", calc_reward=True, return_actions=True, return_entropy=False,
                       return_hidden=False, return_init_embeds=False, return_sum_log_likelihood=True, actions=None,
@@ -309,6 +344,7 @@ class RRNetPolicy(nn.Module):
             dump.update({"first": st["first"], "tanh_clip": strategy.tanh_clipping, "temperature": strategy.temperature})
         status = getattr(self, "_range_status", None)
         if status is not None and getattr(self, "_range_sync", True):      # the range guard's one host read (before anything looks at the tours)
+            self._range_read = True
             flags = int(status.item())
             if flags != 0:
                 raise _RangeRetry(flags)

@@ -93,7 +93,8 @@ def test_deferred_mode_marks_the_log_likelihood_and_raises_at_the_next_call_then
                          "sample_idx": fx["sample_idx"].cuda()}, batch_size=[fx["B"]])
         return pol(env.reset(td), env, phase="val", decode_type="multistart_greedy", num_starts=fx["S"], return_actions=True)
     out = call()                                               # auto -> deferred: returns without a host read
-    assert torch.isnan(out["log_likelihood"]).any()
+    assert torch.isnan(out["log_likelihood"]).all()
+    assert torch.isnan(out["reward"]).all()                    # a caller that only reads the rewards (test.py:204-213) cannot miss it
     with pytest.raises(FloatingPointError):
         pol.check_range()
     out2 = call()                                              # sticky fp32 from now on
@@ -103,3 +104,52 @@ def test_deferred_mode_marks_the_log_likelihood_and_raises_at_the_next_call_then
     call()
     with pytest.raises(FloatingPointError):
         call()                                                 # ... or the next call raises
+
+
+def test_deferred_mode_leaves_clean_calls_untouched_and_sticky_fp32_ends_with_new_weights():
+    from rrnco_amd import TensorDict
+    from rrnco_amd.envs import ATSPEnv
+    fx = H.load_fixture("atsp_n20_b4_pomo")
+    w = H.atsp_weights(fx)
+    pol = H.make_policy(w, device="cuda:0")
+    env = ATSPEnv(generator_params=dict(num_loc=fx["N"]), check_solution=False)
+
+    def call(p, **kw):
+        td = TensorDict({"locs": fx["locs"].cuda(), "distance_matrix": fx["distance_matrix"].cuda(),
+                         "sample_idx": fx["sample_idx"].cuda()}, batch_size=[fx["B"]])
+        return p(env.reset(td), env, phase="val", decode_type="multistart_greedy", num_starts=fx["S"], return_actions=True, **kw)
+    a = call(pol, range_guard="deferred")
+    b = call(pol, range_guard="sync")
+    assert torch.equal(a["reward"], b["reward"]) and torch.equal(a["log_likelihood"], b["log_likelihood"])      # + 0.0 changes nothing
+    pol.check_range()
+    # several pending words are all read (one host read); a raised one among them is reported
+    bad = H.make_policy(_scaled_mlp(w, 2048.0), device="cuda:0")
+    call(bad, range_guard="deferred")
+    assert len(bad._range_pending) == 1
+    with pytest.raises(FloatingPointError):
+        bad.check_range()
+    assert bad._range_sticky_fp32
+    # new weights end the fp32 exile (the flag used to stay for the life of the policy)
+    bad.load_state_dict({k: v.cuda() for k, v in w.items()}, strict=False)
+    bad.invalidate_pack()
+    assert not bad._range_sticky_fp32
+    c = call(bad, range_guard="sync")
+    assert bad.last_range_flags == 0 and (c["actions"].cpu() == fx["actions"]).all()
+
+
+def test_stepwise_decode_path_reads_the_guard_word_too():
+    """fused=False never launched the fused rollout, so nobody read the word there: a weight image out of range
+    (bit 1, set at pack time) must repeat the step-wise call on the fp32 kernels as well."""
+    from rrnco_amd import TensorDict
+    from rrnco_amd.envs import ATSPEnv
+    fx = H.load_fixture("atsp_n20_b4_pomo")
+    pol = H.make_policy(_scaled_mlp(H.atsp_weights(fx), 16384.0), device="cuda:0")
+    env = ATSPEnv(generator_params=dict(num_loc=fx["N"]), check_solution=False)
+    td = TensorDict({"locs": fx["locs"].cuda(), "distance_matrix": fx["distance_matrix"].cuda(),
+                     "sample_idx": fx["sample_idx"].cuda()}, batch_size=[fx["B"]])
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        out = pol(env.reset(td), env, phase="val", decode_type="multistart_greedy", num_starts=fx["S"], return_actions=True,
+                  range_guard="sync", fused=False)
+    assert pol.last_range_flags & 2 and any("fp16 range" in str(m.message) for m in rec)
+    assert (out["actions"].cpu() == fx["actions"]).all()

@@ -107,6 +107,36 @@ def test_fused_optimizer_updates_are_seen_by_the_pack_cache():
     assert float(same.float().mean()) > 0.9
 
 
+def test_consecutive_fused_optimizer_steps_use_current_encoder_packs():
+    """torch.optim.Adam(fused=True) bumps no version counter, so after invalidate_pack() the in-scope pack key of
+    step k + 1 used to equal step k's and the ENCODER's training packs (transposed projections, FFN packs: models/enc_backward.py)
+    were taken from the previous weights.  Three fused steps at a large learning rate; the gradients of the third step must equal
+    those of a fresh policy that was handed the same weights (same tours: same seed, same sample)."""
+    fx = H.load_fixture("atsp_n20_b4_pomo")
+    w, pol, model, st, td_in = _model(fx)
+    opt = torch.optim.Adam(pol.parameters(), lr=2e-3, fused=True)
+    for it in range(2):
+        model.training_step(td_in, optimizer=opt, seed=40 + it)
+    assert getattr(pol, "_enc_train_pack", None) is None               # invalidate_pack() drops every derived pack
+    weights_now = {n: p.detach().clone() for n, p in pol.named_parameters()}
+    assert sum(int(not torch.equal(weights_now[n].cpu(), w[n])) for n in weights_now) > 150
+    out = model.training_step(td_in, seed=99)                          # step 3 on the twice-updated weights (no optimizer: keep the grads)
+    g_live = {n: p.grad.detach().clone() for n, p in pol.named_parameters()}
+    # a fresh policy with the same weights: nothing cached anywhere
+    w2, pol2, model2, st2, td2 = _model(fx)
+    with torch.no_grad():
+        for n, p in pol2.named_parameters():
+            p.copy_(weights_now[n])
+    pol2.invalidate_pack()
+    out2 = model2.training_step(td2, seed=99)
+    assert torch.equal(out["actions"], out2["actions"])
+    gn = sum(float((p.grad ** 2).sum()) for _, p in pol2.named_parameters()) ** 0.5
+    err = sum(float(((g_live[n] - p.grad) ** 2).sum()) for n, p in pol2.named_parameters()) ** 0.5
+    assert err <= 1e-6 * gn, (err, gn)                                  # same kernels, same operands: (near) bit-equal
+    enc = [n for n in g_live if n.startswith("encoder.net.layers.")]
+    assert enc and all(torch.allclose(g_live[n], dict(pol2.named_parameters())[n].grad, rtol=1e-5, atol=1e-7 * gn) for n in enc)
+
+
 def test_pack_scope_verifies_once_per_step_and_expires():
     """RRNet.training_step checks the weight pack once (RRNetPolicy.pack_scope: forward and backward of one step see the same
     weights); outside a scope every packed() call verifies again, so an in-place update that bumps no version counter is seen."""
