@@ -79,7 +79,26 @@ def main():
     time.sleep(0.5)                      # idle samples
     t_start = time.perf_counter()
     R.TIMING = []
-    if what != "idle":
+    gemm_tf = None
+    if what.startswith("gemm"):          # a dense library GEMM on random data: what the fp16 / bf16 matrix pipe sustains under the power cap
+        dt_ = torch.bfloat16 if what == "gemm_bf16" else torch.float16
+        n = 8192
+        a = torch.randn(n, n, device=dev, dtype=dt_); b = torch.randn(n, n, device=dev, dtype=dt_)
+        for _ in range(3):
+            a @ b
+        torch.cuda.synchronize()
+        t_start = time.perf_counter()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps * 40):
+            a @ b
+        e1.record()
+        torch.cuda.synchronize()
+        gemm_tf = steps * 40 * 2 * n ** 3 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    elif what.startswith("cmd:"):        # sample while a child process (a clockprobe binary) runs
+        r = subprocess.run(what[4:], shell=True, capture_output=True, text=True)
+        print("child output:", (r.stdout + r.stderr)[-1500:])
+    elif what != "idle":
         for _ in range(steps):
             bench.hot_path_step(pol, env, inst)
     torch.cuda.synchronize()
@@ -91,7 +110,7 @@ def main():
     busy = [s for s in samples if t_start + 0.2 <= s["t"] <= t_end]
     idle = [s for s in samples if s["t"] < t_start]
     print(f"workload {what}: {steps} steps, {(t_end - t_start) / max(steps, 1) * 1e3:.2f} ms per step, rollout kernel {sum(ks) / max(len(ks), 1):.2f} ms; "
-          f"{len(busy)} busy samples, {len(idle)} idle samples")
+          f"{len(busy)} busy samples, {len(idle)} idle samples" + (f"; GEMM 8192^3: {gemm_tf:.0f} TFLOP/s" if gemm_tf else ""))
 
     def stat(rows, k):
         v = [r[k] for r in rows if isinstance(r.get(k), (int, float))]
