@@ -182,7 +182,15 @@ def gen_atsp_beam(tag, B, N, W, sample_size, seed, layers=6):
     print(f"wrote {path}  ({os.path.getsize(path)/1e3:.0f} kB)  reward={out['reward'].tolist()}")
 
 
-def gen_rcvrp(tag, B, N, S, sample_size, seed, capacity, layers=6, keep_trace=True):
+def _load_trained(weights_file, tmpl):
+    """An .npz state_dict under tests/golden/ (tools/train_fixture_weights.py: trained on the MI355X engine) for the reference to run."""
+    z = np.load(os.path.join(GOLD, weights_file))
+    w = {k: torch.from_numpy(z[k]).float() for k in z.files}
+    assert {k: tuple(v.shape) for k, v in w.items()} == tmpl, "trained state_dict does not match the reference's template"
+    return w
+
+
+def gen_rcvrp(tag, B, N, S, sample_size, seed, capacity, layers=6, keep_trace=True, weights_file=None):
     from rrnco.envs.rcvrp.env import RCVRPEnv
     from rrnco.models.policy import RRNetPolicy
 
@@ -195,7 +203,7 @@ def gen_rcvrp(tag, B, N, S, sample_size, seed, capacity, layers=6, keep_trace=Tr
     tmpl = {k: tuple(v.shape) for k, v in pol.state_dict().items()}
     assert tmpl == restate.rcvrp_weight_template(128, layers, 512, sample_size), \
         (set(tmpl) ^ set(restate.rcvrp_weight_template(128, layers, 512, sample_size)))
-    w = restate.make_weights(tmpl, seed)
+    w = restate.make_weights(tmpl, seed) if weights_file is None else _load_trained(weights_file, tmpl)
     pol.load_state_dict(w, strict=True)
     td = env.reset(TensorDict({k: v.clone() for k, v in inst.items()}, batch_size=[B]))
     enc_out = []
@@ -246,12 +254,18 @@ def gen_rcvrp(tag, B, N, S, sample_size, seed, capacity, layers=6, keep_trace=Tr
     if keep_trace:
         fx["trace_logits"] = torch.stack(trace["logits"], 0)
         fx["trace_mask"] = torch.stack(trace["mask"], 0)
+    if weights_file is not None:
+        fx["weights_file"] = weights_file
+        lp = torch.stack(trace["logp"], 1)                      # [R, T, N+1] log-softmax rows of the restatement
+        live = torch.isfinite(lp).any(-1)
+        fx["mean_chosen_prob"] = float(torch.nan_to_num(lp, neginf=-1e9).max(-1).values[live].exp().mean())      # greedy: the chosen action is the row maximum
+        print(f"  trained weights {weights_file}: mean probability of the chosen action {fx['mean_chosen_prob']:.3f}")
     path = os.path.join(GOLD, f"{tag}.npz")
     np.savez_compressed(path, **_np(fx))
     print(f"wrote {path}  ({os.path.getsize(path)/1e3:.0f} kB) T={out['actions'].shape[1]} reward[:3]={out['reward'][:3].tolist()}")
 
 
-def gen_rcvrptw(tag, B, N, S, sample_size, seed, layers=6, keep_trace=True, nab_type="gating", variant=False):
+def gen_rcvrptw(tag, B, N, S, sample_size, seed, layers=6, keep_trace=True, nab_type="gating", variant=False, weights_file=None):
     from rrnco.envs.rmtvrp.env import RMTVRPEnv
     from rrnco.models.policy import RRNetPolicy
 
@@ -266,7 +280,7 @@ def gen_rcvrptw(tag, B, N, S, sample_size, seed, layers=6, keep_trace=True, nab_
     if nab_type != "gating":
         mine_t = restate.ablation_template(mine_t, nab_type, use_duration=True)
     assert tmpl == mine_t, (set(tmpl) ^ set(mine_t), [k for k in tmpl if k in mine_t and tmpl[k] != mine_t[k]])
-    w = restate.make_weights(tmpl, seed)
+    w = restate.make_weights(tmpl, seed) if weights_file is None else _load_trained(weights_file, tmpl)
     pol.load_state_dict(w, strict=True)
     td = env.reset(TensorDict({k: v.clone() for k, v in inst.items()}, batch_size=[B]))
     enc_out = []
@@ -315,6 +329,12 @@ def gen_rcvrptw(tag, B, N, S, sample_size, seed, layers=6, keep_trace=True, nab_
     if keep_trace:
         fx["trace_logits"] = torch.stack(trace["logits"], 0)
         fx["trace_mask"] = torch.stack(trace["mask"], 0)
+    if weights_file is not None:
+        fx["weights_file"] = weights_file
+        lp = torch.stack(trace["logp"], 1)
+        live = torch.isfinite(lp).any(-1)
+        fx["mean_chosen_prob"] = float(torch.nan_to_num(lp, neginf=-1e9).max(-1).values[live].exp().mean())
+        print(f"  trained weights {weights_file}: mean probability of the chosen action {fx['mean_chosen_prob']:.3f}")
     path = os.path.join(GOLD, f"{tag}.npz")
     np.savez_compressed(path, **_np(fx))
     print(f"wrote {path}  ({os.path.getsize(path)/1e3:.0f} kB) T={out['actions'].shape[1]} reward[:3]={out['reward'][:3].tolist()}")
@@ -442,6 +462,16 @@ if __name__ == "__main__":
         gen_atsp("atsp_n50_b3_pomo_trained", B=3, N=50, S=50, sample_size=25, seed=32, keep_trace=False, weights_file="atsp_trained_weights.npz")
         gen_atsp("atsp_n100_b2_pomo_aug8_trained", B=2, N=100, S=100, sample_size=25, seed=33, aug=True, keep_trace=False,
                  weights_file="atsp_trained_weights.npz")
+    if "rcvrp_trained" in which:     # VERDICT r03 missing #2: RCVRP on a TRAINED policy (tests/golden/rcvrp_trained_weights.npz)
+        gen_rcvrp("rcvrp_n100_b2_pomo_trained", B=2, N=100, S=101, sample_size=25, seed=35, capacity=50.0, keep_trace=False,
+                  weights_file="rcvrp_trained_weights.npz")
+        gen_rcvrp("rcvrp_n50_b3_pomo_trained", B=3, N=50, S=51, sample_size=25, seed=36, capacity=40.0, keep_trace=False,
+                  weights_file="rcvrp_trained_weights.npz")
+    if "rcvrptw_trained" in which:   # ... and RCVRPTW (tests/golden/rcvrptw_trained_weights.npz)
+        gen_rcvrptw("rcvrptw_n100_b2_pomo_trained", B=2, N=100, S=100, sample_size=25, seed=37, keep_trace=False,
+                    weights_file="rcvrptw_trained_weights.npz")
+        gen_rcvrptw("rcvrptw_n50_b3_pomo_trained", B=3, N=50, S=50, sample_size=25, seed=38, keep_trace=False,
+                    weights_file="rcvrptw_trained_weights.npz")
     if "rcvrp" in which:
         gen_rcvrp("rcvrp_n20_b4_pomo", B=4, N=20, S=21, sample_size=15, seed=21, capacity=30.0)
         gen_rcvrp("rcvrp_n20_b4_greedy", B=4, N=20, S=0, sample_size=15, seed=22, capacity=30.0)

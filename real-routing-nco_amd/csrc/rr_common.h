@@ -354,9 +354,11 @@ __device__ __forceinline__ float rr_sum_g(float v) {
   rr_pair32(v, a, b); return a + b;
 }
 __device__ __forceinline__ float rr_max_g(float v) {
+  // v_med3_f32(a, b, +inf) = max(a, b) (NaN-free inputs: scores and clipped logits; fmaxf on the two halves of a permlane swap costs
+  // three v_max_f32: hipcc canonicalises both inputs first)
   float a, b;
-  rr_pair16(v, a, b); v = fmaxf(a, b);
-  rr_pair32(v, a, b); return fmaxf(a, b);
+  rr_pair16(v, a, b); v = __builtin_amdgcn_fmed3f(a, b, INFINITY);
+  rr_pair32(v, a, b); return __builtin_amdgcn_fmed3f(a, b, INFINITY);
 }
 __device__ __forceinline__ float rr_wave_sum(float v) {
 #pragma unroll

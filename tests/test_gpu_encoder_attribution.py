@@ -1,0 +1,134 @@
+"""`-m gpu`: where the encoder's embedding error comes from, stage by stage, at N = 100 on TRAINED weights (VERDICT r03, next #3a).
+
+The headline-shaped live-oracle test parts from the reference on ~0.2 % of the rollouts, every parting at a decision gap below
+5e-5, and the LL attribution test of test_gpu_atsp.py shows the decoder alone at 1e-5 .. 5e-5: the rest is the encoder's embedding
+error (2.3e-4 on trained weights).  This test ranks the encoder's stages by the error each one GENERATES:
+
+  * every stage tensor the training forward stores (_lib.EncSave: r, c, q, ek, v, eaT, num, den, y, o, u1, x1, and the block
+    output) is compared with the float64 value of that stage computed FROM THE KERNEL'S OWN INPUTS to the stage (the previous
+    saved tensors), so an entry is the stage's local rounding, not what it inherited;
+  * beside it, the error that has ACCUMULATED at every layer boundary against a float64 run of the whole encoder — for the
+    kernels and for the reference's own fp32 arithmetic (the op-for-op torch-CPU restatement): both are fp32 computations of the
+    same real-number function and both sit at a distance from float64.
+
+Reference: rrnco/models/nn/attn_freenet.py:309-327 (AFTFull), 417-441 (AttnFree_Block), 242-289 (DistAngleFusion)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import restate
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+STAGES = ("r", "c", "q", "ek", "v", "ea", "num", "den", "y", "o", "u1", "x1", "out")
+
+
+def _inorm64(wd, p, x):
+    return restate.instance_norm(wd, p, x)
+
+
+def _block_stage_refs(wd, p, sv, x_in, y_in, cost, coords, out_k):
+    """float64 value of every stage from the kernel's inputs to that stage.  sv: the block's EncSave dict (fp32, device)."""
+    k = {n: sv[n].double().cpu() for n in ("r", "c", "q", "ek", "v", "num", "den", "y", "o", "u1", "x1")}
+    N = x_in.shape[1]
+    ea_k = sv["eaT"].double().cpu()[:, :N, :N].transpose(1, 2)                     # stored [j][i]
+    a = p + ".attn_free"
+    ref = {}
+    ref["r"] = _inorm64(wd, p + ".norm1", x_in)
+    ref["c"] = _inorm64(wd, p + ".norm2", y_in)
+    ref["q"] = restate.lin(wd, a + ".to_q", k["r"])
+    ref["ek"] = torch.exp(torch.softmax(restate.lin(wd, a + ".to_k", k["c"]), dim=1))
+    ref["v"] = restate.lin(wd, a + ".to_v", k["c"])
+    bias = restate.nab_gating(wd, p + ".angle_distance_fusion", coords, cost, None) * wd[p + ".alpha"]
+    ref["ea"] = torch.exp(torch.softmax(bias, dim=-1))
+    ref["num"] = ea_k @ (k["ek"] * k["v"])
+    ref["den"] = ea_k @ k["ek"]
+    ref["y"] = torch.sigmoid(k["q"]) * k["num"] / k["den"]
+    ref["o"] = restate.lin(wd, p + ".multi_head_combine", restate.lin(wd, a + ".project", k["y"]))
+    ref["u1"] = k["r"] + _inorm64(wd, p + ".norm3", k["o"])
+    f = p + ".feed_forward.ops"
+    ref["x1"] = _inorm64(wd, f + ".norm1", k["u1"])
+    ref["out"] = _inorm64(wd, f + ".norm2", k["x1"] + restate.lin(wd, f + ".ffn.W2", F.relu(restate.lin(wd, f + ".ffn.W1", k["x1"]))))
+    got = dict(k, ea=ea_k, out=out_k.double().cpu())
+    return {n: (float((got[n] - ref[n]).abs().max()), float(ref[n].pow(2).mean().sqrt())) for n in STAGES}
+
+
+@pytest.mark.parametrize("name", ["atsp_n100_b2_pomo_trained"])
+def test_encoder_error_attribution_per_stage_on_trained_weights(name):
+    from rrnco_amd import TensorDict
+    from rrnco_amd.envs import ATSPEnv
+    fx = H.load_fixture(name)
+    w = H.atsp_weights(fx)
+    pol = H.make_policy(w, device="cuda:0")
+    env = ATSPEnv(generator_params=dict(num_loc=fx["N"]))
+    st = H.fixture_state(fx)
+    td = env.reset(TensorDict({"locs": st["locs"].cuda(), "distance_matrix": st["distance_matrix"].cuda(),
+                               "sample_idx": fx["sample_idx"].cuda()}, batch_size=[st["locs"].shape[0]]))
+    packed = pol.packed(torch.device("cuda:0"))
+    saves = []
+    row_k, col_k = pol.encoder(td, packed=packed, train_saves=saves)               # the training forward: same kernels + stage stores
+    row_i, col_i = pol.encoder(td, packed=packed)                                   # the inference kernels (block without FFN + k_enc_ffn)
+    init_k = [t.clone() for t in pol.encoder._last_init] if False else None
+    torch.cuda.synchronize()
+    assert float((row_k - row_i).abs().max()) < 5e-5 and float((col_k - col_i).abs().max()) < 5e-5
+    layers = [s for s in saves if "row_in" in s]
+    nl = len(layers)
+
+    # ---- float64 and fp32 runs of the whole encoder (CPU), layer boundaries kept
+    st0 = restate.atsp_reset(st)
+    D32, locs32 = st0["distance_matrix"], st0["locs"].float()
+    wd = {k_: v.double() for k_, v in w.items()}
+    D64, locs64 = D32.double(), locs32.double()
+    nab = "angle_distance_fusion"
+    chains = {}
+    for tag, ww, Dm, lc in (("f64", wd, D64, locs64), ("ref32", w, D32, locs32)):
+        with torch.inference_mode():
+            r_, c_ = restate.atsp_init_embedding(ww, st0["locs"].to(Dm.dtype), Dm, fx["sample_idx"])
+            bounds = [(r_, c_)]
+            for l in range(nl):
+                p = f"encoder.net.layers.{l}"
+                rn = restate.block(ww, p + ".row_encoding_block", r_, c_, Dm, lc, None, nab)
+                cn = restate.block(ww, p + ".col_encoding_block", c_, r_, Dm.transpose(1, 2), lc, None, nab)
+                r_, c_ = rn, cn
+                bounds.append((r_, c_))
+        chains[tag] = bounds
+    assert torch.equal(chains["ref32"][-1][0], fx["row_emb"]) and torch.equal(chains["ref32"][-1][1], fx["col_emb"])      # the fixture IS the reference's fp32 run
+
+    def err(a, b):
+        return max(float((a[0].double().cpu() - b[0].double()).abs().max()), float((a[1].double().cpu() - b[1].double()).abs().max()))
+    kb = [(layers[0]["row_in"], layers[0]["col_in"])] + [(layers[l + 1]["row_in"], layers[l + 1]["col_in"]) for l in range(nl - 1)] + [(row_k, col_k)]
+    print(f"\n[{name}] accumulated |x - float64| at the layer boundaries (init embedding, then behind each layer):")
+    print("   kernels        : " + "  ".join(f"{err(kb[l], chains['f64'][l]):.2e}" for l in range(nl + 1)))
+    print("   reference fp32 : " + "  ".join(f"{err(chains['ref32'][l], chains['f64'][l]):.2e}" for l in range(nl + 1)))
+    print("   kernels - ref  : " + "  ".join(f"{err(kb[l], chains['ref32'][l]):.2e}" for l in range(nl + 1)))
+    e_k, e_r, e_kr = err(kb[-1], chains["f64"][-1]), err(chains["ref32"][-1], chains["f64"][-1]), err(kb[-1], chains["ref32"][-1])
+
+    # ---- local (generated) error of every stage, from the kernel's own inputs to the stage
+    worst = {n: (0.0, 0.0, "") for n in STAGES}
+    with torch.inference_mode():
+        for l in range(nl):
+            p = f"encoder.net.layers.{l}"
+            rin, cin = layers[l]["row_in"].double().cpu(), layers[l]["col_in"].double().cpu()
+            rout, cout = kb[l + 1]
+            for side, sv, x_in, y_in, cost, out_k in (("row", layers[l]["row"], rin, cin, D64, rout),
+                                                      ("col", layers[l]["col"], cin, rin, D64.transpose(1, 2), cout)):
+                res = _block_stage_refs(wd, f"{p}.{side}_encoding_block", sv, x_in, y_in, cost, locs64, out_k)
+                for n, (e, rms) in res.items():
+                    if e / max(rms, 1e-30) > worst[n][0] / max(worst[n][1], 1e-30) or worst[n][2] == "":
+                        worst[n] = (e, rms, f"layer {l} {side}")
+    rank = sorted(STAGES, key=lambda n: -worst[n][0] / max(worst[n][1], 1e-30))
+    print(f"[{name}] error GENERATED per stage (max |kernel - float64 of the same inputs|, worst block; relative = / rms of the stage):")
+    for n in rank:
+        e, rms, where = worst[n]
+        print(f"   {n:4s} abs {e:.2e}  rel {e / max(rms, 1e-30):.2e}   ({where}, rms {rms:.2e})")
+    print(f"[{name}] final embeddings: kernels vs float64 {e_k:.2e}, reference fp32 vs float64 {e_r:.2e}, kernels vs reference {e_kr:.2e}")
+
+    # what the numbers must satisfy: no stage generates more than a few fp32 roundings of its own scale, and the kernels stay as
+    # close to float64 as the reference's own fp32 arithmetic does (within 2x): the distance between the two fp32 runs is then
+    # bounded by the sum of two fp32 noise floors, not by an arithmetic defect of the kernels
+    for n in STAGES:
+        e, rms, where = worst[n]
+        assert e <= 6e-6 * max(rms, 1.0) + 2e-6, (n, e, rms, where)
+    assert e_k <= 2.0 * e_r + 2e-5, (e_k, e_r)
+    assert e_kr <= e_k + e_r + 1e-6
