@@ -41,8 +41,8 @@ PEAK_F16_MFMA_TFLOPS = 2500.0            # ... dense fp16 / bf16 matrix peak (me
 SPLIT_PRODUCTS = 3
 EXECUTED_F16_FLOP_PER_TILE_STEP = 1104 * 16384
 EXECUTED_F16_FLOP_PER_ROLLOUT_STEP = EXECUTED_F16_FLOP_PER_TILE_STEP // 16      # (a full tile; tools/bench_train.py)
-ROLLOUT_KERNEL = "k_rollout_w<7, 0, 0, true, true>"
-ROLLOUT_KERNEL_FP32 = "k_rollout_w<7, 0, 0, false, false>"
+ROLLOUT_KERNEL = "k_rollout_w<7, 0, 0, true, true, false>"
+ROLLOUT_KERNEL_FP32 = "k_rollout_w<7, 0, 0, false, false, false>"
 # HBM-side traffic of ONE rollout launch at the default workload: rocprofv3 PMC, separate FETCH_SIZE / WRITE_SIZE passes,
 # (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B — FETCH_SIZE doubled for gfx950's 16-B/lane reads as MI355X_MICROARCH.md §HBM
 # prescribes; Infinity-Cache hits are included in the counter.  Read at run time from the committed summary
@@ -298,10 +298,10 @@ def other_configs(dev):
 
     env = RCVRPEnv(generator_params=dict(num_loc=N_NODES, device=dev), check_solution=False, device=dev)
     inference("C3 RCVRP n=100 B=512 POMO S=101 greedy (configs[2])", env, vrp_policy("rcvrp"), 512, 101, False, "multistart_greedy",
-              "k_rollout_w<7, 1, 0, true, true>")
+              "k_rollout_w<7, 1, 0, true, true, false>")
     env = RMTVRPEnv(generator_params=dict(num_loc=N_NODES, device=dev), device=dev)
     inference("C4 RCVRPTW n=100 B=256 x8 aug S=100 sampling (configs[3])", env, vrp_policy("rcvrptw"), 256, 100, True, "multistart_sampling",
-              "k_rollout_w<7, 2, 1, true, true>")
+              "k_rollout_w<7, 2, 1, true, true, false>")
     torch.cuda.empty_cache()
 
     # configs[4], one rank's shard: REINFORCE step on 512 ATSP instances (sampling rollout with the training dump, hand-written
@@ -349,7 +349,7 @@ def other_configs(dev):
     o = state["out"]
     out["C5 ATSP n=100 REINFORCE step, 512 instances (one rank's shard of configs[4])"] = {
         "value": 512 / sec, "unit": "trained instances/s", "ms_per_step": sec * 1e3, "steps": n,
-        "kernel_ms": sum(ks) / max(len(ks), 1), "kernel": "k_rollout_w<7, 0, 1, true, true> (sampling rollout with the training dump)",
+        "kernel_ms": sum(ks) / max(len(ks), 1), "kernel": "k_rollout_w<7, 0, 1, true, true, false> (sampling rollout with the training dump)",
         "backward_kernels_ms_per_step": {k: round(v, 3) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
         "loss": float(o["loss"]), "grad_norm": float(o["grad_norm"]), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
         "roofline": roof}
@@ -524,6 +524,17 @@ def main():
             R.SPLIT_MLP = True
             os.environ.pop("RR_MLP_SPLIT")
             pol.invalidate_pack()
+            # the reference's own GPU arithmetic mode (torch.autocast in test.py:183 / Lightning 16-mixed): one fp16 piece per operand in
+            # the fused rollout, fp32 accumulation; encoder and cache unchanged.  NOT the headline: other arithmetic, other tolerance
+            # (tests/test_gpu_mixed.py: inside the reference's own autocast deviation).  Priced against the plain fp16 peak.
+            pol.precision = "16-mixed"
+            v16, k16 = timed("16-mixed")
+            pol.precision = "32"
+            a16 = rollout_steps * FLOP_PER_ROLLOUT_STEP / (k16 * 1e-3) / 1e12
+            v16["dtype"] = "f16 operands (one piece), f32 accumulate, f32 softmax / logits"
+            v16["roofline"] = {"bound": "mfma", "kernel": "k_rollout_w<7, 0, 0, true, true, true>", "achieved": a16, "peak": PEAK_F16_MFMA_TFLOPS,
+                               "unit": "TFLOP/s", "frac": a16 / PEAK_F16_MFMA_TFLOPS}
+            line["variants"]["16_mixed_rollout (precision='16-mixed', the reference's autocast mode)"] = v16
         if world == 1 and not args.no_other_configs:
             del pol
             torch.cuda.empty_cache()

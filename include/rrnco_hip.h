@@ -79,7 +79,11 @@ typedef struct {                /* arguments of the persistent rollout: see csrc
   float *dump_g0, *dump_g; uint32_t *dump_meta; float *dump_scal; int dumpT;
   int use_split;                /* 1: greedy / sampling launch on the fp16 matrix pipe with two-piece split fp32 operands (x~ = hi + lo,
                                  * three f16 MFMAs per product, error of a dot product 4e-8 of sum |a b|: csrc/rr_common.h); needs DecW.w1s /
-                                 * w2s and the three images below, otherwise the fp32 MFMA kernel runs */
+                                 * w2s and the three images below, otherwise the fp32 MFMA kernel runs.
+                                 * 2: "16-mixed" — the reference's own GPU arithmetic mode (torch.autocast in test.py:183, Lightning
+                                 * precision 16-mixed in configs/trainer/default.yaml:8, fp32 logits per rrnco/models/decoder.py:195-196):
+                                 * ONE fp16 piece per operand (the hi halves of the same images / packs), fp32 accumulation; instance-mode
+                                 * launches (7 rollout tiles per instance) only, other shapes run as use_split = 1 */
   const void *Ks, *Vts, *Ls;    /* rr_pack_f16x2 images of K / Vt / L (same shapes) */
   int* status;                  /* optional device word: bit 2 is set when a split launch meets a non-finite log-probability — an
                                  * operand left the fp16 range somewhere upstream (|x| >= 65504 after its image's scale); the caller

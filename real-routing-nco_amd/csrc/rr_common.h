@@ -166,6 +166,17 @@ __device__ __forceinline__ rr_f16x8 rr_cat4(rr_f16x4 a, rr_f16x4 b) { return __b
 __device__ __forceinline__ rr_f16x4 rr_lo4(rr_f16x8 v) { return __builtin_shufflevector(v, v, 0, 1, 2, 3); }
 __device__ __forceinline__ rr_f16x4 rr_hi4(rr_f16x8 v) { return __builtin_shufflevector(v, v, 4, 5, 6, 7); }
 __device__ __forceinline__ rr_f16x8 rr_as_f16x8(float4 v) { return __builtin_bit_cast(rr_f16x8, v); }
+// one fp16 piece per value (the 16-mixed rollout, rr_rollout_w.inc HALF): v_cvt_pk_f16_f32, round to nearest even
+__device__ __forceinline__ rr_f16x4 rr_cvt4h(const float (&x)[4]) {
+  typedef float f4_ __attribute__((ext_vector_type(4)));
+  const f4_ v = {x[0], x[1], x[2], x[3]};
+  return __builtin_convertvector(v, rr_f16x4);
+}
+__device__ __forceinline__ rr_f16x8 rr_cvt8h(const float (&x)[8]) {
+  typedef float f8_ __attribute__((ext_vector_type(8)));
+  const f8_ v = {x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]};
+  return __builtin_convertvector(v, rr_f16x8);
+}
 __device__ __forceinline__ f32x4 rr_mfma_f16k16(rr_f16x4 a, rr_f16x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
 }

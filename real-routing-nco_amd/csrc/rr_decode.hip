@@ -488,8 +488,13 @@ extern "C" int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStrea
   do {                                                                                                       \
     if constexpr ((NTV) == 7) {                                                                              \
       const size_t shm_i = 3 * 16384 + 2 * (size_t)(NTV) * 8192;                                             \
+      if (io->use_split == 2 && (P) <= 2) {        /* 16-mixed: one fp16 piece per operand (rr_rollout_w.inc, HALF) */ \
+        (void)hipFuncSetAttribute((const void*)k_rollout_w<NTV, ((P) <= 2 ? (P) : 0), M, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_i); \
+        hipLaunchKernelGGL((k_rollout_w<NTV, ((P) <= 2 ? (P) : 0), M, true, true, true>), dim3(io->Bp), blk_s, shm_i, st, *w, *io, 0, 0); \
+      } else {                                                                                               \
       (void)hipFuncSetAttribute((const void*)k_rollout_w<NTV, P, M, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_i); \
       hipLaunchKernelGGL((k_rollout_w<NTV, P, M, true, true>), dim3(io->Bp), blk_s, shm_i, st, *w, *io, 0, 0); \
+      }                                                                                                      \
     }                                                                                                        \
   } while (0)
   // the split-bf16 pointer MLP is opt-in (RR_MLP_SPLIT=1), for the greedy / sampling rollouts of every problem

@@ -1254,6 +1254,10 @@ __global__ __launch_bounds__(256, BF ? 2 : 1) void k_dec_attn_bwd(DecAttnIO io) 
     float4 qv = tv.qb;
     qv.x += tv.qa.x; qv.y += tv.qa.y; qv.z += tv.qa.z; qv.w += tv.qa.w;
     float sc4[4] = {tv.sv.x, tv.sv.y, tv.sv.z, tv.sv.w};
+    // Rows the rollout never reached (finished routes: live flag 0) were never written: their state scalars are whatever the
+    // allocator left there, NaN patterns included, and a NaN query poisons dK of the whole instance through 0 x NaN (found by
+    // training RCVRPTW for 1 600 steps: profiles/r04/NOTES.md).  Dead rows get a finite query; their dh is zeroed below.
+    if (!live) { sc4[0] = 0.f; sc4[1] = 0.f; sc4[2] = 0.f; sc4[3] = 0.f; }
     if (io.nscal > 0) {
 #pragma unroll
       for (int k = 0; k < 4; ++k)

@@ -169,7 +169,17 @@ def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
                                  L.ptr(G.buf(pname + ".normalizer.weight")), L.ptr(G.buf(pname + ".normalizer.bias")), Bp, N, acc, st),
                 "rr_inorm_bwd")
 
+    trace = os.environ.get("RR_NAN_TRACE", "0") == "1"      # diagnostic: name the first kernel output of the backward that is not finite
+
+    def chk(where, **tensors):
+        if trace:
+            for n_, t_ in tensors.items():
+                if t_ is not None and not bool(torch.isfinite(t_).all()):
+                    bad = (~torch.isfinite(t_)).nonzero()
+                    raise FloatingPointError(f"encoder_backward: {n_} is not finite after {where} ({bad.shape[0]} entries, first at {bad[0].tolist()})")
+
     with torch.no_grad():
+        chk("decoder_backward", **{k_: v_ for k_, v_ in dec.items() if torch.is_tensor(v_) and v_.is_floating_point()})
         # ---- decoder.py:214-232 backwards: embeddings -> K, V, L (col) and the step-context tables (row)
         cp = packs["cache"]
         d_col, d_row = new(), new()
@@ -218,17 +228,22 @@ def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
                 F = new()
                 L.check(lib.rr_mlp_rows(mlp["fwd"], 0, L.ptr(S["x1"]), None, L.ptr(F), None, 1, M, M, st), "rr_mlp_rows")
                 dF = new()
+                chk(b + " recomputed F", F=F, dout=dout)
                 inorm(F, dout, None, b + ".feed_forward.ops.norm2", dF)
+                chk(b + " ffn.norm2 backward", dF=dF)
                 dx1 = F                                                                   # reuse
                 L.check(lib.rr_mlp_rows(mlp["bwd"], 1, L.ptr(S["x1"]), L.ptr(dF), L.ptr(dx1), None, 1, M, M, st), "rr_mlp_rows")
                 f = b + ".feed_forward.ops.ffn"
                 L.check(lib.rr_mlp_wgrad(mlp["wgrad"], L.ptr(S["x1"]), L.ptr(dF), L.ptr(G.buf(f + ".W1.weight")), L.ptr(G.buf(f + ".W1.bias")),
                                          L.ptr(G.buf(f + ".W2.weight")), L.ptr(G.buf(f + ".W2.bias")), None, 1, M, M, L.ptr(ws_wg), st), "rr_mlp_wgrad")
+                chk(b + " FFN backward", dx1=dx1)
                 # x1 = ffn.norm1(r + norm3(o)) (:355, 436)
                 dU1 = dF                                                                  # reuse
                 inorm(S["u1"], dx1, None, b + ".feed_forward.ops.norm1", dU1)
+                chk(b + " ffn.norm1 backward", dU1=dU1)
                 dO = dx1
                 inorm(S["o"], dU1, None, b + ".norm3", dO)
+                chk(b + " norm3 backward", dO=dO)
                 # o = combine(project(y)) (:325, 435): one folded Linear Wpc = Wc Wp
                 dbpc, dWpc = dbpc_all[bidx], dWpc_all[bidx]                               # (zero-filled views of one buffer each)
                 bidx += 1
@@ -243,6 +258,7 @@ def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
                                                                     L.ptr(S["den"]), L.ptr(S["eaT"]))
                 io.dq, io.dk, io.dv, io.dbias, io.N = L.ptr(dq), L.ptr(dk), L.ptr(dv), L.ptr(dbias), N
                 L.check(lib.rr_aft_bwd(io, Bp, st), "rr_aft_bwd")
+                chk(b + " rr_aft_bwd", dY=dY, dq=dq, dk=dk, dv=dv, dbias=dbias, **{"saved " + k_: S[k_] for k_ in ("q", "ek", "v", "num", "den", "eaT")})
                 if vtw:       # alpha * NAB with duration (:226-237, 265-286): d bias is all the kernels contribute
                     dur_todo.append((b, si, dbias))
                 else:
@@ -267,8 +283,10 @@ def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
                 wgrad(dk, S["c"], G.buf(b + ".attn_free.to_k.weight"))
                 wgrad(dv, S["c"], G.buf(b + ".attn_free.to_v.weight"))
                 # r = norm1(x) (:421; also the residual into ffn.norm1), c = norm2(y) (:422)
+                chk(b + " projections backward", dr=dr, dc=dc)
                 inorm(x_in, dU1, dr, b + ".norm1", dx_out, acc=si)           # the col block adds to what the row block wrote
                 inorm(y_in, dc, None, b + ".norm2", dy_out, acc=si)
+                chk(b + " norm1 / norm2 backward", dx_out=dx_out, dy_out=dy_out)
             d_row, d_col = n_row, n_col
         small += [(Wpc_all, dWpc_all), (bpc_all, dbpc_all)]
         if nab_tabs:          # the NAB moments of all blocks -> d (folded tables), one batched prefix-sum pass

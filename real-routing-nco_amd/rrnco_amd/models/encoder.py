@@ -123,6 +123,13 @@ class _Gating(nn.Module):        # ContextualGating env_embeddings/atsp.py:108-1
         self.gating_fc = nn.Sequential(nn.Linear(2 * E, 2 * E), nn.ReLU(), nn.Linear(2 * E, 1))
 
 
+def rank_noise_seed(seed: int, rank: int) -> int:
+    """Seed of the device-side neighbour sampler on data-parallel rank `rank`: the ranks share torch.manual_seed (same initial
+    weights, hence the same CPU draw), so every rank offsets it by a multiple of the 64-bit golden ratio — distinct noise fields,
+    reproducible from (seed, rank) alone (a resumed run restores the CPU generator and continues the same per-rank streams)."""
+    return (int(seed) + 0x9E3779B97F4A7C15 * int(rank)) % (2 ** 62)
+
+
 class ATSPInitEmbedding(nn.Module):   # env_embeddings/atsp.py:5-35
     def __init__(self, embed_dim, linear_bias=True, use_coords=True, use_polar_feats=False, use_dist=True,
                  use_matnet_init=True, sample_type="prob", sample_size=25):
@@ -143,10 +150,8 @@ class ATSPInitEmbedding(nn.Module):   # env_embeddings/atsp.py:5-35
             # on the device: Gumbel top-k (the same Plackett-Luce law as multinomial without replacement), one pass, keyed
             # counter-based noise; the seed advances torch's CPU generator like any draw would (csrc/rr_sample.hip)
             out = torch.empty(B, N, sample_size, dtype=torch.int64, device=distance.device)
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-            # data-parallel ranks share torch.manual_seed (same initial weights): every rank its own noise field
             import os
-            seed = (seed + 0x9E3779B97F4A7C15 * int(os.environ.get("RANK", "0"))) % (2 ** 62)
+            seed = rank_noise_seed(int(torch.randint(0, 2 ** 62, (1,)).item()), int(os.environ.get("RANK", "0")))
             L.check(L.lib().rr_sample_neighbors(L.ptr(distance.float().contiguous()), L.ptr(out), B, N, int(sample_size), seed,
                                                 L.stream()), "rr_sample_neighbors")
             return out

@@ -21,8 +21,15 @@ class RRNetPolicy(nn.Module):
                  sdpa_fn_decoder=None, mask_inner=True, out_bias_pointer_attn=False, check_nan=True,
                  temperature=1.0, tanh_clipping=10.0, mask_logits=True, train_decode_type="sampling",
                  val_decode_type="greedy", test_decode_type="greedy", moe_kwargs={"encoder": None, "decoder": None},
-                 nab_type="gating", **unused_kwargs):
+                 nab_type="gating", precision="32", **unused_kwargs):
         super().__init__()
+        # "32" (default): fp32-equivalent arithmetic everywhere (two-piece fp16 operands, three partial products).  "16-mixed": the
+        # fused inference rollout multiplies ONE fp16 piece per operand with fp32 accumulation, as the reference does under
+        # torch.autocast (test.py:183) / Lightning 16-mixed (configs/trainer/default.yaml:8); the encoder and the decoder cache stay
+        # fp32-equivalent.  Opt-in: its results are NOT held to the fp32 golden tolerances (tests/test_gpu_mixed.py states its own).
+        if precision not in ("32", "32-true", "16-mixed"):
+            raise ValueError(f"precision {precision!r}: '32' or '16-mixed'")
+        self.precision = "16-mixed" if precision == "16-mixed" else "32"
         self.encoder = encoder if encoder is not None else RRNetEncoder(
             embed_dim=embed_dim, num_heads=num_heads, num_layers=num_encoder_layers, env_name=env_name,
             normalization=normalization, feedforward_hidden=feedforward_hidden, net=encoder_network,
@@ -327,11 +334,14 @@ class RRNetPolicy(nn.Module):
             Sd = R // Bp
             dT = (N - t0 - 1) if self.env_name == "atsp" else (T - t0)      # ATSP: the forced last move is not evaluated
             rows = Bp * dT * Sd
+            # (rows a finished instance never reaches stay unwritten: the backward must not let them through — tests poison them with NaN)
+            alloc = (lambda *sh: torch.full(sh, float("nan"), device=dev)) if getattr(self, "_debug_poison_dump", False) \
+                else (lambda *sh: torch.empty(*sh, device=dev))
             dump.update({"T": dT, "S": Sd, "Bp": Bp, "N": N, "t0": t0,
-                         "g0": torch.empty(rows, 128, device=dev), "g": torch.empty(rows, 128, device=dev),
+                         "g0": alloc(rows, 128), "g": alloc(rows, 128),
                          # zeroed: rows a finished tile of rollouts never reaches must read as "not live"
                          "meta": torch.zeros(rows, 8, dtype=torch.int32, device=dev),
-                         "scal": None if self.env_name == "atsp" else torch.empty(rows, 4, device=dev)})
+                         "scal": None if self.env_name == "atsp" else alloc(rows, 4)})
         ain = None
         if actions_in is not None:                      # evaluate: actions[..., step] feeds decode step `step`
             ain = torch.zeros(R, T, dtype=torch.int64, device=dev)
@@ -339,7 +349,8 @@ class RRNetPolicy(nn.Module):
         st = launch_rollout(self.env_name, packed, cache, td, strategy.num_starts, actions=acts, logp=logp, t0=t0,
                             nsteps=nsteps, mode=strategy.mode, actions_in=ain, write_state=True,
                             tanh_clip=strategy.tanh_clipping, temperature=strategy.temperature, seed=strategy.seed,
-                            steps_out=steps_out, dump=dump, status=getattr(self, "_range_status", None))
+                            steps_out=steps_out, dump=dump, status=getattr(self, "_range_status", None),
+                            precision=getattr(self, "precision", "32"))
         if dump is not None:
             dump.update({"first": st["first"], "tanh_clip": strategy.tanh_clipping, "temperature": strategy.temperature})
         status = getattr(self, "_range_status", None)

@@ -20,7 +20,7 @@ TIMING = None   # bench.py sets this to a list to collect (start, end) HIP event
 
 def launch_rollout(env_name, packed, cache, td, num_starts, *, actions=None, logp=None, t0=0, nsteps=1,
                    mode="greedy", actions_in=None, logits_out=None, logits_only=False, write_state=False,
-                   tanh_clip=10.0, temperature=1.0, seed=0, steps_out=None, state=None, dump=None, status=None):
+                   tanh_clip=10.0, temperature=1.0, seed=0, steps_out=None, state=None, dump=None, status=None, precision="32"):
     """Runs `nsteps` decode steps (nsteps <= 0: until every rollout is done) for all rollouts of `td`.
     `td` is the batchified rollout state (R = S*Bp rows, per-instance keys left at Bp rows)."""
     if env_name not in PROB_ID:
@@ -96,6 +96,11 @@ def launch_rollout(env_name, packed, cache, td, num_starts, *, actions=None, log
         # training rollouts run on the same split-operand kernel (fp32-level accuracy; the reference trains in 16-bit mixed
         # precision, configs/trainer/default.yaml:8)
         io.use_split = int(os.environ.get("RR_TRAIN_SPLIT", "1") != "0" and split_on)
+    if precision == "16-mixed" and io.use_split and dump is None:
+        # the reference's own GPU arithmetic mode (torch.autocast, test.py:183; Lightning "16-mixed", configs/trainer/default.yaml:8):
+        # one fp16 piece per operand, fp32 accumulation, fp32 softmax / logits (decoder.py:195-196) — csrc/rr_rollout_w.inc, HALF.
+        # Inference launches in instance mode only (7 tiles per instance); other shapes fall back to the two-piece kernels.
+        io.use_split = 2
     if io.use_split and not logits_only and mode != "evaluate":
         ks, vts, ls = cache.split_images(status)
         io.Ks, io.Vts, io.Ls = L.ptr(ks), L.ptr(vts), L.ptr(ls)

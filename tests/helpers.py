@@ -11,6 +11,10 @@ from oracle import restate
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+def fixture_path(name):
+    return os.path.join(GOLD, name + ".npz")
+
+
 def load_fixture(name):
     z = np.load(os.path.join(GOLD, name + ".npz"))
     out = {}
@@ -70,7 +74,14 @@ def tour_agreement(act_hip, act_ref, gaps=None):
     return float((first < 0).float().mean()), first
 
 
+def _trained(fx):
+    z = np.load(os.path.join(GOLD, str(fx["weights_file"])))
+    return {k: torch.from_numpy(z[k]).float() for k in z.files}
+
+
 def rcvrp_weights(fx):
+    if "weights_file" in fx:           # a policy trained on the engine (tools/train_fixture_weights.py --problem rcvrp), run through the reference
+        return _trained(fx)
     return restate.make_weights(restate.rcvrp_weight_template(128, fx["layers"], 512, fx["sample_size"]), fx["seed"])
 
 
@@ -79,6 +90,8 @@ def rcvrp_instance(fx):
 
 
 def rcvrptw_weights(fx):
+    if "weights_file" in fx:
+        return _trained(fx)
     t = restate.rcvrptw_weight_template(128, fx["layers"], 512, fx["sample_size"])
     if fx.get("nab_type", "gating") != "gating":
         t = restate.ablation_template(t, fx["nab_type"], use_duration=True)

@@ -42,7 +42,7 @@ def _assert_reference_outputs(out, trace, fx):
     assert torch.allclose(trace["row_emb"], fx["row_emb"], rtol=0, atol=2e-6) and torch.allclose(trace["col_emb"], fx["col_emb"], rtol=0, atol=2e-6)
 
 
-@pytest.mark.parametrize("name", ["rcvrp_n20_b4_pomo", "rcvrp_n20_b4_greedy", "rcvrp_n100_b2_pomo"])
+@pytest.mark.parametrize("name", ["rcvrp_n20_b4_pomo", "rcvrp_n20_b4_greedy", "rcvrp_n100_b2_pomo", "rcvrp_n50_b3_pomo_trained"])
 def test_oracle_reproduces_reference_golden_rcvrp(name):
     fx = H.load_fixture(name)
     w = H.rcvrp_weights(fx)
@@ -55,7 +55,7 @@ def test_oracle_reproduces_reference_golden_rcvrp(name):
 
 
 @pytest.mark.parametrize("name", ["rcvrptw_n20_b4_pomo", "rcvrptw_n20_b4_greedy", "rcvrptw_n100_b2_pomo", "rmtvrp_n20_b8_pomo_variants",
-                                  "rcvrptw_n20_b4_pomo_heuristic", "rcvrptw_n20_b4_pomo_naive"])
+                                  "rcvrptw_n20_b4_pomo_heuristic", "rcvrptw_n20_b4_pomo_naive", "rcvrptw_n50_b3_pomo_trained"])
 def test_oracle_reproduces_reference_golden_rcvrptw(name):
     """RCVRPTW (vrptw preset), the multi-task RMTVRP variants and the ablation bias modules with the duration matrix."""
     fx = H.load_fixture(name)
@@ -245,6 +245,45 @@ def test_sharded_bench_logic_gloo_world2(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     got = sorted(open(os.path.join(tmp_path, f"rank{i}.txt")).read() for i in range(2))
     assert got[0].split()[1:] == got[1].split()[1:]        # both ranks agree on the aggregate (max time, total units)
+
+
+def test_strong_scaling_shards_partition_the_batch_for_world_1_to_8():
+    """bench.py --scaling strong / SURVEY 8(e): parallel.shard_range hands every rank a contiguous block; the blocks tile
+    [0, batch) exactly for world sizes 1 .. 8, remainders included, and differ by at most one instance."""
+    from rrnco_amd.parallel import shard_range
+    for batch in (512, 513, 519, 4096, 100, 7, 8, 1):
+        for world in range(1, 9):
+            rs = [shard_range(batch, r, world) for r in range(world)]
+            assert rs[0][0] == 0 and rs[-1][1] == batch
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))            # contiguous, no overlap, no gap
+            sizes = [hi - lo for lo, hi in rs]
+            assert sum(sizes) == batch and max(sizes) - min(sizes) <= 1 and min(sizes) >= 0
+            assert sizes == sorted(sizes, reverse=True)                                # the remainder goes to the first ranks
+
+
+def test_per_rank_seeds_differ_and_a_resumed_run_continues_its_streams():
+    """Weak scaling: every rank solves its own instances (bench.instance_seed) with its own neighbour-sample draws (bench.sample_seed,
+    encoder.rank_noise_seed); strong scaling: ONE batch, the same seed on every rank, partitioned by shard_range.  train.py keys its
+    instance stream by (seed, rank, epoch it restarts at): a resumed run does not replay epoch 0 and ranks never share a batch."""
+    import bench
+    import train
+    from rrnco_amd.models.encoder import rank_noise_seed
+    weak = {(nb, r): bench.instance_seed(nb, r, "weak") for nb in range(bench.N_INSTANCE_BATCHES) for r in range(8)}
+    assert len(set(weak.values())) == len(weak)                                        # distinct per (batch, rank)
+    strong = {nb: {bench.instance_seed(nb, r, "strong") for r in range(8)} for nb in range(bench.N_INSTANCE_BATCHES)}
+    assert all(len(v) == 1 for v in strong.values()) and len({next(iter(v)) for v in strong.values()}) == bench.N_INSTANCE_BATCHES
+    ss = {(r, k): bench.sample_seed(r, k) for r in range(8) for k in range(-1, 40)}
+    assert len(set(ss.values())) == len(ss)
+    base = 123456789012345
+    ns = [rank_noise_seed(base, r) for r in range(8)]
+    assert len(set(ns)) == 8 and ns[0] == base and all(0 <= v < 2 ** 62 for v in ns)
+    assert [rank_noise_seed(base, r) for r in range(8)] == ns                          # a function of (seed, rank) only: restoring the CPU generator restores it
+    st = {(r, e): train.instance_stream_seed(1234, r, e) for r in range(8) for e in range(0, 201)}
+    assert len(set(st.values())) == len(st)
+    assert train.instance_stream_seed(1234, 3, 17) != train.instance_stream_seed(1234, 3, 0)      # resume at epoch 17: a new stream
+    # the bench's devices field: one entry per rank, and under nccl every rank names its own device
+    names = [f"rank {r}: cuda:{r} (MI355X)" for r in range(8)]
+    assert len({n.split(":", 1)[1].split()[0] + n.split(":")[2].split()[0] for n in names}) == 8
 
 
 def test_gradient_replay_matches_oracle_autograd():

@@ -71,3 +71,11 @@ def test_rccl_paths_when_two_devices_are_visible(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and len(line["devices"]) == 2 and "cuda:0" in line["devices"][0] and "cuda:1" in line["devices"][1]
+    assert len({d.split(":", 1)[1].split("(")[0].strip() for d in line["devices"]}) == 2          # two DISTINCT devices, one per rank
+    assert abs(line["value"] - 2 * 64 * 2 / (line["ms_per_step"] * 2e-3)) / line["value"] < 1e-6   # whole-job units / max-over-ranks time
+    # strong scaling over RCCL: ONE batch of 64 partitioned by parallel.shard_range
+    r = subprocess.run(cmd + [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "64", "--scaling", "strong",
+                              "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["scaling"] == "strong" and line["config"]["rollouts_per_gpu"] == 32 * 8 * 100 and len(line["devices"]) == 2

@@ -22,7 +22,7 @@ def test_headline_shaped_step_matches_the_live_oracle(build, monkeypatch):
     from rrnco_amd.envs import ATSPEnv, ATSPGenerator
     from rrnco_amd.models.encoder import ATSPInitEmbedding
     dev = torch.device("cuda")
-    B, N, S, A = 4, bench.N_NODES, bench.STARTS, bench.AUG
+    B, N, S, A = int(os.environ.get("RR_HEADLINE_ORACLE_B", "16")), bench.N_NODES, bench.STARTS, bench.AUG
     pol, w = bench.make_policy(dev)
     env = ATSPEnv(generator_params=dict(num_loc=N, device=dev), check_solution=True, device=dev)
     td = ATSPGenerator(num_loc=N, device=dev)(B, generator=torch.Generator(device=dev).manual_seed(2026))

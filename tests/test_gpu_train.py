@@ -208,6 +208,9 @@ def test_rcvrp_training_step_gradients_match_oracle_autograd():
     fx = H.load_fixture("rcvrp_n20_b4_pomo")
     w = H.rcvrp_weights(fx)
     pol = H.make_policy(w, env_name="rcvrp").train()
+    # every dump row the rollout does not write (steps behind an instance's longest route) holds NaN instead of whatever the allocator
+    # left there: the backward must not let them through (a NaN state scalar of a dead row used to poison dK of its instance)
+    pol._debug_poison_dump = True
     env = RCVRPEnv(generator_params=dict(num_loc=fx["N"]), check_solution=True)
     model = RRNet(env, policy=pol)
     inst = H.rcvrp_instance(fx)
@@ -249,6 +252,7 @@ def test_rcvrptw_training_step_gradients_match_oracle_autograd(fixture):
     fx = H.load_fixture(fixture)
     w = H.rcvrptw_weights(fx)
     pol = H.make_policy(w, env_name="rcvrptw").train()
+    pol._debug_poison_dump = True          # unwritten dump rows read NaN (see the RCVRP test above)
     env = RMTVRPEnv(generator_params=dict(num_loc=fx["N"]))
     model = RRNet(env, policy=pol)
     inst = H.rcvrptw_instance(fx)

@@ -4,7 +4,7 @@ root = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        name = r.get("Kernel_Name", "")[:40]
+        name = r.get("Kernel_Name", "")[:64]
         if not (name.startswith("void k_") or name.startswith("k_")):
             continue
         acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))

@@ -10,7 +10,7 @@ out = {"kernel": bench.ROLLOUT_KERNEL, "source_hash": bench.rollout_source_hash(
 for path in sys.argv[1:]:
     lines = open(path).read().splitlines()
     for i, l in enumerate(lines):
-        if l.startswith("void " + bench.ROLLOUT_KERNEL):
+        if l.startswith(("void " + bench.ROLLOUT_KERNEL)[:len(l)]) and len(l) >= 40:
             m = re.search(r"(FETCH_SIZE|WRITE_SIZE)\s+n=\s*(\d+) mean=([0-9.e+]+)", lines[i + 1])
             out[m.group(1) + "_KB"] = float(m.group(3)); out[m.group(1) + "_n"] = int(m.group(2))
 enc = {"source_hash": bench.encoder_source_hash(), "batch": bench.BATCH, "kernels": {k: {} for k in bench.ENCODER_LAYER_KERNELS}}
@@ -28,7 +28,7 @@ for path in sys.argv[1:]:
     lines = open(path).read().splitlines()
     for i, l in enumerate(lines):
         for k in (bench.ROLLOUT_KERNEL,) + tuple(bench.ENCODER_LAYER_KERNELS):
-            if not l.startswith("void " + k[:35]):
+            if not (l.startswith(("void " + k)[:len(l)]) and len(l) >= min(40, len(k) + 5)):
                 continue
             vals = {}
             for ll in lines[i + 1:i + 12]:

@@ -17,6 +17,12 @@ sys.path.insert(0, os.path.join(ROOT, "real-routing-nco_amd"))
 import torch  # noqa: E402
 
 
+def instance_stream_seed(seed: int, rank: int, start_epoch: int) -> int:
+    """Seed of the training-instance generator: one stream per data-parallel rank, keyed by the epoch the run (re)starts at, so a
+    resumed run continues with new instances instead of replaying epoch 0's and no two ranks ever draw the same batch."""
+    return int(seed) + 1000 * int(rank) + 1_000_003 * int(start_epoch)
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--problem", default="atsp", choices=["atsp", "rcvrp", "rcvrptw"])
@@ -75,7 +81,7 @@ def main(argv=None):
             if "cpu_rng_state" in blob:              # the encoder's neighbour-sample seeds come from torch's CPU generator
                 torch.set_rng_state(blob["cpu_rng_state"])
     # a resumed run continues the instance stream instead of replaying epoch 0's data: the stream is keyed by the epoch it starts at
-    gen = torch.Generator(device=dev).manual_seed(o.seed + 1000 * rank + 1_000_003 * start_epoch)
+    gen = torch.Generator(device=dev).manual_seed(instance_stream_seed(o.seed, rank, start_epoch))
     val_gen = torch.Generator(device=dev).manual_seed(o.seed + 7)     # same validation set every epoch, on every rank
     steps_per_epoch = max(o.train_data_size // (o.batch_size * world), 1)
     val_batch = env.generator(min(o.val_data_size, 4 * o.batch_size), generator=val_gen)
