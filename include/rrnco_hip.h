@@ -142,8 +142,10 @@ int rr_select(const float* logits, const uint8_t* mask, const int64_t* action_in
               uint64_t seed, uint32_t step, int top_k, float top_p, hipStream_t stream);
 
 /* One Attn_Free_Layer = row block + col block (rrnco/models/nn/attn_freenet.py:472-488). */
-/* theta [Bp][N][N] = rr_edge_angles(locs) (may be NULL: angles are then recomputed per block, slower);
- * bias_pre [Bp][2][N*N] = rr_nab_dur output when the encoder uses the duration matrix, else NULL. */
+/* theta [Bp][N][N] = rr_edge_angles(locs), or bias_pre [Bp][2][N*N] = the rr_nab_dur / rr_nab_simple output when the bias is
+ * evaluated by a kernel of its own (duration matrix, ablation biases): one of the two is required (RR_EINVAL otherwise).
+ * dbg: reserved, must be NULL (the stage dumps of the first-generation kernel left the library in round 4; the stage tensors of
+ * rr_enc_layer_train serve the per-stage parity test). */
 int rr_enc_layer(const EncBlockW* wrow, const EncBlockW* wcol, const float* row_in, const float* col_in,
                  float* row_out, float* col_out, const float* D, const float* locs, const float* theta,
                  const float* bias_pre, int Bp, int N, int norm_affine_only /* Normalization (attn_freenet.py:78-116) of the five norms:

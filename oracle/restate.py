@@ -176,7 +176,7 @@ def contextual_gating(w: W, p: str, coord: Tensor, dist: Tensor) -> Tensor:
 def atsp_init_embedding(w: W, locs: Tensor, distance: Tensor, sidx: Tensor):
     """atsp.py:69-91 (use_coords and use_dist)."""
     p = "encoder.init_embedding"
-    node = lin(w, p + ".init_embed", locs.float())
+    node = lin(w, p + ".init_embed", locs.to(w[p + ".init_embed.weight"].dtype))      # (.float() in the reference: fp32 weights; a float64 run of the oracle keeps its dtype)
     rowd = distance.gather(2, sidx)
     cold = distance.transpose(1, 2).gather(2, sidx)
     row = lin(w, p + ".row_embed", rowd.sort(dim=-1).values)
@@ -339,7 +339,7 @@ def num_layers_of(w: W) -> int:
 def atsp_encoder(w: W, td: dict, sidx: Tensor):
     """RRNetEncoder.forward encoder.py:80-112 for env_name='atsp'."""
     row, col = atsp_init_embedding(w, td["locs"], td["distance_matrix"], sidx)
-    return encoder_net(w, row, col, td["distance_matrix"], td["locs"].float(), None, num_layers_of(w))
+    return encoder_net(w, row, col, td["distance_matrix"], td["locs"].to(row.dtype), None, num_layers_of(w))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -399,7 +399,8 @@ def atsp_decoder_step(w: W, td_flat: dict, cache: dict, S: int):
         bias = w["decoder.alpha"] * gather_by_index(D.unsqueeze(1).expand(-1, S, -1, -1), td["current_node"], dim=-2)
     else:
         bias = w["decoder.alpha"] * gather_by_index(D, td["current_node"], dim=-2)
-    logits = torch.log(torch.exp(logits.to(torch.float32) - bias.to(torch.float32)) + 1e-6)
+    _ft = torch.float64 if logits.dtype == torch.float64 else torch.float32      # (decoder.py:195-196 casts to fp32; a float64 run of the oracle stays float64)
+    logits = torch.log(torch.exp(logits.to(_ft) - bias.to(_ft)) + 1e-6)
     if S > 1:
         logits = logits.permute(1, 0, 2).reshape(-1, logits.shape[-1])  # 'b s l -> (s b) l'
         mask = mask.permute(1, 0, 2).reshape(-1, mask.shape[-1])
@@ -744,7 +745,8 @@ def rcvrp_decoder_step(w: W, td_flat: dict, cache: dict, S: int):
         bias = w["decoder.alpha"] * gather_by_index(D.unsqueeze(1).expand(-1, S, -1, -1), td["current_node"], dim=-2)
     else:
         bias = w["decoder.alpha"] * gather_by_index(D, td["current_node"], dim=-2)
-    logits = torch.log(torch.exp(logits.to(torch.float32) - bias.to(torch.float32)) + 1e-6)
+    _ft = torch.float64 if logits.dtype == torch.float64 else torch.float32      # (decoder.py:195-196 casts to fp32; a float64 run of the oracle stays float64)
+    logits = torch.log(torch.exp(logits.to(_ft) - bias.to(_ft)) + 1e-6)
     if S > 1:
         logits = logits.permute(1, 0, 2).reshape(-1, logits.shape[-1])
         mask = mask.permute(1, 0, 2).reshape(-1, mask.shape[-1])
@@ -973,7 +975,8 @@ def rcvrptw_decoder_step(w: W, td_flat: dict, cache: dict, S: int):
         dist = gather_by_index(D, td["current_node"], dim=-2)
         dur = gather_by_index(T, td["current_node"], dim=-2)
     bias = w["decoder.alpha"] * dist + w["decoder.beta"] * dur
-    logits = torch.log(torch.exp(logits.to(torch.float32) - bias.to(torch.float32)) + 1e-6)
+    _ft = torch.float64 if logits.dtype == torch.float64 else torch.float32      # (decoder.py:195-196 casts to fp32; a float64 run of the oracle stays float64)
+    logits = torch.log(torch.exp(logits.to(_ft) - bias.to(_ft)) + 1e-6)
     if S > 1:
         logits = logits.permute(1, 0, 2).reshape(-1, logits.shape[-1])
         mask = mask.permute(1, 0, 2).reshape(-1, mask.shape[-1])

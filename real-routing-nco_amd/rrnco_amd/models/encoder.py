@@ -232,7 +232,6 @@ class RRNetEncoder(nn.Module):
                                       L.ptr(col), Bp, N, sidx.shape[-1], L.stream()), "rr_init_embed")
         self._last_init = (row, col)
         row2, col2 = torch.empty_like(row), torch.empty_like(col)
-        dbg = getattr(self, "_debug_buffer", None)
         has_dur = self.env_name not in ("atsp", "rcvrp")   # encoder.py:98-106: duration matrix only for rcvrptw
         simple = packed.get("nab_kind", "gating") != "gating"
         use_dur = len(packed["nabdur"]) > 0 or simple         # "bias_pre" path: NAB evaluated by a kernel of its own
@@ -268,12 +267,9 @@ class RRNetEncoder(nn.Module):
                 continue
             L.check(lib.rr_enc_layer(wr, wc, L.ptr(row), L.ptr(col), L.ptr(row2), L.ptr(col2), L.ptr(D), L.ptr(locs),
                                      L.ptr(theta) if theta is not None else None, L.ptr(bias) if use_dur else None,
-                                     Bp, N, norm_mode, L.ptr(dbg) if (dbg is not None and l == 0) else None, L.stream()),
+                                     Bp, N, norm_mode, None, L.stream()),
                     "rr_enc_layer")
-            if l == 0 and dbg is not None:
-                row, col, row2, col2 = row2, col2, torch.empty_like(row), torch.empty_like(col)
-            else:
-                row, col, row2, col2 = row2, col2, row, col
+            row, col, row2, col2 = row2, col2, row, col
         if train_saves is not None:
             if theta is None:      # duration NAB: the kernels take the angles from the coordinates; the backward wants the matrix
                 theta = torch.empty(Bp, N, N, device=dev, dtype=torch.float32)

@@ -97,10 +97,11 @@ def test_select_kernel_argmax_takes_first_index_on_exact_ties():
 def test_encoder_matches_reference_embeddings(name):
     fx, w, pol, st, env, td_in = _setup(name)
     row, col = pol.encoder(env.reset(td_in), packed=pol.packed(torch.device("cuda")))
-    # trained weights amplify the rounding differences of BOTH builds about twofold (measured on MI355X: default-init <= 7.6e-5 split
-    # / 7.5e-5 fp32 MFMA; trained <= 2.3e-4 split / 1.8e-4 fp32 MFMA, embeddings of magnitude <= 5.1): 2e-4 and 4e-4 absolute
-    tol = 2 * ENC_ATOL if name in TRAINED else ENC_ATOL
-    assert torch.allclose(row.cpu(), fx["row_emb"], atol=tol) and torch.allclose(col.cpu(), fx["col_emb"], atol=tol)
+    # one tolerance for every fixture again: since the AFT mixing runs on ea - 1 (round 4: the stage that generated most of the
+    # error, tests/test_gpu_encoder_attribution.py) the trained weights sit at 1.1e-4 (was 2.3e-4, tolerance 4e-4), default-init <= 7.6e-5
+    err = max(float((row.cpu() - fx["row_emb"]).abs().max()), float((col.cpu() - fx["col_emb"]).abs().max()))
+    print(f"\n[{name}] max |embedding - reference| {err:.2e}")
+    assert err < ENC_ATOL
 
 
 def test_decoder_forward_logits_match_golden_trace_given_reference_embeddings():
@@ -207,8 +208,10 @@ def test_log_likelihood_error_attribution_encoder_vs_decoder(name, monkeypatch, 
         print(f"\n[{name}] |LL - reference|: whole policy {e_full:.2e} (tours equal {float(same_full.float().mean()):.4f}); decoder alone on the "
               f"reference's embeddings {e_dec:.2e} (tours equal {float(same_dec.float().mean()):.4f})")
     assert float(same_dec.float().mean()) >= 0.995
-    assert e_dec < 1e-4                                    # (measured 2e-5 .. 4e-5)
+    assert e_dec < 1e-4                                    # (measured 1e-5 .. 5e-5)
     assert e_full < LL_ATOL + LL_RTOL * float(fx["log_likelihood"].abs().max())
+    if "trained" in name:                                  # (round 4: 3.9e-4 / 2.7e-4; 8.9e-4 before the mixing ran on ea - 1)
+        assert e_full < 5e-4
 
 
 @pytest.mark.parametrize("fused", [True, False])

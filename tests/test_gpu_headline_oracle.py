@@ -70,6 +70,22 @@ def test_headline_shaped_step_matches_the_live_oracle(build, monkeypatch):
     drw = float((out["reward"].cpu()[same] - ref["reward"][same]).abs().max())
     print(f"[{build}] headline shape, {B} instances: tours identical to the oracle {frac:.5f} ({int((~same).sum())} of {acts.shape[0]} part, largest oracle gap "
           f"at a parting {worst:.2e}); |best-of-800 cost - oracle| {db:.2e}; |LL - oracle| {dll:.2e}; |cost - oracle| {drw:.2e}")
-    assert frac >= 0.995          # (measured 0.9978 .. 0.9981 on both builds: every parting sits at an oracle gap below GAP_TOL, asserted above)
+    # The noise floor of "identical tours": the SAME oracle in float64 (weights, instances, every product; the fp32 cast of
+    # decoder.py:195-196 lifted).  fp32 arithmetic — the reference's own included — parts from the float64 tours at near-ties;
+    # two fp32 evaluations of the policy cannot be expected to agree more often with each other than each agrees with float64.
+    if build == "split":
+        wd = {k: v.double() for k, v in w.items()}
+        sd = {k: (v.double() if v.is_floating_point() else v) for k, v in st.items()}
+        with torch.inference_mode():
+            ref64 = restate.atsp_policy(wd, sd, seen["sidx"].cpu(), S, "greedy")
+        f_ref = float((racts == ref64["actions"]).all(1).float().mean())
+        f_ker = float((acts == ref64["actions"]).all(1).float().mean())
+        s_r, s_k = (racts == ref64["actions"]).all(1), (acts == ref64["actions"]).all(1)
+        print(f"[{build}] against the float64 oracle: the fp32 oracle keeps {f_ref:.5f} of the tours, the kernels {f_ker:.5f} "
+              f"(|LL - float64| on the tours kept: fp32 oracle {float((ref['log_likelihood'].double() - ref64['log_likelihood'].double())[s_r].abs().max()):.2e}, "
+              f"kernels {float((out['log_likelihood'].cpu().double() - ref64['log_likelihood'].double())[s_k].abs().max()):.2e})")
+        # the kernels are an fp32 evaluation as good as the reference's: as close to the float64 tours as the fp32 oracle is
+        assert f_ker >= f_ref - 2.5e-3
+    assert frac >= 0.995          # (measured 0.9966 .. 0.9981 on both builds: every parting sits at an oracle gap below GAP_TOL, asserted above)
     assert db < 1e-5 * float(rb.abs().max()) + 1e-5
     assert drw < 1e-4 and dll < 2e-3
