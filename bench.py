@@ -178,12 +178,24 @@ def cpu_baseline(w, seed=4321, budget_s=20.0, max_inst=8):
     done, spent = run(threads, budget_s, max_inst)
     rec = {"value": done / spent, "unit": "instances/s", "cores": threads, "threads": threads, "host_cores": host_cores, "kind": "port",
            "sample": f"{done} ATSP n=100 instance(s) x8 aug x100 starts greedy, torch-CPU fp32 oracle, {spent:.1f} s"}
-    if host_cores > threads:                   # the same box's host cores, ALL of them, as a second point (bounded: ~8 s)
-        d2, s2 = run(host_cores, 8.0, 4)
-        rec["all_host_cores"] = {"value": d2 / s2, "unit": "instances/s", "cores": host_cores,
-                                 "sample": f"{d2} instance(s), {s2:.1f} s, torch threads = {host_cores}"}
-        if d2 / s2 > rec["value"]:             # report the faster of the two as the baseline
-            rec.update({"value": d2 / s2, "cores": host_cores, "threads": host_cores, "sample": rec["all_host_cores"]["sample"] + " (all host cores)"})
+    if host_cores > threads:
+        # BASELINE.md §3 asks for the box's host cores: a second point with torch's intra-op pool at ALL of them, in a child process
+        # under a hard time limit — on the 256-core GPU boxes that pool oversubscribes these small ops badly (measured: 505 s for ONE
+        # instance at 256 threads against 1.8 s at 32), so the point is reported as measured or as "timed out", never waited for
+        import subprocess
+        code = ("import sys,time,torch;sys.path.insert(0,%r);import bench;from oracle import restate;torch.set_num_threads(%d);"
+                "pol,w=bench.make_policy('cpu');inst=restate.atsp_synthetic(1,bench.N_NODES,%d);t=time.perf_counter();\n"
+                "with torch.inference_mode():\n st=restate.atsp_reset(restate.augment_state(inst));sidx=restate.sample_neighbor_indices(st['distance_matrix'],25);"
+                "restate.atsp_policy(w,st,sidx,bench.STARTS,'greedy')\nprint('SECONDS',time.perf_counter()-t)") % (ROOT, host_cores, seed)
+        try:
+            r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=45, env={**os.environ, "OMP_NUM_THREADS": str(host_cores)})
+            sec = float([l for l in r.stdout.splitlines() if l.startswith("SECONDS")][-1].split()[1])
+            rec["all_host_cores"] = {"value": 1.0 / sec, "unit": "instances/s", "cores": host_cores, "sample": f"1 instance, {sec:.1f} s, torch threads = {host_cores} (child process)"}
+            if 1.0 / sec > rec["value"]:       # report the faster of the two as the baseline
+                rec.update({"value": 1.0 / sec, "cores": host_cores, "threads": host_cores, "sample": rec["all_host_cores"]["sample"] + " (all host cores)"})
+        except Exception as e:  # noqa: BLE001  (timeout, or no output: the point is recorded as such)
+            rec["all_host_cores"] = {"value": None, "cores": host_cores, "sample": f"not finished within 45 s at {host_cores} torch threads ({type(e).__name__}); "
+                                     f"the {threads}-thread figure stands"}
     return rec
 
 
