@@ -92,6 +92,11 @@ __device__ __forceinline__ float4 rr_bld4(__amdgpu_buffer_rsrc_t r, unsigned vof
   rr_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, soff_bytes, 0);
   return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
 }
+__device__ __forceinline__ float2 rr_bld2(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
+  typedef unsigned rr_u32x2_ __attribute__((ext_vector_type(2)));
+  const rr_u32x2_ v = __builtin_amdgcn_raw_buffer_load_b64(r, voff_bytes, soff_bytes, 0);   // out of range -> 0
+  return make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
+}
 __device__ __forceinline__ float rr_bld1(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff_bytes, soff_bytes, 0));   // out of range -> 0
 }

@@ -751,8 +751,13 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
                                                                const int64_t* __restrict__ sidx, const float* __restrict__ vfeat,
                                                                float* __restrict__ row_out, float* __restrict__ col_out, int N, int SS) {
   __shared__ __attribute__((aligned(16))) float smem[3 * BUF_FLOATS];
-  float* comb = smem;                      // [N][256] = [node | dist-embedding]
-  float* scr = smem + 2 * BUF_FLOATS;      // sorted samples [N][MAXSS], then gate partials [16][112]
+  // comb rows are 260 floats apart, not 256: the gate GEMM reads one 16-byte group per lane with the NODE on the lane axis, and a
+  // stride of 256 floats put the 16 nodes of a tile on the same four LDS banks (SQ_LDS_BANK_CONFLICT 3.2e8 of this kernel's 1.9e9
+  // wave cycles in profiles/r03/bench_r03v16_pmc_counters.txt); 260 = 4 mod 64 spreads them over all 64
+  constexpr int CLD = 260;
+  float* comb = smem;                      // [N][CLD] = [node | dist-embedding | pad]
+  float* scr = smem + ((RR_MAXN * CLD + 3) & ~3);      // sorted samples [N][MAXSS], then gate partials [16][112]
+  static_assert(((RR_MAXN * 260 + 3) & ~3) + RR_MAXN * MAXSS + 16 * 112 <= 3 * BUF_FLOATS, "k_init_embed LDS layout");
   float* gpart = scr + RR_MAXN * MAXSS;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -812,13 +817,13 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
     for (int e = tid; e < N * RR_E; e += ENC_THREADS) {
       int i = e >> 7, f = e & 127;
       if (KIND == 0) {
-        comb[i * 256 + f] = fmaf(w.wi[f * 2 + 1], lcs[i * 2 + 1], w.wi[f * 2] * lcs[i * 2]) + w.bi[f];
+        comb[i * CLD + f] = fmaf(w.wi[f * 2 + 1], lcs[i * 2 + 1], w.wi[f * 2] * lcs[i * 2]) + w.bi[f];
       } else if (i == 0) {   // CoordinateExpert: depot Linear(2,E)
         comb[f] = fmaf(w.wdep[f * 2 + 1], lcs[1], w.wdep[f * 2] * lcs[0]) + w.bdep[f];
       } else {               // customers Linear(3,E) on (x, y, atan2(y - y_depot, x - x_depot))
         float x = lcs[i * 2], y = lcs[i * 2 + 1];
         float ang = atan2f(y - lcs[1], x - lcs[0]);
-        comb[i * 256 + f] = fmaf(w.wi[f * 3 + 2], ang, fmaf(w.wi[f * 3 + 1], y, w.wi[f * 3] * x)) + w.bi[f];
+        comb[i * CLD + f] = fmaf(w.wi[f * 3 + 2], ang, fmaf(w.wi[f * 3 + 1], y, w.wi[f * 3] * x)) + w.bi[f];
       }
       float acc = 0.f;
 #pragma unroll
@@ -829,7 +834,7 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
         if (s4 + 2 < SS) acc = fmaf(wreg[s4 + 2], v.z, acc);
         if (s4 + 3 < SS) acc = fmaf(wreg[s4 + 3], v.w, acc);
       }
-      comb[i * 256 + 128 + f] = acc + bd[f];
+      comb[i * CLD + 128 + f] = acc + bd[f];
     }
     __syncthreads();
     // hidden = relu(W0 comb + b0) [2E]; gate logit = w2 . hidden + b2 ; two feature tiles per wave
@@ -845,7 +850,7 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
         h0[nt] = f32x4{64.f * ba.x, 64.f * ba.y, 64.f * ba.z, 64.f * ba.w};
         h1[nt] = f32x4{64.f * bb.x, 64.f * bb.y, 64.f * bb.z, 64.f * bb.w};
       }
-      ie_gemm_split2<NT>(h0, h1, g0s, wave, wave + 8, comb, 256, N, lane);
+      ie_gemm_split2<NT>(h0, h1, g0s, wave, wave + 8, comb, CLD, N, lane);
       const float4 wa = rr_ld4(g2 + 16 * wave + 4 * g), wb = rr_ld4(g2 + 16 * (wave + 8) + 4 * g);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
@@ -863,7 +868,7 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
       f32x4 h[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) h[nt] = rr_zero4();
-      ie_gemm_wx16<NT>(h, g0 + (size_t)t * 16 * 64, comb, 256, N, lane);
+      ie_gemm_wx16<NT>(h, g0 + (size_t)t * 16 * 64, comb, CLD, N, lane);
       rr_add_bias<NT>(h, g0b, 16 * t, lane);
       float4 w2v = rr_ld4(g2 + 16 * t + 4 * g);
 #pragma unroll
@@ -886,14 +891,14 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
     for (int e = tid; e < N * RR_E; e += ENC_THREADS) {
       int i = e >> 7, f = e & 127;
       const float gt = scr[i];
-      float gated = gt * comb[i * 256 + f] + (1.0f - gt) * comb[i * 256 + 128 + f];
+      float gated = gt * comb[i * CLD + f] + (1.0f - gt) * comb[i * CLD + 128 + f];
       if (KIND == 0) outp[e] = gated;
       else {
         const float* vf = vfeat + ((size_t)b * N + i) * w.nfeat;
         float de = w.bdm[f];
         for (int q = 0; q < w.nfeat; ++q) de = fmaf(w.wdm[f * w.nfeat + q], vf[q], de);
-        comb[i * 256 + f] = gated;            // [gated | demand_emb] feeds combine_{row,col}_embed
-        comb[i * 256 + 128 + f] = de;
+        comb[i * CLD + f] = gated;            // [gated | demand_emb] feeds combine_{row,col}_embed
+        comb[i * CLD + 128 + f] = de;
       }
     }
     __syncthreads();
@@ -901,7 +906,7 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
       f32x4 o[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) o[nt] = rr_zero4();
-      rr_gemm_wx<NT>(o, (pass == 0 ? w.cmr : w.cmc) + (size_t)wave * 16 * 64, 0, 16, comb, 256, 0, N, lane);
+      rr_gemm_wx<NT>(o, (pass == 0 ? w.cmr : w.cmc) + (size_t)wave * 16 * 64, 0, 16, comb, CLD, 0, N, lane);
       rr_add_bias<NT>(o, pass == 0 ? w.cmrb : w.cmcb, 16 * wave, lane);
       rr_store_tiles<NT>(o, outp, RR_E, 16 * wave, N, lane);
       __syncthreads();

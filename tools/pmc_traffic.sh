@@ -12,5 +12,5 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/pmc_$C
 done
 cat $R/gpurun_out/pmc_FETCH_SIZE.txt $R/gpurun_out/pmc_WRITE_SIZE.txt
-python3 $R/tools/pmc_traffic_json.py $R/gpurun_out/pmc_FETCH_SIZE.txt $R/gpurun_out/pmc_WRITE_SIZE.txt > $R/gpurun_out/bench_pmc_hbm_traffic.json
+python3 $R/tools/pmc_traffic_json.py $R/gpurun_out/pmc_FETCH_SIZE.txt $R/gpurun_out/pmc_WRITE_SIZE.txt $R/gpurun_out/pmc_mfma.txt > $R/gpurun_out/bench_pmc_hbm_traffic.json
 cat $R/gpurun_out/bench_pmc_hbm_traffic.json

@@ -3,28 +3,31 @@ bench.py reads (with the hash of the rollout's sources, so that a stale summary 
 pass of tools/pmc_mfma.sh (gpurun_out/pmc_mfma.txt), adds `counters`: per kernel the matrix-pipe busy fraction
 (SQ_VALU_MFMA_BUSY_CYCLES / 1 024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs) and vector instructions per matrix instruction."""
 import json, os, re, sys
+_paths = [a for a in sys.argv[1:] if os.path.exists(a)]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
 out = {"kernel": bench.ROLLOUT_KERNEL, "source_hash": bench.rollout_source_hash(), "batch": bench.BATCH}
-for path in sys.argv[1:]:
+for path in _paths:
     lines = open(path).read().splitlines()
     for i, l in enumerate(lines):
         if l.startswith(("void " + bench.ROLLOUT_KERNEL)[:len(l)]) and len(l) >= 40:
             m = re.search(r"(FETCH_SIZE|WRITE_SIZE)\s+n=\s*(\d+) mean=([0-9.e+]+)", lines[i + 1])
-            out[m.group(1) + "_KB"] = float(m.group(3)); out[m.group(1) + "_n"] = int(m.group(2))
+            if m:
+                out[m.group(1) + "_KB"] = float(m.group(3)); out[m.group(1) + "_n"] = int(m.group(2))
 enc = {"source_hash": bench.encoder_source_hash(), "batch": bench.BATCH, "kernels": {k: {} for k in bench.ENCODER_LAYER_KERNELS}}
-for path in sys.argv[1:]:
+for path in _paths:
     lines = open(path).read().splitlines()
     for i, l in enumerate(lines):
         for k in bench.ENCODER_LAYER_KERNELS:
             if l.startswith("void " + k[:24]) and (k != bench.ENCODER_LAYER_KERNELS[0] or l.startswith("void " + k)):
                 m = re.search(r"(FETCH_SIZE|WRITE_SIZE)\s+n=\s*(\d+) mean=([0-9.e+]+)", lines[i + 1])
-                enc["kernels"][k][m.group(1) + "_KB"] = float(m.group(3)); enc["kernels"][k][m.group(1) + "_n"] = int(m.group(2))
+                if m:
+                    enc["kernels"][k][m.group(1) + "_KB"] = float(m.group(3)); enc["kernels"][k][m.group(1) + "_n"] = int(m.group(2))
 if all(len(v) == 4 for v in enc["kernels"].values()):
     out["encoder"] = enc
 ctr = {"rollout_source_hash": bench.rollout_source_hash(), "encoder_source_hash": bench.encoder_source_hash(), "kernels": {}}
-for path in sys.argv[1:]:
+for path in _paths:
     lines = open(path).read().splitlines()
     for i, l in enumerate(lines):
         for k in (bench.ROLLOUT_KERNEL,) + tuple(bench.ENCODER_LAYER_KERNELS):
