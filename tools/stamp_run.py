@@ -48,7 +48,8 @@ en = (["norm2,K,softmaxK,V", "NAB", "norm1,Q,mix", "P,M,norm3,normf1", "FFN+norm
       else ["load+norm1/2", "NAB+softmax", "KV,softmaxK,den,num", "Q,Y,P,M,norms", "FFN+norm"])
 if os.environ.get("RR_ENC_FINE"):
     en = ["NAB stage+barrier", "NAB input wait", "NAB eval x7", "NAB softmax", "-", "KV stage", "rest"]
-ew = eout[7]; et = sum(eout[i] for i in range(len(en)))
+en = en + ["  (of phase 0) load + norm2", "  (of phase 0) K projection"]
+ew = eout[7]; et = sum(eout[i] for i in range(7))
 print(f"encoder block: waves={ew} cycles/wave/block={et/ew:.0f}")
 for i, n in enumerate(en):
-    print(f"  {n:22s} {eout[i]/ew:10.0f} cycles  {100*eout[i]/et:5.1f}%")
+    print(f"  {n:28s} {eout[i]/ew:10.0f} cycles  {100*eout[i]/et:5.1f}%")
