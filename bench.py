@@ -124,6 +124,48 @@ def measured_mfma_busy(kernel, batch, encoder=False):
     return k.get("mfma_busy") if k else None
 
 
+def power_limited_mfma(seconds=1.5):
+    """What the fp16 matrix pipe sustains ON DATA under the board's power cap: tools/clockprobe/powerprobe.hip (register-resident
+    v_mfma_f32_16x16x32_f16 loops on 16 rotating pseudo-random operand sets per wave, nothing else on the chip) run as a child process
+    for `seconds`, socket power and clock sampled beside it (amdsmi).  The guide's 2 500 TFLOP/s is measured with constant operands
+    (2 417 here at 756 W); on data the same loop draws the full cap and the clock drops (profiles/r04/NOTES.md section 1).  Reported
+    beside `roofline.peak`, never instead of it.  -> dict or None."""
+    import subprocess, threading
+    exe = os.path.join(ROOT, "tools", "clockprobe", "powerprobe")
+    try:
+        if not os.path.exists(exe):
+            subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", exe + ".hip", "-o", exe], check=True, capture_output=True, timeout=300)
+        samples, stop = [], threading.Event()
+
+        def sampler():
+            try:
+                import amdsmi
+                amdsmi.amdsmi_init()
+                h = amdsmi.amdsmi_get_processor_handles()[int(os.environ.get("LOCAL_RANK", 0))]
+                while not stop.is_set():
+                    pw = amdsmi.amdsmi_get_power_info(h)
+                    ck = amdsmi.amdsmi_get_clock_info(h, amdsmi.AmdSmiClkType.GFX)
+                    samples.append((time.perf_counter(), pw.get("current_socket_power", pw.get("average_socket_power")), ck.get("clk", ck.get("cur_clk")), pw.get("power_limit")))
+                    time.sleep(0.01)
+            except Exception:  # noqa: BLE001  (no amdsmi: the rate alone is reported)
+                pass
+        th = threading.Thread(target=sampler, daemon=True)
+        th.start()
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, str(seconds), "1"], capture_output=True, text=True, timeout=60)
+        t1 = time.perf_counter()
+        stop.set(); th.join(timeout=2)
+        tf = float(r.stdout.split(" TFLOP/s")[0].split()[-1])
+        busy = [x for x in samples if t0 + 0.4 * (t1 - t0) <= x[0] <= t1 and isinstance(x[1], (int, float))]
+        out = {"mfma_f16_on_data_tflops": tf, "probe": "tools/clockprobe/powerprobe.hip mode 1, %.1f s" % seconds}
+        if busy:
+            out.update({"socket_power_w": sum(x[1] for x in busy) / len(busy), "sclk_mhz": sum(x[2] for x in busy) / len(busy),
+                        "power_limit_w": (busy[0][3] / 1e6 if busy[0][3] and busy[0][3] > 1e5 else busy[0][3])})
+        return out
+    except Exception as e:  # noqa: BLE001
+        return {"mfma_f16_on_data_tflops": None, "error": f"{type(e).__name__}: {e}"[:200]}
+
+
 def make_policy(device, seed=1234):
     """Random-init RRNet of configs/experiment/rrnet.yaml (torch's default layer initialisation under a fixed seed; no
     checkpoint can be fetched here).  Returns the policy and a CPU copy of its weights — the latter only feeds the
@@ -553,6 +595,15 @@ def main():
             line["configs"] = other_configs(dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w)
+        if world == 1 and not args.no_other_configs:      # (a diagnostic beside the contract's fields; ~3 s)
+            torch.cuda.synchronize()
+            pl = power_limited_mfma()
+            if pl and pl.get("mfma_f16_on_data_tflops"):
+                pk = pl["mfma_f16_on_data_tflops"] / SPLIT_PRODUCTS
+                pl.update({"peak_fp32_equivalent": pk, "frac": line["roofline"]["achieved"] / pk,
+                           "note": "the rollout's achieved rate over what a pure fp16 matrix stream on data sustains under the 1 400 W cap, "
+                                   "three partial products per product; roofline.frac above is against the guide's 2 500 / 3"})
+            line["roofline"]["power_limited"] = pl
         print(json.dumps(line))
     if dist:
         td_.destroy_process_group()
