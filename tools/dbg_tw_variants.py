@@ -22,6 +22,6 @@ if len(sys.argv) > 1:
     missing = sorted(set(range(1, n + 1)) - set(a[0].tolist()))
     print(f"{sys.argv[1]}: T {a.shape[1]} (fixture {fx['actions'].shape[1]}), tours identical {same:.3f}, every customer once {cust_ok}, rollout 0 misses {missing[:10]}")
 else:
-    for m in ("librrnco_hip_tw0.so", "librrnco_hip_tw31.so"):
+    for m in ("librrnco_hip.so", "librrnco_hip_exact.so"):
         r = subprocess.run([sys.executable, __file__, m], capture_output=True, text=True)
         print((r.stdout.strip().splitlines() or [r.stderr[-300:]])[-1])
