@@ -340,22 +340,46 @@ def other_configs(dev):
         k_ms = sum(ks) / max(len(ks), 1)
         o = res["out"]
         T, Rr = int(o["actions"].shape[1]), int(o["actions"].shape[0])
-        # executed decoder evaluations: every rollout of a tile runs until the instance's longest route ends (T - 1 evaluated steps)
-        ach = Rr * (T - 1) * FLOP_PER_ROLLOUT_STEP / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        # LIVE decoder evaluations only: a rollout counts up to the step that closes its last route (its last
+        # customer + the return to the depot); what a finished rollout's tile keeps executing until the instance's longest route ends
+        # is padding, reported separately as `executed`
+        acts = o["actions"]
+        pos = torch.arange(T, device=acts.device)
+        live_steps = int((((acts != 0).long() * pos).max(dim=1).values + 1).clamp(max=T - 1).sum())
+        ach = live_steps * FLOP_PER_ROLLOUT_STEP / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        exe = Rr * (T - 1) * FLOP_PER_ROLLOUT_STEP / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         out[label] = {"value": B / sec, "unit": "instances/s", "ms_per_step": sec * 1e3, "steps": n, "kernel_ms": k_ms,
-                      "rollouts": Rr, "decode_steps": T,
+                      "rollouts": Rr, "decode_steps": T, "live_rollout_steps": live_steps, "executed_rollout_steps": Rr * (T - 1),
                       "mean_best_cost": float(-o["reward"].view(S, -1).max(0).values.mean()),
                       "roofline": {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": peak_split, "unit": "TFLOP/s",
-                                   "frac": ach / peak_split, "traffic": None,
-                                   "note": "404 480 flop per rollout and decode step x rollouts x (decode steps of the longest route - 1); "
-                                           "fp32-equivalent peak of the fp16 pipe with 3 partial products"}}
+                                   "frac": ach / peak_split, "traffic": None, "executed": {"achieved": exe, "frac": exe / peak_split},
+                                   "note": "404 480 flop per LIVE rollout-step (each rollout up to the step that closes its last route); `executed` "
+                                           "counts every rollout until the instance's longest route ends; fp32-equivalent peak of the fp16 pipe "
+                                           "with 3 partial products"}}
+        return step
 
     env = RCVRPEnv(generator_params=dict(num_loc=N_NODES, device=dev), check_solution=False, device=dev)
     inference("C3 RCVRP n=100 B=512 POMO S=101 greedy (configs[2])", env, vrp_policy("rcvrp"), 512, 101, False, "multistart_greedy",
               "k_rollout_w<7, 1, 0, true, true, false>")
     env = RMTVRPEnv(generator_params=dict(num_loc=N_NODES, device=dev), device=dev)
-    inference("C4 RCVRPTW n=100 B=256 x8 aug S=100 sampling (configs[3])", env, vrp_policy("rcvrptw"), 256, 100, True, "multistart_sampling",
-              "k_rollout_w<7, 2, 1, true, true, false>")
+    c4 = "C4 RCVRPTW n=100 B=256 x8 aug S=100 sampling (configs[3])"
+    c4_step = inference(c4, env, vrp_policy("rcvrptw"), 256, 100, True, "multistart_sampling", "k_rollout_w<7, 2, 1, true, true, false>")
+    # the step's second kernel: the Neural Adaptive Bias with the duration matrix (k_nab_dur_lds, 6 launches per step), VALU-bound on the
+    # SiLU of its gate: per edge and gate unit one v_exp_f32 and one v_rcp_f32 — quarter-rate instructions (16 lanes per SIMD and 4 cycles)
+    with kernel_timers("rr_nab_dur") as kt:
+        for _ in range(3):
+            c4_step()
+        torch.cuda.synchronize()
+        nd_ms, nd_calls = kt.ms("rr_nab_dur")
+    if nd_ms > 0:
+        edge_units = 256 * 8 * 2 * (N_NODES + 1) ** 2 * 128          # instances x aug x (row, col block) x edges x gate units, per launch
+        peak_trans = 256 * 4 * 16 / 4 * 2.4e9                         # CUs x SIMDs x 16 lanes / 4 (quarter rate) x clock = 9.8e12 per second
+        tr = 2 * edge_units / (nd_ms * 1e-3)
+        out[c4]["roofline_nab_dur"] = {"bound": "valu", "kernel": "k_nab_dur_lds<5>", "kernel_ms": nd_ms, "launches_per_step": nd_calls / 3,
+                                       "achieved": tr / 1e12, "peak": peak_trans / 1e12, "unit": "T transcendental instructions (lane) / s",
+                                       "frac": tr / peak_trans,
+                                       "note": "2 transcendentals (exp, rcp of the gate's SiLU) per edge and gate unit against the quarter-rate "
+                                               "issue limit of the vector pipe; the packed fp32 arithmetic around them shares the same issue port"}
     torch.cuda.empty_cache()
 
     # configs[4], one rank's shard: REINFORCE step on 512 ATSP instances (sampling rollout with the training dump, hand-written
