@@ -203,7 +203,8 @@ class RRNetEncoder(nn.Module):
                                       "encoder with torch ops in that mode (models/grad_replay.encode_for_policy)")
         D = td["distance_matrix"].contiguous()
         L.require_gpu(D)
-        if D.shape[-1] > 103:                 # more nodes than the on-chip kernels hold: row-parallel kernels (csrc/rr_bign.hip)
+        import os as _os
+        if D.shape[-1] > 103 or _os.environ.get("RR_FORCE_BIGN", "0") == "1":   # more nodes than the on-chip kernels hold: row-parallel kernels (csrc/rr_bign.hip); RR_FORCE_BIGN=1: diagnostic, any N
             from . import bign
             if D.shape[-1] > bign.MAX_N_BIG or not bign.supported(self.env_name, packed, self.normalization) or train_saves is not None:
                 raise NotImplementedError(f"{D.shape[-1]} nodes: the encoder kernels cover N <= 103 for every configuration and "
