@@ -283,6 +283,20 @@ int rr_inorm_bwd(const float* x, const float* dy1, const float* dy2, const float
  * gradient with pack_a(W^T); colsum [128] (optional) += sum_m x[m][:] (the bias gradient when x is an output gradient). */
 int rr_linear_rows(const void* Wp, const float* bias, const float* X, float* out, long long M, int accumulate, float* colsum,
                    hipStream_t stream);
+/* out[m][0..127] = bias + sum_{k<K} X[m][k] W[n][k], K <= 32, X rows ldx floats apart, W [128][K] as nn.Linear stores it: the narrow
+ * Linear maps of the init embeddings (coordinates, sorted sampled distances: rrnco/models/env_embeddings/atsp.py:69-91) recomputed
+ * for their backward (their weight gradients are rr_gemm_tn products). */
+int rr_linear_smallk(const float* X, int ldx, int K, const float* W, const float* bias, float* out, long long M, hipStream_t stream);
+/* ContextualGating (atsp.py:108-121) around its scalar gate, forward recomputed and differentiated in one pass over M rows.
+ * In: hA | hB = the 256 pre-activations of gating_fc.0 (bias included), w2 [256] / b2 [1] = gating_fc.2, node / dist = the two
+ * embeddings the gate mixes, dout = d loss / d (g node + (1 - g) dist).  Out: dh over hA | hB, dnode (+= when acc_node) = g dout,
+ * ddist = (1 - g) dout, dw2 [256] and db2 [1] ADDED to. */
+typedef struct { float *hA, *hB; const float *w2, *b2, *node, *dist, *dout; float *dnode, *ddist, *dw2, *db2; long long M; int acc_node; } GateBwdIO;
+int rr_gate_bwd(const GateBwdIO* io, hipStream_t stream);
+/* C[b] = op(A[b]) op(B[b]), row-major [batch][M][K] x [batch][K][N] (transX: the operand is stored transposed), float or double (f64 != 0):
+ * the small products of the host-side weight folds (project o multi_head_combine, attn_freenet.py:325, 435) and of their chain rule in
+ * the training step — so that no BLAS library is involved in a repack or a REINFORCE step. */
+int rr_small_gemm(const void* A, const void* B, void* C, int batch, int M, int N, int K, int transA, int transB, int f64, hipStream_t stream);
 typedef struct { const float *dy, *q, *ek, *v, *num, *den, *eaT; float *dq, *dk, *dv, *dbias; int N; } AftBwdIO;
 /* AFTFull (attn_freenet.py:309-324) backward per instance from the saved forward tensors: d q, d k, d v [Bp][N][128] and
  * d loss / d (alpha * NAB bias) [Bp][N][N]. */

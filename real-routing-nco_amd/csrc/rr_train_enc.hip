@@ -351,3 +351,136 @@ extern "C" int rr_aft_bwd(const AftBwdIO* io, int Bp, hipStream_t st) {
   else hipLaunchKernelGGL((k_aft_bwd<7>), dim3(Bp), dim3(448), 0, st, *io);
   return rr_check(hipGetLastError());
 }
+
+// ------------------------------------------------------------------------------------------------ init embedding backward (ATSP)
+// rrnco/models/env_embeddings/atsp.py:69-121 differentiated on kernels: the narrow Linear maps of the coordinates / the sorted sampled
+// distances (k_linear_smallk; their weight gradients are rr_gemm_tn products), the 256 -> 256 layer of ContextualGating as four
+// 128 x 128 rr_linear_rows blocks each way, and the scalar gate in between (k_gate_bwd).  Host side: models/init_backward.py.
+
+// out[m][0..127] = bias + sum_{k < K} X[m][k] W[n][k],  K <= 32, X rows ldx floats apart.  A workgroup = 8 rows x 32 lanes of four
+// output features; W^T in LDS.
+__global__ __launch_bounds__(256) void k_linear_smallk(const float* __restrict__ X, int ldx, int K, const float* __restrict__ W,
+                                                       const float* __restrict__ bias, float* __restrict__ out, long long M) {
+  __shared__ __attribute__((aligned(16))) float Wt[32 * RR_E];
+  const int tid = threadIdx.x, l = tid & 31, slot = tid >> 5;
+  for (int i = tid; i < K * RR_E; i += 256) { const int n = i / K, k = i - n * K; Wt[k * RR_E + n] = W[i]; }
+  __syncthreads();
+  const float4 b4 = bias ? rr_ld4(bias + 4 * l) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long long m = (long long)blockIdx.x * 8 + slot; m < M; m += (long long)gridDim.x * 8) {
+    const float* x = X + m * ldx;
+    float4 a = b4;
+    for (int k = 0; k < K; ++k) {
+      const float xv = x[k];
+      const float4 w = rr_ld4(Wt + k * RR_E + 4 * l);
+      a.x = fmaf(xv, w.x, a.x); a.y = fmaf(xv, w.y, a.y); a.z = fmaf(xv, w.z, a.z); a.w = fmaf(xv, w.w, a.w);
+    }
+    rr_st4(out + m * RR_E + 4 * l, a);
+  }
+}
+extern "C" int rr_linear_smallk(const float* X, int ldx, int K, const float* W, const float* bias, float* out, long long M, hipStream_t st) {
+  if (X == nullptr || W == nullptr || out == nullptr || M <= 0 || K < 1 || K > 32 || ldx < K) return RR_EINVAL;
+  const long long want = (M + 7) / 8;
+  hipLaunchKernelGGL(k_linear_smallk, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, st, X, ldx, K, W, bias, out, M);
+  return rr_check(hipGetLastError());
+}
+
+// ContextualGating (atsp.py:108-121) around its scalar gate, forward recomputed and differentiated in one pass over the rows:
+//   h = relu(hA | hB)  (the 256 pre-activations, bias included),  g = sigmoid(w2 . h + b2),  out = g node + (1 - g) dist
+//   d gate = dout . (node - dist),  d pre = d gate g (1 - g),  dh = d pre w2 . 1(h > 0)  -> written over hA | hB
+//   dnode (+)= g dout,  ddist = (1 - g) dout,  dw2 += sum_m d pre h,  db2 += sum_m d pre.
+// A workgroup = 8 rows x 32 lanes (four features of each 128-vector per lane); the parameter gradients are folded over the
+// workgroup's rows in LDS and added with one float atomic per feature and workgroup.
+struct GateBwdIO {
+  float *hA, *hB;
+  const float *w2, *b2, *node, *dist, *dout;
+  float *dnode, *ddist, *dw2, *db2;
+  long long M;
+  int acc_node;
+};
+__device__ __forceinline__ float gb_sum32(float v) {
+  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
+  return v;
+}
+__global__ __launch_bounds__(256) void k_gate_bwd(GateBwdIO io) {
+  __shared__ float part[8][264];
+  const int tid = threadIdx.x, l = tid & 31, slot = tid >> 5;
+  const float4 wa = rr_ld4(io.w2 + 4 * l), wb = rr_ld4(io.w2 + RR_E + 4 * l);
+  const float b2 = io.b2[0];
+  float4 ga = make_float4(0.f, 0.f, 0.f, 0.f), gb = ga;
+  float gb2 = 0.f;
+  for (long long m = (long long)blockIdx.x * 8 + slot; m < io.M; m += (long long)gridDim.x * 8) {
+    const size_t o = (size_t)m * RR_E + 4 * l;
+    const float4 a = rr_ld4(io.hA + o), b = rr_ld4(io.hB + o), nd = rr_ld4(io.node + o), ds = rr_ld4(io.dist + o), dq_ = rr_ld4(io.dout + o);
+    const float4 ra = make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f));
+    const float4 rb = make_float4(fmaxf(b.x, 0.f), fmaxf(b.y, 0.f), fmaxf(b.z, 0.f), fmaxf(b.w, 0.f));
+    float s = wa.x * ra.x + wa.y * ra.y + wa.z * ra.z + wa.w * ra.w + wb.x * rb.x + wb.y * rb.y + wb.z * rb.z + wb.w * rb.w;
+    float dg = dq_.x * (nd.x - ds.x) + dq_.y * (nd.y - ds.y) + dq_.z * (nd.z - ds.z) + dq_.w * (nd.w - ds.w);
+    s = gb_sum32(s); dg = gb_sum32(dg);
+    const float g = 1.0f / (1.0f + expf(-(s + b2)));
+    const float dp = dg * g * (1.0f - g);
+    rr_st4(io.hA + o, make_float4(a.x > 0.f ? dp * wa.x : 0.f, a.y > 0.f ? dp * wa.y : 0.f, a.z > 0.f ? dp * wa.z : 0.f, a.w > 0.f ? dp * wa.w : 0.f));
+    rr_st4(io.hB + o, make_float4(b.x > 0.f ? dp * wb.x : 0.f, b.y > 0.f ? dp * wb.y : 0.f, b.z > 0.f ? dp * wb.z : 0.f, b.w > 0.f ? dp * wb.w : 0.f));
+    float4 dn = make_float4(g * dq_.x, g * dq_.y, g * dq_.z, g * dq_.w);
+    if (io.acc_node) { const float4 p = rr_ld4(io.dnode + o); dn.x += p.x; dn.y += p.y; dn.z += p.z; dn.w += p.w; }
+    rr_st4(io.dnode + o, dn);
+    const float h1 = 1.0f - g;
+    rr_st4(io.ddist + o, make_float4(h1 * dq_.x, h1 * dq_.y, h1 * dq_.z, h1 * dq_.w));
+    ga.x = fmaf(dp, ra.x, ga.x); ga.y = fmaf(dp, ra.y, ga.y); ga.z = fmaf(dp, ra.z, ga.z); ga.w = fmaf(dp, ra.w, ga.w);
+    gb.x = fmaf(dp, rb.x, gb.x); gb.y = fmaf(dp, rb.y, gb.y); gb.z = fmaf(dp, rb.z, gb.z); gb.w = fmaf(dp, rb.w, gb.w);
+    gb2 += dp;
+  }
+  float* p = &part[slot][0];
+  p[4 * l] = ga.x; p[4 * l + 1] = ga.y; p[4 * l + 2] = ga.z; p[4 * l + 3] = ga.w;
+  p[RR_E + 4 * l] = gb.x; p[RR_E + 4 * l + 1] = gb.y; p[RR_E + 4 * l + 2] = gb.z; p[RR_E + 4 * l + 3] = gb.w;
+  if (l == 0) p[256] = gb2;
+  __syncthreads();
+  for (int i = tid; i < 257; i += 256) {
+    float tot = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) tot += part[s][i];
+    atomicAdd(i < 256 ? io.dw2 + i : io.db2, tot);
+  }
+}
+extern "C" int rr_gate_bwd(const GateBwdIO* io, hipStream_t st) {
+  if (io == nullptr || io->hA == nullptr || io->hB == nullptr || io->w2 == nullptr || io->b2 == nullptr || io->node == nullptr ||
+      io->dist == nullptr || io->dout == nullptr || io->dnode == nullptr || io->ddist == nullptr || io->dw2 == nullptr ||
+      io->db2 == nullptr || io->M <= 0)
+    return RR_EINVAL;
+  const long long want = (io->M + 7) / 8;
+  hipLaunchKernelGGL(k_gate_bwd, dim3((unsigned)(want < 1024 ? want : 1024)), dim3(256), 0, st, *io);
+  return rr_check(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------ small dense products of the weight folds
+// C[b] = op(A[b]) op(B[b]) for the handful of 128 x 128 (x 12 blocks) products of the host-side folds — project o multi_head_combine
+// (attn_freenet.py:325, 435) and their chain rule in the training step — in float or double (the inference pack folds in float64).
+// Plain 16 x 16 LDS tiling, one thread per output element: these are ~50 MFLOP per call; the point is that no BLAS library sits in the
+// per-step repack / backward, not speed.
+template <typename T>
+__global__ __launch_bounds__(256) void k_small_gemm(const T* __restrict__ A, const T* __restrict__ B, T* __restrict__ C, int M, int N, int K,
+                                                    int ta, int tb) {
+  __shared__ T As[16][17], Bs[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int m = blockIdx.y * 16 + ty, n = blockIdx.x * 16 + tx;
+  const T* Ab = A + (size_t)blockIdx.z * M * K;
+  const T* Bb = B + (size_t)blockIdx.z * K * N;
+  T acc = (T)0;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    const int ka = k0 + tx, kb = k0 + ty;
+    As[ty][tx] = (m < M && ka < K) ? (ta ? Ab[(size_t)ka * M + m] : Ab[(size_t)m * K + ka]) : (T)0;
+    Bs[ty][tx] = (kb < K && n < N) ? (tb ? Bb[(size_t)n * K + kb] : Bb[(size_t)kb * N + n]) : (T)0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc = fma(As[ty][k], Bs[k][tx], acc);
+    __syncthreads();
+  }
+  if (m < M && n < N) C[(size_t)blockIdx.z * M * N + (size_t)m * N + n] = acc;
+}
+extern "C" int rr_small_gemm(const void* A, const void* B, void* C, int batch, int M, int N, int K, int transA, int transB, int f64,
+                             hipStream_t st) {
+  if (A == nullptr || B == nullptr || C == nullptr || batch <= 0 || M <= 0 || N <= 0 || K <= 0 || batch > 65535) return RR_EINVAL;
+  const dim3 grid((N + 15) / 16, (M + 15) / 16, batch);
+  if (f64) hipLaunchKernelGGL(k_small_gemm<double>, grid, dim3(256), 0, st, (const double*)A, (const double*)B, (double*)C, M, N, K, transA, transB);
+  else hipLaunchKernelGGL(k_small_gemm<float>, grid, dim3(256), 0, st, (const float*)A, (const float*)B, (float*)C, M, N, K, transA, transB);
+  return rr_check(hipGetLastError());
+}

@@ -100,6 +100,10 @@ class DecBigIO(C.Structure):            # csrc/rr_bign.hip
                                   "b1", "b2", "logits")] + [(n, i32) for n in ("Bp", "N", "NP", "S", "nscal")] + [("alpha", f32), ("beta", f32)]
 
 
+class GateBwdIO(C.Structure):
+    _fields_ = [(n, vp) for n in ("hA", "hB", "w2", "b2", "node", "dist", "dout", "dnode", "ddist", "dw2", "db2")] + [("M", C.c_longlong), ("acc_node", i32)]
+
+
 class MtvrpExtra(C.Structure):
     _fields_ = [(n, vp) for n in ("demand_b", "used_b", "open_route", "dist_limit", "bclass")]
 
@@ -136,6 +140,9 @@ _SIGS = {
     "rr_inorm_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "rr_linear_rows": [vp, vp, vp, vp, C.c_longlong, i32, vp, vp],
     "rr_aft_bwd": [C.POINTER(AftBwdIO), i32, vp],
+    "rr_linear_smallk": [vp, i32, i32, vp, vp, vp, C.c_longlong, vp],
+    "rr_gate_bwd": [C.POINTER(GateBwdIO), vp],
+    "rr_small_gemm": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "rr_inorm_fwd": [vp, vp, vp, vp, vp, i32, i32, vp],
     "rr_nab_pwl_fwd": [vp, vp, vp, vp, i32, i32, i32, vp],
     "rr_colsoftmax_exp": [vp, vp, vp, vp, i32, i32, i32, vp],

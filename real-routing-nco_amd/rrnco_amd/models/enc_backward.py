@@ -35,7 +35,7 @@ def train_packs(policy) -> dict:
         # all blocks' matrices packed together (a handful of launches per shape, not per matrix: this runs every step)
         names = [f"encoder.net.layers.{l}.{side}_encoding_block" for l in range(nl) for side in ("row", "col")]
         stk = lambda k: torch.stack([sd[f"{b}.{k}"].float() for b in names])                  # noqa: E731
-        Wpc = torch.bmm(stk("multi_head_combine.weight").double(), stk("attn_free.project.weight").double()).float()
+        Wpc = packing.small_gemm(stk("multi_head_combine.weight").double(), stk("attn_free.project.weight").double()).float()
         T = packing.pack_a(torch.stack([stk("attn_free.to_q.weight"), stk("attn_free.to_k.weight"), stk("attn_free.to_v.weight"), Wpc])
                            .transpose(-1, -2).contiguous())                                     # [4][nb] packs of the TRANSPOSED matrices
         mlps = packing.pack_mlp_train_batched([sd[f"{b}.feed_forward.ops.ffn.W1.weight"] for b in names], [sd[f"{b}.feed_forward.ops.ffn.W1.bias"] for b in names],
@@ -56,6 +56,10 @@ def train_packs(policy) -> dict:
         if policy.env_name == "atsp":
             cache["wc1T"] = C[4]
     out = {"blocks": blocks, "cache": cache, "keep": keep, "num_layers": nl}
+    if policy.env_name == "atsp" and "encoder.init_embedding.gating_network_row.gating_fc.0.weight" in sd:
+        from .init_backward import gate_packs
+        with torch.no_grad():
+            out["init_gate"] = gate_packs(sd)
     policy._enc_train_pack = (key, out)
     return out
 
@@ -79,7 +83,7 @@ def _nab_tabs_batched(P, prefixes, alphas):
         wgh = wg[:, f * E:(f + 1) * E]
         W2, b2 = st(f".{nm}.2.weight"), st(f".{nm}.2.bias")             # [nb,E,E], [nb,E]
         rows += [st(f".{nm}.0.weight")[:, :, 0], st(f".{nm}.0.bias"),
-                 torch.einsum("bji,bj->bi", W2, wo), torch.einsum("bji,bj->bi", W2, wgh)]
+                 (W2 * wo[:, :, None]).sum(1), (W2 * wgh[:, :, None]).sum(1)]      # W2^T wo, W2^T wg (elementwise: no BLAS in the step)
         ks += [(wo * b2).sum(1), (wgh * b2).sum(1)]
     alpha = torch.stack([a.reshape(()) for a in alphas])
     scal = torch.stack([ks[0], ks[1], ks[2], ks[3], bg, bo, alpha, torch.zeros_like(alpha)], dim=1)
@@ -203,11 +207,6 @@ def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
         # gradients in one buffer each: the kernels fill the per-block views, autograd unstacks at the end (a dozen launches, not 12 x 8)
         order_all = [f"encoder.net.layers.{l}.{side}_encoding_block" for l in reversed(range(packs["num_layers"])) for side in ("row", "col")]
         dWpc_all, dbpc_all, bidx = torch.zeros(len(order_all), E, E, device=dev), torch.zeros(len(order_all), E, device=dev), 0
-        with torch.enable_grad():
-            Wc_all = torch.stack([P[b + ".multi_head_combine.weight"] for b in order_all])
-            Wpc_all = torch.bmm(Wc_all, torch.stack([P[b + ".attn_free.project.weight"] for b in order_all]))
-            bpc_all = (torch.bmm(Wc_all, torch.stack([P[b + ".attn_free.project.bias"] for b in order_all])[:, :, None])[:, :, 0]
-                       + torch.stack([P[b + ".multi_head_combine.bias"] for b in order_all]))
         tabs_all = None       # the folded NAB tables of all blocks in processing order as ONE expression (RR_NAB_TAB_PERBLOCK=1: one per block)
         if not vtw and os.environ.get("RR_NAB_TAB_PERBLOCK", "0") != "1":
             order = [f"encoder.net.layers.{l}.{side}_encoding_block" for l in reversed(range(packs["num_layers"])) for side in ("row", "col")]
@@ -288,15 +287,29 @@ def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
                 inorm(y_in, dc, None, b + ".norm2", dy_out, acc=si)
                 chk(b + " norm1 / norm2 backward", dx_out=dx_out, dy_out=dy_out)
             d_row, d_col = n_row, n_col
-        small += [(Wpc_all, dWpc_all), (bpc_all, dbpc_all)]
+        # chain rule through the fold Wpc = Wc Wp, bpc = Wc bp + bc (attn_freenet.py:325, 435), all blocks at once, on rr_small_gemm:
+        # dWc = dWpc Wp^T + dbpc (x) bp,  dWp = Wc^T dWpc,  dbp = Wc^T dbpc,  dbc = dbpc
+        stk_ = lambda k: torch.stack([P[b + k].detach().float() for b in order_all])                  # noqa: E731
+        Wc_all, Wp_all, bp_all = stk_(".multi_head_combine.weight"), stk_(".attn_free.project.weight"), stk_(".attn_free.project.bias")
+        dWc = packing.small_gemm(dWpc_all, Wp_all, transB=True) + dbpc_all[:, :, None] * bp_all[:, None, :]
+        dWp = packing.small_gemm(Wc_all, dWpc_all, transA=True)
+        dbp = (Wc_all * dbpc_all[:, :, None]).sum(1)
+        for i, b in enumerate(order_all):
+            G.buf(b + ".multi_head_combine.weight").add_(dWc[i]); G.buf(b + ".attn_free.project.weight").add_(dWp[i])
+            G.buf(b + ".attn_free.project.bias").add_(dbp[i]); G.buf(b + ".multi_head_combine.bias").add_(dbpc_all[i])
         if nab_tabs:          # the NAB moments of all blocks -> d (folded tables), one batched prefix-sum pass
             if tabs_all is None:
                 gtabs = nab_grad_from_hist(torch.stack([t.detach() for t in nab_tabs]), nab_hists)
                 small += [(t, gtabs[i]) for i, t in enumerate(nab_tabs)]
             else:
                 small.append((tabs_all, nab_grad_from_hist(tabs_all.detach(), nab_hists)))
+        # ---- ATSP init embedding (atsp.py:69-121) on kernels too (models/init_backward.py); the VRPs' goes through autograd below
+        from . import init_backward as IB
+        init_on_kernels = "init_gate" in packs and IB.supported(policy, sample_idx) and os.environ.get("RR_INIT_BWD_TORCH", "0") != "1"
+        if init_on_kernels:
+            IB.init_embedding_backward_atsp(P, G, packs["init_gate"], locs, D, sample_idx, d_row, d_col, ws_tn, MS)
     G.flush()
-    # ---- chain rule through the folds and the init embedding (autograd on tiny / [Bp*N,128] tensors)
+    # ---- chain rule through the folds (tiny tensors) and, for the VRPs, the init embedding (autograd on [Bp*N,128] tensors)
     vrp = policy.env_name == "rcvrp"
     with torch.enable_grad():
         # duration NAB of every block: csrc/rr_train_nabdur.hip on the kernels' d bias; the angles are the same for row and col
@@ -310,6 +323,10 @@ def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
             row0, col0 = GR._init_embedding_vrp(P, locs, td["demand_linehaul"].float()[:, 1:], D, sample_idx, extra, "init_embed")
         elif vrp:
             row0, col0 = GR._init_embedding_vrp(P, locs, td["demand"].float(), D, sample_idx, None, "demand_init")
-        else:
+        elif not init_on_kernels:
             row0, col0 = GR._init_embedding(P, locs, D, sample_idx)
-        torch.autograd.backward([t for t, _ in small] + [row0, col0], [g for _, g in small] + [d_row, d_col])
+        if init_on_kernels:
+            if small:
+                torch.autograd.backward([t for t, _ in small], [g for _, g in small])
+        else:
+            torch.autograd.backward([t for t, _ in small] + [row0, col0], [g for _, g in small] + [d_row, d_col])

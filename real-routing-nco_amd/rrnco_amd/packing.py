@@ -43,6 +43,26 @@ def pack_a(Wm: torch.Tensor) -> torch.Tensor:
     return x.view(*lead, Mp // 16, Kp // 16, 64, 4)
 
 
+def small_gemm(A: torch.Tensor, B: torch.Tensor, transA: bool = False, transB: bool = False) -> torch.Tensor:
+    """op(A) @ op(B) for [batch, ., .] (or 2-D) float32 / float64 DEVICE tensors on csrc/rr_train_enc.hip:k_small_gemm — the weight
+    folds' products without a BLAS library in the per-step repack; CPU tensors (unit tests of the folds) take torch.matmul."""
+    if not A.is_cuda:
+        return torch.matmul(A.transpose(-1, -2) if transA else A, B.transpose(-1, -2) if transB else B)
+    from . import _lib as L
+    squeeze = A.dim() == 2
+    A3, B3 = (A[None], B[None]) if squeeze else (A, B)
+    A3, B3 = A3.contiguous(), B3.contiguous()
+    assert A3.dtype == B3.dtype and A3.dtype in (torch.float32, torch.float64) and A3.shape[0] == B3.shape[0]
+    nb = A3.shape[0]
+    M, K = (A3.shape[2], A3.shape[1]) if transA else (A3.shape[1], A3.shape[2])
+    N, K2 = (B3.shape[1], B3.shape[2]) if transB else (B3.shape[2], B3.shape[1])
+    assert K == K2, (A.shape, B.shape, transA, transB)
+    Cm = torch.empty(nb, M, N, dtype=A3.dtype, device=A3.device)
+    L.check(L.lib().rr_small_gemm(L.ptr(A3), L.ptr(B3), L.ptr(Cm), nb, M, N, K, int(transA), int(transB), int(A3.dtype == torch.float64),
+                                  L.stream()), "rr_small_gemm")
+    return Cm[0] if squeeze else Cm
+
+
 _FORCE_FP32 = 0      # > 0 inside force_fp32(): the range guard's second pass (models/policy.py) runs every kernel on the fp32 MFMA
 
 
@@ -294,7 +314,7 @@ def fold_nab_pwl_batched(sd, prefixes, alphas) -> torch.Tensor:
         wgh = wg[:, f * E:(f + 1) * E]
         a, b = st(f".{nm}.0.weight")[:, :, 0], st(f".{nm}.0.bias")                         # [nb,E]
         W2, b2 = st(f".{nm}.2.weight"), st(f".{nm}.2.bias")                                # [nb,E,E], [nb,E]
-        co, cg = torch.einsum("bji,bj->bi", W2, wo), torch.einsum("bji,bj->bi", W2, wgh)   # W2^T wo, W2^T wg
+        co, cg = (W2 * wo[:, :, None]).sum(1), (W2 * wgh[:, :, None]).sum(1)               # W2^T wo, W2^T wg (elementwise: no BLAS in a repack)
         ko, kg = (wo * b2).sum(1), (wgh * b2).sum(1)
         nz = a != 0
         t = torch.where(nz, -b / torch.where(nz, a, torch.ones_like(a)), torch.full_like(a, float("inf"))).sort(dim=1).values
@@ -518,13 +538,14 @@ def _pack_policy(sd: dict, env_name: str, device) -> dict:
     p1, p2 = pack_a(W1s), pack_a(W2s)
     # AFTFull.project (attn_freenet.py:325) feeds multi_head_combine (:435) directly: one Linear, folded in float64
     Wc64, Wp64 = stk("multi_head_combine.weight").double(), stk("attn_free.project.weight").double()
-    ppc = pack_a(torch.bmm(Wc64, Wp64).float())
-    bpc = (torch.bmm(Wc64, stk("attn_free.project.bias").double()[:, :, None])[:, :, 0] + stk("multi_head_combine.bias").double()).float().contiguous()
+    Wpc32 = small_gemm(Wc64, Wp64).float()
+    ppc = pack_a(Wpc32)
+    bpc = ((Wc64 * stk("attn_free.project.bias").double()[:, None, :]).sum(2) + stk("multi_head_combine.bias").double()).float().contiguous()
     ar.keep += [sq, p1, p2, ppc, bpc]
     if split:      # FFN weights again as 3-way bf16 splits for the bf16-pipe FFN
         p1s, p2s = pack_a_f16u(W1s), pack_a_f16u(W2s)          # second-form images (x 2^6, csrc/rr_common.h): encoder FFN
         sqs = pack_a_f16x2(torch.stack([stk("attn_free.to_q.weight"), stk("attn_free.to_k.weight"), stk("attn_free.to_v.weight"),
-                                        torch.bmm(Wc64, Wp64).float()]))                       # [4][nb][8][4][2][64][8]
+                                        Wpc32]))                                               # [4][nb][8][4][2][64][8]
         ar.keep += [p1s, p2s, sqs]
     for bi, b in enumerate(names):
         l = bi // 2
@@ -642,7 +663,7 @@ def _pack_policy(sd: dict, env_name: str, device) -> dict:
         if split:
             cw.wcas, cw.wcbs = ar.put(f16x2_image(pack_a(wctx[:, :E]))), ar.put(f16x2_image(pack_a(wctx[:, E:2 * E])))
         ph = sd["decoder.context_embedding.W_placeholder"].detach().float()
-        dw.q0 = ar.put(wctx @ ph.to(wctx.device))
+        dw.q0 = ar.put((wctx * ph.to(wctx.device)[None, :]).sum(1))
         dw.wstate = None
     else:
         cw.wca, cw.wcb = None, ar.put(pack_a(wctx[:, :E]))

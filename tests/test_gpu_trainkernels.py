@@ -341,3 +341,78 @@ def test_duration_nab_backward_kernels_match_float64_autograd(split):
     for n, x, r in zip(names, got, ref):
         err = (x.reshape(r.shape) - r).norm() / (r.norm() + 1e-12)
         assert err < (5e-3 if n in ("a", "b") else 2e-4), (n, split, float(err))       # a / b: ReLU-kink flips of single units (see the MLP tests)
+
+
+def test_linear_smallk_and_gate_backward_match_autograd():
+    """csrc/rr_train_enc.hip: k_linear_smallk (the narrow Linear maps of the init embedding) and k_gate_bwd (ContextualGating,
+    rrnco/models/env_embeddings/atsp.py:108-121, recomputed and differentiated around its scalar gate) against float64 autograd."""
+    from rrnco_amd import _lib as L
+    g = torch.Generator().manual_seed(11)
+    M, K, Kp = 1003, 25, 28
+    X = torch.zeros(M, Kp); X[:, :K] = torch.rand(M, K, generator=g)
+    W, b = torch.randn(E, K, generator=g) / 5, torch.randn(E, generator=g)
+    out = torch.empty(M, E, device="cuda")
+    Xc, Wc, bc = X.cuda(), W.cuda(), b.cuda()
+    L.check(L.lib().rr_linear_smallk(L.ptr(Xc), Kp, K, L.ptr(Wc), L.ptr(bc), L.ptr(out), M, L.stream()), "smallk")
+    assert _rel(out.cpu(), F.linear(X[:, :K].double(), W.double(), b.double())) < 1e-6
+    # gate: h = relu(hA | hB), g = sigmoid(w2 . h + b2), out = g node + (1 - g) dist
+    hpre = torch.randn(M, 2 * E, generator=g).double().requires_grad_()
+    node, dist = torch.randn(M, E, generator=g).double().requires_grad_(), torch.randn(M, E, generator=g).double().requires_grad_()
+    w2, b2 = (torch.randn(2 * E, generator=g) / 8).double().requires_grad_(), torch.randn(1, generator=g).double().requires_grad_()
+    dout, dn0 = torch.randn(M, E, generator=g).double(), torch.randn(M, E, generator=g)
+    gt = torch.sigmoid(F.relu(hpre) @ w2 + b2)[:, None]
+    ((gt * node + (1 - gt) * dist) * dout).sum().backward()
+    c = lambda t: t.detach().float().contiguous().cuda()                                              # noqa: E731
+    hA, hB = c(hpre[:, :E]), c(hpre[:, E:])
+    dnode, ddist = dn0.clone().cuda(), torch.empty(M, E, device="cuda")
+    dw2, db2 = torch.zeros(2 * E, device="cuda"), torch.zeros(1, device="cuda")
+    keep = [c(w2), c(b2), c(node), c(dist), c(dout)]
+    io = L.GateBwdIO()
+    io.hA, io.hB, io.w2, io.b2, io.node, io.dist, io.dout = [L.ptr(t) for t in [hA, hB] + keep]
+    io.dnode, io.ddist, io.dw2, io.db2, io.M, io.acc_node = L.ptr(dnode), L.ptr(ddist), L.ptr(dw2), L.ptr(db2), M, 1
+    L.check(L.lib().rr_gate_bwd(io, L.stream()), "gate")
+    assert _rel(torch.cat([hA, hB], 1).cpu(), hpre.grad) < 2e-6
+    # (node.grad / dist.grad of the reference include nothing through hpre here: exactly the kernel's g dout / (1 - g) dout)
+    assert _rel(dnode.cpu() - dn0, node.grad) < 2e-6 and _rel(ddist.cpu(), dist.grad) < 2e-6
+    assert _rel(dw2.cpu(), w2.grad) < 1e-5 and _rel(db2.cpu(), b2.grad) < 1e-5
+
+
+def test_init_embedding_backward_on_kernels_equals_the_autograd_path(monkeypatch):
+    """models/init_backward.py (ATSP init embedding differentiated on the library's kernels) against the torch-autograd formulation
+    it replaced (RR_INIT_BWD_TORCH=1), through a whole training step on the same sampled tours."""
+    from tests.test_gpu_train import _model
+    fx = H.load_fixture("atsp_n100_b2_pomo")
+    grads = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("RR_INIT_BWD_TORCH", flag)
+        w, pol, model, st, td_in = _model(fx)
+        model.training_step(td_in, seed=11)
+        grads.append({n: p.grad.clone() for n, p in pol.named_parameters()})
+    names = [n for n in grads[0] if n.startswith("encoder.init_embedding.")]
+    assert len(names) >= 12
+    for n in names:
+        assert float(grads[1][n].abs().max()) > 0, n
+        assert _rel(grads[0][n], grads[1][n]) < 2e-4, (n, _rel(grads[0][n], grads[1][n]))
+    gnorm = sum(float((g.double() ** 2).sum()) for g in grads[1].values()) ** 0.5
+    for n in grads[0]:
+        if n not in names:           # (float atomics in a few kernels: not bit-equal; analytically zero gradients — to_k.bias — are rounding noise)
+            err = float((grads[0][n].double() - grads[1][n].double()).norm())
+            assert err <= 1e-5 * float(grads[1][n].double().norm()) + 5e-7 * gnorm, (n, err)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_small_gemm_of_the_weight_folds(dtype):
+    """csrc/rr_train_enc.hip: k_small_gemm (the folds' 128 x 128 products, so that no BLAS library runs in a repack or a training step)
+    with both transposes, batches and sizes that are not multiples of the 16 x 16 tile."""
+    from rrnco_amd import packing
+    g = torch.Generator().manual_seed(2)
+    for (nb, M, N, K) in ((12, 128, 128, 128), (3, 37, 50, 129), (1, 16, 1, 5)):
+        for ta in (False, True):
+            for tb in (False, True):
+                A = torch.randn((nb, K, M) if ta else (nb, M, K), generator=g, dtype=dtype)
+                B = torch.randn((nb, N, K) if tb else (nb, K, N), generator=g, dtype=dtype)
+                got = packing.small_gemm(A.cuda(), B.cuda(), ta, tb).cpu()
+                ref = torch.matmul((A.transpose(1, 2) if ta else A).double(), (B.transpose(1, 2) if tb else B).double())
+                assert got.dtype == dtype and _rel(got, ref) < (1e-6 if dtype == torch.float32 else 1e-14)
+    A2, B2 = torch.randn(40, 30, generator=g), torch.randn(30, 20, generator=g)
+    assert _rel(packing.small_gemm(A2.cuda(), B2.cuda()).cpu(), A2.double() @ B2.double()) < 1e-6
