@@ -284,27 +284,56 @@ __device__ __forceinline__ f32x4 nd_mfma3(ndfrag ah, ndfrag al, ndfrag bh, ndfra
   return rr_mfma_bf16(ah, bh, c);
 }
 
-__global__ __launch_bounds__(256, 2) void k_nabdur_bwd_edges2(NabDurBwdW w, const float* __restrict__ xd, const float* __restrict__ xa,
+// The two weight images (Mcat as A operands of Z^T = Mcat H^T, Mcat^T as A operands of dH^T = Mcat^T dZ^T: 192 KB each as [hi | lo]
+// bf16 fragments) go through LDS in 16 stages of 24 KB per round of tiles — 8 stages = the 8 unit tiles u of Mcat, 8 stages = three
+// hidden tiles t of Mcat^T each — fetched ONCE per workgroup and round by LDS-DMA (three 1 KB requests per wave and stage, double
+// buffered, one barrier per stage) and read by its eight waves.  With every wave streaming its own fragments from L2 (round 3) a
+// 16-edge tile cost 384 KB of L2 reads: 63 GB per call at configs-4 size, 6.3 ms = the L2's bandwidth, ten times the matrix work.
+#define ND_STAGE (24 * 1024)
+__global__ __launch_bounds__(512, 1) void k_nabdur_bwd_edges2(NabDurBwdW w, const float* __restrict__ xd, const float* __restrict__ xa,
                                                               const float* __restrict__ xt, const float* __restrict__ gout,
                                                               char* __restrict__ dzf, float* __restrict__ grads, long long M) {
   __shared__ __attribute__((aligned(16))) float par[3 * 384 + 128 + 384 + 16];
   __shared__ __attribute__((aligned(16))) float acc[ND_GRADS];
+  __shared__ __attribute__((aligned(1024))) char stage[2][ND_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < 384; i += 256) { par[i] = w.a[i]; par[384 + i] = w.b[i]; par[768 + i] = w.co[i]; par[1280 + i] = w.wg2[i]; }
-  for (int i = tid; i < 128; i += 256) par[1152 + i] = w.cg[i];
+  for (int i = tid; i < 384; i += 512) { par[i] = w.a[i]; par[384 + i] = w.b[i]; par[768 + i] = w.co[i]; par[1280 + i] = w.wg2[i]; }
+  for (int i = tid; i < 128; i += 512) par[1152 + i] = w.cg[i];
   if (tid < 9) par[1664 + tid] = w.scal[tid];
-  for (int i = tid; i < ND_GRADS; i += 256) acc[i] = 0.f;
+  for (int i = tid; i < ND_GRADS; i += 512) acc[i] = 0.f;
   __syncthreads();
   const float *pa = par, *pb = par + 384, *pco = par + 768, *pcg = par + 1152, *pw = par + 1280, *ps = par + 1664;
   const float inv_tau = ps[6], bo = ps[7], alpha = ps[8];
   const long long ntile = ((M + 31) / 32) * 2;                // 16-edge tiles, an even number: both halves of every 32-edge dZ tile are written
-  const __amdgpu_buffer_rsrc_t rM = rr_make_buf(w.mcat_s, 128 * 384 * 4), rMT = rr_make_buf(w.mcatT_s, 128 * 384 * 4);
   const unsigned lane16 = (unsigned)lane * 16u;
+  const unsigned sbase = rr_lds_offset(&stage[0][0]) + (unsigned)(3 * wave) * 1024u;
+  // stage q of a round (0..7: Mcat unit tile q, 8..15: Mcat^T hidden tiles 3 (q - 8) ..) into buffer `buf`: this wave's three fragments
+  auto issue = [&](int q, int buf) {
+    const char* src = (q < 8 ? (const char*)w.mcat_s + (size_t)q * ND_STAGE : (const char*)w.mcatT_s + (size_t)(q - 8) * ND_STAGE) + (size_t)(3 * wave) * 1024;
+#pragma unroll
+    for (int f = 0; f < 3; ++f) rr_dma1(sbase + (unsigned)buf * (unsigned)ND_STAGE + (unsigned)f * 1024u, src + f * 1024, lane16);
+  };
+  auto frag = [&](int buf, int f) { return *reinterpret_cast<const ndfrag*>(&stage[buf][f * 1024 + lane * 16]); };
+  // every wave of the workgroup walks the same number of rounds (the stages are workgroup-wide); a wave past the last tile computes on zeros and writes nothing
+  const long long per_round = (long long)gridDim.x * 8;
+  const long long rounds = (ntile + per_round - 1) / per_round;
   float s_bg[3] = {0.f, 0.f, 0.f}, s_ko[3] = {0.f, 0.f, 0.f}, s_tau = 0.f, s_bo = 0.f, s_al = 0.f;
-  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntile; tile += (long long)gridDim.x * 4) {
+  // Per-unit sums over the wave's edges in REGISTERS: after the row reduction all 16 lanes of a row hold the tile's sum, so lane j keeps
+  // the running totals of unit tile u = j (d cg, d Wg2: aZ) and of hidden tiles t = j and t = 16 + j (d a, d b, d co: aH) — 40 registers,
+  // flushed to LDS once per kernel.  The 416 four-lane ds_add_f32 per tile they replace were 1.5 of the kernel's 5.8 ms (LDS float
+  // atomics are served lane after lane on this chip, see k_nab_hist_bwd).
+  f32x4 aZ[4], aH[2][3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) aZ[i] = rr_zero4();
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { aH[0][i] = rr_zero4(); aH[1][i] = rr_zero4(); }
+  issue(0, 0);
+  for (long long rd = 0; rd < rounds; ++rd) {
+    const long long tile = (rd * gridDim.x + blockIdx.x) * 8 + wave;
+    const bool tvalid = tile < ntile;
     const long long e = tile * 16 + j;
-    const bool valid = e < M;
+    const bool valid = tvalid && e < M;
     const float x[3] = {valid ? xd[e] : 0.f, valid ? xa[e] : 0.f, valid ? xt[e] : 0.f};
     const float go = valid ? gout[e] : 0.f;
     // ---- H^T (unit 16t + 4g + r of edge j), po = co . h per family, then H as bf16 pieces in k = 32 operand order
@@ -331,11 +360,14 @@ __global__ __launch_bounds__(256, 2) void k_nabdur_bwd_edges2(NabDurBwdW w, cons
     for (int u = 0; u < 8; ++u) {
       const float4 c4 = rr_ld4(pcg + 16 * u + 4 * g);
       f32x4 c0 = {c4.x, c4.y, c4.z, c4.w}, c1 = rr_zero4();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                      // stage u landed (every wave's requests); the stage before it is consumed by every wave
+      issue(u + 1, (u + 1) & 1);
 #pragma unroll
       for (int sl = 0; sl < 12; sl += 2) {
         if ((sl & 3) == 0) __builtin_amdgcn_sched_barrier(0);
-        const ndfrag a0h = rr_bldh(rM, lane16, (unsigned)((u * 12 + sl) * 2) * 1024u), a0l = rr_bldh(rM, lane16, (unsigned)((u * 12 + sl) * 2 + 1) * 1024u);
-        const ndfrag a1h = rr_bldh(rM, lane16, (unsigned)((u * 12 + sl + 1) * 2) * 1024u), a1l = rr_bldh(rM, lane16, (unsigned)((u * 12 + sl + 1) * 2 + 1) * 1024u);
+        const ndfrag a0h = frag(u & 1, sl * 2), a0l = frag(u & 1, sl * 2 + 1);
+        const ndfrag a1h = frag(u & 1, (sl + 1) * 2), a1l = frag(u & 1, (sl + 1) * 2 + 1);
         c0 = nd_mfma3(a0h, a0l, Hh[sl], Hl[sl], c0);
         c1 = nd_mfma3(a1h, a1l, Hh[sl + 1], Hl[sl + 1], c1);
       }
@@ -352,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void k_nabdur_bwd_edges2(NabDurBwdW w, cons
       const float ww0[4] = {w0.x, w0.y, w0.z, w0.w}, ww1[4] = {w1.x, w1.y, w1.z, w1.w}, ww2[4] = {w2.x, w2.y, w2.z, w2.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float sv = Z[u][r] / (1.0f + __expf(-Z[u][r]));
+        const float sv = Z[u][r] * __builtin_amdgcn_rcpf(1.0f + __expf(-Z[u][r]));      // (v_rcp_f32, 1 ulp: a division is ~10 instructions, 64 of them per tile)
         l[0] = fmaf(ww0[r], sv, l[0]); l[1] = fmaf(ww1[r], sv, l[1]); l[2] = fmaf(ww2[r], sv, l[2]);
       }
     }
@@ -392,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void k_nabdur_bwd_edges2(NabDurBwdW w, cons
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float z = Z[u][r];
-        const float sg = 1.0f / (1.0f + __expf(-z)), sv = z * sg;
+        const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-z)), sv = z * sg;
         const float ds = ww0[r] * dlr[0] + ww1[r] * dlr[1] + ww2[r] * dlr[2];
         DZ[u][r] = ds * (sg * (1.0f + z * (1.0f - sg)));
         r0[r] = dlr[0] * sv; r1[r] = dlr[1] * sv; r2[r] = dlr[2] * sv;
@@ -400,18 +432,19 @@ __global__ __launch_bounds__(256, 2) void k_nabdur_bwd_edges2(NabDurBwdW w, cons
         const __bf16 hi = (__bf16)DZ[u][r];
         const __bf16 lo = (__bf16)(DZ[u][r] - (float)hi);
         char* d = dst0 + (size_t)(u * 2) * 1024 + (4 * g + r) * 16;
-        *reinterpret_cast<__bf16*>(d) = hi;
-        *reinterpret_cast<__bf16*>(d + 1024) = lo;
+        if (tvalid) {
+          *reinterpret_cast<__bf16*>(d) = hi;
+          *reinterpret_cast<__bf16*>(d + 1024) = lo;
+        }
       }
       f32x4 dc = DZ[u];
       nd_rowsum4(dc); nd_rowsum4(r0); nd_rowsum4(r1); nd_rowsum4(r2);
-      if (j == 0) {
+      {
+        const float mine = j == u ? 1.0f : 0.0f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          atomicAdd(&acc[ND_DCG + 16 * u + 4 * g + r], dc[r]);
-          atomicAdd(&acc[ND_DWG2 + 16 * u + 4 * g + r], r0[r]);
-          atomicAdd(&acc[ND_DWG2 + 128 + 16 * u + 4 * g + r], r1[r]);
-          atomicAdd(&acc[ND_DWG2 + 256 + 16 * u + 4 * g + r], r2[r]);
+          aZ[0][r] = fmaf(mine, dc[r], aZ[0][r]); aZ[1][r] = fmaf(mine, r0[r], aZ[1][r]);
+          aZ[2][r] = fmaf(mine, r1[r], aZ[2][r]); aZ[3][r] = fmaf(mine, r2[r], aZ[3][r]);
         }
       }
     }
@@ -422,13 +455,19 @@ __global__ __launch_bounds__(256, 2) void k_nabdur_bwd_edges2(NabDurBwdW w, cons
       nd_split8(dv, Dh[sl], Dl[sl]);
     }
     // ---- dH^T = Mcat^T dZ^T tile by tile; d pre-activation; d a, d b, d co row sums
-#pragma unroll 1
-    for (int t = 0; t < 24; ++t) {
+    auto dh_tile = [&](int t, f32x4 (&A)[3]) {
+      const int q = 8 + t / 3, tt = t - (t / 3) * 3;
+      if (tt == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (q + 1 < 16) issue(q + 1, (q + 1) & 1);
+        else if (rd + 1 < rounds) issue(0, 0);            // the next round's first stage
+      }
       f32x4 c0 = rr_zero4(), c1 = rr_zero4();
 #pragma unroll
       for (int sl = 0; sl < 4; sl += 2) {
-        const ndfrag a0h = rr_bldh(rMT, lane16, (unsigned)((t * 4 + sl) * 2) * 1024u), a0l = rr_bldh(rMT, lane16, (unsigned)((t * 4 + sl) * 2 + 1) * 1024u);
-        const ndfrag a1h = rr_bldh(rMT, lane16, (unsigned)((t * 4 + sl + 1) * 2) * 1024u), a1l = rr_bldh(rMT, lane16, (unsigned)((t * 4 + sl + 1) * 2 + 1) * 1024u);
+        const ndfrag a0h = frag(q & 1, (tt * 4 + sl) * 2), a0l = frag(q & 1, (tt * 4 + sl) * 2 + 1);
+        const ndfrag a1h = frag(q & 1, (tt * 4 + sl + 1) * 2), a1l = frag(q & 1, (tt * 4 + sl + 1) * 2 + 1);
         c0 = nd_mfma3(a0h, a0l, Dh[sl], Dl[sl], c0);
         c1 = nd_mfma3(a1h, a1l, Dh[sl + 1], Dl[sl + 1], c1);
       }
@@ -447,15 +486,27 @@ __global__ __launch_bounds__(256, 2) void k_nabdur_bwd_edges2(NabDurBwdW w, cons
         da[r] = dpre * xx; db[r] = dpre; dco[r] = h * dpf;
       }
       nd_rowsum4(da); nd_rowsum4(db); nd_rowsum4(dco);
-      if (j == 0) {
+      const float mine = j == (t & 15) ? 1.0f : 0.0f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          atomicAdd(&acc[ND_DA + 16 * t + 4 * g + r], da[r]);
-          atomicAdd(&acc[ND_DB + 16 * t + 4 * g + r], db[r]);
-          atomicAdd(&acc[ND_DCO + 16 * t + 4 * g + r], dco[r]);
-        }
-      }
+      for (int r = 0; r < 4; ++r) { A[0][r] = fmaf(mine, da[r], A[0][r]); A[1][r] = fmaf(mine, db[r], A[1][r]); A[2][r] = fmaf(mine, dco[r], A[2][r]); }
+    };
+#pragma unroll 1
+    for (int t = 0; t < 16; ++t) dh_tile(t, aH[0]);
+#pragma unroll 1
+    for (int t = 16; t < 24; ++t) dh_tile(t, aH[1]);
+  }
+  // (0 * inf: a non-finite sum of a tile this lane does not own would turn into NaN through the multiply by `mine` = 0 — and that is
+  // the right answer: the gradient buffer is poisoned either way, as it was with the atomics)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (j < 8) {
+      atomicAdd(&acc[ND_DCG + 16 * j + 4 * g + r], aZ[0][r]); atomicAdd(&acc[ND_DWG2 + 16 * j + 4 * g + r], aZ[1][r]);
+      atomicAdd(&acc[ND_DWG2 + 128 + 16 * j + 4 * g + r], aZ[2][r]); atomicAdd(&acc[ND_DWG2 + 256 + 16 * j + 4 * g + r], aZ[3][r]);
+      atomicAdd(&acc[ND_DA + 16 * (16 + j) + 4 * g + r], aH[1][0][r]); atomicAdd(&acc[ND_DB + 16 * (16 + j) + 4 * g + r], aH[1][1][r]);
+      atomicAdd(&acc[ND_DCO + 16 * (16 + j) + 4 * g + r], aH[1][2][r]);
     }
+    atomicAdd(&acc[ND_DA + 16 * j + 4 * g + r], aH[0][0][r]); atomicAdd(&acc[ND_DB + 16 * j + 4 * g + r], aH[0][1][r]);
+    atomicAdd(&acc[ND_DCO + 16 * j + 4 * g + r], aH[0][2][r]);
   }
   {
     float v[9] = {s_bg[0], s_bg[1], s_bg[2], s_ko[0], s_ko[1], s_ko[2], s_tau, s_bo, s_al};
@@ -463,7 +514,7 @@ __global__ __launch_bounds__(256, 2) void k_nabdur_bwd_edges2(NabDurBwdW w, cons
     for (int q = 0; q < 9; ++q) { const float r = nd_rowsum1(v[q]); if (lane == 0) atomicAdd(&acc[ND_DSC + q], r); }
   }
   __syncthreads();
-  for (int i = tid; i < ND_GRADS; i += 256) { const float v = acc[i]; if (v != 0.f) atomicAdd(&grads[i], v); }
+  for (int i = tid; i < ND_GRADS; i += 512) { const float v = acc[i]; if (v != 0.f) atomicAdd(&grads[i], v); }
 }
 
 __global__ __launch_bounds__(512, 2) void k_nabdur_bwd_mcat2(NabDurBwdW w, const float* __restrict__ xd, const float* __restrict__ xa,
@@ -543,8 +594,8 @@ extern "C" int rr_nabdur_bwd(const NabDurBwdW* w, const float* xd, const float* 
   static const int f32only = getenv("RR_NABDUR_F32") ? atoi(getenv("RR_NABDUR_F32")) : 0;
   if (w->mcat_s != nullptr && w->mcatT_s != nullptr && !f32only) {      // bf16 pipe, two-piece operands
     const long long nt16 = ((M + 31) / 32) * 2, nt32 = (M + 31) / 32;
-    const int g1 = (int)((nt16 + 3) / 4 < 2048 ? (nt16 + 3) / 4 : 2048);
-    hipLaunchKernelGGL(k_nabdur_bwd_edges2, dim3(g1), dim3(256), 0, st, *w, xd, xa, xt, gout, (char*)dzf, grads, M);
+    const int g1 = (int)((nt16 + 7) / 8 < 256 ? (nt16 + 7) / 8 : 256);          // one workgroup of eight waves per CU
+    hipLaunchKernelGGL(k_nabdur_bwd_edges2, dim3(g1), dim3(512), 0, st, *w, xd, xa, xt, gout, (char*)dzf, grads, M);
     const int g2 = (int)(nt32 < 512 ? nt32 : 512);
     hipLaunchKernelGGL(k_nabdur_bwd_mcat2, dim3(g2), dim3(512), 0, st, *w, xd, xa, xt, (const char*)dzf, dmcat, M);
     return rr_check(hipGetLastError());
