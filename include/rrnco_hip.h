@@ -290,8 +290,9 @@ int rr_linear_smallk(const float* X, int ldx, int K, const float* W, const float
 /* ContextualGating (atsp.py:108-121) around its scalar gate, forward recomputed and differentiated in one pass over M rows.
  * In: hA | hB = the 256 pre-activations of gating_fc.0 (bias included), w2 [256] / b2 [1] = gating_fc.2, node / dist = the two
  * embeddings the gate mixes, dout = d loss / d (g node + (1 - g) dist).  Out: dh over hA | hB, dnode (+= when acc_node) = g dout,
- * ddist = (1 - g) dout, dw2 [256] and db2 [1] ADDED to. */
-typedef struct { float *hA, *hB; const float *w2, *b2, *node, *dist, *dout; float *dnode, *ddist, *dw2, *db2; long long M; int acc_node; } GateBwdIO;
+ * ddist = (1 - g) dout, dw2 [256] and db2 [1] ADDED to; mix (optional) = the forward value g node + (1 - g) dist, which the VRPs'
+ * combine layer reads (rcvrp.py:96-101). */
+typedef struct { float *hA, *hB; const float *w2, *b2, *node, *dist, *dout; float *dnode, *ddist, *dw2, *db2; long long M; int acc_node; float* mix; } GateBwdIO;
 int rr_gate_bwd(const GateBwdIO* io, hipStream_t stream);
 /* C[b] = op(A[b]) op(B[b]), row-major [batch][M][K] x [batch][K][N] (transX: the operand is stored transposed), float or double (f64 != 0):
  * the small products of the host-side weight folds (project o multi_head_combine, attn_freenet.py:325, 435) and of their chain rule in

@@ -396,6 +396,7 @@ struct GateBwdIO {
   float *dnode, *ddist, *dw2, *db2;
   long long M;
   int acc_node;
+  float* mix;          // optional: the forward value g node + (1 - g) dist (the VRPs' combine layer reads it: rcvrp.py:96-101)
 };
 __device__ __forceinline__ float gb_sum32(float v) {
   v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
@@ -425,6 +426,7 @@ __global__ __launch_bounds__(256) void k_gate_bwd(GateBwdIO io) {
     rr_st4(io.dnode + o, dn);
     const float h1 = 1.0f - g;
     rr_st4(io.ddist + o, make_float4(h1 * dq_.x, h1 * dq_.y, h1 * dq_.z, h1 * dq_.w));
+    if (io.mix != nullptr) rr_st4(io.mix + o, make_float4(fmaf(g, nd.x, h1 * ds.x), fmaf(g, nd.y, h1 * ds.y), fmaf(g, nd.z, h1 * ds.z), fmaf(g, nd.w, h1 * ds.w)));
     ga.x = fmaf(dp, ra.x, ga.x); ga.y = fmaf(dp, ra.y, ga.y); ga.z = fmaf(dp, ra.z, ga.z); ga.w = fmaf(dp, ra.w, ga.w);
     gb.x = fmaf(dp, rb.x, gb.x); gb.y = fmaf(dp, rb.y, gb.y); gb.z = fmaf(dp, rb.z, gb.z); gb.w = fmaf(dp, rb.w, gb.w);
     gb2 += dp;

@@ -101,7 +101,7 @@ class DecBigIO(C.Structure):            # csrc/rr_bign.hip
 
 
 class GateBwdIO(C.Structure):
-    _fields_ = [(n, vp) for n in ("hA", "hB", "w2", "b2", "node", "dist", "dout", "dnode", "ddist", "dw2", "db2")] + [("M", C.c_longlong), ("acc_node", i32)]
+    _fields_ = [(n, vp) for n in ("hA", "hB", "w2", "b2", "node", "dist", "dout", "dnode", "ddist", "dw2", "db2")] + [("M", C.c_longlong), ("acc_node", i32), ("mix", vp)]
 
 
 class MtvrpExtra(C.Structure):

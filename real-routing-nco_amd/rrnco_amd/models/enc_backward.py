@@ -56,10 +56,10 @@ def train_packs(policy) -> dict:
         if policy.env_name == "atsp":
             cache["wc1T"] = C[4]
     out = {"blocks": blocks, "cache": cache, "keep": keep, "num_layers": nl}
-    if policy.env_name == "atsp" and "encoder.init_embedding.gating_network_row.gating_fc.0.weight" in sd:
+    if policy.env_name in ("atsp", "rcvrp", "rcvrptw") and "encoder.init_embedding.gating_network_row.gating_fc.0.weight" in sd:
         from .init_backward import gate_packs
         with torch.no_grad():
-            out["init_gate"] = gate_packs(sd)
+            out["init_gate"] = gate_packs(sd, vrp=policy.env_name != "atsp")
     policy._enc_train_pack = (key, out)
     return out
 
@@ -303,11 +303,18 @@ def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
                 small += [(t, gtabs[i]) for i, t in enumerate(nab_tabs)]
             else:
                 small.append((tabs_all, nab_grad_from_hist(tabs_all.detach(), nab_hists)))
-        # ---- ATSP init embedding (atsp.py:69-121) on kernels too (models/init_backward.py); the VRPs' goes through autograd below
+        # ---- init embedding (atsp.py:69-121, rcvrp.py:88-150) on kernels too (models/init_backward.py); RR_INIT_BWD_TORCH=1: torch autograd below
         from . import init_backward as IB
         init_on_kernels = "init_gate" in packs and IB.supported(policy, sample_idx) and os.environ.get("RR_INIT_BWD_TORCH", "0") != "1"
         if init_on_kernels:
-            IB.init_embedding_backward_atsp(P, G, packs["init_gate"], locs, D, sample_idx, d_row, d_col, ws_tn, MS)
+            feats = None
+            if policy.env_name == "rcvrp":
+                dm = td["demand"].float()
+                feats = torch.cat([torch.zeros_like(dm[:, :1]), dm], dim=1)[..., None]
+            elif vtw:
+                feats = torch.cat([td["demand_linehaul"].float()[..., None], td["time_windows"].float(), td["service_time"].float()[..., None]], -1)
+                feats[:, 0, 0] = 0.0                                  # (the depot's demand entry: grad_replay._init_embedding_vrp prepends a zero)
+            IB.init_embedding_backward(policy.env_name, P, G, packs["init_gate"], locs, D, sample_idx, d_row, d_col, ws_tn, MS, feats)
     G.flush()
     # ---- chain rule through the folds (tiny tensors) and, for the VRPs, the init embedding (autograd on [Bp*N,128] tensors)
     vrp = policy.env_name == "rcvrp"
@@ -318,12 +325,14 @@ def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
         for b, si, dbias in dur_todo:
             cost_, dur_ = (D, Dur) if si == 0 else (Dt, Tt)
             GR.nab_duration_backward_hip(P, b + ".neural_adaptive_bias", cost_, theta, dur_, P[b + ".alpha"], dbias)
-        if vtw:
+        if init_on_kernels:
+            pass
+        elif vtw:
             extra = torch.cat([td["time_windows"].float(), td["service_time"].float()[..., None]], -1)
             row0, col0 = GR._init_embedding_vrp(P, locs, td["demand_linehaul"].float()[:, 1:], D, sample_idx, extra, "init_embed")
         elif vrp:
             row0, col0 = GR._init_embedding_vrp(P, locs, td["demand"].float(), D, sample_idx, None, "demand_init")
-        elif not init_on_kernels:
+        else:
             row0, col0 = GR._init_embedding(P, locs, D, sample_idx)
         if init_on_kernels:
             if small:
