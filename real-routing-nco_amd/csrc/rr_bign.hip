@@ -394,7 +394,7 @@ extern "C" int rr_dec_fwd_big(const DecBigIO* io, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------ selection, N <= 256
-// One wave per row, keys lane + 64 q.  mode 0 greedy (first index on ties), 1 sampling (Gumbel-max, keyed noise), 2 evaluate.
+// One wave per row, keys lane + 64 q.  mode 0 greedy (first index on ties), 1 sampling (inverse CDF, keyed uniform: rr_common.h), 2 evaluate.
 __global__ __launch_bounds__(256) void k_select_big(const float* __restrict__ logits, const uint8_t* __restrict__ mask,
                                                     const int64_t* __restrict__ action_in, int64_t* __restrict__ action_out,
                                                     float* __restrict__ logp_out, float* __restrict__ logp_all, int R, int N,
@@ -425,6 +425,20 @@ __global__ __launch_bounds__(256) void k_select_big(const float* __restrict__ lo
   const int want = mode == 2 ? (int)action_in[r] : -1;
   float bv = -INFINITY, blp = 0.f;
   int bi = 0x7fffffff;
+  // sampling: inverse CDF over the keys in ascending order (rr_common.h): a key's value is its index where it is eligible — it has mass
+  // and its exclusive prefix is <= target — so the maximum below is the last eligible key
+  float en[4] = {0.f, 0.f, 0.f, 0.f}, cpre[4] = {0.f, 0.f, 0.f, 0.f}, target = 0.f;
+  if (mode == 1) {
+    float base = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      en[q] = (lane + 64 * q < N) ? rr_exp(x[q] - m) : 0.f;
+      float tq;
+      cpre[q] = base + rr_wave_excl_scan(en[q], tq);
+      base += tq;
+    }
+    target = rr_cdf_target(rr_uniform(seed, (uint32_t)r, step, RR_CDF_SLOT), base);
+  }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int jx = lane + 64 * q;
@@ -432,7 +446,7 @@ __global__ __launch_bounds__(256) void k_select_big(const float* __restrict__ lo
     if (logp_all != nullptr && jx < N) logp_all[(size_t)r * N + jx] = lp;
     float sv;
     if (mode == 2) sv = jx == want ? 1.f : -INFINITY;
-    else if (mode == 1) sv = (jx < N && lp > -INFINITY) ? lp + rr_gumbel(seed, (uint32_t)r, step, (uint32_t)jx) : -INFINITY;
+    else if (mode == 1) sv = (en[q] > 0.f && cpre[q] <= target) ? (float)jx : -INFINITY;
     else sv = jx < N ? lp : -INFINITY;
     const bool better = sv > bv || (bi == 0x7fffffff && jx < N && mode == 0);
     bv = better ? sv : bv; bi = better ? jx : bi; blp = better ? lp : blp;

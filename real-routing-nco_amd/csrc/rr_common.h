@@ -457,6 +457,34 @@ __device__ __forceinline__ float rr_gumbel_k(uint32_t h1, uint32_t step, uint32_
   const float LN2 = 0.693147180559945309f;
   return -LN2 * __builtin_amdgcn_logf(-LN2 * __builtin_amdgcn_logf(rr_uniform_k(h1, step, key)));
 }
+// ---- sampling = inverse CDF over the keys in ascending order, one uniform per (seed, rollout, step) (key slot RR_CDF_SLOT): the fused
+// rollout (rr_rollout_w.inc, its own lane layout) and the selection kernels draw the same way.  A draw is the LAST key that has mass and
+// whose exclusive prefix is <= target; the target stays strictly below the total, and the first key with mass has prefix 0 — so a key
+// is always found, and a key without mass never is, whatever the rounding of the prefix sums.
+#define RR_CDF_SLOT 0xffffu
+__device__ __forceinline__ float rr_cdf_target(float u, float total) {
+  return fminf(u * total, __uint_as_float(__float_as_uint(total) - 1u));
+}
+// exclusive prefix sum over the 64 lanes of a wave (lane 0: 0) and the wave's total
+__device__ __forceinline__ float rr_wave_excl_scan(float v, float& total) {
+  const int lane = (int)(threadIdx.x & 63);
+  float inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const float t = __shfl_up(inc, d); inc += lane >= d ? t : 0.f; }
+  total = __shfl(inc, 63);
+  const float ex = __shfl_up(inc, 1);
+  return lane == 0 ? 0.f : ex;
+}
+// the same over each 16-lane row of a wave
+__device__ __forceinline__ float rr_row16_excl_scan(float v, float& total) {
+  const int p = (int)(threadIdx.x & 15);
+  float inc = v;
+#pragma unroll
+  for (int d = 1; d < 16; d <<= 1) { const float t = __shfl_up(inc, d, 16); inc += p >= d ? t : 0.f; }
+  total = __shfl(inc, 15, 16);
+  const float ex = __shfl_up(inc, 1, 16);
+  return p == 0 ? 0.f : ex;
+}
 __device__ __forceinline__ float rr_uniform(uint64_t seed, uint32_t r, uint32_t step, uint32_t key) {
   return rr_uniform_k(rr_noise_key(seed, r), step, key);
 }

@@ -444,7 +444,7 @@ extern "C" int rr_submatrix_gather(const float* dist, const float* dur, const in
 // ------------------------------------------------------------------------------------------------
 // logits -> (action, logp): process_logits + greedy / sampling / evaluate
 // (rrnco/models/decoding.py:311-361, 272-298, 266).  One wave per row, N <= 128.
-// mode: 0 greedy (first index on ties), 1 sampling (inverse-CDF on a counter-based uniform),
+// mode: 0 greedy (first index on ties), 1 sampling (inverse CDF over ascending keys on a counter-based uniform: rr_common.h),
 //       2 evaluate (action given).  logp_all (optional) receives the full log-softmax row.
 // ------------------------------------------------------------------------------------------------
 #define SEL_ROWS 4   // rows per wave: all their loads are issued before the first row is reduced (bytes in flight)
@@ -523,20 +523,17 @@ __device__ __forceinline__ void rr_select_row(const float (&raw)[2], const uint8
     }
     sel = bi;
   } else {
-    // Gumbel-max: argmax(logp + G) is an exact draw from softmax(logits); same noise keying as the
-    // fused rollout kernel so both paths draw identical actions for a given (seed, rollout, step)
-    float bv = -INFINITY; int bi = 0x7fffffff;
-    if (lane < N && lp0 > -INFINITY) { bv = lp0 + rr_gumbel(seed, (uint32_t)r, step, (uint32_t)lane); bi = lane; }
-    if (lane + 64 < N && lp1 > -INFINITY) {
-      float v1 = lp1 + rr_gumbel(seed, (uint32_t)r, step, (uint32_t)(lane + 64));
-      if (v1 > bv) { bv = v1; bi = lane + 64; }
-    }
+    // inverse CDF over the keys in ascending order (rr_common.h: same uniform, same rule as the fused rollout kernel, so both paths draw
+    // the same action for a given (seed, rollout, step) unless fp32 noise moves a boundary across the target)
+    float t0, t1;
+    const float x0 = rr_wave_excl_scan(e0, t0), x1 = rr_wave_excl_scan(e1, t1);
+    const float target = rr_cdf_target(rr_uniform(seed, (uint32_t)r, step, RR_CDF_SLOT), t0 + t1);
+    int cand = -1;
+    if (e0 > 0.f && x0 <= target) cand = lane;
+    if (e1 > 0.f && t0 + x1 <= target) cand = lane + 64;
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-      float ov = __shfl_xor(bv, o); int oi = __shfl_xor(bi, o);
-      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
-    sel = bi;
+    for (int o = 32; o >= 1; o >>= 1) cand = max(cand, __shfl_xor(cand, o));
+    sel = cand < 0 ? 0x7fffffff : cand;
   }
   float lpsel = (sel & 64) ? __shfl(lp1, sel & 63) : __shfl(lp0, sel & 63);
   if (lane == 0) { action_out[r] = sel; logp_out[r] = lpsel; }
@@ -686,13 +683,33 @@ __global__ __launch_bounds__(256) void k_select16(const float* __restrict__ logi
     float bv = -INFINITY, blp = 0.f;
     int bi = 0x7fffffff;
     float lp[8];
+    // sampling: inverse CDF over the keys in ascending order (rr_common.h; keys 4p .. 4p+3 of the row's first 64, then of its second 64):
+    // a key's value is its index where it is eligible, so the maximum below is the last eligible key
+    float cpre[2] = {0.f, 0.f}, target = 0.f;
+    if (mode == 1) {
+      float s0 = 0.f, s1 = 0.f, t0, t1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s0 += (4 * p + e < N) ? rr_exp_fast(x[e] - m) : 0.f;
+        s1 += (64 + 4 * p + e < N) ? rr_exp_fast(x[4 + e] - m) : 0.f;
+      }
+      cpre[0] = rr_row16_excl_scan(s0, t0);
+      cpre[1] = t0 + rr_row16_excl_scan(s1, t1);
+      target = rr_cdf_target(rr_uniform(seed, (uint32_t)r, step, RR_CDF_SLOT), t0 + t1);
+    }
+    float crun = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int j = 4 * (p + 16 * (e >> 2)) + (e & 3);
       lp[e] = x[e] - m - lse;
       float sv;
       if (mode == 2) sv = j == want ? 1.f : -INFINITY;
-      else if (mode == 1) sv = (j < N && lp[e] > -INFINITY) ? lp[e] + rr_gumbel(seed, (uint32_t)r, step, (uint32_t)j) : -INFINITY;
+      else if (mode == 1) {
+        if ((e & 3) == 0) crun = cpre[e >> 2];
+        const float en = j < N ? rr_exp_fast(x[e] - m) : 0.f;
+        sv = (en > 0.f && crun <= target) ? (float)j : -INFINITY;
+        crun += en;
+      }
       else sv = j < N ? lp[e] : -INFINITY;
       const bool better = sv > bv || (bi == 0x7fffffff && j < N && mode == 0);   // ascending keys in the lane: first maximum kept
       bv = better ? sv : bv; bi = better ? j : bi; blp = better ? lp[e] : blp;

@@ -41,7 +41,9 @@ def test_training_step_gradients_match_oracle_autograd(name):
     r = out["normalized_reward"].cpu().view(S, B)
     adv = (r - r.mean(0, keepdim=True)).reshape(-1)
     assert torch.allclose(out["advantage"].cpu(), adv, atol=1e-5)
-    assert abs(float(out["loss"]) - float(-(adv * out["log_likelihood"].cpu()).mean())) < 1e-4
+    terms = adv.double() * out["log_likelihood"].cpu().double()
+    # (fp32 sum of S*B terms of size |advantage x LL| — LL is -200 at N = 100 on random weights — with heavy cancellation)
+    assert abs(float(out["loss"]) + float(terms.mean())) < 4 * len(terms) ** 0.5 * 6e-8 * float(terms.abs().max()) + 1e-5
     gll = out["grad_log_likelihood"].cpu()
     assert torch.allclose(gll, -adv / (S * B), atol=1e-7)
     # oracle: autograd through the sequential CPU restatement on the sampled tours
