@@ -135,7 +135,7 @@ int rr_tour_cost(const float* D, const int64_t* actions, const float* mn, const 
                  rmtvrp/env.py:433 zeroes the arcs into the depot of open routes */, hipStream_t stream);
 
 /* process_logits + Greedy/Sampling/Evaluate._step + logp gather (rrnco/models/decoding.py:311-361, 272-298, 266).
- * mode 0 greedy, 1 sampling (Gumbel-max on a counter-based generator), 2 evaluate (action_in).
+ * mode 0 greedy, 1 sampling (inverse CDF over the keys in ascending order on one counter-based uniform per (seed, row, step)), 2 evaluate (action_in).
  * top_k > 0 / 0 < top_p < 1: the filters of decoding.py:37-63 applied after masking and temperature (0 = off). */
 int rr_select(const float* logits, const uint8_t* mask, const int64_t* action_in, int64_t* action_out,
               float* logp_out, float* logp_all, int R, int N, float tanh_clip, float temperature, int mode,
