@@ -106,3 +106,38 @@ def rcvrptw_instance(fx):
 
 def matnet_weights(fx):
     return restate.make_weights(restate.matnet_weight_template(fx["embed_dim"], fx["heads"], fx["layers"], 512, fx["env_name"]), fx["seed"])
+
+
+def sampling_law_check(pol, env, inst: dict, sample_idx, S: int, B: int = 2048, seed: int = 11, min_rows: int = 1500):
+    """The fused rollout's sampler on B copies of ONE instance: rollouts that share their first action(s) share the distribution of the
+    next one, so the empirical frequencies must match exp(reported log-probability) (every category within 5 standard errors), and the
+    reported log-probability of a (context, action) pair is one number.  Returns (number of contexts checked, worst deviation in sigmas)."""
+    import torch
+    from rrnco_amd import TensorDict
+    one = {k: v[:1].expand(B, *v.shape[1:]).contiguous().cuda() for k, v in inst.items()}
+    td = TensorDict(one, batch_size=[B])
+    td["sample_idx"] = sample_idx[:1].expand(B, -1, -1).contiguous().cuda()
+    out = pol(env.reset(td), env, phase="val", decode_type="multistart_sampling", num_starts=S, seed=seed, return_actions=True,
+              return_sum_log_likelihood=False)
+    acts, lps = out["actions"].cpu(), out["log_likelihood"].cpu()
+    assert acts.shape[0] == S * B and lps.shape == acts.shape
+    NK = int(acts.max()) + 1
+    worst, seen = 0.0, 0
+    for t in (1, 2):                      # the second action given the start; the third given (start, second)
+        ctx = acts[:, 0] if t == 1 else acts[:, 0] * NK + acts[:, 1]
+        for c in ctx.unique().tolist():
+            rows = ctx == c
+            n = int(rows.sum())
+            if n < min_rows:
+                continue
+            a, lp = acts[rows, t], lps[rows, t]
+            freq = torch.bincount(a, minlength=NK).double() / n
+            p = torch.zeros(NK, dtype=torch.float64)
+            p[a] = lp.double().exp()
+            for k in a.unique().tolist():                                  # one reported probability per (context, action)
+                assert float(lp[a == k].max() - lp[a == k].min()) < 1e-5
+            assert (0.98 if t == 1 else 0.95) < float(p.sum()) < 1.0 + 1e-4   # the actions never drawn carry little mass
+            sigma = (p * (1 - p) / n).sqrt().clamp_min(1e-3 / n ** 0.5)
+            worst = max(worst, float((((freq - p).abs() - 3.0 / n).clamp_min(0) / sigma).max()))      # (3 counts of slack: rare categories are Poisson, not normal)
+            seen += 1
+    return seen, worst

@@ -341,35 +341,9 @@ def test_fused_rollout_sampling_draws_from_the_policy_distribution():
     on 2 048 copies of one instance: the rollouts that share a start node share the distribution of their second action, so the
     empirical frequencies of (start, second action) must match exp(reported log-probability) — and the reported log-probabilities are
     the oracle's (test_sampling_decode_is_valid_reproducible_and_consistent_between_fused_and_stepwise)."""
-    from rrnco_amd import TensorDict
     fx, w, pol, st, env, td_in = _setup("atsp_n20_b4_pomo")
-    N, S, B = fx["N"], fx["S"], 2048
-    one = {k: v[:1].expand(B, *v.shape[1:]).contiguous().cuda() for k, v in st.items()}
-    td = TensorDict(one, batch_size=[B])
-    td["sample_idx"] = fx["sample_idx"][:1].expand(B, -1, -1).contiguous().cuda()
-    out = pol(env.reset(td), env, phase="val", decode_type="multistart_sampling", num_starts=S, seed=11, return_actions=True,
-              return_sum_log_likelihood=False)
-    acts, lps = out["actions"].cpu(), out["log_likelihood"].cpu()
-    assert acts.shape == (S * B, N) and lps.shape == (S * B, N)
-    worst, seen = 0.0, 0
-    for t in (1, 2):                      # the second action given the start; the third given (start, second = the most frequent one)
-        ctx = acts[:, 0] if t == 1 else acts[:, 0] * N + acts[:, 1]
-        for c in ctx.unique().tolist()[:: (1 if t == 1 else 7)]:
-            rows = ctx == c
-            n = int(rows.sum())
-            if n < 1500:
-                continue
-            a, lp = acts[rows, t], lps[rows, t]
-            freq = torch.bincount(a, minlength=N).double() / n
-            p = torch.zeros(N, dtype=torch.float64)
-            p[a] = lp.double().exp()
-            for k in a.unique().tolist():                                  # one reported probability per (context, action)
-                assert float(lp[a == k].max() - lp[a == k].min()) < 1e-5
-            assert float(p.sum()) > (0.98 if t == 1 else 0.95) and float(p.sum()) < 1.0 + 1e-4   # the actions never drawn carry little mass
-            sigma = (p * (1 - p) / n).sqrt().clamp_min(1e-3 / n ** 0.5)
-            worst = max(worst, float(((freq - p).abs() / sigma).max()))
-            seen += 1
-    assert seen >= S and worst < 5.0, (seen, worst)                         # every category within 5 standard errors
+    seen, worst = H.sampling_law_check(pol, env, st, fx["sample_idx"], fx["S"])
+    assert seen >= fx["S"] and worst < 5.0, (seen, worst)                         # every category within 5 standard errors
 
 
 def test_stepwise_sampling_draws_from_the_softmax_distribution():

@@ -87,3 +87,10 @@ def test_rcvrp_policy_greedy_routes_match_reference(name, fused):
     assert torch.allclose(out["log_likelihood"].cpu()[same], fx["log_likelihood"][same], rtol=LL_RTOL, atol=LL_ATOL)
     if frac == 1.0:
         assert acts.shape == fx["actions"].shape               # data-dependent route length trimmed like torch.stack
+
+
+def test_fused_rollout_sampling_draws_from_the_policy_distribution_rcvrp():
+    """The RCVRP instantiation of the fused rollout's inverse-CDF sampler (capacity mask, depot returns): tests/helpers.sampling_law_check."""
+    fx, w, pol, inst, env, td_in = _setup("rcvrp_n20_b4_pomo")
+    seen, worst = H.sampling_law_check(pol, env, inst, fx["sample_idx"], fx["S"])
+    assert seen >= fx["S"] and worst < 5.0, (seen, worst)

@@ -226,3 +226,10 @@ def test_rmtvrp_generator_presets_env_dynamics_match_oracle(preset):
         if bool(otd["done"].all()):
             break
     assert bool(otd["done"].all())
+
+
+def test_fused_rollout_sampling_draws_from_the_policy_distribution_rcvrptw():
+    """... and the RCVRPTW instantiation (time-window mask): tests/helpers.sampling_law_check."""
+    fx, w, pol, inst, env, td_in = _setup("rcvrptw_n20_b4_pomo")
+    seen, worst = H.sampling_law_check(pol, env, inst, fx["sample_idx"], fx["S"])
+    assert seen >= fx["S"] and worst < 5.0, (seen, worst)
