@@ -475,15 +475,16 @@ __device__ __forceinline__ float rr_wave_excl_scan(float v, float& total) {
   const float ex = __shfl_up(inc, 1);
   return lane == 0 ? 0.f : ex;
 }
-// the same over each 16-lane row of a wave
+// the same over each 16-lane row of a wave, on DPP (row_shr:n with bound_ctrl: lanes without a source add 0; row_newbcast:15 = the row's
+// last lane to all of the row): no LDS crossbar round trips as with __shfl_up
+template <int CTRL> __device__ __forceinline__ float rr_dpp0(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float rr_row16_excl_scan(float v, float& total) {
-  const int p = (int)(threadIdx.x & 15);
   float inc = v;
-#pragma unroll
-  for (int d = 1; d < 16; d <<= 1) { const float t = __shfl_up(inc, d, 16); inc += p >= d ? t : 0.f; }
-  total = __shfl(inc, 15, 16);
-  const float ex = __shfl_up(inc, 1, 16);
-  return p == 0 ? 0.f : ex;
+  inc += rr_dpp0<0x111>(inc); inc += rr_dpp0<0x112>(inc); inc += rr_dpp0<0x114>(inc); inc += rr_dpp0<0x118>(inc);
+  total = rr_dpp0<0x15F>(inc);
+  return rr_dpp0<0x111>(inc);
 }
 __device__ __forceinline__ float rr_uniform(uint64_t seed, uint32_t r, uint32_t step, uint32_t key) {
   return rr_uniform_k(rr_noise_key(seed, r), step, key);

@@ -661,11 +661,12 @@ __global__ __launch_bounds__(256) void k_select16(const float* __restrict__ logi
       }
       m = rr_row16_max(m);
     }
-    float ssum = 0.f;
+    float ssum = 0.f, en[8];                            // the softmax numerators (sampling reads them again for its CDF)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int j = 4 * (p + 16 * (e >> 2)) + (e & 3);
-      ssum += j < N ? rr_exp_fast(x[e] - m) : 0.f;       // arguments in [-2 clip / T, 0]; same form as the fused rollout
+      en[e] = j < N ? rr_exp_fast(x[e] - m) : 0.f;       // arguments in [-2 clip / T, 0]; same form as the fused rollout
+      ssum += en[e];
     }
     const float lse = rr_log(rr_row16_sum(ssum));
     if (MODE == 0 && logp_all == nullptr) {          // greedy: argmax by equality with the row maximum, first index on ties
@@ -687,12 +688,8 @@ __global__ __launch_bounds__(256) void k_select16(const float* __restrict__ logi
     // a key's value is its index where it is eligible, so the maximum below is the last eligible key
     float cpre[2] = {0.f, 0.f}, target = 0.f;
     if (mode == 1) {
-      float s0 = 0.f, s1 = 0.f, t0, t1;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        s0 += (4 * p + e < N) ? rr_exp_fast(x[e] - m) : 0.f;
-        s1 += (64 + 4 * p + e < N) ? rr_exp_fast(x[4 + e] - m) : 0.f;
-      }
+      const float s0 = ((en[0] + en[1]) + en[2]) + en[3], s1 = ((en[4] + en[5]) + en[6]) + en[7];
+      float t0, t1;
       cpre[0] = rr_row16_excl_scan(s0, t0);
       cpre[1] = t0 + rr_row16_excl_scan(s1, t1);
       target = rr_cdf_target(rr_uniform(seed, (uint32_t)r, step, RR_CDF_SLOT), t0 + t1);
@@ -706,9 +703,8 @@ __global__ __launch_bounds__(256) void k_select16(const float* __restrict__ logi
       if (mode == 2) sv = j == want ? 1.f : -INFINITY;
       else if (mode == 1) {
         if ((e & 3) == 0) crun = cpre[e >> 2];
-        const float en = j < N ? rr_exp_fast(x[e] - m) : 0.f;
-        sv = (en > 0.f && crun <= target) ? (float)j : -INFINITY;
-        crun += en;
+        sv = (en[e] > 0.f && crun <= target) ? (float)j : -INFINITY;
+        crun += en[e];
       }
       else sv = j < N ? lp[e] : -INFINITY;
       const bool better = sv > bv || (bi == 0x7fffffff && j < N && mode == 0);   // ascending keys in the lane: first maximum kept
