@@ -353,3 +353,26 @@ def test_batch_norm_train_mode_step_runs_and_matches_the_torch_replay():
     pol.zero_grad(set_to_none=True)
     out = model.training_step(batch, optimizer=None, seed=8, replay="hip")
     assert torch.allclose(out["replay_log_likelihood"], out["log_likelihood"], atol=2e-3)
+
+
+@pytest.mark.parametrize("problem", ["atsp", "rcvrp"])
+def test_training_step_launches_no_blas_kernel(problem):
+    """The REINFORCE step (forward repack included) runs on the library's kernels and torch elementwise / reduction glue only: no
+    hipBLASLt / rocBLAS kernel (`Cijk_*`, `rocblas_*`, gemv) among the device events of a step — the init embeddings and the fold chain
+    are differentiated by models/init_backward.py and rr_small_gemm.  RCVRPTW keeps its duration-NAB fold chain
+    on torch autograd and is not covered."""
+    from torch.profiler import profile, ProfilerActivity
+    if problem == "atsp":
+        w, pol, model, st, td_in = _model(H.load_fixture("atsp_n20_b4_pomo"))
+    else:
+        from tests.test_gpu_trainkernels import _vrp_model
+        pol, model, td_in = _vrp_model(problem)
+    opt = torch.optim.Adam(pol.parameters(), lr=1e-4, fused=True)
+    model.training_step(td_in, optimizer=opt, seed=1)                    # (first call: allocations, lazy initialisation)
+    with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+        model.training_step(td_in, optimizer=opt, seed=2)
+        torch.cuda.synchronize()
+    names = {e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA}
+    assert any(n.startswith("k_") or n.startswith("void k_") for n in names)
+    blas = sorted(n for n in names if n.startswith("Cijk_") or "rocblas" in n.lower() or "gemv" in n.lower() or "hipblas" in n.lower())
+    assert not blas, blas[:5]
