@@ -166,6 +166,25 @@ class _NabDurationFolded(torch.autograd.Function):
         return None, da, db, dMcat, dcg, dco, dko, dWg2, dbg2, dinv_tau, dbo, dalpha
 
 
+class _SmallMM(torch.autograd.Function):
+    """A @ B for the folds' small matrices on csrc/rr_train_enc.hip:k_small_gemm (packing.small_gemm), differentiable: no BLAS library in
+    the training step (CPU tensors — the unit tests of the gradient math — take torch.matmul inside small_gemm)."""
+
+    @staticmethod
+    def forward(ctx, A, B):
+        from ..packing import small_gemm
+        A, B = A.contiguous(), B.contiguous()
+        ctx.save_for_backward(A, B)
+        return small_gemm(A, B)
+
+    @staticmethod
+    def backward(ctx, g):
+        from ..packing import small_gemm
+        A, B = ctx.saved_tensors
+        g = g.contiguous()
+        return small_gemm(g, B, transB=True), small_gemm(A, g, transA=True)
+
+
 def _nab_duration_params(P, p, alpha):
     """The folded parameters of DistAngleFusion(use_duration_matrix=True) as torch expressions of the module's (packing.py's fold:
     M_f = Wg0_f W2_f, cg = sum_f Wg0_f b2_f + bg0, co_f = W2_f^T wo, ko_f = wo . b2_f): (a [384], b [384], Mcat [128,384],
@@ -178,8 +197,8 @@ def _nab_duration_params(P, p, alpha):
         W2, b2 = P[f"{p}.{nm}.2.weight"], P[f"{p}.{nm}.2.bias"]
         Wg0f = Wg0[:, f * E:(f + 1) * E]
         a_.append(P[f"{p}.{nm}.0.weight"][:, 0]); b_.append(P[f"{p}.{nm}.0.bias"])
-        Ms.append(Wg0f @ W2); cg = cg + Wg0f @ b2
-        cos.append(W2.t() @ wo); kos.append(wo @ b2)
+        Ms.append(_SmallMM.apply(Wg0f, W2)); cg = cg + (Wg0f * b2[None, :]).sum(1)          # Wg0_f W2, Wg0_f b2 (elementwise: no BLAS)
+        cos.append((W2 * wo[:, None]).sum(0)); kos.append((wo * b2).sum())                    # W2^T wo, wo . b2
     return (torch.cat(a_), torch.cat(b_), torch.cat(Ms, dim=1), cg, torch.cat(cos), torch.stack(kos),
             P[p + ".gate.2.weight"], P[p + ".gate.2.bias"], torch.exp(-P[p + ".gate_temperature"]), bo, alpha.reshape(()))
 

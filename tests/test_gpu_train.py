@@ -355,12 +355,12 @@ def test_batch_norm_train_mode_step_runs_and_matches_the_torch_replay():
     assert torch.allclose(out["replay_log_likelihood"], out["log_likelihood"], atol=2e-3)
 
 
-@pytest.mark.parametrize("problem", ["atsp", "rcvrp"])
+@pytest.mark.parametrize("problem", ["atsp", "rcvrp", "rcvrptw"])
 def test_training_step_launches_no_blas_kernel(problem):
     """The REINFORCE step (forward repack included) runs on the library's kernels and torch elementwise / reduction glue only: no
     hipBLASLt / rocBLAS kernel (`Cijk_*`, `rocblas_*`, gemv) among the device events of a step — the init embeddings and the fold chain
-    are differentiated by models/init_backward.py and rr_small_gemm.  RCVRPTW keeps its duration-NAB fold chain
-    on torch autograd and is not covered."""
+    are differentiated by models/init_backward.py and rr_small_gemm; the duration NAB's fold chain (RCVRPTW) stays
+    on torch autograd with its matrix products on rr_small_gemm (grad_replay._SmallMM)."""
     from torch.profiler import profile, ProfilerActivity
     if problem == "atsp":
         w, pol, model, st, td_in = _model(H.load_fixture("atsp_n20_b4_pomo"))
