@@ -906,6 +906,7 @@ __global__ __launch_bounds__(512, 1) void k_dec_logit_bwd_s(DecLogitIO io, int t
   const float inv_sqe = 1.0f / ((float)(1 << RR_KS) * sqrtf((float)RR_E)), inv_temp = 1.0f / io.temperature;     // (the L image carries 2^RR_KS)
   const float inv_sqg = 1.0f / sqrtf((float)RR_E);
   const bool clip = io.tanh_clip > 0.f;
+  const float cs_clip = io.tanh_clip * inv_temp;
   float da_acc = 0.f, db_acc = 0.f;
   uint32_t nmw = 0;                         // nibble kt: which of this lane's four keys of key tile kt exist (key < N)
 #pragma unroll
@@ -995,11 +996,13 @@ __global__ __launch_bounds__(512, 1) void k_dec_logit_bwd_s(DecLogitIO io, int t
       const uint32_t bits = (mw[kt >> 1] >> (16 * (kt & 1))) & (nmw >> (4 * kt));      // this lane's four keys of the tile
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
+        // (the rollout's own forms, rr_rollout_w.inc: one v_exp_f32 on the base-2 argument, v_rcp_f32 — the replayed log-likelihood then
+        //  repeats the rollout's; the corrected exponential and the IEEE divisions this used to spend were ~900 of the tile's vector instructions)
         const float x = la[kt][r] * inv_sqe - (io.alpha * dd[kt][r] + io.beta * tt[kt][r]);
-        const float u = rr_exp(x) + 1e-6f;
+        const float u = rr_exp_fast(x) + 1e-6f;
         uu[kt][r] = u;
         float v;
-        if (clip) v = (1.0f - 2.0f / fmaf(u, u, 1.0f)) * io.tanh_clip * inv_temp;      // tanh(log u) = (u^2-1)/(u^2+1)
+        if (clip) v = fmaf(__builtin_amdgcn_rcpf(fmaf(u, u, 1.0f)), -2.0f * cs_clip, cs_clip);      // tanh(log u) = (u^2-1)/(u^2+1)
         else v = rr_log(u) * inv_temp;
         v = (bits & (1u << r)) ? v : -INFINITY;
         vv[kt][r] = v;
@@ -1012,7 +1015,7 @@ __global__ __launch_bounds__(512, 1) void k_dec_logit_bwd_s(DecLogitIO io, int t
 #pragma unroll
     for (int kt = 0; kt < TD_NT; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sum += rr_exp(vv[kt][r] - mx);
+      for (int r = 0; r < 4; ++r) sum += rr_exp_fast(vv[kt][r] - mx);
     sum = rr_sum_g(sum);
     const float lse = rr_log(sum);
     float lpt = 0.f, da = 0.f, db = 0.f;
@@ -1027,13 +1030,13 @@ __global__ __launch_bounds__(512, 1) void k_dec_logit_bwd_s(DecLogitIO io, int t
         const bool ok = v > -INFINITY;
         const float lp = v - mx - lse;
         if (key == target) lpt += ok ? lp : 0.f;
-        const float p = ok ? rr_exp(lp) : 0.f;
+        const float p = ok ? rr_exp_fast(lp) : 0.f;
         float dv = gl * ((key == target ? 1.0f : 0.f) - p);          // d loss / d v (log-softmax picked at the target)
         dv = (ok && live) ? dv : 0.f;
         const float u = uu[kt][r];
         float dx;                                                    // through v(u), u = exp(x) + 1e-6
-        if (clip) { const float w = fmaf(u, u, 1.0f); dx = dv * io.tanh_clip * inv_temp * (4.0f * u / (w * w)) * (u - 1e-6f); }
-        else dx = dv * inv_temp * (u - 1e-6f) / u;
+        if (clip) { const float rw = __builtin_amdgcn_rcpf(fmaf(u, u, 1.0f)); dx = dv * cs_clip * (4.0f * u * rw * rw) * (u - 1e-6f); }
+        else dx = dv * inv_temp * (u - 1e-6f) * __builtin_amdgcn_rcpf(u);
         dl4[r] = dx * inv_sqg;
         da -= dx * dd[kt][r];
         db -= dx * tt[kt][r];
