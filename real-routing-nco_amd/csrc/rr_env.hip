@@ -680,6 +680,31 @@ __global__ __launch_bounds__(256) void k_select16(const float* __restrict__ logi
       if (p == 0 && r < R) { action_out[r] = bi; logp_out[r] = -lse; }      // x[best] - m - lse with x[best] == m
       continue;
     }
+    if (MODE == 1 && logp_all == nullptr) {
+      // sampling without the full log-probability row: inverse CDF over the keys in ascending order (rr_common.h; keys 4p .. 4p+3 of the
+      // row's first 64, then of its second 64).  The draw is the LAST key with mass whose exclusive prefix is <= target: ascending keys
+      // in the lane (a later eligible key overwrites), then the largest candidate of the row; only the winner's logit is carried along.
+      const float s0 = ((en[0] + en[1]) + en[2]) + en[3], s1 = ((en[4] + en[5]) + en[6]) + en[7];
+      float t0, t1;
+      const float c0 = rr_row16_excl_scan(s0, t0), c1 = t0 + rr_row16_excl_scan(s1, t1);
+      const float target = rr_cdf_target(rr_uniform(seed, (uint32_t)r, step, RR_CDF_SLOT), t0 + t1);
+      int cand = -1;
+      float xs = 0.f, crun = c0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (e == 4) crun = c1;
+        const bool el = en[e] > 0.f && crun <= target;
+        cand = el ? 4 * (p + 16 * (e >> 2)) + (e & 3) : cand;
+        xs = el ? x[e] : xs;
+        crun += en[e];
+      }
+#define RR_CAND_STEP(CTRL) { const int oc = rr_dppi<CTRL>(cand); const float ox = __int_as_float(rr_dppi<CTRL>(__float_as_int(xs))); \
+                             const bool take = oc > cand; cand = take ? oc : cand; xs = take ? ox : xs; }
+      RR_CAND_STEP(0xB1) RR_CAND_STEP(0x4E) RR_CAND_STEP(0x141) RR_CAND_STEP(0x140)
+#undef RR_CAND_STEP
+      if (p == 0 && r < R) { action_out[r] = cand < 0 ? 0x7fffffff : cand; logp_out[r] = xs - m - lse; }
+      continue;
+    }
     const int want = (mode == 2 && r < R) ? (int)action_in[r] : -1;
     float bv = -INFINITY, blp = 0.f;
     int bi = 0x7fffffff;
