@@ -541,18 +541,27 @@ __global__ __launch_bounds__(512, 2) void k_nabdur_bwd_mcat2(NabDurBwdW w, const
     rr_dma1(fdst0 + (unsigned)buf * 16384u + 1024u, gb, fvo0 + 1024u);
   };
   int buf = 0;
-  if ((long long)blockIdx.x < ntile) issue(blockIdx.x, 0);
-  for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tile + gridDim.x < ntile) issue(tile + gridDim.x, buf ^ 1);
-    float xs[3][8];
+  // the three scalars of a tile's edges, requested one tile ahead like the dZ fragments (they used to be loaded behind the barrier: a
+  // round trip to L2 exposed in front of every tile's 72 matrix instructions)
+  float xn[3][8];
+  auto load_x = [&](long long tile) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const long long e = tile * 32 + 8 * g + q;
       const bool ok = e < M;
-      xs[0][q] = ok ? xd[e] : 0.f; xs[1][q] = ok ? xa[e] : 0.f; xs[2][q] = ok ? xt[e] : 0.f;
+      xn[0][q] = ok ? xd[e] : 0.f; xn[1][q] = ok ? xa[e] : 0.f; xn[2][q] = ok ? xt[e] : 0.f;
     }
+  };
+  if ((long long)blockIdx.x < ntile) { issue(blockIdx.x, 0); load_x(blockIdx.x); }
+  for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float xs[3][8];
+#pragma unroll
+    for (int f = 0; f < 3; ++f)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) xs[f][q] = xn[f][q];
+    if (tile + gridDim.x < ntile) { issue(tile + gridDim.x, buf ^ 1); load_x(tile + gridDim.x); }
     ndfrag Bh[8], Bl[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
