@@ -39,7 +39,9 @@ if os.environ.get("PROFILE_HOST"):
         print(f"  x{e.count:<6d} {e.self_cpu_time_total / 1e3:8.2f} ms self-cpu  {e.key[:80]}")
 ev = sorted([e for e in prof.key_averages() if e.self_device_time_total > 0], key=lambda e: -e.self_device_time_total)
 tot = sum(e.self_device_time_total for e in ev)
-print(f"GPU time of one training step: {tot / 1e3:.2f} ms over {sum(e.count for e in ev)} launches")
+nk = sum(1 for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA)
+print(f"GPU time of one training step: {tot / 1e3:.2f} ms; {nk} device kernels / copies launched ({sum(e.count for e in ev)} rows below count "
+      "operator ranges too)")
 acc = 0.0
 for e in ev[:40]:
     acc += e.self_device_time_total
