@@ -233,6 +233,7 @@ def test_ctypes_struct_sizes_match_header_layout():
     assert C.sizeof(_lib.DecLogitIO) == 11 * 8 + 4 * 4 + 8 + 4 * 4 + 8 and C.sizeof(_lib.DecAttnIO) == 15 * 8 + 5 * 4 + 4 + 8
     assert C.sizeof(_lib.MlpRowsW) == 40 and C.sizeof(_lib.MlpWgradW) == 24
     assert C.sizeof(_lib.EncSave) == 12 * 8 and C.sizeof(_lib.AftBwdIO) == 11 * 8 + 8
+    assert C.sizeof(_lib.GateBwdIO) == 11 * 8 + 8 + 4 + 4 + 8          # 11 pointers, long long M, int acc_node (+ padding), mix
 
 
 # ---------------------------------------------------------------- multi-process (gloo, world_size 2)
