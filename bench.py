@@ -319,19 +319,34 @@ def other_configs(dev):
         return RRNetPolicy(env_name=env_name, embed_dim=128, num_heads=8, num_encoder_layers=6, normalization="instance",
                            use_graph_context=False, nab_type="gating", init_embedding_kwargs=dict(sample_size=25)).to(dev).eval()
 
-    def inference(label, env, pol, B, S, aug, decode, kernel):
+    def two_streams(env, pol, make_pol, step_of, B, seconds=1.5):
+        """The same batches through TWO streams (rrnco_amd.parallel.run_on_streams: one host thread and one policy object per stream, same
+        weights) -> (seconds per batch over both streams, batches): whole-job throughput, every batch still one complete pass."""
+        from rrnco_amd.parallel import run_on_streams
+        pols = [pol, make_pol()]
+        pols[1].load_state_dict(pol.state_dict())
+        steps = [step_of(p) for p in pols]
+        run_on_streams(steps, 2)                               # each stream's allocations and packs
+        est = run_on_streams(steps, 2) / 4
+        n = max(3, int(seconds / est / 2))
+        return run_on_streams(steps, n) / (2 * n), 2 * n
+
+    def inference(label, env, pol, B, S, aug, decode, kernel, make_pol=None):
         inst = env.generator(B, generator=torch.Generator(device=dev).manual_seed(5))
         sidx = ATSPInitEmbedding.sample_indices(env.reset(inst)["distance_matrix"], 25)
         if aug:
             sidx = sidx.repeat(8, 1, 1).contiguous()
         res = {}
 
-        def step():
-            td = TensorDict(dict(inst.items()), batch_size=[B])
-            if aug:
-                td = StateAugmentation(augment_fn="dihedral8", no_aug_coords=False)(td)
-            td["sample_idx"] = sidx
-            res["out"] = pol(env.reset(td), env, phase="val", decode_type=decode, num_starts=S, seed=1)
+        def step_of(p):
+            def step():
+                td = TensorDict(dict(inst.items()), batch_size=[B])
+                if aug:
+                    td = StateAugmentation(augment_fn="dihedral8", no_aug_coords=False)(td)
+                td["sample_idx"] = sidx
+                res["out"] = p(env.reset(td), env, phase="val", decode_type=decode, num_starts=S, seed=1)
+            return step
+        step = step_of(pol)
         step()
         R.TIMING = []
         sec, n = timed_loop(step)
@@ -356,6 +371,13 @@ def other_configs(dev):
                                    "note": "404 480 flop per LIVE rollout-step (each rollout up to the step that closes its last route); `executed` "
                                            "counts every rollout until the instance's longest route ends; fp32-equivalent peak of the fp16 pipe "
                                            "with 3 partial products"}}
+        if make_pol is not None:
+            sec2, n2 = two_streams(env, pol, make_pol, step_of, B)
+            out[label]["two_streams"] = {"value": B / sec2, "unit": "instances/s", "ms_per_batch": sec2 * 1e3, "batches": n2,
+                                         "note": "the same batches through two HIP streams, one host thread and one policy object each (same "
+                                                 "weights): one stream's encoder / NAB kernels fill the CUs that the other's draining rollout "
+                                                 "(workgroup = instance, length = its longest route) leaves idle, and cover its host-side step-count "
+                                                 "read; `value` above stays the single-stream figure of the earlier rounds"}
         return step
 
     env = RCVRPEnv(generator_params=dict(num_loc=N_NODES, device=dev), check_solution=False, device=dev)
@@ -363,7 +385,8 @@ def other_configs(dev):
               "k_rollout_w<7, 1, 0, true, true, false>")
     env = RMTVRPEnv(generator_params=dict(num_loc=N_NODES, device=dev), device=dev)
     c4 = "C4 RCVRPTW n=100 B=256 x8 aug S=100 sampling (configs[3])"
-    c4_step = inference(c4, env, vrp_policy("rcvrptw"), 256, 100, True, "multistart_sampling", "k_rollout_w<7, 2, 1, true, true, false>")
+    c4_step = inference(c4, env, vrp_policy("rcvrptw"), 256, 100, True, "multistart_sampling", "k_rollout_w<7, 2, 1, true, true, false>",
+                        make_pol=lambda: vrp_policy("rcvrptw"))
     # the step's second kernel: the Neural Adaptive Bias with the duration matrix (k_nab_dur_lds, 6 launches per step), VALU-bound on the
     # SiLU of its gate: per edge and gate unit one v_exp_f32 and one v_rcp_f32 — quarter-rate instructions (16 lanes per SIMD and 4 cycles)
     with kernel_timers("rr_nab_dur") as kt:

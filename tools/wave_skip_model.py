@@ -35,3 +35,21 @@ for name, Env, env_name, B, S, aug, dec in (("C4", RMTVRPEnv, "rcvrptw", 64, 100
     t_now = 2.0 * wg.float()
     print(name, "T", T, "mean wg steps", float(wg.float().mean()), "live/executed rollout-steps", float(length.float().sum() / (wg.float().sum() * S)),
           "model time with wave skip / now:", float(t_skip.sum() / t_now.sum()))
+    # ---- list scheduling of the workgroups on 256 CUs (one resident workgroup each): dispatch order as launched, longest first (oracle),
+    # and by a proxy known before the launch (total demand: more routes = more depot returns = more steps)
+    import heapq
+
+    def makespan(durs):
+        h = [0.0] * 256
+        heapq.heapify(h)
+        for d in durs:
+            heapq.heappush(h, heapq.heappop(h) + d)
+        return max(h)
+    full = {"C4": 2048, "C3": 512}[name]
+    d = wg.float().cpu()
+    d = d.repeat((full + len(d) - 1) // len(d))[:full]
+    dem = td["demand_linehaul"].sum(-1) if env_name == "rcvrptw" else td["demand"].sum(-1)
+    dem = dem.float().cpu().repeat((full + len(dem) - 1) // len(dem))[:full]
+    ideal = float(d.sum()) / 256
+    print(f"   {full} workgroups: makespan / (sum / 256): as launched {makespan(d.tolist()) / ideal:.3f}, longest first {makespan(d.sort(descending=True).values.tolist()) / ideal:.3f}, "
+          f"by total demand {makespan(d[dem.argsort(descending=True)].tolist()) / ideal:.3f}; corr(demand, steps) {float(torch.corrcoef(torch.stack([dem, d]))[0, 1]):.2f}")
