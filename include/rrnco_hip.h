@@ -153,6 +153,18 @@ int rr_enc_layer(const EncBlockW* wrow, const EncBlockW* wcol, const float* row_
                  by the caller); 2 "layer" (one mean / unbiased variance per instance, no affine); 3 RMSNorm (n*g = weight) */,
                  float* dbg, hipStream_t stream);
 
+/* The same layer (inference, InstanceNorm1d, two-piece weight images, 64 < N <= 103) re-cut for occupancy into three
+ * launches (csrc/rr_enc_split.inc): K / V of both blocks as one row-parallel GEMM over all rows (attn_freenet.py:314-315, 422),
+ * the AFT mixing per (instance, block) with two workgroups per CU (:318-323), and the rest of the block on a loader-fed FFN
+ * kernel (:313, 324-325, 421, 435-441, 355-356).  Results are bit-identical to rr_enc_layer's.
+ * stats_in [2][Bp][2][128]: per (tensor 0 row | 1 col, instance): mean[128], rsqrt(var + 1e-5)[128] of the layer's INPUT over the
+ * node axis (what Normalization("instance"), :84, 104-105, derives first): rr_enc_stats for the init embedding, stats_out of the
+ * previous layer afterwards (NULL: not written).  work: 6 * Bp * N * 128 floats of scratch (K, V, mixing ratio of both blocks). */
+int rr_enc_stats(const float* row, const float* col, float* stats, int Bp, int N, hipStream_t stream);
+int rr_enc_layer_split(const EncBlockW* wrow, const EncBlockW* wcol, const float* row_in, const float* col_in,
+                       float* row_out, float* col_out, const float* D, const float* theta, const float* bias_pre,
+                       const float* stats_in, float* stats_out, float* work, int Bp, int N, hipStream_t stream);
+
 /* theta[b][i][j] = atan2(y_i - y_j, x_i - x_j): the angle input of the Neural Adaptive Bias
  * (rrnco/models/nn/attn_freenet.py:262-264), computed once per instance and shared by every encoder block. */
 int rr_edge_angles(const float* locs, float* theta, int Bp, int N, hipStream_t stream);

@@ -5,6 +5,10 @@
 // convention of rr_common.h.  Reference: rrnco/models/nn/attn_freenet.py (cited per stage below).
 #include "rr_common.h"
 #include "rr_gemm_f16.h"
+// No implicit a * b + c contraction in this translation unit: which products hipcc fuses depends on the code around them, and the
+// same statistics / NAB / epilogue expressions are inlined into kernels of different shapes (rr_enc_w.inc, rr_enc_split.inc) that
+// must agree bit for bit.  Every fused multiply-add below is written as fmaf.
+#pragma clang fp contract(off)
 
 #define ENC_THREADS 512
 #define ENC_WAVES 8
@@ -13,6 +17,23 @@
 #define BUF_FLOATS (RR_MAXN * LD)
 
 #ifdef RR_STAMP
+__device__ unsigned long long rr_split_stamps[32];      // k_enc_mix: slots 0..7 (+ count in 15), k_enc_tail: 16..30 (+ count in 31)
+#define RR_ES(i)                                                                             \
+  do {                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    unsigned long long _n = __builtin_amdgcn_s_memtime();                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                       \
+    _sacc[i] += _n - _st0; _st0 = _n;                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+  } while (0)
+#define RR_ES_BEGIN(NS) unsigned long long _sacc[NS] = {0}; unsigned long long _st0 = __builtin_amdgcn_s_memtime()
+#define RR_ES_END(BASE, NSLOT)                                                               \
+  do {                                                                                       \
+    if (lane == 0 && (blockIdx.x & 63) == 0) {   /* a sample: 5.8 M same-address atomics would be the longest thing in the launch */ \
+      for (int i_ = 0; i_ < NSLOT; ++i_) atomicAdd(&rr_split_stamps[BASE + i_], _sacc[i_]);  \
+      atomicAdd(&rr_split_stamps[BASE + 15], 1ull);                                          \
+    }                                                                                        \
+  } while (0)
 __device__ unsigned long long rr_enc_stamps[8];
 #define RR_ET(i)                                                                             \
   do {                                                                                       \
@@ -24,6 +45,9 @@ __device__ unsigned long long rr_enc_stamps[8];
   } while (0)
 #else
 #define RR_ET(i)
+#define RR_ES(i)
+#define RR_ES_BEGIN(NS)
+#define RR_ES_END(BASE, NSLOT)
 #endif
 
 struct EncBlockW {
@@ -89,7 +113,8 @@ __device__ __forceinline__ float nab_edge_pwl(const float* tab, float d, float t
 
 // Grid-accelerated variant for four edges at once (k_enc_block_w).  After the tables above the host appends, per
 // family, NAB_G bytes: for cell c of a uniform grid over the input's range ([0,1] for the min-max-normalised distance,
-// [-pi,pi] for the angle) a conservative lower bound of "number of breakpoints <= x" for every x that lands in c.  The
+// [-pi,pi] for the angle) a conservative lower bound (bits 0-6) of "number of breakpoints <= x" for every x that lands in c, and
+// bit 7 = a breakpoint may lie among the inputs of c, i.e. the scan is needed at all (packing.nab_grid_cells).  The
 // search is then a forward scan from that bound — usually one or two steps instead of the eight of the bisection — and
 // ends at exactly the same segment, so the result is bit-identical to nab_edge_pwl for any x (inputs below the range scan
 // from the first breakpoint, inputs above it from the last cell's bound: correct, just longer).
@@ -98,26 +123,33 @@ __device__ __forceinline__ float nab_edge_pwl(const float* tab, float d, float t
 #define NAB_TS_LD 132
 __device__ __forceinline__ void nab_edge4_grid(const float* tab, const float* ts, const float (&d)[4], const float (&th)[4], float (&out)[4]) {
   const unsigned char* cell = reinterpret_cast<const unsigned char*>(tab + NAB_TAB_FLOATS);
-  float x[8]; int m[8];
+  float x[8]; int m[8], need[8], more = 0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     x[q] = fminf(d[q], 3.0e38f); x[4 + q] = fminf(th[q], 3.0e38f);   // the +inf sentinel must stop the scan
     int cd = (int)(d[q] * (float)NAB_G);
     int ca = (int)((th[q] + 3.14159265358979f) * ((float)NAB_G / 6.28318530717959f));
     const int sd = cell[min(max(cd, 0), NAB_G - 1)], sa = cell[NAB_G + min(max(ca, 0), NAB_G - 1)];
-    m[q] = cd < 0 ? 0 : sd; m[4 + q] = ca < 0 ? 0 : sa;       // below the range: scan from the first breakpoint
+    m[q] = cd < 0 ? 0 : (sd & 127); m[4 + q] = ca < 0 ? 0 : (sa & 127);       // below the range: scan from the first breakpoint
+#ifdef NAB_SCAN_ALWAYS          // diagnostic: every search reads a breakpoint (the form before the cells carried bit 7)
+    need[q] = 1; need[4 + q] = 1;
+#else
+    need[q] = (cd < 0 || (sd & 128)) ? 1 : 0; need[4 + q] = (ca < 0 || (sa & 128)) ? 1 : 0;   // bit 7: a breakpoint may lie inside the cell
+#endif
+    more |= need[q] | need[4 + q];
   }
-  // forward scan on the sentinel-terminated copies ts[f][0..128] (ts[f][128] = +inf): branch-free, 8 searches in flight
-  int more;
-  do {
+  // forward scan on the sentinel-terminated copies ts[f][0..128] (ts[f][128] = +inf): branch-free, 8 searches in flight.  A search
+  // that is settled (its cell holds no breakpoint, or its last comparison failed) reads the sentinel: all such lanes share one
+  // address, which the LDS serves as a broadcast — the gathers of this function are bound by bank conflicts among random addresses.
+  while (__any(more)) {
     more = 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float tv = ts[(e >= 4 ? NAB_TS_LD : 0) + m[e]];
+      const float tv = ts[(e >= 4 ? NAB_TS_LD : 0) + (need[e] ? m[e] : 128)];
       const int adv = tv <= x[e] ? 1 : 0;
-      m[e] += adv; more |= adv;
+      m[e] += adv; need[e] = adv; more |= adv;
     }
-  } while (__any(more));
+  }
   const float* s = tab + 256 + 1032;                  // bg, bo, alpha
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -132,7 +164,7 @@ __device__ __forceinline__ void nab_edge4_grid(const float* tab, const float* ts
       fo[f] = fmaf(sg.x, dx, sg.y); fg[f] = fmaf(sg.z, dx, sg.w);
     }
     const float gt = rr_sigmoid(fg[0] + fg[1] + s[0]);
-    out[q] = (gt * fo[0] + (1.0f - gt) * fo[1] + s[1]) * s[2];
+    out[q] = (fmaf(gt, fo[0], (1.0f - gt) * fo[1]) + s[1]) * s[2];      // (the contraction written out: every kernel that inlines this gets the same bits)
   }
 }
 
@@ -156,6 +188,34 @@ extern "C" int rr_edge_angles(const float* locs, float* theta, int Bp, int N, hi
 // which reads the stage tensors of the training forward instead.)
 
 #include "rr_enc_w.inc"
+#include "rr_enc_split.inc"
+
+extern "C" int rr_enc_stats(const float* row, const float* col, float* stats, int Bp, int N, hipStream_t st) {
+  if (Bp <= 0 || N <= 64 || N > RR_MAXN || row == nullptr || col == nullptr || stats == nullptr) return RR_EINVAL;
+  hipLaunchKernelGGL((k_enc_stats<7>), dim3(Bp, 2), dim3(64 * 7), 0, st, row, col, stats, Bp, N);
+  return rr_check(hipGetLastError());
+}
+
+// One Attn_Free_Layer at the headline shape as k_enc_kv -> k_enc_mix -> k_enc_tail (rr_enc_split.inc).  work: 6 Bp N 128 floats
+// (K, V, ratio of both blocks); stats_in / stats_out: [2][Bp][2][128] (rr_enc_stats layout; stats_out may be NULL for the last layer).
+extern "C" int rr_enc_layer_split(const EncBlockW* wrow, const EncBlockW* wcol, const float* row_in, const float* col_in,
+                                  float* row_out, float* col_out, const float* D, const float* theta, const float* bias_pre,
+                                  const float* stats_in, float* stats_out, float* work, int Bp, int N, hipStream_t st) {
+  if (Bp <= 0 || N <= 64 || N > RR_MAXN || wrow == nullptr || wcol == nullptr || work == nullptr || stats_in == nullptr) return RR_EINVAL;
+  if (theta == nullptr && bias_pre == nullptr) return RR_EINVAL;
+  if (!(wrow->w1s && wrow->w2s && wcol->w1s && wcol->w2s && wrow->wqs && wrow->wks && wrow->wvs && wrow->wps && wcol->wqs &&
+        wcol->wks && wcol->wvs && wcol->wps))
+    return RR_EINVAL;                                        // two-piece weight images required (packing.mlp_split_enabled)
+  if (bias_pre == nullptr && (wrow->nab == nullptr || wcol->nab == nullptr)) return RR_EINVAL;
+  EncBlockW2 ws; ws.blk[0] = *wrow; ws.blk[1] = *wcol;
+  const size_t R = (size_t)Bp * N * RR_E;
+  float *Kb = work, *Vb = work + 2 * R, *Rt = work + 4 * R;
+  static const int kv_grid = [] { const char* e = getenv("RR_ENC_KV_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
+  hipLaunchKernelGGL(k_enc_kv, dim3(kv_grid, 2), dim3(64 * EKV_WAVES), 0, st, ws, row_in, col_in, stats_in, Kb, Vb, Bp, N);
+  hipLaunchKernelGGL((k_enc_mix<7>), dim3(Bp, 2), dim3(64 * 7), 0, st, ws, Kb, Vb, Rt, D, theta, bias_pre, Bp, N);
+  hipLaunchKernelGGL((k_enc_tail<7>), dim3(Bp, 2), dim3(64 * 8), 0, st, ws, row_in, col_in, Rt, stats_in, row_out, col_out, stats_out, Bp, N);
+  return rr_check(hipGetLastError());
+}
 
 static int rr_enc_layer_impl(const EncBlockW* wrow, const EncBlockW* wcol, const float* row_in, const float* col_in,
                              float* row_out, float* col_out, const float* D, const float* locs, const float* theta,
@@ -1015,6 +1075,11 @@ extern "C" int rr_dec_cache(const CacheW* w, const float* row_emb, const float* 
 }
 
 #ifdef RR_STAMP
+extern "C" int rr_debug_split_stamps(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rr_split_stamps), sizeof(unsigned long long) * 32) != hipSuccess) return RR_ELAUNCH;
+  if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rr_split_stamps), z, sizeof(z)) != hipSuccess) return RR_ELAUNCH; }
+  return RR_OK;
+}
 extern "C" int rr_debug_enc_stamps(unsigned long long* out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rr_enc_stamps), sizeof(unsigned long long) * 8) != hipSuccess) return RR_ELAUNCH;
   if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rr_enc_stamps), z, sizeof(z)) != hipSuccess) return RR_ELAUNCH; }

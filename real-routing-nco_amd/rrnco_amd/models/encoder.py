@@ -243,6 +243,16 @@ class RRNetEncoder(nn.Module):
         else:   # the angle matrix only depends on the coordinates: once per instance, shared by all twelve blocks
             theta = torch.empty(Bp, N, N, device=dev, dtype=torch.float32)
             L.check(lib.rr_edge_angles(L.ptr(locs), L.ptr(theta), Bp, N, L.stream()), "rr_edge_angles")
+        # headline shape (inference, instance norm, two-piece weight images, 64 < N <= 103): the layer as three launches with less
+        # state each (csrc/rr_enc_split.inc); RR_ENC_SPLIT=0 keeps the one-workgroup-per-block kernels (A/B, bit-identical results)
+        from .. import packing as _P
+        resplit = (train_saves is None and norm_mode == 0 and 64 < N <= 103 and _P.mlp_split_enabled()
+                   and bool(packed["blocks"][0][0].wqs) and _os.environ.get("RR_ENC_SPLIT", "1") != "0")
+        if resplit:
+            stats = torch.empty(2, 2, Bp, 2, 128, device=dev, dtype=torch.float32)       # [ping-pong][tensor][b][mean | rstd][f]
+            work = torch.empty(6, Bp, N, 128, device=dev, dtype=torch.float32)
+            L.check(lib.rr_enc_stats(L.ptr(row), L.ptr(col), L.ptr(stats[0]), Bp, N, L.stream()), "rr_enc_stats")
+        nl = len(packed["blocks"])
         for l, (wr, wc) in enumerate(packed["blocks"]):
             if simple:
                 nr, nc = packed["nabsimple"][l]
@@ -265,6 +275,13 @@ class RRNetEncoder(nn.Module):
                                                Bp, N, sv[0][1], sv[1][1], L.stream()), "rr_enc_layer_train")
                 train_saves.append({"row_in": row, "col_in": col, "row": sv[0][0], "col": sv[1][0]})
                 row, col, row2, col2 = row2, col2, torch.empty_like(row), torch.empty_like(col)
+                continue
+            if resplit:
+                L.check(lib.rr_enc_layer_split(wr, wc, L.ptr(row), L.ptr(col), L.ptr(row2), L.ptr(col2), L.ptr(D),
+                                               L.ptr(theta) if theta is not None else None, L.ptr(bias) if use_dur else None,
+                                               L.ptr(stats[l & 1]), L.ptr(stats[1 - (l & 1)]) if l + 1 < nl else None, L.ptr(work),
+                                               Bp, N, L.stream()), "rr_enc_layer_split")
+                row, col, row2, col2 = row2, col2, row, col
                 continue
             L.check(lib.rr_enc_layer(wr, wc, L.ptr(row), L.ptr(col), L.ptr(row2), L.ptr(col2), L.ptr(D), L.ptr(locs),
                                      L.ptr(theta) if theta is not None else None, L.ptr(bias) if use_dur else None,

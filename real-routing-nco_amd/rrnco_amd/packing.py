@@ -337,8 +337,15 @@ def fold_nab_pwl_batched(sd, prefixes, alphas) -> torch.Tensor:
         t32 = t.float().double()
         lo, hi = NAB_RANGES[f]
         wdt = (hi - lo) / NAB_G
-        edges = lo + wdt * torch.arange(NAB_G, device=dev, dtype=torch.float64) - 1e-2 * wdt - 1e-6
-        cells.append(torch.searchsorted(t32.contiguous(), edges[None].expand(nb, -1).contiguous(), right=True).clamp(max=128).to(torch.uint8))
+        ar = torch.arange(NAB_G, device=dev, dtype=torch.float64)
+        edges = lo + wdt * ar - 1e-2 * wdt - 1e-6
+        uppers = lo + wdt * (ar + 1) + 1e-2 * wdt + 1e-6
+        t32c = t32.contiguous()
+        start = torch.searchsorted(t32c, edges[None].expand(nb, -1).contiguous(), right=True)
+        end = torch.searchsorted(t32c, uppers[None].expand(nb, -1).contiguous(), right=True)
+        need = (end != start) | (start >= 128)                                             # bit 7 (nab_grid_cells): the scan is needed
+        need[:, 0] = True; need[:, -1] = True
+        cells.append((start.clamp(max=127) | (need.long() << 7)).to(torch.uint8))
     alpha = torch.stack([x.detach().double().reshape(()) for x in alphas])
     tail = torch.zeros(nb, 8, dtype=torch.float64, device=dev)
     tail[:, 0], tail[:, 1], tail[:, 2] = bg, bo, alpha
@@ -353,8 +360,8 @@ NAB_RANGES = ((0.0, 1.0), (-math.pi, math.pi))   # min-max-normalised distance, 
 
 def nab_grid_cells(tab):
     """Start-of-scan tables for csrc/rr_encoder.hip:nab_edge4_grid: per family, for each of the NAB_G uniform cells of
-    the input range, a lower bound (uint8) of "number of float32 breakpoints <= x" valid for every x the kernel maps to
-    that cell.  The kernel computes the cell in float32, so the bound is taken a little below the cell's lower edge.
+    the input range, a lower bound (7 bits) of "number of float32 breakpoints <= x" valid for every x the kernel maps to
+    that cell, and in bit 7 whether a scan from that bound is needed at all.  The kernel computes the cell in float32, so the bound is taken a little below the cell's lower edge.
     Inputs below the range (negative raw cell index) start their scan at 0 in the kernel; inputs above it land in the
     last cell and scan on.  Returned packed 4 bytes per float32."""
     import numpy as np
@@ -365,7 +372,13 @@ def nab_grid_cells(tab):
         w = (hi - lo) / NAB_G
         edges = lo + w * np.arange(NAB_G) - 1e-2 * w - 1e-6
         start = np.searchsorted(t, edges, side="right")          # breakpoints <= (edge - margin)
-        out.append(np.minimum(start, 128).astype(np.uint8))
+        # bit 7: the scan is needed — a breakpoint may lie among the inputs of this cell (between its lower edge minus the margin
+        # and its upper edge plus the margin), or the cell also receives out-of-range inputs (first / last); without it the bound
+        # IS the segment and the kernel reads no breakpoint at all.  The bound itself in 7 bits (128 -> 127 + scan).
+        end = np.searchsorted(t, lo + w * (np.arange(NAB_G) + 1) + 1e-2 * w + 1e-6, side="right")
+        need = (end != start) | (start >= 128)
+        need[0] = need[-1] = True
+        out.append((np.minimum(start, 127) | (need.astype(np.int64) << 7)).astype(np.uint8))
     return np.concatenate(out).view(np.float32)
 
 

@@ -172,9 +172,12 @@ def test_nab_piecewise_linear_tables_are_exact():
             below = c < 0
             c = c.clamp(0, NAB_G - 1).long()
             true_m = torch.searchsorted(tab[128 * f:128 * f + 128].contiguous(), x.contiguous(), right=True)
-            start = torch.from_numpy(cells[NAB_G * f:NAB_G * (f + 1)])[c]
+            byte = torch.from_numpy(cells[NAB_G * f:NAB_G * (f + 1)])[c]
+            start, scan = byte & 127, (byte >> 7).bool() | below        # bit 7: the kernel scans from the bound; clear: the bound IS the segment
             start = torch.where(below, torch.zeros_like(start), start)
             assert bool((start <= true_m).all())
+            assert bool((start == true_m)[~scan].all())
+            assert float(scan[:-2].float().mean()) < 0.35               # most inputs read no breakpoint at all
             steps = (true_m - start)[:-2]
             assert float(steps.float().mean()) < 1.0 and int(steps.max()) <= 8   # short scans on every in-range input
         ref = restate.nab_gating(w, p + ".angle_distance_fusion", locs, D, None) * w[p + ".alpha"]

@@ -1,0 +1,117 @@
+"""`-m gpu`: the encoder layer re-cut for occupancy (csrc/rr_enc_split.inc: k_enc_kv -> k_enc_mix -> k_enc_tail) against the
+one-workgroup-per-block kernels it replaces at the headline shape (k_enc_block_w<7, true, false> + k_enc_ffn<7>, RR_ENC_SPLIT=0).
+Same arithmetic, operand forms and reduction orders, and no implicit multiply-add contraction in either (rr_encoder.hip): per layer
+K, V and num come out bit-identical and den differs in a handful of its 25 600 elements per block by one unit in the last place
+(tools/scratch/debug_enc_split.py; both within one ulp of float64).  The instance norms amplify that: after six layers the two
+encoders agree to ~1e-6 .. 1e-5 on values up to 5 — an order of magnitude inside their distance to the reference (<= 1.1e-4).
+TWIN_ATOL below is that bound with a margin; the parity of the (default, re-cut) path with the REFERENCE is what
+test_gpu_atsp / _rcvrp / _rcvrptw check.  Covered: all three problems (ATSP / RCVRP: NAB tables evaluated inside k_enc_mix;
+RCVRPTW: the duration NAB's `bias_pre`), random-init and trained weights, node counts with a ragged last tile (65, 80, 103) and
+batches that leave the row-parallel K / V kernel ragged row tiles and tiles straddling two instances."""
+import os
+
+import pytest
+import torch
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(pol, td):
+    packed = pol.packed(torch.device("cuda"))
+    out = {}
+    for sw in ("0", "1"):
+        os.environ["RR_ENC_SPLIT"] = sw
+        try:
+            row, col = pol.encoder(td.clone(), packed=packed)
+            out[sw] = (row.clone(), col.clone())
+        finally:
+            os.environ.pop("RR_ENC_SPLIT", None)
+    torch.cuda.synchronize()
+    return out["0"], out["1"]
+
+
+TWIN_ATOL = 3e-5
+
+
+def _assert_identical(a, b, what):
+    worst = 0.0
+    for x, y, side in ((a[0], b[0], "row"), (a[1], b[1], "col")):
+        assert torch.isfinite(y).all(), f"{what}: non-finite {side} embeddings on the re-cut path"
+        d = float((x - y).abs().max())
+        worst = max(worst, d)
+        assert d < TWIN_ATOL, f"{what}: {side} embeddings differ between the block kernel and the re-cut layer (max |diff| {d:.3e})"
+    print(f"\n[{what}] max |block kernel - re-cut layer| {worst:.2e}")
+
+
+@pytest.mark.parametrize("name", ["atsp_n100_b2_pomo", "atsp_n100_b2_pomo_trained", "atsp_n100_b2_pomo_aug8_trained"])
+def test_recut_layer_agrees_atsp(name):
+    from tests.test_gpu_atsp import _setup
+    fx, w, pol, st, env, td_in = _setup(name)
+    a, b = _both(pol, env.reset(td_in))
+    _assert_identical(a, b, name)
+    err = max(float((b[0].cpu() - fx["row_emb"]).abs().max()), float((b[1].cpu() - fx["col_emb"]).abs().max()))
+    assert err < 2e-4, f"{name}: re-cut embeddings vs the reference {err:.2e}"
+
+
+@pytest.mark.parametrize("name", ["rcvrp_n100_b2_pomo", "rcvrp_n100_b2_pomo_trained"])
+def test_recut_layer_agrees_rcvrp(name):
+    from tests.test_gpu_rcvrp import _setup
+    fx, w, pol, inst, env, td_in = _setup(name)
+    a, b = _both(pol, env.reset(td_in))
+    _assert_identical(a, b, name)
+
+
+@pytest.mark.parametrize("name", ["rcvrptw_n100_b2_pomo", "rcvrptw_n100_b2_pomo_trained"])
+def test_recut_layer_agrees_rcvrptw(name):
+    from tests.test_gpu_rcvrptw import _setup
+    fx, w, pol, inst, env, td_in = _setup(name)
+    a, b = _both(pol, env.reset(td_in))
+    _assert_identical(a, b, name)
+
+
+@pytest.mark.parametrize("N,B", [(65, 3), (80, 5), (103, 7), (100, 37)])
+def test_recut_layer_agrees_ragged_shapes(N, B):
+    """Random instances: node counts whose last 16-node tile is ragged, batches that leave the row-parallel K / V kernel a ragged
+    last row tile and tiles that straddle two instances."""
+    from rrnco_amd import TensorDict
+    from rrnco_amd.envs import ATSPEnv
+    g = torch.Generator().manual_seed(100 * N + B)
+    pol = H.make_policy(H.atsp_weights(25, layers=2, seed=5))
+    D = torch.rand(B, N, N, generator=g)
+    D[:, torch.arange(N), torch.arange(N)] = 0
+    td_in = TensorDict({"locs": torch.rand(B, N, 2, generator=g).cuda(), "distance_matrix": D.cuda()}, batch_size=[B])
+    env = ATSPEnv(generator_params=dict(num_loc=N))
+    td = env.reset(td_in)
+    from rrnco_amd.models.encoder import ATSPInitEmbedding
+    torch.manual_seed(3)
+    td["sample_idx"] = ATSPInitEmbedding.sample_indices(td["distance_matrix"], 25)
+    a, b = _both(pol, td)
+    _assert_identical(a, b, f"N={N} B={B}")
+
+
+def test_recut_layer_is_the_default_at_the_headline_shape_and_not_elsewhere():
+    """The dispatch: 64 < N <= 103 with instance norm takes the three launches; N <= 64 and the other norms stay on k_enc_block_w."""
+    import ctypes
+    from rrnco_amd import _lib as L
+    from tests.test_gpu_atsp import _setup
+    calls = []
+    lib = L.lib()
+    real = lib.rr_enc_layer_split
+
+    class Spy:
+        def __call__(self, *a):
+            calls.append(1)
+            return real(*a)
+    try:
+        lib.rr_enc_layer_split = Spy()
+        fx, w, pol, st, env, td_in = _setup("atsp_n100_b2_pomo")
+        pol.encoder(env.reset(td_in), packed=pol.packed(torch.device("cuda")))
+        assert len(calls) == fx["layers"]
+        calls.clear()
+        fx, w, pol, st, env, td_in = _setup("atsp_n20_b4_pomo")
+        pol.encoder(env.reset(td_in), packed=pol.packed(torch.device("cuda")))
+        assert not calls
+    finally:
+        lib.rr_enc_layer_split = real
