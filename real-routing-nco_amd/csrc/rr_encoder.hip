@@ -213,7 +213,8 @@ extern "C" int rr_enc_layer_split(const EncBlockW* wrow, const EncBlockW* wcol, 
   static const int kv_grid = [] { const char* e = getenv("RR_ENC_KV_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
   hipLaunchKernelGGL(k_enc_kv, dim3(kv_grid, 2), dim3(64 * EKV_WAVES), 0, st, ws, row_in, col_in, stats_in, Kb, Vb, Bp, N);
   hipLaunchKernelGGL((k_enc_mix<7>), dim3(Bp, 2), dim3(64 * 7), 0, st, ws, Kb, Vb, Rt, D, theta, bias_pre, Bp, N);
-  hipLaunchKernelGGL((k_enc_tail<7>), dim3(Bp, 2), dim3(64 * 8), 0, st, ws, row_in, col_in, Rt, stats_in, row_out, col_out, stats_out, Bp, N);
+  static const int upw = [] { const char* e = getenv("RR_ENC_TAIL_UPW"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 8; }();     // instances per workgroup
+  hipLaunchKernelGGL((k_enc_tail<7>), dim3((Bp + upw - 1) / upw, 2), dim3(64 * 8), 0, st, ws, row_in, col_in, Rt, stats_in, row_out, col_out, stats_out, Bp, N, upw);
   return rr_check(hipGetLastError());
 }
 
