@@ -47,7 +47,7 @@ ROLLOUT_KERNEL_FP32 = "k_rollout_w<7, 0, 0, false, false, false>"
 # (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B — FETCH_SIZE doubled for gfx950's 16-B/lane reads as MI355X_MICROARCH.md §HBM
 # prescribes; Infinity-Cache hits are included in the counter.  Read at run time from the committed summary
 # (tools/pmc_traffic.sh writes it together with a hash of the rollout's sources): a summary of other sources -> null.
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04", "bench_pmc_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05", "bench_pmc_hbm_traffic.json")
 ROLLOUT_SOURCES = ("rr_decode.hip", "rr_rollout_w.inc", "rr_common.h")
 
 
@@ -71,8 +71,9 @@ def rollout_source_hash():
     return h.hexdigest()[:16]
 
 
-ENCODER_SOURCES = ("rr_encoder.hip", "rr_enc_w.inc", "rr_common.h", "rr_gemm_f16.h")
-ENCODER_LAYER_KERNELS = ("k_enc_block_w<7, true, false>", "k_enc_ffn<7>")      # one encoder layer at the headline shape = these two launches
+ENCODER_SOURCES = ("rr_encoder.hip", "rr_enc_w.inc", "rr_enc_split.inc", "rr_common.h", "rr_gemm_f16.h")
+# one encoder layer at the headline shape = these three launches (csrc/rr_enc_split.inc; rounds 2-4: k_enc_block_w<7, true, false> + k_enc_ffn<7>)
+ENCODER_LAYER_KERNELS = ("k_enc_kv", "k_enc_mix<7>", "k_enc_tail<7>")
 
 
 def encoder_source_hash():
@@ -164,6 +165,48 @@ def power_limited_mfma(seconds=1.5):
         return out
     except Exception as e:  # noqa: BLE001
         return {"mfma_f16_on_data_tflops": None, "error": f"{type(e).__name__}: {e}"[:200]}
+
+
+class clock_power_sampler:
+    """Socket power and shader clock (amdsmi, every 20 ms, a host thread of its own) while a block runs: `with clock_power_sampler() as s: ...;
+    s.summary()` -> {"sclk_mhz": mean, "socket_power_w": mean, "power_limit_w": ..., "samples": n} or None without amdsmi.  Reported in
+    `roofline.headline_loop`: what the timed loop itself drew, beside the power-limited matrix rate of the probe."""
+
+    def __init__(self, period=0.02):
+        import threading
+        self.period, self.samples, self.stop, self.th = period, [], threading.Event(), None
+
+    def _run(self):
+        try:
+            import amdsmi
+            amdsmi.amdsmi_init()
+            h = amdsmi.amdsmi_get_processor_handles()[int(os.environ.get("LOCAL_RANK", 0))]
+            while not self.stop.is_set():
+                pw = amdsmi.amdsmi_get_power_info(h)
+                ck = amdsmi.amdsmi_get_clock_info(h, amdsmi.AmdSmiClkType.GFX)
+                self.samples.append((pw.get("current_socket_power", pw.get("average_socket_power")), ck.get("clk", ck.get("cur_clk")), pw.get("power_limit")))
+                time.sleep(self.period)
+        except Exception:  # noqa: BLE001  (no amdsmi / no permission: nothing is reported)
+            pass
+
+    def __enter__(self):
+        import threading
+        self.th = threading.Thread(target=self._run, daemon=True)
+        self.th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop.set()
+        self.th.join(timeout=2)
+        return False
+
+    def summary(self):
+        v = [x for x in self.samples[len(self.samples) // 5:] if isinstance(x[0], (int, float)) and isinstance(x[1], (int, float))]   # (the first fifth: ramp-up)
+        if not v:
+            return None
+        lim = v[0][2]
+        return {"sclk_mhz": sum(x[1] for x in v) / len(v), "socket_power_w": sum(x[0] for x in v) / len(v),
+                "power_limit_w": (lim / 1e6 if isinstance(lim, (int, float)) and lim > 1e5 else lim), "samples": len(v)}
 
 
 def make_policy(device, seed=1234):
@@ -325,6 +368,7 @@ def other_configs(dev):
         from rrnco_amd.parallel import run_on_streams
         pols = [pol, make_pol()]
         pols[1].load_state_dict(pol.state_dict())
+        pols[1].lazy_trim = getattr(pol, "lazy_trim", False)
         steps = [step_of(p) for p in pols]
         run_on_streams(steps, 2)                               # each stream's allocations and packs
         est = run_on_streams(steps, 2) / 4
@@ -348,22 +392,30 @@ def other_configs(dev):
             return step
         step = step_of(pol)
         step()
+        sec_exact, n_exact = timed_loop(step)                   # actions trimmed to the longest route: one host read of the step count per call
+        pol.lazy_trim = True                                    # the throughput form (models/policy.py): padded actions, step count on the device
+        step()
         R.TIMING = []
         sec, n = timed_loop(step)
         ks = [a.elapsed_time(b) for a, b in R.TIMING]
         R.TIMING = None
         k_ms = sum(ks) / max(len(ks), 1)
         o = res["out"]
-        T, Rr = int(o["actions"].shape[1]), int(o["actions"].shape[0])
+        pol.check_range()
+        T, Rr = int(o["steps"].item()) + 1, int(o["actions"].shape[0])      # decode steps of the longest rollout + the multistart move
         # LIVE decoder evaluations only: a rollout counts up to the step that closes its last route (its last
         # customer + the return to the depot); what a finished rollout's tile keeps executing until the instance's longest route ends
         # is padding, reported separately as `executed`
-        acts = o["actions"]
+        acts = o["actions"][:, :T]
         pos = torch.arange(T, device=acts.device)
         live_steps = int((((acts != 0).long() * pos).max(dim=1).values + 1).clamp(max=T - 1).sum())
         ach = live_steps * FLOP_PER_ROLLOUT_STEP / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         exe = Rr * (T - 1) * FLOP_PER_ROLLOUT_STEP / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         out[label] = {"value": B / sec, "unit": "instances/s", "ms_per_step": sec * 1e3, "steps": n, "kernel_ms": k_ms,
+                      "call_form": "policy.lazy_trim = True: actions / log-probabilities keep their allocated length (depot / 0.0 behind each "
+                                   "route's end), the step count stays on the device, the range guard runs deferred — no host read in the call",
+                      "exact_shape": {"value": B / sec_exact, "ms_per_step": sec_exact * 1e3, "steps": n_exact,
+                                      "note": "the reference's output shape (actions trimmed to the longest route): one host read per call"},
                       "rollouts": Rr, "decode_steps": T, "live_rollout_steps": live_steps, "executed_rollout_steps": Rr * (T - 1),
                       "mean_best_cost": float(-o["reward"].view(S, -1).max(0).values.mean()),
                       "roofline": {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": peak_split, "unit": "TFLOP/s",
@@ -469,6 +521,7 @@ def main():
                     help="weak: --batch instances per GPU (the default); strong: --batch instances in all, parallel.shard_range per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs[2..4] (timed on one GPU after the headline)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the fp32-MFMA and 16-mixed variants of the headline (diagnostic library builds hold only the headline kernel)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -521,7 +574,7 @@ def main():
     R.SPLIT_MLP = True
     for k in range(args.warmup):
         hot_path_step(pol, env, insts[k % N_INSTANCE_BATCHES])
-    with kernel_timers("rr_enc_layer", "rr_init_embed", "rr_dec_cache") as kt:
+    with kernel_timers("rr_enc_layer", "rr_enc_layer_split", "rr_init_embed", "rr_dec_cache") as kt, clock_power_sampler() as cps:
         R.TIMING = []
         sync_all()
         t0 = time.perf_counter()
@@ -533,7 +586,9 @@ def main():
         pol.check_range()                  # the range guard's deferred word (models/policy.py): a raised one fails the run loudly
         kern_ms = [a.elapsed_time(b) for a, b in R.TIMING]
         R.TIMING = None
-        enc_ms, enc_calls = kt.ms("rr_enc_layer")
+        enc_ms, enc_calls = kt.ms("rr_enc_layer_split")          # the layer as three launches (default at this shape) ...
+        if enc_calls == 0:
+            enc_ms, enc_calls = kt.ms("rr_enc_layer")            # ... or RR_ENC_SPLIT=0: block kernel + FFN kernel
         init_ms, _ = kt.ms("rr_init_embed")
         cache_ms, _ = kt.ms("rr_dec_cache")
     total_inst, dt = aggregate_throughput(local_batch * args.steps, dt, dist, dev if backend == "nccl" else torch.device("cpu"))
@@ -580,19 +635,23 @@ def main():
                          "mfma_busy": measured_mfma_busy(ROLLOUT_KERNEL, local_batch),
                          "mfma_busy_note": "matrix-pipe busy fraction from the committed rocprofv3 --pmc pass of these sources (SQ_VALU_MFMA_BUSY_CYCLES / "
                                            "1 024 SIMDs over GRBM_GUI_ACTIVE / 8); null: the summary is of other sources",
-                         "algorithmic_flop_per_launch": rollout_steps * FLOP_PER_ROLLOUT_STEP},
-            "roofline_encoder": {"bound": "mfma", "kernel": ENC_KERNEL + " (one launch = the row and the column AttnFree_Block of a layer)",
+                         "algorithmic_flop_per_launch": rollout_steps * FLOP_PER_ROLLOUT_STEP,
+                         "headline_loop": cps.summary(),
+                         "headline_loop_note": "shader clock and socket power sampled (amdsmi, 20 ms) over the timed steps; null: amdsmi not "
+                                               "available to this user.  power_limited (below, default runs): the fp16 matrix rate of a pure "
+                                               "register-resident matrix stream on data under the same cap"},
+            "roofline_encoder": {"bound": "mfma", "kernel": ENC_KERNEL + " (one rr_enc_layer_split call = the row and the column AttnFree_Block of a layer)",
                                  "achieved": enc_ach, "peak": peak_split, "unit": "TFLOP/s", "frac": enc_ach / peak_split if peak_split else 0.0,
                                  "kernel_ms": enc_ms, "launches_per_step": enc_calls / max(args.steps, 1),
                                  "traffic": measured_encoder_traffic(local_batch),
                                  "mfma_busy": {k: measured_mfma_busy(k, local_batch, encoder=True) for k in ENCODER_LAYER_KERNELS},
-                                 "traffic_note": "HBM-side bytes of one layer (block kernel + FFN kernel), same PMC passes as the rollout's; "
+                                 "traffic_note": "HBM-side bytes of one layer (its three kernels), same PMC passes as the rollout's; "
                                                  "null: the committed summary is of other encoder sources",
                                  "algorithmic_flop_per_launch": 2 * ENC_BLOCK_FLOP * local_batch * AUG,
                                  "init_embed_ms": init_ms, "dec_cache_ms": cache_ms},
             "mean_best_cost": float(-best.mean().item()),
         }
-        if world == 1:
+        if world == 1 and not args.no_variants:
             def timed(label):
                 hot_path_step(pol, env, insts[0])                      # (warm-up of the variant's kernels / packs)
                 R.TIMING = []

@@ -43,6 +43,11 @@ class RRNetPolicy(nn.Module):
         self.train_decode_type, self.val_decode_type, self.test_decode_type = \
             train_decode_type, val_decode_type, test_decode_type
         self._pack_cache = None
+        # Throughput knob for the VRPs (not a constructor argument of the reference): their rollouts end after a data-dependent number
+        # of steps, and trimming `actions` / the log-probabilities to it costs one host read per call.  lazy_trim = True leaves them at
+        # the allocated length 2 N + 2 (depot / 0.0 behind each route's end: neutral for the reward, the log-likelihood and the
+        # validity check), returns the step count as a DEVICE scalar in out["steps"] and lets the range guard run deferred.
+        self.lazy_trim = False
 
     # ---- packed (MFMA-ordered / folded) weights, rebuilt when any parameter changes (versions + packing.weights_fingerprint)
     def invalidate_pack(self) -> None:
@@ -55,6 +60,9 @@ class RRNetPolicy(nn.Module):
         # (the encoder's training packs) would be taken for current after every optimizer step but the first.
         self._pack_gen = getattr(self, "_pack_gen", 0) + 1
         self._range_sticky_fp32 = False      # new weights: the split kernels get another chance (a raised word sets it again)
+        # words of calls made with the OLD weights say nothing about the new ones (their outputs were NaN-marked on the device): without
+        # this a word raised before load_state_dict would throw at the first call afterwards and send the new weights straight back to fp32
+        self._range_pending = None
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
@@ -151,11 +159,13 @@ class RRNetPolicy(nn.Module):
           "sync"     the word is read once per call, before anything looks at the tours; a call that raised it is repeated on the
                      fp32-MFMA kernels, which have no such limit — costs one host synchronisation per call (~2 ms of pipeline bubble
                      on the 80 ms headline step);
-          "deferred" no host read in the call: every float output of a flagged call (reward, normalized_reward, log_likelihood) is
-                     NaN-marked ON THE DEVICE (one scalar `where` + three adds, no synchronisation), so a caller that only reads the
-                     rewards (test.py:204-213) cannot consume a bad batch as a plausible number; the word itself joins a list that is
-                     read at the start of the next call and by check_range(): a raised word raises FloatingPointError there and the
-                     policy runs in fp32 until its weights change (invalidate_pack / load_state_dict);
+          "deferred" no host read in the call and none that waits for it later: every float output of a flagged call (reward,
+                     normalized_reward, log_likelihood) is NaN-marked ON THE DEVICE (one scalar `where` + three adds), so a caller that
+                     only reads the rewards (test.py:204-213) cannot consume a bad batch as a plausible number; the word itself is copied
+                     into a pinned host word behind the call (asynchronous copy + event).  Later calls POLL the events of earlier ones —
+                     the host never waits for the device: it runs one call ahead, so a word is typically seen two calls later — and
+                     check_range() waits for all of them: a raised word raises FloatingPointError there and the policy runs in fp32
+                     until its weights change (invalidate_pack / load_state_dict);
           "auto"     (default) "sync" where the call synchronises anyway (the VRPs read their step count; training steps),
                      "deferred" otherwise (ATSP inference);  "off": no guard.
         The step-wise decode paths (fused=False, N > 103, top-k / top-p, beam search) run the same split encoder / cache kernels: "sync"
@@ -163,7 +173,8 @@ class RRNetPolicy(nn.Module):
         import os
         mode = range_guard or os.environ.get("RR_RANGE_GUARD", "auto")
         mode = {"1": "sync", "0": "off"}.get(mode, mode)
-        self.check_range()                                       # a deferred word of the previous call
+        self._range_poll(wait=False)                             # deferred words of earlier calls that have landed (no wait: round 4 read the
+        #                                                          previous call's word here and so serialised the host behind the device)
         if getattr(self, "_range_sticky_fp32", False):
             with packing.force_fp32():
                 return self._forward_core(td, env, *args, capture=capture, **kwargs)
@@ -171,7 +182,8 @@ class RRNetPolicy(nn.Module):
             self._range_status = None
             return self._forward_core(td, env, *args, capture=capture, **kwargs)
         if mode == "auto":
-            mode = "sync" if (self.env_name != "atsp" or capture is not None) else "deferred"
+            syncs_anyway = capture is not None or (self.env_name != "atsp" and not getattr(self, "lazy_trim", False))
+            mode = "sync" if syncs_anyway else "deferred"
         self._range_status = self.packed(td.device)["range_status"].clone()
         self._range_sync = mode == "sync"
         self.last_range_flags = 0
@@ -181,9 +193,7 @@ class RRNetPolicy(nn.Module):
                 out = self._forward_core(td, env, *args, capture=capture, **kwargs)
             finally:
                 self._range_status = None
-                pend = getattr(self, "_range_pending", None) or []
-                pend.append(status)
-                self._range_pending = pend[-64:]                 # (a caller that never checks: bounded)
+                self._range_push(status)
             # device-side poison: 0 for a clean word, NaN for a raised one — added to every float output of the call
             poison = torch.where(status != 0, torch.full((), float("nan"), device=status.device), torch.zeros((), device=status.device))
             for k in ("reward", "normalized_reward", "log_likelihood"):
@@ -213,19 +223,54 @@ class RRNetPolicy(nn.Module):
         finally:
             self._range_status = None
 
-    def check_range(self) -> None:
-        """Reads the range-guard word a "deferred" call left behind (one host read of a finished call).  If it is raised:
-        FloatingPointError — that call's log-likelihoods were NaN-marked and its tours are not to be trusted — and the policy
-        runs on the fp32-MFMA kernels from now on."""
+    def _range_push(self, status) -> None:
+        """A deferred call's guard word -> pending list.  Outside a graph capture: an asynchronous copy into a pinned host word (a small
+        ring of them) and an event behind it, both on the call's stream.  Inside a capture nothing may be read back or recorded against
+        the host: the device word itself stays pending for check_range()."""
+        pend = getattr(self, "_range_pending", None) or []
+        if status.is_cuda and not torch.cuda.is_current_stream_capturing():
+            ring = getattr(self, "_range_ring", None)
+            if ring is None:
+                ring = self._range_ring = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(8)]
+                self._range_ring_next = 0
+            if len(pend) >= len(ring):                           # a ring slot is only reused after its word was read
+                self._range_pending = pend
+                self._range_poll(wait=True)
+                pend = self._range_pending or []
+            host = ring[self._range_ring_next]
+            self._range_ring_next = (self._range_ring_next + 1) % len(ring)
+            host.copy_(status.reshape(1), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            pend.append((host, ev))
+        else:
+            pend.append((status, None))
+        self._range_pending = pend
+
+    def _range_poll(self, wait: bool) -> None:
+        """Reads the pending guard words whose call has finished (wait=False: event query, never blocks) or all of them (wait=True)."""
         pend = getattr(self, "_range_pending", None)
         if not pend:
             return
-        if pend[0].is_cuda and torch.cuda.is_current_stream_capturing():
-            return          # inside a hipGraph capture nothing may be read back: the words stay pending (the captured calls still NaN-mark)
-        self._range_pending = None
-        flags = 0
-        for f in torch.stack([p.reshape(()) for p in pend]).tolist():      # ONE host read for every pending call
-            flags |= int(f)
+        capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+        flags, keep, dev_words = 0, [], []
+        for word, ev in pend:
+            if ev is None:                                       # a device word (captured call, CPU tensor): only an explicit check reads it
+                if wait and not capturing:
+                    dev_words.append(word)
+                else:
+                    keep.append((word, ev))
+            elif wait and not capturing:
+                ev.synchronize()
+                flags |= int(word[0])
+            elif not capturing and ev.query():
+                flags |= int(word[0])
+            else:
+                keep.append((word, ev))
+        if dev_words:
+            for f in torch.stack([p.reshape(()) for p in dev_words]).tolist():      # ONE host read for all of them
+                flags |= int(f)
+        self._range_pending = keep or None
         self.last_range_flags = flags
         if flags != 0:
             self._range_sticky_fp32 = True
@@ -233,6 +278,11 @@ class RRNetPolicy(nn.Module):
                 f"rrnco_amd: an earlier policy call left the fp16 range of the split kernels (flags {flags:#x}: 1 = K/V/L image, 2 = weight "
                 "image, 4 = non-finite log-probability); its outputs were NaN-marked (reward, log-likelihood).  This policy now runs on the "
                 "fp32 MFMA kernels until its weights change: repeat the call (range_guard='sync' repeats such calls by itself).")
+
+    def check_range(self) -> None:
+        """Waits for and reads every range-guard word "deferred" calls left behind.  If one is raised: FloatingPointError — that call's
+        log-likelihoods were NaN-marked and its tours are not to be trusted — and the policy runs on the fp32-MFMA kernels from now on."""
+        self._range_poll(wait=True)
 
     def _forward_core(self, td, env=None, phase="train", calc_reward=True, return_actions=True, return_entropy=False,
                       return_hidden=False, return_init_embeds=False, return_sum_log_likelihood=True, actions=None,
@@ -309,6 +359,9 @@ class RRNetPolicy(nn.Module):
             out["normalized_reward"] = normd
         if return_actions:
             out["actions"] = actions_out
+        if getattr(self, "_last_steps", None) is not None:
+            out["steps"] = self._last_steps                                         # lazy_trim: see __init__
+            self._last_steps = None
         if return_entropy:
             out["entropy"] = calculate_entropy(logprobs)                            # policy.py:248-249
         if return_hidden:
@@ -359,11 +412,15 @@ class RRNetPolicy(nn.Module):
             flags = int(status.item())
             if flags != 0:
                 raise _RangeRetry(flags)
+        self._last_steps = None
         if self.env_name != "atsp":
-            T_used = t0 + int(steps_out.item())
-            if dump is not None:
-                dump["T_used"] = T_used - t0
-            acts, logp = acts[:, :T_used].contiguous(), logp[:, :T_used].contiguous()
+            if getattr(self, "lazy_trim", False) and dump is None:
+                self._last_steps = steps_out                 # device scalar: decode steps of the longest rollout (t0 not included)
+            else:
+                T_used = t0 + int(steps_out.item())
+                if dump is not None:
+                    dump["T_used"] = T_used - t0
+                acts, logp = acts[:, :T_used].contiguous(), logp[:, :T_used].contiguous()
         td.update({"current_node": st["cur"], "action_mask": st["mask"].bool(), "action": acts[:, -1]})
         if st["first"] is not None:
             td.set("first_node", st["first"])

@@ -102,8 +102,58 @@ def test_deferred_mode_marks_the_log_likelihood_and_raises_at_the_next_call_then
     pol3 = H.make_policy(_scaled_mlp(H.atsp_weights(fx), 2048.0), device="cuda:0")
     pol, pol_old = pol3, pol
     call()
+    torch.cuda.synchronize()                                   # (calls only POLL earlier words: one that has not finished yet is seen by a later call)
     with pytest.raises(FloatingPointError):
-        call()                                                 # ... or the next call raises
+        call()                                                 # ... or a later call raises, once the flagged one has finished
+
+
+def test_deferred_calls_never_read_the_device_and_new_weights_drop_old_words():
+    """VERDICT r04 #5 / ADVICE r04: a steady-state ATSP inference call dispatches no host read (round 4 read the previous call's word at
+    its entry and so ran the host in lock-step with the device); the word travels through a pinned host word + event and is polled.
+    A word raised under OLD weights must not throw at the first call with new ones."""
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from rrnco_amd import TensorDict
+    from rrnco_amd.envs import ATSPEnv
+    fx = H.load_fixture("atsp_n100_b2_pomo")
+    w = H.atsp_weights(fx)
+    pol = H.make_policy(w, device="cuda:0")
+    env = ATSPEnv(generator_params=dict(num_loc=fx["N"]), check_solution=False)
+
+    def call(p):
+        td = TensorDict({"locs": fx["locs"].cuda(), "distance_matrix": fx["distance_matrix"].cuda(),
+                         "sample_idx": fx["sample_idx"].cuda()}, batch_size=[fx["B"]])
+        return p(env.reset(td), env, phase="val", decode_type="multistart_greedy", num_starts=fx["S"], return_actions=True)
+    for _ in range(3):
+        call(pol)
+    reads = []
+
+    class Spy(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            name = str(func)
+            if ("_local_scalar_dense" in name or "item" in name) and args and torch.is_tensor(args[0]) and args[0].is_cuda:
+                reads.append(name)                             # (a scalar read of a DEVICE tensor: the host waits for the stream)
+            if "_to_copy" in name and (kwargs or {}).get("device", None) is not None and str((kwargs or {})["device"]).startswith("cpu") \
+                    and not (kwargs or {}).get("non_blocking", False):
+                reads.append(name)
+            return func(*args, **(kwargs or {}))
+    with Spy():
+        for _ in range(4):
+            out = call(pol)
+    assert not reads, f"host reads inside deferred ATSP calls: {reads}"
+    assert len(pol._range_pending or []) <= 8
+    pol.check_range()
+    assert pol.last_range_flags == 0 and not pol._range_pending
+    assert (out["actions"].cpu() == fx["actions"]).all(1).float().mean() >= 0.99
+    # a raised word of the old weights dies with them
+    bad = H.make_policy(_scaled_mlp(w, 2048.0), device="cuda:0")
+    o = call(bad)
+    assert torch.isnan(o["reward"]).all() and bad._range_pending
+    torch.cuda.synchronize()
+    bad.load_state_dict({k: v.cuda() for k, v in w.items()}, strict=False)
+    assert not bad._range_pending
+    c = call(bad)                                              # does not raise
+    bad.check_range()
+    assert torch.isfinite(c["reward"]).all()
 
 
 def test_deferred_mode_leaves_clean_calls_untouched_and_sticky_fp32_ends_with_new_weights():

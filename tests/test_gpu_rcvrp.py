@@ -94,3 +94,42 @@ def test_fused_rollout_sampling_draws_from_the_policy_distribution_rcvrp():
     fx, w, pol, inst, env, td_in = _setup("rcvrp_n20_b4_pomo")
     seen, worst = H.sampling_law_check(pol, env, inst, fx["sample_idx"], fx["S"])
     assert seen >= fx["S"] and worst < 5.0, (seen, worst)
+
+
+@pytest.mark.parametrize("problem,name", [("rcvrp", "rcvrp_n100_b2_pomo_trained"), ("rcvrptw", "rcvrptw_n100_b2_pomo_trained")])
+def test_lazy_trim_returns_the_same_routes_without_a_host_read(problem, name):
+    """policy.lazy_trim: the VRP call no longer reads its step count — actions / log-probabilities keep the allocated
+    length, depot / 0.0 behind each route's end — and everything a caller derives from them is unchanged."""
+    from torch.utils._python_dispatch import TorchDispatchMode
+    if problem == "rcvrp":
+        fx, w, pol, inst, env, td_in = _setup(name)
+    else:
+        from tests.test_gpu_rcvrptw import _setup as setup_tw
+        fx, w, pol, inst, env, td_in = setup_tw(name)
+    S = fx["S"]
+    env.check_solution = False                                  # (the validity replay is a host loop; throughput callers switch it off like test.py:156)
+    kw = dict(phase="val", decode_type="multistart_greedy", num_starts=S, return_actions=True)
+    ref = pol(env.reset(td_in.clone()), env, **kw)
+    pol.lazy_trim = True
+    pol(env.reset(td_in.clone()), env, **kw)                    # (warm-up of the deferred guard's pinned words)
+    reads = []
+
+    class Spy(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            if "_local_scalar_dense" in str(func) and args and torch.is_tensor(args[0]) and args[0].is_cuda:
+                import traceback
+                where = [f"{f.filename.split('/')[-1]}:{f.lineno}" for f in traceback.extract_stack(limit=12) if "rrnco_amd" in f.filename]
+                reads.append(where[-1] if where else str(func))
+            return func(*args, **(kwargs or {}))
+    td0 = env.reset(td_in.clone())
+    import traceback
+    with Spy():
+        out = pol(td0, env, **kw)
+    assert not reads, f"host reads in a lazy_trim call: {len(reads)} ({reads[:1]})"
+    pol.check_range()
+    T = ref["actions"].shape[1]
+    assert out["actions"].shape[1] == 2 * (fx["N"] + 1) + 2 and int(out["steps"].item()) + 1 == T
+    assert torch.equal(out["actions"][:, :T], ref["actions"]) and not out["actions"][:, T:].any()
+    # (sums over 2 N + 2 columns instead of T: the same terms plus zeros, another reduction tree)
+    assert torch.allclose(out["reward"], ref["reward"], rtol=0, atol=2e-6)
+    assert torch.allclose(out["log_likelihood"], ref["log_likelihood"], rtol=2e-6, atol=1e-5)

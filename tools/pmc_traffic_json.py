@@ -20,7 +20,7 @@ for path in _paths:
     lines = open(path).read().splitlines()
     for i, l in enumerate(lines):
         for k in bench.ENCODER_LAYER_KERNELS:
-            if l.startswith("void " + k[:24]) and (k != bench.ENCODER_LAYER_KERNELS[0] or l.startswith("void " + k)):
+            if l.startswith("void " + k + "(") or l.startswith(k + "("):      # (a non-template kernel is listed without its return type)
                 m = re.search(r"(FETCH_SIZE|WRITE_SIZE)\s+n=\s*(\d+) mean=([0-9.e+]+)", lines[i + 1])
                 if m:
                     enc["kernels"][k][m.group(1) + "_KB"] = float(m.group(3)); enc["kernels"][k][m.group(1) + "_n"] = int(m.group(2))
@@ -31,7 +31,7 @@ for path in _paths:
     lines = open(path).read().splitlines()
     for i, l in enumerate(lines):
         for k in (bench.ROLLOUT_KERNEL,) + tuple(bench.ENCODER_LAYER_KERNELS):
-            if not (l.startswith(("void " + k)[:len(l)]) and len(l) >= min(40, len(k) + 5)):
+            if not (l.startswith("void " + k + "(") or l.startswith(k + "(")):
                 continue
             vals = {}
             for ll in lines[i + 1:i + 12]:
