@@ -11,7 +11,7 @@ import torch
 from oracle import restate
 
 pytestmark = pytest.mark.gpu
-GAP_TOL = 1e-3          # a tour may part from the oracle's only at a decision whose top-1 / top-2 gap is below this
+GAP_TOL = 3e-4          # (largest gap observed at a parting on any build: 1.5e-4) a tour may part from the oracle's only at a decision whose top-1 / top-2 gap is below this
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
