@@ -129,16 +129,21 @@ __device__ __forceinline__ int nh_segment(const float* t, float x) {        // n
 // changed nothing), `ds_add_u64` costs next to nothing (116 us with, 111 us without any atomics).  Scale per workgroup: a first pass over
 // its edges takes max |d bias|; max * |alpha| maps to 2^36, which leaves 2^26 of headroom for (the other factors of a moment: x, f_o
 // differences) x (5 120 edges per workgroup) — values beyond are clamped, a non-finite d bias poisons every sum of the workgroup.
-// Integer sums are exact and order-independent; the resolution, 2^-36 of the largest term, is finer than a float accumulator's.
+// Integer sums are exact and order-independent; the resolution is 2^-36 of the workgroup's largest term (a float accumulator keeps 2^-24 of the running sum).
 __device__ __forceinline__ void nh_add(unsigned long long* h, float v, float scale) {
   const float lim = 9.0e14f;                                    // (2^62 / 5 120 edges)
-  // float -> 64-bit integer by hand: high word = floor(x / 2^32), low word = the remainder (exact: x has 24 significant bits) — two
-  // conversions and an fma instead of the dozen instructions of the generic (long long) cast, eight times per edge
+  // float -> 64-bit integer by hand, on the MAGNITUDE: high word = floor(|x| / 2^32), low word = the remainder, both exactly
+  // representable (|x| has 24 significant bits: the remainder is either |x| itself or a multiple of the ulp of |x| >= 2^32, below 2^32)
+  // — two conversions and an fma instead of the dozen instructions of the generic (long long) cast, eight times per edge; a negative
+  // value is added as the two's complement of its magnitude.  (Until round 5 the split ran on the signed value: for x < 0 the
+  // remainder lay in [2^31, 2^32) or rounded to 2^32 itself — inexact by up to 2^-28 of the term, and the conversion of 2^32 to
+  // unsigned relied on v_cvt_u32_f32 saturating.)
   const float x = fminf(fmaxf(v * scale, -lim), lim);
-  const float hi = floorf(x * 2.3283064365386963e-10f);
-  const float lo = fmaf(hi, -4294967296.0f, x);                 // in [0, 2^32)
-  const unsigned long long q = ((unsigned long long)(unsigned)(int)hi << 32) | (unsigned long long)(unsigned)lo;
-  atomicAdd(h, q);
+  const float ax = fabsf(x);
+  const float hi = floorf(ax * 2.3283064365386963e-10f);
+  const float lo = fmaf(hi, -4294967296.0f, ax);                // in [0, 2^32), exact
+  const unsigned long long mag = ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo;
+  atomicAdd(h, x < 0.f ? 0ull - mag : mag);
 }
 __global__ __launch_bounds__(256) void k_nab_hist_bwd(const float* __restrict__ pwl, const float* __restrict__ xd,
                                                       const float* __restrict__ xa, const float* __restrict__ gout,

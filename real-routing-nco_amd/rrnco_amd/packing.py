@@ -63,7 +63,12 @@ def small_gemm(A: torch.Tensor, B: torch.Tensor, transA: bool = False, transB: b
     return Cm[0] if squeeze else Cm
 
 
-_FORCE_FP32 = 0      # > 0 inside force_fp32(): the range guard's second pass (models/policy.py) runs every kernel on the fp32 MFMA
+import threading as _threading
+
+# > 0 inside force_fp32(): the range guard's second pass (models/policy.py) runs every kernel on the fp32 MFMA.  PER THREAD: with
+# parallel.run_on_streams two policies run on two host threads, and a retry in one must not flip the other's kernel selection (and
+# pack-cache key) in the middle of its call.
+_TLS = _threading.local()
 
 
 def mlp_split_enabled() -> bool:
@@ -72,19 +77,18 @@ def mlp_split_enabled() -> bool:
     rollouts equal the fp32-MFMA build's, tests/test_gpu_fullsize.py); RR_MLP_SPLIT=0 packs for and runs the all-fp32-MFMA kernels,
     and so does a call whose operands left the fp16 range (force_fp32, the range guard of models/policy.py)."""
     import os
-    return _FORCE_FP32 == 0 and os.environ.get("RR_MLP_SPLIT", "1") != "0"
+    return getattr(_TLS, "force_fp32", 0) == 0 and os.environ.get("RR_MLP_SPLIT", "1") != "0"
 
 
 class force_fp32:
-    """Context: every kernel of the policy on the fp32 MFMA (the pack cache is keyed by mlp_split_enabled())."""
+    """Context: every kernel of the policy on the fp32 MFMA, for the calling THREAD (the pack cache is keyed by mlp_split_enabled();
+    the C side selects by which weight images the pack carries, not by the environment)."""
 
     def __enter__(self):
-        global _FORCE_FP32
-        _FORCE_FP32 += 1
+        _TLS.force_fp32 = getattr(_TLS, "force_fp32", 0) + 1
 
     def __exit__(self, *exc):
-        global _FORCE_FP32
-        _FORCE_FP32 -= 1
+        _TLS.force_fp32 -= 1
         return False
 
 

@@ -57,9 +57,14 @@ def run_on_streams(workers, repeats: int):
     route ends (145 +- 12 decode steps at n = 100), so the last workgroups of a launch run on a mostly idle chip, and the call ends in a
     host read of the step count; a second stream's encoder / Neural-Adaptive-Bias kernels fill both holes (RCVRPTW, BASELINE configs[3]:
     +7.5 % instances/s; ATSP, whose workgroups all take the same 99 steps: +0.9 %).  The GIL is released while a thread waits for its
-    stream.  Returns seconds for everything."""
+    stream.  Returns seconds for everything.
+    State that stays process-wide (one policy object per stream does NOT isolate it): models.rollout.TIMING (a shared event list:
+    switched off here for the duration), models.rollout.SPLIT_MLP and the RR_* environment switches (read by both threads alike; the
+    csrc launchers read RR_MLP_SPLIT / RR_ENC_* per call).  The range guard's fp32 override (packing.force_fp32) is per thread."""
     import threading
     import time
+    from .models import rollout as _R
+    timing, _R.TIMING = _R.TIMING, None
     streams = [torch.cuda.Stream() for _ in workers]
 
     def drive(i):
@@ -75,4 +80,5 @@ def run_on_streams(workers, repeats: int):
     for t in threads:
         t.join()
     torch.cuda.synchronize()
+    _R.TIMING = timing
     return time.perf_counter() - t0
