@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round artefacts in one GPU call: the bench line (headline + BASELINE configs[2..4] + cpu_baseline), rocprofv3 kernel stats of the
 # same command, HBM-side PMC traffic of the rollout, MFMA / VALU / LDS counters, training-step profile.  Run through gpurun; copy
-# gpurun_out/<TAG>_* into profiles/rNN/ (bench.py reads profiles/r04/bench_pmc_hbm_traffic.json).
+# gpurun_out/<TAG>_* into profiles/rNN/ (bench.py reads profiles/r05/bench_pmc_hbm_traffic.json).
 TAG=${1:-v1}
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
