@@ -26,6 +26,8 @@ typedef struct {                /* one AttnFree_Block: rrnco/models/nn/attn_free
   const float *nab;             /* folded DistAngleFusion (:201-289): piecewise-linear tables, packing.fold_nab_pwl */
   const void *w1s, *w2s;        /* optional two-piece fp16 splits of w1 / w2 (packing.pack_a_f16x2): FFN on the fp16 pipe (default; RR_MLP_SPLIT=0 turns it off) */
   const void *wqs, *wks, *wvs, *wps;   /* likewise for the four 128 x 128 projections (all six or none) */
+  const float *muk;             /* [128] mean over the nodes of to_k(norm2(y)) = Wk n2.beta + bk (norm2's output has mean beta exactly): the shift
+                                 * of the node softmax in rr_enc_layer_split (softmax is shift-invariant; :319-321); may be NULL for rr_enc_layer */
 } EncBlockW;
 
 typedef struct {                /* ATSPInitEmbedding (rrnco/models/env_embeddings/atsp.py:5-121) and

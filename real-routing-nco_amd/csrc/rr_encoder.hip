@@ -57,6 +57,7 @@ struct EncBlockW {
   const float* nab;  // folded NAB: rows a_d,b_d,co_d,cg_d,a_a,b_a,co_a,cg_a [8][E] + 8 scalars
   const void *w1s, *w2s;  // optional two-piece fp16 splits of w1 / w2 (packing.pack_a_f16x2): FFN on the fp16 pipe
   const void *wqs, *wks, *wvs, *wps;   // likewise for the four 128 x 128 projections
+  const float* muk;       // [E] Wk n2.beta + bk: the mean over the nodes of the K projection (shift of the node softmax in rr_enc_split.inc)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -207,6 +208,7 @@ extern "C" int rr_enc_layer_split(const EncBlockW* wrow, const EncBlockW* wcol, 
         wcol->wks && wcol->wvs && wcol->wps))
     return RR_EINVAL;                                        // two-piece weight images required (packing.mlp_split_enabled)
   if (bias_pre == nullptr && (wrow->nab == nullptr || wcol->nab == nullptr)) return RR_EINVAL;
+  if (wrow->muk == nullptr || wcol->muk == nullptr) return RR_EINVAL;
   EncBlockW2 ws; ws.blk[0] = *wrow; ws.blk[1] = *wcol;
   const size_t R = (size_t)Bp * N * RR_E;
   float *Kb = work, *Vb = work + 2 * R, *Rt = work + 4 * R;

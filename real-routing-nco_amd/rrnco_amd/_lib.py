@@ -19,7 +19,7 @@ class EncBlockW(C.Structure):
     _fields_ = [(n, vp) for n in (
         "n1g", "n1b", "n2g", "n2b", "n3g", "n3b", "f1g", "f1b", "f2g", "f2b",
         "wq", "wk", "wv", "wp", "wc", "w1", "w2",
-        "bq", "bk", "bv", "bp", "bc", "b1", "b2", "nab", "w1s", "w2s", "wqs", "wks", "wvs", "wps")]
+        "bq", "bk", "bv", "bp", "bc", "b1", "b2", "nab", "w1s", "w2s", "wqs", "wks", "wvs", "wps", "muk")]
 
 
 class InitW(C.Structure):

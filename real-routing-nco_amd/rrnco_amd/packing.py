@@ -558,7 +558,13 @@ def _pack_policy(sd: dict, env_name: str, device) -> dict:
     Wpc32 = small_gemm(Wc64, Wp64).float()
     ppc = pack_a(Wpc32)
     bpc = ((Wc64 * stk("attn_free.project.bias").double()[:, None, :]).sum(2) + stk("multi_head_combine.bias").double()).float().contiguous()
-    ar.keep += [sq, p1, p2, ppc, bpc]
+    # mean over the nodes of K = to_k(norm2(y)): norm2's output has mean n2.beta per feature whatever the instance (InstanceNorm1d; the
+    # running-statistics / RMS / layer forms never take the kernels that read this), so mean(K) = Wk n2.beta + bk — the shift of the
+    # node softmax in csrc/rr_enc_split.inc (any shift gives the same softmax; this one needs no reduction)
+    n2b = torch.stack([dv(sd[f"{b}.norm2.normalizer.bias"]).double() if f"{b}.norm2.normalizer.bias" in sd else torch.zeros(E, dtype=torch.float64, device=device)
+                       for b in names])
+    muk = ((stk("attn_free.to_k.weight").double() * n2b[:, None, :]).sum(2) + stk("attn_free.to_k.bias").double()).float().contiguous()
+    ar.keep += [sq, p1, p2, ppc, bpc, muk]
     if split:      # FFN weights again as 3-way bf16 splits for the bf16-pipe FFN
         p1s, p2s = pack_a_f16u(W1s), pack_a_f16u(W2s)          # second-form images (x 2^6, csrc/rr_common.h): encoder FFN
         sqs = pack_a_f16x2(torch.stack([stk("attn_free.to_q.weight"), stk("attn_free.to_k.weight"), stk("attn_free.to_v.weight"),
@@ -590,6 +596,7 @@ def _pack_policy(sd: dict, env_name: str, device) -> dict:
                          ("1", "feed_forward.ops.ffn.W1"), ("2", "feed_forward.ops.ffn.W2")):
                 setattr(w, "b" + f, ar.put(sd[f"{b}.{k}.bias"]))
             w.wp, w.bp = ppc[bi].data_ptr(), bpc[bi].data_ptr()
+            w.muk = muk[bi].data_ptr()
             w.wc, w.bc = None, None
             if split:
                 w.w1s, w.w2s = p1s[bi].data_ptr(), p2s[bi].data_ptr()
