@@ -264,23 +264,56 @@ def cpu_baseline(w, seed=4321, budget_s=20.0, max_inst=8):
     rec = {"value": done / spent, "unit": "instances/s", "cores": threads, "threads": threads, "host_cores": host_cores, "kind": "port",
            "sample": f"{done} ATSP n=100 instance(s) x8 aug x100 starts greedy, torch-CPU fp32 oracle, {spent:.1f} s"}
     if host_cores > threads:
-        # BASELINE.md §3 asks for the box's host cores: a second point with torch's intra-op pool at ALL of them, in a child process
-        # under a hard time limit — on the 256-core GPU boxes that pool oversubscribes these small ops badly (measured: 505 s for ONE
-        # instance at 256 threads against 1.8 s at 32), so the point is reported as measured or as "timed out", never waited for
+        # BASELINE.md section 3 asks for the box's host cores.  torch's intra-op pool oversubscribes these small ops badly past a few dozen
+        # threads (measured: 505 s for ONE instance at 256 threads against 1.8 s at 32), so the wider points run in child processes under
+        # hard time limits and are reported as measured or as "timed out", never waited for: 64 and 128 threads in one process, all
+        # cores in one process, and — what a CPU user of the reference would actually do with 256 cores — a POOL of processes with 32
+        # threads each, every process solving its own instances (instances are independent).
         import subprocess
         code = ("import sys,time,torch;sys.path.insert(0,%r);import bench;from oracle import restate;torch.set_num_threads(%d);"
-                "pol,w=bench.make_policy('cpu');inst=restate.atsp_synthetic(1,bench.N_NODES,%d);t=time.perf_counter();\n"
-                "with torch.inference_mode():\n st=restate.atsp_reset(restate.augment_state(inst));sidx=restate.sample_neighbor_indices(st['distance_matrix'],25);"
-                "restate.atsp_policy(w,st,sidx,bench.STARTS,'greedy')\nprint('SECONDS',time.perf_counter()-t)") % (ROOT, host_cores, seed)
-        try:
-            r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=45, env={**os.environ, "OMP_NUM_THREADS": str(host_cores)})
-            sec = float([l for l in r.stdout.splitlines() if l.startswith("SECONDS")][-1].split()[1])
-            rec["all_host_cores"] = {"value": 1.0 / sec, "unit": "instances/s", "cores": host_cores, "sample": f"1 instance, {sec:.1f} s, torch threads = {host_cores} (child process)"}
-            if 1.0 / sec > rec["value"]:       # report the faster of the two as the baseline
-                rec.update({"value": 1.0 / sec, "cores": host_cores, "threads": host_cores, "sample": rec["all_host_cores"]["sample"] + " (all host cores)"})
-        except Exception as e:  # noqa: BLE001  (timeout, or no output: the point is recorded as such)
-            rec["all_host_cores"] = {"value": None, "cores": host_cores, "sample": f"not finished within 45 s at {host_cores} torch threads ({type(e).__name__}); "
-                                     f"the {threads}-thread figure stands"}
+                "pol,w=bench.make_policy('cpu');n=%d;t=time.perf_counter();\n"
+                "for k in range(n):\n"
+                " inst=restate.atsp_synthetic(1,bench.N_NODES,%d+k)\n"
+                " with torch.inference_mode():\n"
+                "  st=restate.atsp_reset(restate.augment_state(inst));sidx=restate.sample_neighbor_indices(st['distance_matrix'],25);"
+                "restate.atsp_policy(w,st,sidx,bench.STARTS,'greedy')\n"
+                "print('SECONDS',time.perf_counter()-t)")
+
+        def child(nthreads, ninst, limit, first_seed):
+            return subprocess.Popen([sys.executable, "-c", code % (ROOT, nthreads, ninst, first_seed)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                    text=True, env={**os.environ, "OMP_NUM_THREADS": str(nthreads)}), limit
+
+        def seconds(proc, limit):
+            try:
+                out, _ = proc.communicate(timeout=limit)
+                return float([l for l in out.splitlines() if l.startswith("SECONDS")][-1].split()[1])
+            except Exception:  # noqa: BLE001  (timeout or no output)
+                proc.kill()
+                return None
+        points = {}
+        for nt, lim in ((64, 25), (128, 25), (host_cores, 45)):
+            if nt > host_cores or str(nt) in points:
+                continue
+            sec = seconds(*child(nt, 1, lim, seed))
+            points[str(nt)] = ({"value": 1.0 / sec, "unit": "instances/s", "threads": nt, "sample": f"1 instance, {sec:.1f} s, one process"} if sec
+                               else {"value": None, "threads": nt, "sample": f"not finished within {lim} s in one process"})
+        nproc, per = max(host_cores // threads, 1), 2
+        t0 = time.perf_counter()
+        procs = [child(threads, per, 60, seed + 100 * i) for i in range(nproc)]
+        secs = [seconds(pr, lim) for pr, lim in procs]
+        wall = time.perf_counter() - t0
+        if all(x is not None for x in secs):
+            # throughput over the slowest process's solve time (interpreter start-up and the imports are not the workload)
+            points["pool"] = {"value": nproc * per / max(secs), "unit": "instances/s", "processes": nproc, "threads_per_process": threads,
+                              "cores": nproc * threads, "sample": f"{nproc} processes x {per} instances, slowest {max(secs):.1f} s (wall incl. start-up {wall:.1f} s)"}
+        else:
+            points["pool"] = {"value": None, "sample": f"{nproc} processes x {threads} threads: not finished within 60 s"}
+        rec["wider"] = points
+        rec["all_host_cores"] = points.get(str(host_cores))
+        best = max((v for v in points.values() if v and v.get("value")), key=lambda v: v["value"], default=None)
+        if best and best["value"] > rec["value"]:            # the fastest measured point is the baseline
+            rec.update({"value": best["value"], "cores": best.get("cores", best.get("threads")), "threads": best.get("threads", best.get("threads_per_process")),
+                        "sample": best["sample"] + f" ({'pool of processes' if 'processes' in best else 'one process'}; 32-thread single process: {done / spent:.3f} instances/s)"})
     return rec
 
 

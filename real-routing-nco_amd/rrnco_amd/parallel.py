@@ -25,6 +25,25 @@ def aggregate_throughput(local_units: int, local_seconds: float, distributed: bo
     return int(round(u.item())), float(t.item())
 
 
+ALLREDUCE_LOG = []      # (seconds | (start event, end event), bytes) of the last gradient all-reduces: train.py prints their mean with its step log
+
+
+def allreduce_summary(reset: bool = True):
+    """-> (mean ms per all-reduce, MB per all-reduce, count) over ALLREDUCE_LOG's finished entries, or None."""
+    ms, nbytes = [], 0
+    for t, b in ALLREDUCE_LOG:
+        if isinstance(t, tuple):
+            if not t[1].query():
+                continue
+            ms.append(t[0].elapsed_time(t[1]))
+        else:
+            ms.append(t * 1e3)
+        nbytes = b
+    if reset:
+        ALLREDUCE_LOG.clear()
+    return (sum(ms) / len(ms), nbytes / 1e6, len(ms)) if ms else None
+
+
 def allreduce_flat_gradients(grads, world: int):
     """Data-parallel gradient combine as Lightning's DDPStrategy does for the reference (configs/trainer/default.yaml:12-15):
     ONE flat fp32 buffer (13.5-17.2 MB for RRNet), one sum all-reduce over RCCL / xGMI, then / world (mean).  Parameters
@@ -36,11 +55,21 @@ def allreduce_flat_gradients(grads, world: int):
     flat = torch.cat([g.reshape(-1).float() for g in grads])
     if world > 1:
         if flat.is_cuda and dist.get_backend() != "nccl":      # gloo (ranks sharing a GPU in the tests): through the host
+            import time
             host = flat.cpu()
+            t0 = time.perf_counter()
             dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            ALLREDUCE_LOG.append((time.perf_counter() - t0, flat.numel() * 4))
             flat.copy_(host)
+        elif flat.is_cuda:                                      # RCCL: device time of the collective by events on its stream, read lazily
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            e1.record()
+            ALLREDUCE_LOG.append(((e0, e1), flat.numel() * 4))
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        del ALLREDUCE_LOG[:-256]
         flat /= world
     out, off = [], 0
     for g in grads:

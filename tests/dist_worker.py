@@ -20,6 +20,10 @@ assert units == 1001 and abs(tmax - 0.75) < 1e-9
 g = [torch.full((3, 2), float(rank + 1)), torch.zeros(5), torch.arange(4.0) * (rank + 1)]
 red = allreduce_flat_gradients(g, world)
 assert torch.allclose(red[0], torch.full((3, 2), 1.5)) and torch.equal(red[1], torch.zeros(5)) and torch.allclose(red[2], torch.arange(4.0) * 1.5)
+# CPU tensors over gloo are not timed; the device paths are (train.py prints allreduce_summary() with its step log: the first real
+# multi-GPU run yields the all-reduce time without a code change)
+from rrnco_amd.parallel import allreduce_summary
+assert allreduce_summary() is None
 
 # ---- data-parallel REINFORCE gradient (BASELINE configs[4]): each rank replays ITS shard of instances with the loss mean
 # taken over its own rollouts, one flat all-reduce (mean) — must equal the single-process gradient over all instances

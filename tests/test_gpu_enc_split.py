@@ -2,7 +2,7 @@
 one-workgroup-per-block kernels it replaces at the headline shape (k_enc_block_w<7, true, false> + k_enc_ffn<7>, RR_ENC_SPLIT=0).
 Same arithmetic, operand forms and reduction orders, and no implicit multiply-add contraction in either (rr_encoder.hip): per layer
 K, V and num come out bit-identical and den differs in a handful of its 25 600 elements per block by one unit in the last place
-(tools/scratch/debug_enc_split.py; both within one ulp of float64).  The instance norms amplify that: after six layers the two
+(tools/debug_enc_split.py; both within one ulp of float64).  The instance norms amplify that: after six layers the two
 encoders agree to ~1e-6 .. 1e-5 on values up to 5 — an order of magnitude inside their distance to the reference (<= 1.1e-4).
 TWIN_ATOL below is that bound with a margin; the parity of the (default, re-cut) path with the REFERENCE is what
 test_gpu_atsp / _rcvrp / _rcvrptw check.  Covered: all three problems (ATSP / RCVRP: NAB tables evaluated inside k_enc_mix;

@@ -97,8 +97,11 @@ def main(argv=None):
             if (it + 1) % o.log_every == 0 or it + 1 == steps_per_epoch:
                 run_loss, run_rew = float(out["loss"]), float(out["reward"].mean())
                 if rank == 0:
+                    from rrnco_amd.parallel import allreduce_summary
+                    ar = allreduce_summary()          # the step's one collective (RCCL over xGMI): device time by events, None on a single rank
                     print(f"epoch {epoch} step {it + 1}/{steps_per_epoch}  loss {run_loss:.4f}  train/reward {run_rew:.4f}  "
-                          f"grad_norm {float(out['grad_norm']):.3f}  {seen * world / (time.perf_counter() - t0):.0f} inst/s", flush=True)
+                          f"grad_norm {float(out['grad_norm']):.3f}  {seen * world / (time.perf_counter() - t0):.0f} inst/s"
+                          + (f"  all-reduce {ar[0]:.3f} ms / {ar[1]:.1f} MB (mean of {ar[2]})" if ar else ""), flush=True)
         sched.step()
         policy.eval()
         val = model.shared_step(val_batch, phase="val")
