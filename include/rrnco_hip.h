@@ -176,6 +176,13 @@ int rr_edge_angles(const float* locs, float* theta, int Bp, int N, hipStream_t s
 int rr_nab_dur(const NabDurW* wrow, const NabDurW* wcol, const float* D, const float* T, const float* locs,
                float* bias_out, int Bp, int N, hipStream_t stream);
 
+/* rr_nab_dur for a batch of n_aug (= 8) augmentations of Bp / n_aug base instances, augmentation-major as
+ * StateAugmentation builds it (rrnco/models/utils/transforms.py:142-154: instance a B + b holds the matrices of base instance b
+ * and its own reflected coordinates): distance and duration are read from the first block and their share of the evaluation is
+ * done once per edge for all copies.  RR_EINVAL for anything else (callers then use rr_nab_dur).  Same output layout. */
+int rr_nab_dur_aug(const NabDurW* wrow, const NabDurW* wcol, const float* D, const float* T, const float* locs,
+                   float* bias_out, int Bp, int N, int n_aug, hipStream_t stream);
+
 /* Ablation bias modules, nab_type "heuristic" (kind 0, rrnco/models/nn/attn_freenet.py:119-167) and "naive" (kind 1,
  * :170-199; needs T and locs), for the row and col block of one layer -> bias_out [Bp][2][N*N] (x alpha), fed to
  * rr_enc_layer as bias_pre. */

@@ -621,6 +621,134 @@ __global__ __launch_bounds__(NABL_THREADS) void k_nab_dur_lds(NabDurW wr, NabDur
   }
 }
 
+// The same evaluation for a batch that is A augmentations of B base instances, augmentation-major (StateAugmentation: instance
+// a B + b carries the matrices of base instance b and its own reflected coordinates; BASELINE configs[3] runs x8).  The distance and
+// duration inputs of an edge — two of the three table-row gathers and two of the three piecewise-linear evaluations per gate unit —
+// are the same for all A copies: a thread takes ONE edge of a base instance and all its A angles.  Per edge, unit pair and copy:
+// one 16-byte LDS read and 11 vector instructions instead of three reads and 14 (k_nab_dur_lds), the 4 transcendentals unchanged.
+template <int A>
+__global__ __launch_bounds__(NABL_THREADS) void k_nab_dur_aug(NabDurW wr, NabDurW wc, const float* __restrict__ D,
+                                                              const float* __restrict__ T, const float* __restrict__ locs,
+                                                              float* __restrict__ bias_out, int N, int B) {
+  extern __shared__ __attribute__((aligned(16))) float nabl_sm[];
+  float* head = nabl_sm;
+  float* tab = nabl_sm + NABL_HEAD;
+  const int b = blockIdx.y, is_col = blockIdx.z;
+  const NabDurW& w = is_col ? wc : wr;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < NABD_ROWS; i += NABL_THREADS) head[i] = w.pwl[i];
+  __syncthreads();
+  const int NN = N * N;
+  const int e0 = blockIdx.x * NABL_THREADS;
+  const float* Db = D + (size_t)b * NN;
+  const float* Tb = T + (size_t)b * NN;
+  const unsigned char* cell = reinterpret_cast<const unsigned char*>(head + NABD_CELL);
+  int e = e0 + tid; e = e < NN ? e : NN - 1;
+  const int i = e / N, jj = e - i * N;
+  // ---- segments and anchor distances: d and t once, the angle per copy
+  float dx0, dx2, dxa[A];
+  unsigned seg02, sega[A];
+  {
+    float x[2 + A];
+    x[0] = is_col ? Db[jj * N + i] : Db[e];
+    x[1] = is_col ? Tb[jj * N + i] : Tb[e];
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+      const float* lc = locs + (size_t)(a * B + b) * N * 2;
+      x[2 + a] = atan2f(lc[i * 2 + 1] - lc[jj * 2 + 1], lc[i * 2] - lc[jj * 2]);
+    }
+    int m[2 + A];
+#pragma unroll
+    for (int k = 0; k < 2 + A; ++k) {
+      const int f = k == 0 ? 0 : k == 1 ? 2 : 1;            // table family: 0 distance, 1 angle, 2 duration
+      x[k] = fminf(x[k], 3.0e38f);
+      const int c = f == 1 ? (int)((x[k] + 3.14159265358979f) * ((float)NAB_G / 6.28318530717959f)) : (int)(x[k] * (float)NAB_G);
+      const int s0 = cell[f * NAB_G + min(max(c, 0), NAB_G - 1)];
+      m[k] = c < 0 ? 0 : s0;
+    }
+    int more;
+    do {                                                   // forward scan to the segment (sentinel +inf at index 128)
+      more = 0;
+#pragma unroll
+      for (int k = 0; k < 2 + A; ++k) {
+        const int f = k == 0 ? 0 : k == 1 ? 2 : 1;
+        const int adv = head[f * NABD_TS + m[k]] <= x[k] ? 1 : 0;
+        m[k] += adv; more |= adv;
+      }
+    } while (__any(more));
+    dx0 = x[0] - head[NABD_ANC + 0 * NABD_TS + m[0]];
+    dx2 = x[1] - head[NABD_ANC + 2 * NABD_TS + m[1]];
+    seg02 = (unsigned)m[0] | ((unsigned)m[1] << 8);
+#pragma unroll
+    for (int a = 0; a < A; ++a) { dxa[a] = x[2 + a] - head[NABD_ANC + 1 * NABD_TS + m[2 + a]]; sega[a] = (unsigned)m[2 + a]; }
+  }
+  f32x2 c0[A], c1[A], c2[A];                               // the three gate logits per copy, two partial sums each (even / odd units)
+#pragma unroll
+  for (int a = 0; a < A; ++a) { c0[a] = f32x2{0.f, 0.f}; c1[a] = f32x2{0.f, 0.f}; c2[a] = f32x2{0.f, 0.f}; }
+  const float* rows = w.pwl + NABD_ROWS + 3 * NABD_SEG * 2 * RR_E;
+#pragma unroll 1
+  for (int s = 0; s < 4; ++s) {
+    __syncthreads();                                       // everyone is done with the previous slice
+    const float4* src = reinterpret_cast<const float4*>(rows + (size_t)s * NABL_SLICE);
+    for (int q = tid; q < NABL_SLICE / 4; q += NABL_THREADS) {
+      const float4 v = src[q];
+      const int row = q >> 4, c = (q & 15) * 4;
+      *reinterpret_cast<float4*>(tab + row * NABL_RS + c) = v;
+    }
+    __syncthreads();
+    const float* g0 = w.wg2 + 32 * s;
+    const float4* r0 = reinterpret_cast<const float4*>(tab) + (seg02 & 255u) * (NABL_RS / 4);
+    const float4* r2 = reinterpret_cast<const float4*>(tab) + (2 * NABD_SEG + (seg02 >> 8)) * (NABL_RS / 4);
+    const f32x2 d0 = {dx0, dx0}, d2 = {dx2, dx2};
+#pragma unroll 2
+    for (int p = 0; p < 16; ++p) {
+      const float4 q0 = r0[p], q2 = r2[p];
+      const f32x2 F0 = {q0.x, q0.y}, S0 = {q0.z, q0.w}, F2 = {q2.x, q2.y}, S2 = {q2.z, q2.w};
+      const f32x2 zdt = (S0 * d0 + F0) + (S2 * d2 + F2);   // distance + duration part of the pair's pre-activation: shared by the copies
+      const f32x2 w0 = {g0[2 * p], g0[2 * p + 1]}, w1 = {g0[128 + 2 * p], g0[128 + 2 * p + 1]}, w2 = {g0[256 + 2 * p], g0[256 + 2 * p + 1]};
+#pragma unroll
+      for (int a = 0; a < A; ++a) {
+        const float4 q1 = (reinterpret_cast<const float4*>(tab) + (NABD_SEG + sega[a]) * (NABL_RS / 4))[p];
+        const f32x2 F1 = {q1.x, q1.y}, S1 = {q1.z, q1.w}, d1 = {dxa[a], dxa[a]};
+        const f32x2 z = zdt + (S1 * d1 + F1);
+        const f32x2 t = z * -1.44269504088896341f;
+        f32x2 ex = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};   // SiLU, as k_nab_dur_lds
+        ex = ex + 1.0f;
+        const f32x2 rc = {__builtin_amdgcn_rcpf(ex.x), __builtin_amdgcn_rcpf(ex.y)};
+        const f32x2 zs = z * rc;
+        c0[a] = w0 * zs + c0[a]; c1[a] = w1 * zs + c1[a]; c2[a] = w2 * zs + c2[a];
+      }
+    }
+  }
+  const int m0 = (int)(seg02 & 255u), m2 = (int)(seg02 >> 8);
+  const float* os0 = head + NABD_OSC + (0 * NABD_SEG + m0) * 2;
+  const float* os2 = head + NABD_OSC + (2 * NABD_SEG + m2) * 2;
+  const float ox0 = fmaf(os0[1], dx0, os0[0]), ox2 = fmaf(os2[1], dx2, os2[0]);
+#pragma unroll
+  for (int a = 0; a < A; ++a) {
+    const float* os1 = head + NABD_OSC + (1 * NABD_SEG + (int)sega[a]) * 2;
+    const float ox1 = fmaf(os1[1], dxa[a], os1[0]);
+    const float l0 = ((c0[a].x + c0[a].y) + w.bg2[0]) * w.inv_tau, l1 = ((c1[a].x + c1[a].y) + w.bg2[1]) * w.inv_tau,
+                l2 = ((c2[a].x + c2[a].y) + w.bg2[2]) * w.inv_tau;
+    const float mx = fmaxf(l0, fmaxf(l1, l2));
+    const float e0x = rr_exp(l0 - mx), e1x = rr_exp(l1 - mx), e2x = rr_exp(l2 - mx);
+    const float inv = 1.0f / (e0x + e1x + e2x);
+    const float bias = (e0x * inv) * ox0 + (e1x * inv) * ox1 + (e2x * inv) * ox2 + w.bo;
+    if (e0 + tid < NN) bias_out[((size_t)(a * B + b) * 2 + is_col) * NN + e] = bias * w.alpha;
+  }
+}
+
+extern "C" int rr_nab_dur_aug(const NabDurW* wrow, const NabDurW* wcol, const float* D, const float* T, const float* locs,
+                              float* bias_out, int Bp, int N, int n_aug, hipStream_t st) {
+  if (Bp <= 0 || N < 2 || wrow == nullptr || wcol == nullptr || !D || !T || !locs || !bias_out) return RR_EINVAL;
+  if (n_aug != 8 || Bp % 8 != 0 || wrow->pwl == nullptr || wcol->pwl == nullptr || N * N < 2048) return RR_EINVAL;   // the x8 dihedral form only: callers fall back to rr_nab_dur
+  const int NN = N * N, B = Bp / 8;
+  (void)hipFuncSetAttribute((const void*)k_nab_dur_aug<8>, hipFuncAttributeMaxDynamicSharedMemorySize, NABL_LDS_BYTES);
+  hipLaunchKernelGGL(k_nab_dur_aug<8>, dim3((NN + NABL_THREADS - 1) / NABL_THREADS, B, 2), dim3(NABL_THREADS), NABL_LDS_BYTES, st, *wrow, *wcol,
+                     D, T, locs, bias_out, N, B);
+  return rr_check(hipGetLastError());
+}
+
 extern "C" int rr_nab_dur(const NabDurW* wrow, const NabDurW* wcol, const float* D, const float* T, const float* locs,
                           float* bias_out, int Bp, int N, hipStream_t st) {
   if (Bp <= 0 || N < 2 || wrow == nullptr || wcol == nullptr || !D || !T || !locs || !bias_out) return RR_EINVAL;

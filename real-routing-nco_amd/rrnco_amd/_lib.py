@@ -122,6 +122,7 @@ _SIGS = {
     "rr_enc_layer_split": [C.POINTER(EncBlockW), C.POINTER(EncBlockW), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "rr_edge_angles": [vp, vp, i32, i32, vp],
     "rr_nab_dur": [C.POINTER(NabDurW), C.POINTER(NabDurW), vp, vp, vp, vp, i32, i32, vp],
+    "rr_nab_dur_aug": [C.POINTER(NabDurW), C.POINTER(NabDurW), vp, vp, vp, vp, i32, i32, i32, vp],
     "rr_nab_simple": [C.POINTER(NabSimpleW), C.POINTER(NabSimpleW), i32, vp, vp, vp, vp, i32, i32, vp],
     "rr_rmtvrp_step": [vp] * 16 + [i32, i32, i32, C.POINTER(MtvrpExtra), vp],
     "rr_reinforce_loss": [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],

@@ -13,6 +13,13 @@ from ..tensordict_lite import TensorDict
 from .base import EnvBase
 
 
+def _aug_note(td) -> dict:
+    """StateAugmentation's host-side note (the batch is num_augment copies of the base instances that differ in `locs` only) survives
+    the reset: the encoder's duration NAB shares the distance / duration part of its evaluation over the copies (rr_nab_dur_aug)."""
+    n = getattr(td, "meta", {}).get("num_augment") if hasattr(td, "meta") else None
+    return {"num_augment": n} if n else {}
+
+
 def vrptw_capacity(n: int) -> float:
     return 30.0 + (n // 5 if n > 20 else 0)          # rmtvrp/generator.py:20-33
 
@@ -164,7 +171,7 @@ class RMTVRPEnv(EnvBase):
             visited=torch.zeros((*batch_size, n1), dtype=torch.bool, device=dev))
         if td.get("sample_idx", None) is not None:
             out["sample_idx"] = td["sample_idx"]
-        res = TensorDict(out, batch_size=batch_size, meta={"i": 0, "mtvrp_variant": variant})
+        res = TensorDict(out, batch_size=batch_size, meta={"i": 0, "mtvrp_variant": variant, **_aug_note(td)})
         res.set("action_mask", self.get_action_mask(res))
         return res
 

@@ -260,7 +260,14 @@ class RRNetEncoder(nn.Module):
                                           L.ptr(bias), Bp, N, L.stream()), "rr_nab_simple")
             elif use_dur:
                 nr, nc = packed["nabdur"][l]
-                L.check(lib.rr_nab_dur(nr, nc, L.ptr(D), L.ptr(T), L.ptr(locs), L.ptr(bias), Bp, N, L.stream()), "rr_nab_dur")
+                n_aug = getattr(td, "meta", {}).get("num_augment", 1) if hasattr(td, "meta") else 1
+                if (n_aug == 8 and Bp % 8 == 0 and N * N >= 2048 and train_saves is None and nr.pwl and nc.pwl
+                        and _os.environ.get("RR_NABDUR_AUG", "1") != "0"):
+                    # x8 augmentation (StateAugmentation's note): distance and duration are those of the base instance in all 8 copies —
+                    # their table rows and piecewise-linear evaluations once per edge (csrc/rr_encoder.hip: k_nab_dur_aug)
+                    L.check(lib.rr_nab_dur_aug(nr, nc, L.ptr(D), L.ptr(T), L.ptr(locs), L.ptr(bias), Bp, N, 8, L.stream()), "rr_nab_dur_aug")
+                else:
+                    L.check(lib.rr_nab_dur(nr, nc, L.ptr(D), L.ptr(T), L.ptr(locs), L.ptr(bias), Bp, N, L.stream()), "rr_nab_dur")
             if train_saves is not None:
                 sv = []
                 for _ in range(2):

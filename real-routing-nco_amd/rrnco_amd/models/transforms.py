@@ -83,4 +83,9 @@ class StateAugmentation:
             if not self.first_aug_identity:
                 aug[[b], 0] = init
             out[feat] = aug
-        return TensorDict(out, batch_size=[b * self.num_augment, *td.batch_size[1:]], meta=td.meta)
+        # host-side note for the kernels: the batch is num_augment copies of b base instances, augmentation-major, that differ in
+        # `feats` only (the matrices of copy a are those of copy 0) — the duration NAB evaluates the shared part once (rr_nab_dur_aug)
+        meta = dict(td.meta)
+        if self.feats in (["locs"], []):
+            meta["num_augment"] = self.num_augment
+        return TensorDict(out, batch_size=[b * self.num_augment, *td.batch_size[1:]], meta=meta)

@@ -169,6 +169,35 @@ def test_duration_nab_three_kernel_generations_agree(n_nodes, monkeypatch):
         assert (a - c).abs().max() < 2e-5 * (1 + c.abs().max())
 
 
+@pytest.mark.parametrize("n_nodes", [51, 101])
+def test_duration_nab_shared_over_the_eight_augmentations_agrees(n_nodes):
+    """rr_nab_dur_aug (x8 dihedral augmentation: distance / duration part of an edge evaluated once for the 8 copies) against rr_nab_dur
+    on the replicated batch: the same folded formula, the three families summed in another order; and the encoder takes it exactly
+    when StateAugmentation's note says the batch is such a batch."""
+    from rrnco_amd import _lib as L
+    from rrnco_amd import TensorDict
+    from rrnco_amd.models.transforms import StateAugmentation
+    fx, w, pol, inst, env, td_in = _setup("rcvrptw_n20_b4_pomo")
+    packed = pol.packed(torch.device("cuda"))
+    g = torch.Generator().manual_seed(7 * n_nodes)
+    B, N = 3, n_nodes
+    base = TensorDict({"distance_matrix": torch.rand(B, N, N, generator=g).cuda(), "duration_matrix": torch.rand(B, N, N, generator=g).cuda(),
+                       "locs": torch.rand(B, N, 2, generator=g).cuda()}, batch_size=[B])
+    td = StateAugmentation(augment_fn="dihedral8", no_aug_coords=False)(base)
+    assert td.meta.get("num_augment") == 8
+    D, T, locs = td["distance_matrix"].contiguous(), td["duration_matrix"].contiguous(), td["locs"].contiguous()
+    Bp = 8 * B
+    for nr, nc in packed["nabdur"]:
+        a = torch.full((Bp, 2, N * N), float("nan"), device="cuda"); b = torch.full_like(a, float("nan"))
+        L.check(L.lib().rr_nab_dur(nr, nc, L.ptr(D), L.ptr(T), L.ptr(locs), L.ptr(a), Bp, N, L.stream()), "rr_nab_dur")
+        L.check(L.lib().rr_nab_dur_aug(nr, nc, L.ptr(D), L.ptr(T), L.ptr(locs), L.ptr(b), Bp, N, 8, L.stream()), "rr_nab_dur_aug")
+        assert torch.isfinite(b).all()
+        assert (a - b).abs().max() < 1e-5 * (1 + a.abs().max()), float((a - b).abs().max())
+    # anything that is not the x8 form is refused (callers fall back to rr_nab_dur)
+    nr, nc = packed["nabdur"][0]
+    assert L.lib().rr_nab_dur_aug(nr, nc, L.ptr(D), L.ptr(T), L.ptr(locs), L.ptr(a), Bp, N, 4, L.stream()) != 0
+
+
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("name", FIXTURES)
 def test_rcvrptw_policy_greedy_routes_match_reference(name, fused):
