@@ -540,7 +540,18 @@ def other_configs(dev):
     if "achieved" in roof:
         roof["frac"] = roof["achieved"] / roof["peak"]
     o = state["out"]
+    # the opt-in 16-mixed training step (configs/trainer/default.yaml:8 is the reference's own training precision): one bf16 piece per
+    # operand in the pointer MLP's and the encoder FFNs' backward products, fp32 accumulation, gradients and master weights; its
+    # gradient sits 2.3-2.6 % from the fp32-equivalent step's, the reference's own autocast gradient 9-12 % (fp16) / 70-87 % (bf16) from
+    # its fp32 one (tests/test_gpu_mixed.py).  A VARIANT: never `value`.
+    pol.precision = "16-mixed"
+    train_step()
+    sec16, n16 = timed_loop(train_step)
+    pol.precision = "32"
     out["C5 ATSP n=100 REINFORCE step, 512 instances (one rank's shard of configs[4])"] = {
+        "variants": {"16_mixed_training_step (precision='16-mixed')": {
+            "value": 512 / sec16, "unit": "trained instances/s", "ms_per_step": sec16 * 1e3, "steps": n16,
+            "dtype": "bf16 operands (one piece) in the two 128-512-128 MLPs' backward products, f32 accumulate; everything else as the default step"}},
         "value": 512 / sec, "unit": "trained instances/s", "ms_per_step": sec * 1e3, "steps": n,
         "kernel_ms": sum(ks) / max(len(ks), 1), "kernel": "k_rollout_w<7, 0, 1, true, true, false> (sampling rollout with the training dump)",
         "backward_kernels_ms_per_step": {k: round(v, 3) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},

@@ -267,7 +267,8 @@ typedef struct { const void *wa1, *wa2, *wb; const float *b1, *b2; } MlpRowsW;  
 typedef struct { const void *w1n, *w2tn; const float *b1; } MlpWgradW;
 /* The 128 -> 512 -> 128 ReLU MLP with residual on rows (pointer MLP decoder.py:272-277, 296; TransformerFFN
  * attn_freenet.py:330-357) on the bf16 matrix pipe with two-piece split fp32 operands:
- * mode 0: out = x + W2 relu(W1 x + b1) + b2;  mode 1: out = dy + W1^T[(W2^T dy) . 1(W1 x + b1 > 0)].
+ * mode 0: out = x + W2 relu(W1 x + b1) + b2;  mode 1: out = dy + W1^T[(W2^T dy) . 1(W1 x + b1 > 0)];
+ * modes 2 / 3 = 0 / 1 with ONE bf16 piece per operand: the opt-in "16-mixed" training step (configs/trainer/default.yaml:8).
  * Rows: nseg segments of seg_rows rows, seg_stride rows apart; meta (optional, the rollout's [rows][8] dump): rows whose
  * live flag meta[m][6] is 0 hold no data and are read as zero rows. */
 int rr_mlp_rows(const MlpRowsW* w, int mode, const float* X, const float* dY, float* out, const uint32_t* meta,
@@ -276,6 +277,9 @@ int rr_mlp_rows(const MlpRowsW* w, int mode, const float* X, const float* dY, fl
  * or 64 * 2 * 512 * 128 floats: the row splits' partials of dW1 / dW2, added up in a fixed order. */
 int rr_mlp_wgrad(const MlpWgradW* w, const float* X, const float* dY, float* dW1, float* db1, float* dW2, float* db2,
                  const uint32_t* meta, int nseg, int seg_rows, long long seg_stride, float* ws, hipStream_t stream);
+/* the same with ONE bf16 piece per operand (16-mixed; fp32 accumulation, fp32 gradients out) */
+int rr_mlp_wgrad16(const MlpWgradW* w, const float* X, const float* dY, float* dW1, float* db1, float* dW2, float* db2,
+                   const uint32_t* meta, int nseg, int seg_rows, long long seg_stride, float* ws, hipStream_t stream);
 
 typedef struct {
   const float *dg0; const uint32_t *meta; const float *scal; const int64_t *first;

@@ -378,9 +378,15 @@ __device__ __forceinline__ void td_split8(const float (&x)[8], bfrag& hi, bfrag&
     hi[2 * q] = h[0]; hi[2 * q + 1] = h[1]; lo[2 * q] = l[0]; lo[2 * q + 1] = l[1];
   }
 }
+// HALF (the opt-in "16-mixed" training step, configs/trainer/default.yaml:8): ONE bf16 piece per operand — what the reference's own
+// training precision multiplies (autocast: half-precision matmuls, fp32 accumulate and master weights) — a third of the matrix
+// instructions.  Never the default; tolerance: tests/test_gpu_mixed.py against the reference's gradients under autocast.
+template <bool HALF = false>
 __device__ __forceinline__ f32x4 td_mfma3(bfrag ah, bfrag al, bfrag bh, bfrag bl, f32x4 c) {
-  c = rr_mfma_bf16(ah, bl, c);
-  c = rr_mfma_bf16(al, bh, c);
+  if constexpr (!HALF) {
+    c = rr_mfma_bf16(ah, bl, c);
+    c = rr_mfma_bf16(al, bh, c);
+  }
   return rr_mfma_bf16(ah, bh, c);
 }
 __device__ __forceinline__ void td_glds16(const void* gsrc, void* ldst) {
@@ -400,7 +406,7 @@ struct MlpRowsW {
 // A workgroup = 8 waves x 16 rows (two waves per SIMD); the weight fragments of one hidden pair (32 units) are one LDS stage,
 // filled by LDS-DMA one stage ahead, one barrier per stage.  The rows of the workgroup's next block are requested during the
 // first stage of the current one and converted when it is done.
-template <int MODE>
+template <int MODE, bool HALF = false>
 __global__ __launch_bounds__(512, 1) void k_mlp_rows(MlpRowsW w, const float* __restrict__ X, const float* __restrict__ dY,
                                                      float* __restrict__ out, RowSegs rs, const uint32_t* __restrict__ meta) {
   constexpr int NF = MODE == 1 ? 48 : 32;                 // fragments (1 KB each) per stage
@@ -489,10 +495,10 @@ __global__ __launch_bounds__(512, 1) void k_mlp_rows(MlpRowsW w, const float* __
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const bfrag ah = frag(buf, tl * 8 + s * 2), al = frag(buf, tl * 8 + s * 2 + 1);
-          pre[tl] = td_mfma3(ah, al, Xh[s], Xl[s], pre[tl]);
+          pre[tl] = td_mfma3<HALF>(ah, al, Xh[s], Xl[s], pre[tl]);
           if (MODE == 1) {
             const bfrag ch = frag(buf, 16 + tl * 8 + s * 2), cl = frag(buf, 16 + tl * 8 + s * 2 + 1);
-            dpre[tl] = td_mfma3(ch, cl, Yh[s], Yl[s], dpre[tl]);
+            dpre[tl] = td_mfma3<HALF>(ch, cl, Yh[s], Yl[s], dpre[tl]);
           }
         }
       }
@@ -510,7 +516,7 @@ __global__ __launch_bounds__(512, 1) void k_mlp_rows(MlpRowsW w, const float* __
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const bfrag bh = frag(buf, FB + u * 2), bl = frag(buf, FB + u * 2 + 1);
-        acc[u] = td_mfma3(bh, bl, Hh, Hl, acc[u]);
+        acc[u] = td_mfma3<HALF>(bh, bl, Hh, Hl, acc[u]);
       }
     }
     if (vr) {
@@ -527,18 +533,31 @@ extern "C" int rr_mlp_rows(const MlpRowsW* w, int mode, const float* X, const fl
   if (w == nullptr || X == nullptr || out == nullptr || w->wa1 == nullptr || w->wb == nullptr || w->b1 == nullptr) return RR_EINVAL;
   if (mode == 1 && (dY == nullptr || w->wa2 == nullptr)) return RR_EINVAL;
   if (mode == 0 && w->b2 == nullptr) return RR_EINVAL;
+  const bool half = (mode & 2) != 0;                     // modes 2 / 3: modes 0 / 1 with one bf16 piece per operand ("16-mixed")
+  mode &= ~2;
   if (mode < 0 || mode > 1 || nseg <= 0 || seg_rows <= 0 || seg_stride < seg_rows) return RR_EINVAL;
   RowSegs rs{nseg, seg_rows, seg_stride};
   const long long nblk = ((long long)nseg * seg_rows + 127) / 128;
   const unsigned grid = (unsigned)(nblk < 256 * 8 ? nblk : 256 * 8);
+  if (half) {
+    const int shm = 2 * (mode == 1 ? 48 : 32) * 1024 + RR_FF * 4;
+    if (mode == 1) {
+      (void)hipFuncSetAttribute((const void*)k_mlp_rows<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+      hipLaunchKernelGGL((k_mlp_rows<1, true>), dim3(grid), dim3(512), shm, st, *w, X, dY, out, rs, meta);
+    } else {
+      (void)hipFuncSetAttribute((const void*)k_mlp_rows<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+      hipLaunchKernelGGL((k_mlp_rows<0, true>), dim3(grid), dim3(512), shm, st, *w, X, dY, out, rs, meta);
+    }
+    return rr_check(hipGetLastError());
+  }
   if (mode == 1) {
     const int shm = 2 * 48 * 1024 + RR_FF * 4;
-    (void)hipFuncSetAttribute((const void*)k_mlp_rows<1>, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-    hipLaunchKernelGGL((k_mlp_rows<1>), dim3(grid), dim3(512), shm, st, *w, X, dY, out, rs, meta);
+    (void)hipFuncSetAttribute((const void*)k_mlp_rows<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+    hipLaunchKernelGGL((k_mlp_rows<1, false>), dim3(grid), dim3(512), shm, st, *w, X, dY, out, rs, meta);
   } else {
     const int shm = 2 * 32 * 1024 + RR_FF * 4;
-    (void)hipFuncSetAttribute((const void*)k_mlp_rows<0>, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-    hipLaunchKernelGGL((k_mlp_rows<0>), dim3(grid), dim3(512), shm, st, *w, X, dY, out, rs, meta);
+    (void)hipFuncSetAttribute((const void*)k_mlp_rows<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+    hipLaunchKernelGGL((k_mlp_rows<0, false>), dim3(grid), dim3(512), shm, st, *w, X, dY, out, rs, meta);
   }
   return rr_check(hipGetLastError());
 }
@@ -561,6 +580,7 @@ struct MlpWgradW {
 // (f & 3) * WG_TQ + (f >> 2).  A staging thread owns rows 16 rt + 4 gg + (0..3) of four consecutive features: its 8-byte
 // writes run along the slots (lanes = consecutive slots, the two half-waves = the two halves of a slot) and the 16-byte
 // operand reads of a 16-feature tile hit 16 different bank quads: neither side conflicts.
+template <bool HALF>
 __global__ __launch_bounds__(512, 1) void k_mlp_wgrad(MlpWgradW w, const float* __restrict__ X, const float* __restrict__ dY,
                                                       float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2,
                                                       float* __restrict__ db2, RowSegs rs, int nsplit, const uint32_t* __restrict__ meta,
@@ -694,8 +714,8 @@ __global__ __launch_bounds__(512, 1) void k_mlp_wgrad(MlpWgradW w, const float* 
       if (i + 1 < 8) ld_rm(buf, (i + 1) >> 1, (i + 1) & 1, fa[(i + 1) & 1]);
       else ld_tr(buf, 0, fa[0]);
       const int s = i >> 1, rt = i & 1;
-      pre[rt] = td_mfma3(fa[i & 1][0], fa[i & 1][1], W1h[s], W1l[s], pre[rt]);
-      dpre[rt] = td_mfma3(fa[i & 1][2], fa[i & 1][3], W2h[s], W2l[s], dpre[rt]);
+      pre[rt] = td_mfma3<HALF>(fa[i & 1][0], fa[i & 1][1], W1h[s], W1l[s], pre[rt]);
+      dpre[rt] = td_mfma3<HALF>(fa[i & 1][2], fa[i & 1][3], W2h[s], W2l[s], dpre[rt]);
       if ((i & 1) == 0) stage(i >> 1, buf ^ 1, cn, rn);       // (also for the last chunk: the rows past the end stage as zeros)
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -720,8 +740,8 @@ __global__ __launch_bounds__(512, 1) void k_mlp_wgrad(MlpWgradW w, const float* 
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       if (u + 1 < 8) ld_tr(buf, u + 1, fa[(u + 1) & 1]);
-      aW2[u] = td_mfma3(fa[u & 1][2], fa[u & 1][3], Hh, Hl, aW2[u]);      // [feat][hid] += dy^T H
-      aW1[u] = td_mfma3(fa[u & 1][0], fa[u & 1][1], Gh, Gl, aW1[u]);      // [feat][hid] += x^T dH  (= dW1^T)
+      aW2[u] = td_mfma3<HALF>(fa[u & 1][2], fa[u & 1][3], Hh, Hl, aW2[u]);      // [feat][hid] += dy^T H
+      aW1[u] = td_mfma3<HALF>(fa[u & 1][0], fa[u & 1][1], Gh, Gl, aW1[u]);      // [feat][hid] += x^T dH  (= dW1^T)
       if ((u & 1) == 0) stage(4 + (u >> 1), buf ^ 1, cn, rn);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -781,8 +801,8 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 
 // dW1 [512][128], db1 [512], dW2 [128][512], db2 [128]: ADDED to (caller zeroes them).  ws: NULL (float atomics) or 64 * 2 * 512 * 128
 // floats for the row splits' partials of dW1 / dW2 (added up in a fixed order).
-extern "C" int rr_mlp_wgrad(const MlpWgradW* w, const float* X, const float* dY, float* dW1, float* db1, float* dW2, float* db2,
-                            const uint32_t* meta, int nseg, int seg_rows, long long seg_stride, float* ws, hipStream_t st) {
+static int rr_mlp_wgrad_impl(bool half, const MlpWgradW* w, const float* X, const float* dY, float* dW1, float* db1, float* dW2, float* db2,
+                             const uint32_t* meta, int nseg, int seg_rows, long long seg_stride, float* ws, hipStream_t st) {
   if (w == nullptr || w->w1n == nullptr || w->w2tn == nullptr || w->b1 == nullptr || X == nullptr || dY == nullptr ||
       dW1 == nullptr || db1 == nullptr || dW2 == nullptr)
     return RR_EINVAL;
@@ -791,9 +811,19 @@ extern "C" int rr_mlp_wgrad(const MlpWgradW* w, const float* X, const float* dY,
   RowSegs rs{nseg, seg_rows, seg_stride};
   const long long chunks = ((long long)nseg * seg_rows + 31) / 32;
   int nsplit = chunks >= 64 * 8 ? 64 : (chunks >= 64 ? 16 : 8);
-  hipLaunchKernelGGL(k_mlp_wgrad, dim3(4 * nsplit), dim3(512), 0, st, *w, X, dY, dW1, db1, dW2, db2, rs, nsplit, meta, ws);
+  if (half) hipLaunchKernelGGL(k_mlp_wgrad<true>, dim3(4 * nsplit), dim3(512), 0, st, *w, X, dY, dW1, db1, dW2, db2, rs, nsplit, meta, ws);
+  else hipLaunchKernelGGL(k_mlp_wgrad<false>, dim3(4 * nsplit), dim3(512), 0, st, *w, X, dY, dW1, db1, dW2, db2, rs, nsplit, meta, ws);
   if (ws != nullptr) hipLaunchKernelGGL(k_wgrad_reduce, dim3(2 * RR_FF * RR_E / 256), dim3(256), 0, st, ws, dW1, dW2, nsplit);
   return rr_check(hipGetLastError());
+}
+extern "C" int rr_mlp_wgrad(const MlpWgradW* w, const float* X, const float* dY, float* dW1, float* db1, float* dW2, float* db2,
+                            const uint32_t* meta, int nseg, int seg_rows, long long seg_stride, float* ws, hipStream_t st) {
+  return rr_mlp_wgrad_impl(false, w, X, dY, dW1, db1, dW2, db2, meta, nseg, seg_rows, seg_stride, ws, st);
+}
+// the same with ONE bf16 piece per operand (the opt-in 16-mixed training step; see td_mfma3)
+extern "C" int rr_mlp_wgrad16(const MlpWgradW* w, const float* X, const float* dY, float* dW1, float* db1, float* dW2, float* db2,
+                              const uint32_t* meta, int nseg, int seg_rows, long long seg_stride, float* ws, hipStream_t st) {
+  return rr_mlp_wgrad_impl(true, w, X, dY, dW1, db1, dW2, db2, meta, nseg, seg_rows, seg_stride, ws, st);
 }
 
 // ------------------------------------------------------------------------------------------------ attention backward

@@ -156,6 +156,7 @@ _SIGS = {
     "rr_gemm_tn": [vp, vp, vp, i32, i32, i32, i32, i32, i32, C.c_longlong, C.c_longlong, C.c_longlong, i32, i32, vp, vp],
     "rr_mlp_rows": [C.POINTER(MlpRowsW), i32, vp, vp, vp, vp, i32, i32, C.c_longlong, vp],
     "rr_mlp_wgrad": [C.POINTER(MlpWgradW), vp, vp, vp, vp, vp, vp, vp, i32, i32, C.c_longlong, vp, vp],
+    "rr_mlp_wgrad16": [C.POINTER(MlpWgradW), vp, vp, vp, vp, vp, vp, vp, i32, i32, C.c_longlong, vp, vp],
     "rr_dec_attn_bwd": [C.POINTER(DecAttnIO), vp],
 }
 

@@ -102,11 +102,13 @@ def decoder_backward(policy, cache, dump, D, Dur, grad_ll) -> dict:
     dg0 = torch.empty(rows, E, device=dev)
     # ATSP tours all have the same length: every dumped row is live, no flag to consult
     live = None if env_name == "atsp" else dump["meta"]
-    L.check(lib.rr_mlp_rows(mp["bwd"], 1, L.ptr(dump["g0"]), L.ptr(dg), L.ptr(dg0), L.ptr(live), Bp, T * S, seg, st), "rr_mlp_rows")
+    # precision="16-mixed" (opt-in, configs/trainer/default.yaml:8): one bf16 piece per operand in the pointer MLP's backward products
+    half = getattr(policy, "precision", "32") == "16-mixed"
+    L.check(lib.rr_mlp_rows(mp["bwd"], 3 if half else 1, L.ptr(dump["g0"]), L.ptr(dg), L.ptr(dg0), L.ptr(live), Bp, T * S, seg, st), "rr_mlp_rows")
     dW1, db1 = torch.zeros(4 * E, E, device=dev), torch.zeros(4 * E, device=dev)
     dW2, db2 = torch.zeros(E, 4 * E, device=dev), torch.zeros(E, device=dev)
-    L.check(lib.rr_mlp_wgrad(mp["wgrad"], L.ptr(dump["g0"]), L.ptr(dg), L.ptr(dW1), L.ptr(db1), L.ptr(dW2), L.ptr(db2),
-                             L.ptr(live), Bp, T * S, seg, L.ptr(wgrad_workspace(dev)), st), "rr_mlp_wgrad")
+    L.check((lib.rr_mlp_wgrad16 if half else lib.rr_mlp_wgrad)(mp["wgrad"], L.ptr(dump["g0"]), L.ptr(dg), L.ptr(dW1), L.ptr(db1), L.ptr(dW2), L.ptr(db2),
+                                                               L.ptr(live), Bp, T * S, seg, L.ptr(wgrad_workspace(dev)), st), "rr_mlp_wgrad")
     del dg
     # ---- masked multi-head attention: d keys, d values, d query -> the step-context tables
     atsp = env_name == "atsp"

@@ -231,9 +231,10 @@ def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
                 inorm(F, dout, None, b + ".feed_forward.ops.norm2", dF)
                 chk(b + " ffn.norm2 backward", dF=dF)
                 dx1 = F                                                                   # reuse
-                L.check(lib.rr_mlp_rows(mlp["bwd"], 1, L.ptr(S["x1"]), L.ptr(dF), L.ptr(dx1), None, 1, M, M, st), "rr_mlp_rows")
+                half = getattr(policy, "precision", "32") == "16-mixed"      # opt-in: one bf16 piece per operand in the FFN's backward products
+                L.check(lib.rr_mlp_rows(mlp["bwd"], 3 if half else 1, L.ptr(S["x1"]), L.ptr(dF), L.ptr(dx1), None, 1, M, M, st), "rr_mlp_rows")
                 f = b + ".feed_forward.ops.ffn"
-                L.check(lib.rr_mlp_wgrad(mlp["wgrad"], L.ptr(S["x1"]), L.ptr(dF), L.ptr(G.buf(f + ".W1.weight")), L.ptr(G.buf(f + ".W1.bias")),
+                L.check((lib.rr_mlp_wgrad16 if half else lib.rr_mlp_wgrad)(mlp["wgrad"], L.ptr(S["x1"]), L.ptr(dF), L.ptr(G.buf(f + ".W1.weight")), L.ptr(G.buf(f + ".W1.bias")),
                                          L.ptr(G.buf(f + ".W2.weight")), L.ptr(G.buf(f + ".W2.bias")), None, 1, M, M, L.ptr(ws_wg), st), "rr_mlp_wgrad")
                 chk(b + " FFN backward", dx1=dx1)
                 # x1 = ffn.norm1(r + norm3(o)) (:355, 436)

@@ -1,3 +1,4 @@
+import os
 """Throughput of BASELINE configs[4]: ATSP n=100 REINFORCE training step, 512 instances per GPU (S=100 sampled starts),
 data-parallel with one flat RCCL gradient all-reduce.  A parity-test config, not the bench line.
   python tools/bench_train.py [--batch 512] [--steps 2]
@@ -43,6 +44,7 @@ else:
     gp = dict(num_loc=100, device=dev)
     env = RCVRPEnv(generator_params=gp, check_solution=False, device=dev) if args.problem == "rcvrp" else RMTVRPEnv(generator_params=gp, device=dev)
 pol.train()
+pol.precision = os.environ.get("RR_TRAIN_PRECISION", "32")      # "16-mixed": one bf16 piece per operand in the two MLPs' backward products (opt-in)
 model = RRNet(env, policy=pol)
 opt = torch.optim.Adam(pol.parameters(), lr=1e-4, fused=True)
 gen = torch.Generator(device=dev).manual_seed(1234 + rank)
