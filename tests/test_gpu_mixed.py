@@ -70,6 +70,12 @@ def test_sixteen_mixed_rollout_stays_inside_the_references_own_autocast_deviatio
     assert same_ref >= r16_same
     assert float(dll.mean()) <= 0.5 * float(r16_dll.mean()) and float(dll.max()) <= float(r16_dll.max())
     assert gap <= max(r16_gap, 0.0) + 5e-3
+    # ... and a band of its own (the reference's autocast band alone would let a half-broken kernel through): the one-piece
+    # rollout keeps most of the DEFAULT build's tours (measured 0.945 random-init, 0.995 trained) and its log-likelihoods stay within a
+    # fraction of a nat of the default build's on average (measured 0.087 / 0.016; a dropped operand contribution moves them by whole nats)
+    dfull = (half["log_likelihood"] - full["log_likelihood"]).abs()
+    assert same_full >= 0.90, same_full
+    assert float(dfull.mean()) <= 0.2, float(dfull.mean())
     # the reward it reports is the exact cost of the tours it returns (k_tour_cost is fp32 whatever the policy's arithmetic)
     if "normalized_reward" in half:
         D = restate.atsp_reset(H.fixture_state(fx))["distance_matrix"]
