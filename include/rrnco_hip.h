@@ -161,11 +161,16 @@ int rr_enc_layer(const EncBlockW* wrow, const EncBlockW* wcol, const float* row_
  * kernel (:313, 324-325, 421, 435-441, 355-356).  Results are bit-identical to rr_enc_layer's.
  * stats_in [2][Bp][2][128]: per (tensor 0 row | 1 col, instance): mean[128], rsqrt(var + 1e-5)[128] of the layer's INPUT over the
  * node axis (what Normalization("instance"), :84, 104-105, derives first): rr_enc_stats for the init embedding, stats_out of the
- * previous layer afterwards (NULL: not written).  work: 6 * Bp * N * 128 floats of scratch (K, V, mixing ratio of both blocks). */
+ * previous layer afterwards (NULL: not written).  work: 6 * Bp * N * 128 floats of scratch (K, V, mixing ratio of both blocks).
+ * dist_family / n_base (optional): for a batch of Bp / n_base augmentation copies of n_base base instances (instance copy * n_base + b;
+ * StateAugmentation, transforms.py:142-154: the matrices are replicated, only the coordinates differ) the distance family of the folded
+ * NAB, looked up once per base instance by rr_nab_dist_family -> [n_base][2 blocks][N*N][2]; NULL: every instance looks it up itself. */
 int rr_enc_stats(const float* row, const float* col, float* stats, int Bp, int N, hipStream_t stream);
 int rr_enc_layer_split(const EncBlockW* wrow, const EncBlockW* wcol, const float* row_in, const float* col_in,
                        float* row_out, float* col_out, const float* D, const float* theta, const float* bias_pre,
-                       const float* stats_in, float* stats_out, float* work, int Bp, int N, hipStream_t stream);
+                       const float* stats_in, float* stats_out, float* work, const float* dist_family, int n_base,
+                       int Bp, int N, hipStream_t stream);
+int rr_nab_dist_family(const EncBlockW* wrow, const EncBlockW* wcol, const float* D, float* out, int B, int N, hipStream_t stream);
 
 /* theta[b][i][j] = atan2(y_i - y_j, x_i - x_j): the angle input of the Neural Adaptive Bias
  * (rrnco/models/nn/attn_freenet.py:262-264), computed once per instance and shared by every encoder block. */

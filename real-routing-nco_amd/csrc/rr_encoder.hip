@@ -169,6 +169,92 @@ __device__ __forceinline__ void nab_edge4_grid(const float* tab, const float* ts
   }
 }
 
+// One family of the same evaluation for one input: -> (output part, gate part) of that family, bit for bit what nab_edge4_grid computes
+// inside (the same cell, scan, anchor and the same two fmaf).  f = 0 distance, 1 angle.
+__device__ __forceinline__ void nab_family_grid(const float* tab, const float* ts, int f, float xin, float& fo, float& fg) {
+  const unsigned char* cell = reinterpret_cast<const unsigned char*>(tab + NAB_TAB_FLOATS);
+  const float x = fminf(xin, 3.0e38f);
+  const int c = f == 0 ? (int)(xin * (float)NAB_G) : (int)((xin + 3.14159265358979f) * ((float)NAB_G / 6.28318530717959f));
+  const int s0 = cell[f * NAB_G + min(max(c, 0), NAB_G - 1)];
+  int m = c < 0 ? 0 : (s0 & 127);
+  int need = (c < 0 || (s0 & 128)) ? 1 : 0;
+  while (need) {
+    const int adv = ts[(f ? NAB_TS_LD : 0) + m] <= x ? 1 : 0;
+    m += adv; need = adv;
+  }
+  float anchor = tab[128 * f + (m > 0 ? m - 1 : 0)];
+  anchor = anchor < INFINITY ? anchor : 0.f;
+  const float4 sg = rr_ld4(tab + 256 + 516 * f + 4 * m);
+  const float dx = x - anchor;
+  fo = fmaf(sg.x, dx, sg.y); fg = fmaf(sg.z, dx, sg.w);
+}
+// nab_edge4_grid with the distance family handed in (fo_d, fg_d per edge): only the angle is looked up.  Same arithmetic.
+__device__ __forceinline__ void nab_edge4_angle(const float* tab, const float* ts, const float (&fo_d)[4], const float (&fg_d)[4],
+                                                const float (&th)[4], float (&out)[4]) {
+  const unsigned char* cell = reinterpret_cast<const unsigned char*>(tab + NAB_TAB_FLOATS);
+  float x[4]; int m[4], need[4], more = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    x[q] = fminf(th[q], 3.0e38f);
+    const int ca = (int)((th[q] + 3.14159265358979f) * ((float)NAB_G / 6.28318530717959f));
+    const int sa = cell[NAB_G + min(max(ca, 0), NAB_G - 1)];
+    m[q] = ca < 0 ? 0 : (sa & 127);
+    need[q] = (ca < 0 || (sa & 128)) ? 1 : 0;
+    more |= need[q];
+  }
+  while (__any(more)) {
+    more = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float tv = ts[NAB_TS_LD + (need[e] ? m[e] : 128)];
+      const int adv = tv <= x[e] ? 1 : 0;
+      m[e] += adv; need[e] = adv; more |= adv;
+    }
+  }
+  const float* s = tab + 256 + 1032;                  // bg, bo, alpha
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int mm = m[q];
+    float anchor = tab[128 + (mm > 0 ? mm - 1 : 0)];
+    anchor = anchor < INFINITY ? anchor : 0.f;
+    const float4 sg = rr_ld4(tab + 256 + 516 + 4 * mm);
+    const float dx = x[q] - anchor;
+    const float fo_a = fmaf(sg.x, dx, sg.y), fg_a = fmaf(sg.z, dx, sg.w);
+    const float gt = rr_sigmoid(fg_d[q] + fg_a + s[0]);
+    out[q] = (fmaf(gt, fo_d[q], (1.0f - gt) * fo_a) + s[1]) * s[2];
+  }
+}
+
+// The distance family of the folded gating NAB for B BASE instances and both blocks of a layer: out[b][block][i N + j][2] =
+// (output part, gate part) at d = D[b][i][j] (row block) or D[b][j][i] (col block: attn_freenet.py:480-486), so that k_enc_mix reads both
+// blocks row-contiguously.  For batches that are augmentation copies of B instances (StateAugmentation: the matrices are replicated,
+// only the coordinates — the angle family — differ), the eight copies share these values instead of looking them up eight times.
+__global__ __launch_bounds__(256) void k_nab_dist_family(const float* __restrict__ tab_row, const float* __restrict__ tab_col,
+                                                         const float* __restrict__ D, float* __restrict__ out, int N) {
+  __shared__ __attribute__((aligned(16))) float nabtab[NAB_TAB2_FLOATS + 2 * NAB_TS_LD];
+  const int b = blockIdx.y, is_col = blockIdx.z, tid = threadIdx.x;
+  const float* src = is_col ? tab_col : tab_row;
+  for (int i = tid; i < NAB_TAB2_FLOATS; i += 256) nabtab[i] = src[i];
+  for (int i = tid; i < 2 * NAB_TS_LD; i += 256) {
+    const int f = i >= NAB_TS_LD, k = i - f * NAB_TS_LD;
+    nabtab[NAB_TAB2_FLOATS + i] = k < 128 ? src[128 * f + k] : INFINITY;
+  }
+  __syncthreads();
+  const int e = blockIdx.x * 256 + tid;
+  if (e >= N * N) return;
+  const int i = e / N, j = e - i * N;
+  const float d = D[(size_t)b * N * N + (is_col ? j * N + i : e)];
+  float fo, fg;
+  nab_family_grid(nabtab, nabtab + NAB_TAB2_FLOATS, 0, d, fo, fg);
+  reinterpret_cast<float2*>(out)[((size_t)b * 2 + is_col) * N * N + e] = make_float2(fo, fg);
+}
+extern "C" int rr_nab_dist_family(const EncBlockW* wrow, const EncBlockW* wcol, const float* D, float* out, int B, int N, hipStream_t st) {
+  if (B <= 0 || N < 2 || wrow == nullptr || wcol == nullptr || wrow->nab == nullptr || wcol->nab == nullptr || D == nullptr || out == nullptr)
+    return RR_EINVAL;
+  hipLaunchKernelGGL(k_nab_dist_family, dim3((N * N + 255) / 256, B, 2), dim3(256), 0, st, wrow->nab, wcol->nab, D, out, N);
+  return rr_check(hipGetLastError());
+}
+
 // theta[b][i][j] = atan2(y_i - y_j, x_i - x_j) (attn_freenet.py:262-264 computes it per layer; it only depends on the
 // coordinates, so it is computed once per instance and shared by the twelve blocks)
 __global__ void k_edge_angles(const float* __restrict__ locs, float* __restrict__ theta, int N) {
@@ -199,9 +285,12 @@ extern "C" int rr_enc_stats(const float* row, const float* col, float* stats, in
 
 // One Attn_Free_Layer at the headline shape as k_enc_kv -> k_enc_mix -> k_enc_tail (rr_enc_split.inc).  work: 6 Bp N 128 floats
 // (K, V, ratio of both blocks); stats_in / stats_out: [2][Bp][2][128] (rr_enc_stats layout; stats_out may be NULL for the last layer).
+// dist_family (optional, with n_base): rr_nab_dist_family's output for the n_base base instances of an augmented batch (instance b'
+// = copy * n_base + b): k_enc_mix then looks up the angle family only.
 extern "C" int rr_enc_layer_split(const EncBlockW* wrow, const EncBlockW* wcol, const float* row_in, const float* col_in,
                                   float* row_out, float* col_out, const float* D, const float* theta, const float* bias_pre,
-                                  const float* stats_in, float* stats_out, float* work, int Bp, int N, hipStream_t st) {
+                                  const float* stats_in, float* stats_out, float* work, const float* dist_family, int n_base,
+                                  int Bp, int N, hipStream_t st) {
   if (Bp <= 0 || N <= 64 || N > RR_MAXN || wrow == nullptr || wcol == nullptr || work == nullptr || stats_in == nullptr) return RR_EINVAL;
   if (theta == nullptr && bias_pre == nullptr) return RR_EINVAL;
   if (!(wrow->w1s && wrow->w2s && wcol->w1s && wcol->w2s && wrow->wqs && wrow->wks && wrow->wvs && wrow->wps && wcol->wqs &&
@@ -209,12 +298,17 @@ extern "C" int rr_enc_layer_split(const EncBlockW* wrow, const EncBlockW* wcol, 
     return RR_EINVAL;                                        // two-piece weight images required (packing.mlp_split_enabled)
   if (bias_pre == nullptr && (wrow->nab == nullptr || wcol->nab == nullptr)) return RR_EINVAL;
   if (wrow->muk == nullptr || wcol->muk == nullptr) return RR_EINVAL;
+  if (dist_family != nullptr && (bias_pre != nullptr || n_base <= 0 || Bp % n_base != 0)) return RR_EINVAL;
+  if (dist_family == nullptr) n_base = Bp;
   EncBlockW2 ws; ws.blk[0] = *wrow; ws.blk[1] = *wcol;
   const size_t R = (size_t)Bp * N * RR_E;
   float *Kb = work, *Vb = work + 2 * R, *Rt = work + 4 * R;
   static const int kv_grid = [] { const char* e = getenv("RR_ENC_KV_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
   hipLaunchKernelGGL(k_enc_kv, dim3(kv_grid, 2), dim3(64 * EKV_WAVES), 0, st, ws, row_in, col_in, stats_in, Kb, Vb, Bp, N);
-  hipLaunchKernelGGL((k_enc_mix<7>), dim3(Bp, 2), dim3(64 * 7), 0, st, ws, Kb, Vb, Rt, D, theta, bias_pre, Bp, N);
+  if (dist_family != nullptr)
+    hipLaunchKernelGGL((k_enc_mix<7, true>), dim3(Bp, 2), dim3(64 * 7), 0, st, ws, Kb, Vb, Rt, D, theta, bias_pre, dist_family, n_base, Bp, N);
+  else
+    hipLaunchKernelGGL((k_enc_mix<7, false>), dim3(Bp, 2), dim3(64 * 7), 0, st, ws, Kb, Vb, Rt, D, theta, bias_pre, dist_family, n_base, Bp, N);
   static const int upw = [] { const char* e = getenv("RR_ENC_TAIL_UPW"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 8; }();     // instances per workgroup
   hipLaunchKernelGGL((k_enc_tail<7>), dim3((Bp + upw - 1) / upw, 2), dim3(64 * 8), 0, st, ws, row_in, col_in, Rt, stats_in, row_out, col_out, stats_out, Bp, N, upw);
   return rr_check(hipGetLastError());

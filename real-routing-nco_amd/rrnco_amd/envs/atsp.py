@@ -67,7 +67,8 @@ class ATSPEnv(EnvBase):
             out["locs"] = td["locs"]
         if td.get("sample_idx", None) is not None:   # explicit neighbour-sample indices
             out["sample_idx"] = td["sample_idx"]
-        return TensorDict(out, batch_size=batch_size, meta={"i": 0})
+        note = getattr(td, "meta", {}).get("num_augment") if hasattr(td, "meta") else None      # StateAugmentation's note survives the reset
+        return TensorDict(out, batch_size=batch_size, meta={"i": 0, **({"num_augment": note} if note else {})})
 
     def _step(self, td: TensorDict) -> TensorDict:
         """env.py:80-105; `first_node` is fixed by the first step (tracked host-side instead of the

@@ -63,7 +63,8 @@ class RCVRPEnv(EnvBase):
                    visited=torch.zeros((*batch_size, n1), dtype=torch.uint8, device=dev))
         if td.get("sample_idx", None) is not None:
             out["sample_idx"] = td["sample_idx"]
-        res = TensorDict(out, batch_size=batch_size, meta={"i": 0})
+        note = getattr(td, "meta", {}).get("num_augment") if hasattr(td, "meta") else None      # StateAugmentation's note survives the reset
+        res = TensorDict(out, batch_size=batch_size, meta={"i": 0, **({"num_augment": note} if note else {})})
         res.set("action_mask", self.get_action_mask(res))
         return res
 

@@ -252,6 +252,12 @@ class RRNetEncoder(nn.Module):
             stats = torch.empty(2, 2, Bp, 2, 128, device=dev, dtype=torch.float32)       # [ping-pong][tensor][b][mean | rstd][f]
             work = torch.empty(6, Bp, N, 128, device=dev, dtype=torch.float32)
             L.check(lib.rr_enc_stats(L.ptr(row), L.ptr(col), L.ptr(stats[0]), Bp, N, L.stream()), "rr_enc_stats")
+            # x8-augmented batch (StateAugmentation's note in td.meta): the matrices of the 8 copies are the base instance's, so the
+            # distance family of the folded NAB is looked up once per base instance and layer (rr_nab_dist_family), the angle per copy
+            n_aug = getattr(td, "meta", {}).get("num_augment", 1) if hasattr(td, "meta") else 1
+            dfam = None
+            if (not use_dur and n_aug and n_aug > 1 and Bp % n_aug == 0 and _os.environ.get("RR_ENC_AUGSHARE", "1") != "0"):
+                dfam = torch.empty(Bp // n_aug, 2, N * N, 2, device=dev, dtype=torch.float32)
         nl = len(packed["blocks"])
         for l, (wr, wc) in enumerate(packed["blocks"]):
             if simple:
@@ -284,10 +290,12 @@ class RRNetEncoder(nn.Module):
                 row, col, row2, col2 = row2, col2, torch.empty_like(row), torch.empty_like(col)
                 continue
             if resplit:
+                if dfam is not None:
+                    L.check(lib.rr_nab_dist_family(wr, wc, L.ptr(D), L.ptr(dfam), Bp // n_aug, N, L.stream()), "rr_nab_dist_family")
                 L.check(lib.rr_enc_layer_split(wr, wc, L.ptr(row), L.ptr(col), L.ptr(row2), L.ptr(col2), L.ptr(D),
                                                L.ptr(theta) if theta is not None else None, L.ptr(bias) if use_dur else None,
                                                L.ptr(stats[l & 1]), L.ptr(stats[1 - (l & 1)]) if l + 1 < nl else None, L.ptr(work),
-                                               Bp, N, L.stream()), "rr_enc_layer_split")
+                                               L.ptr(dfam), Bp // n_aug if dfam is not None else 0, Bp, N, L.stream()), "rr_enc_layer_split")
                 row, col, row2, col2 = row2, col2, row, col
                 continue
             L.check(lib.rr_enc_layer(wr, wc, L.ptr(row), L.ptr(col), L.ptr(row2), L.ptr(col2), L.ptr(D), L.ptr(locs),

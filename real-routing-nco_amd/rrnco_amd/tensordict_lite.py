@@ -43,6 +43,8 @@ class TensorDict:
 
     def __setitem__(self, key, value):
         self._d[key] = value
+        if key in ("distance_matrix", "duration_matrix"):        # a replaced matrix voids StateAugmentation's "copies share the matrices" note
+            self.meta.pop("num_augment", None)
 
     def __contains__(self, key):
         return key in self._d
@@ -51,11 +53,12 @@ class TensorDict:
         return self._d.get(key, default)
 
     def set(self, key, value, inplace=False):
-        self._d[key] = value
+        self[key] = value
         return self
 
     def update(self, other, **kw):
-        self._d.update(other._d if isinstance(other, TensorDict) else other)
+        for k, v in (other._d if isinstance(other, TensorDict) else other).items():
+            self[k] = v
         return self
 
     def index_rollouts(self, idx):

@@ -91,6 +91,41 @@ def test_recut_layer_agrees_ragged_shapes(N, B):
     _assert_identical(a, b, f"N={N} B={B}")
 
 
+def test_distance_family_shared_over_the_augmentation_copies_is_bit_identical():
+    """x8-augmented batch (transforms.py:142-154: the matrices of the 8 copies are the base instance's): the distance family of the
+    folded NAB looked up once per base instance (rr_nab_dist_family, k_enc_mix<., true>) against every copy looking it up itself.
+    Same table cells, same interpolation arithmetic: the embeddings must be identical bit for bit."""
+    from rrnco_amd.envs import ATSPEnv, ATSPGenerator
+    from rrnco_amd.models.encoder import ATSPInitEmbedding
+    from rrnco_amd.models.transforms import StateAugmentation
+    from rrnco_amd import _lib as L
+    dev = torch.device("cuda")
+    for N, B in ((100, 5), (80, 3)):
+        pol = H.make_policy(H.atsp_weights(25, layers=3, seed=11))
+        env = ATSPEnv(generator_params=dict(num_loc=N, device=dev), check_solution=False, device=dev)
+        td = StateAugmentation(num_augment=8)(env.reset(ATSPGenerator(num_loc=N, device=dev)(B, generator=torch.Generator(device=dev).manual_seed(N))))
+        assert td.meta.get("num_augment") == 8
+        td.set("sample_idx", ATSPInitEmbedding.sample_indices(td["distance_matrix"], 25).contiguous())
+        packed = pol.packed(dev)
+        lib, calls = L.lib(), []
+        real = lib.rr_nab_dist_family
+        lib.rr_nab_dist_family = lambda *a: (calls.append(1), real(*a))[1]
+        try:
+            out = {}
+            for sw in ("0", "1"):
+                os.environ["RR_ENC_AUGSHARE"] = sw
+                try:
+                    row, col = pol.encoder(td.clone(), packed=packed)
+                    out[sw] = (row.clone(), col.clone())
+                finally:
+                    os.environ.pop("RR_ENC_AUGSHARE", None)
+        finally:
+            lib.rr_nab_dist_family = real
+        assert len(calls) == 3                                   # once per layer, on the sharing pass only
+        assert torch.equal(out["0"][0], out["1"][0]) and torch.equal(out["0"][1], out["1"][1])
+        assert torch.isfinite(out["1"][0]).all()
+
+
 def test_recut_layer_is_the_default_at_the_headline_shape_and_not_elsewhere():
     """The dispatch: 64 < N <= 103 with instance norm takes the three launches; N <= 64 and the other norms stay on k_enc_block_w."""
     import ctypes
