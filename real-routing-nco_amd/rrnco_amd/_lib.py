@@ -179,7 +179,62 @@ def lib():
             fn.restype = i32
         _lib.rr_matnet_workspace_bytes.argtypes = [i32] * 4
         _lib.rr_matnet_workspace_bytes.restype = C.c_size_t
+        if os.environ.get("RR_MARKERS", "0") == "1":
+            _wrap_with_markers(_lib)
     return _lib
+
+
+# rocprofv3 range markers per kernel group of SURVEY.md section 3 (K1 .. K10), opt-in (RR_MARKERS=1; `rocprofv3 --marker-trace
+# --kernel-trace`): every launcher call is bracketed by a roctx range named after the reference op sequence it replaces.
+MARKER_LABELS = {
+    "rr_edge_angles": "K1 NAB angles (attn_freenet.py:262-264)",
+    "rr_nab_dist_family": "K1 NAB distance family, shared by the augmentation copies (attn_freenet.py:242-289)",
+    "rr_nab_dur": "K1' NAB with duration (attn_freenet.py:226-237, 265-286)",
+    "rr_nab_dur_aug": "K1' NAB with duration, x8 augmentation (attn_freenet.py:226-237, 265-286)",
+    "rr_nab_simple": "K1 naive / heuristic NAB (attn_freenet.py:119-199)",
+    "rr_enc_stats": "K3 instance-norm statistics of the init embedding (attn_freenet.py:84, 104-105)",
+    "rr_enc_layer": "K1+K2+K3 encoder layer: NAB, AFT, norms, FFN (attn_freenet.py:292-327, 360-488)",
+    "rr_enc_layer_split": "K1+K2+K3 encoder layer, three launches (attn_freenet.py:292-327, 360-488)",
+    "rr_enc_layer_train": "K1+K2+K3 encoder layer, training forward (attn_freenet.py:292-327, 360-488)",
+    "rr_init_embed": "K4 init embedding (env_embeddings/atsp.py:69-91, rcvrp.py:88-124)",
+    "rr_dec_cache": "K5 decoder cache (decoder.py:214-232)",
+    "rr_rollout": "K6-K10 decode loop: context, pointer, inductive bias, select, env.step (policy.py:210-228)",
+    "rr_select": "K9 select (decoding.py:341-361, 272-298)",
+    "rr_atsp_step": "K10 env.step ATSP (atsp/env.py:72-101)",
+    "rr_rcvrp_step": "K10 env.step RCVRP (rcvrp/env.py:90-122, 183-195)",
+    "rr_rmtvrp_step": "K10 env.step RMTVRP (rmtvrp/env.py:343-428)",
+    "rr_tour_cost": "reward (atsp/env.py:103-121, rcvrp/env.py:124-150)",
+}
+
+
+def _wrap_with_markers(lib_):
+    rx = None
+    for name in ("librocprofiler-sdk-roctx.so", "libroctx64.so"):
+        try:
+            rx = C.CDLL(name)
+            break
+        except OSError:
+            continue
+    if rx is None:
+        raise ImportError("RR_MARKERS=1 but neither librocprofiler-sdk-roctx.so nor libroctx64.so can be loaded")
+    rx.roctxRangePushA.argtypes = [C.c_char_p]
+    rx.roctxRangePushA.restype = i32
+    rx.roctxRangePop.restype = i32
+
+    def marked(fn, label):
+        text = label.encode()
+
+        def call(*a):
+            rx.roctxRangePushA(text)
+            try:
+                return fn(*a)
+            finally:
+                rx.roctxRangePop()
+        call.__wrapped__ = fn
+        return call
+    for name in _SIGS:
+        if hasattr(lib_, name):
+            setattr(lib_, name, marked(getattr(lib_, name), MARKER_LABELS.get(name, name)))
 
 
 def exported_symbols():

@@ -774,3 +774,11 @@ def test_batched_nab_tables_equal_the_per_block_expression_and_its_gradients():
     wrt = [P[prefixes[1] + ".dist_emb.2.weight"], alphas[2], P[prefixes[0] + ".gate.0.weight"], P[prefixes[2] + ".angle_emb.0.bias"]]
     for a, b in zip(torch.autograd.grad(one, wrt, w, retain_graph=True), torch.autograd.grad(bat, wrt, w)):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-4)
+
+
+def test_marker_labels_name_exported_launchers():
+    """RR_MARKERS=1 (rrnco_amd/_lib.py): every label belongs to a launcher the library exports."""
+    from rrnco_amd import _lib as L
+    assert set(L.MARKER_LABELS) <= set(L.exported_symbols())
+    for k in ("rr_init_embed", "rr_dec_cache", "rr_rollout", "rr_select", "rr_enc_layer_split"):
+        assert L.MARKER_LABELS[k].startswith("K")

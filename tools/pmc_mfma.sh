@@ -9,4 +9,4 @@ rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INS
 python3 $R/tools/pmc_summary.py $R/gpurun_out/pmc_m_a > $R/gpurun_out/pmc_mfma.txt
 python3 $R/tools/pmc_summary.py $R/gpurun_out/pmc_m_b >> $R/gpurun_out/pmc_mfma.txt
 rm -rf $R/gpurun_out/pmc_m_a $R/gpurun_out/pmc_m_b
-grep -A8 "k_rollout_w<7, 0, 0\|k_enc_mix<7\|k_enc_tail<7\|k_enc_kv" $R/gpurun_out/pmc_mfma.txt
+grep -A8 "k_rollout_w<7, 0, 0\|k_enc_mix<7\|k_enc_tail<7\|k_enc_kv\|k_nab_dist_family" $R/gpurun_out/pmc_mfma.txt
