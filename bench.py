@@ -223,7 +223,7 @@ def make_policy(device, seed=1234):
     return pol.to(device).eval(), w
 
 
-def hot_path_step(pol, env, inst):
+def hot_path_step(pol, env, inst, decode=None):
     """test.py:188-213 shaped: augment -> reset -> policy -> reward -> max over starts, then over augs.  The encoder's
     neighbour sample is drawn INSIDE the step, per forward and over all 8 x B instance-augmentations, as the reference does
     (rrnco/models/env_embeddings/atsp.py:55-67) — on the device (csrc/rr_sample.hip)."""
@@ -233,7 +233,7 @@ def hot_path_step(pol, env, inst):
     td = TensorDict(dict(inst), batch_size=[inst["locs"].shape[0]])
     td = StateAugmentation(augment_fn="dihedral8", no_aug_coords=False)(td)
     td = env.reset(td)
-    out = pol(td, env, phase="val", decode_type="multistart_greedy", num_starts=STARTS, return_actions=True)
+    out = pol(td, env, phase="val", num_starts=STARTS, return_actions=True, **(decode or {"decode_type": "multistart_greedy"}))
     rew = unbatchify(out["reward"], (AUG, STARTS))          # [B, A, S]
     best = rew.max(dim=-1).values.max(dim=-1).values
     return best, out
@@ -749,6 +749,23 @@ def main():
             v16["roofline"] = {"bound": "mfma", "kernel": "k_rollout_w<7, 0, 0, true, true, true>", "achieved": a16, "peak": PEAK_F16_MFMA_TFLOPS,
                                "unit": "TFLOP/s", "frac": a16 / PEAK_F16_MFMA_TFLOPS}
             line["variants"]["16_mixed_rollout (precision='16-mixed', the reference's autocast mode)"] = v16
+            # sampling with process_logits' top-k / top-p filters (decoding.py:352-358): inside the fused rollout since round 5 (FILT builds of
+            # the two-piece kernels); before, such a strategy ran the per-step loop (`per_step_loop`, two steps timed)
+            filt = {"decode_type": "multistart_sampling", "top_k": 10, "top_p": 0.9, "temperature": 1.0, "seed": 3}
+
+            def timed_decode(decode, nv):
+                hot_path_step(pol, env, insts[0], decode)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for k in range(nv):
+                    torch.manual_seed(sample_seed(rank, k))
+                    hot_path_step(pol, env, insts[k % N_INSTANCE_BATCHES], decode)
+                torch.cuda.synchronize()
+                return {"value": local_batch * nv / (time.perf_counter() - t1), "unit": "instances/s", "steps": nv}
+            vf = timed_decode(filt, max(min(args.steps, 8), 1))
+            vf["unfiltered_sampling"] = timed_decode({"decode_type": "multistart_sampling", "temperature": 1.0, "seed": 3}, max(min(args.steps, 8), 1))["value"]
+            vf["per_step_loop"] = timed_decode({**filt, "fused": False}, 2)["value"]
+            line["variants"]["sampling_top_k10_top_p0.9_fused"] = vf
         if world == 1 and not args.no_other_configs:
             del pol
             torch.cuda.empty_cache()

@@ -90,6 +90,10 @@ typedef struct {                /* arguments of the persistent rollout: see csrc
   int* status;                  /* optional device word: bit 2 is set when a split launch meets a non-finite log-probability — an
                                  * operand left the fp16 range somewhere upstream (|x| >= 65504 after its image's scale); the caller
                                  * then repeats the call on the fp32 kernels (use_split = 0) */
+  int top_k; float top_p;       /* process_logits' filters (rrnco/models/decoding.py:37-63, 352-358) applied inside the rollout, top-k first:
+                                 * 0 / 0.0 (or top_k >= N, top_p >= 1) = off.  Served by the two-piece greedy / sampling kernels
+                                 * (use_split = 1, mode 0 / 1); any other launch with a filter set returns RR_EINVAL — the per-step
+                                 * loop (rr_select) carries the same filters */
 } RolloutIO;
 
 /* Backward of the Neural Adaptive Bias with the duration matrix (rrnco/models/nn/attn_freenet.py:226-237, 265-286) in its folded
@@ -111,6 +115,11 @@ int rr_nabdur_bwd(const NabDurBwdW* w, const float* xd, const float* xa, const f
  * operands of the split rollout (rrnco/models/decoder.py:214-232 products).  status (optional device word): bit 0 is set when a
  * value is non-finite or leaves the fp16 range (|2^4 x| >= 65504). */
 int rr_pack_f16x2(const float* src, void* dst, long long n_floats, int* status, hipStream_t stream);
+
+/* The top-k / top-p filters of process_logits (rrnco/models/decoding.py:37-63, 352-358; top-k first) on rows of processed logits
+ * [R][N] (masked keys -inf, already divided by the temperature): out = the rows with every removed key at -inf.  The same device
+ * functions the fused rollout applies in registers when RolloutIO.top_k / top_p are set (N <= 112). */
+int rr_filter_rows(const float* logits, float* out, int R, int N, int top_k, float top_p, hipStream_t stream);
 
 /* ATSPEnv._reset / RCVRPEnv._reset / RMTVRPEnv._reset min-max normalisation
  * (rrnco/envs/atsp/env.py:113-120, rcvrp/env.py:137-146, rmtvrp/env.py:289-300): out = (in-min)/(max-min+1e-6)

@@ -71,6 +71,7 @@ struct RolloutIO {
   int use_split;                         // 1: this launch runs on the fp16 matrix pipe with two-piece split operands (rr_common.h), if DecW has w1s / w2s and Ks / Vts / Ls are given
   const void *Ks, *Vts, *Ls;             // fp16 two-piece images of K / Vt / L (rr_pack_f16x2), same shapes and byte offsets
   int* status;                           // optional: bit 2 <- a split launch met a non-finite log-probability (an operand left the fp16 range)
+  int top_k; float top_p;                // process_logits' filters (decoding.py:352-358) inside the rollout: split greedy / sampling launches only (0 / 0.0: off)
 };
 
 // (The first-generation workgroup-per-instance rollout kernel — activations through LDS, ten barriers per decode step; rounds 1-3 kept
@@ -144,11 +145,23 @@ extern "C" int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStrea
   const int per_x = nwg > theavy ? (nwg - theavy + 7) / 8 : 0;
   const dim3 grid_s(theavy + 8 * per_x), blk_s = blk;
   const int mode = io->logits_only ? 3 : io->mode;
+  // top-k / top-p inside the rollout: FILT builds of the split greedy / sampling kernels (two-piece operands); anything else is the caller's
+  // per-step loop (rr_select carries the same filters)
+  if (io->top_k < 0 || io->top_p < 0.f || io->top_p > 1.f) return RR_EINVAL;
+  const bool filt = !io->logits_only && ((io->top_k > 0 && io->top_k < N) || (io->top_p > 0.f && io->top_p < 1.f));
+  if (filt && !(mlp_split && mode <= 1 && io->use_split != 2)) return RR_EINVAL;
   static const bool inst_on = getenv("RR_ROLLOUT_INST") == nullptr || atoi(getenv("RR_ROLLOUT_INST")) != 0;
 #define RR_LAUNCHW4(NTV, P, M, SP)                                                                            \
   do {                                                                                                       \
     const int lds_inst_s = wstg + 2 * (size_t)(NTV) * 8192 <= per_wg ? 2 : 0;                               \
     const size_t shm = (SP) ? wstg + (size_t)lds_inst_s * (NTV) * 8192 : shmem;              \
+    if constexpr (SP) {                                                                                      \
+      if (filt) {                                                                                            \
+        (void)hipFuncSetAttribute((const void*)k_rollout_w<NTV, P, M, SP, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+        hipLaunchKernelGGL((k_rollout_w<NTV, P, M, SP, false, false, true>), grid_s, blk_s, shm, st, *w, *io, tail_g, lds_inst_s); \
+        break;                                                                                               \
+      }                                                                                                      \
+    }                                                                                                        \
     (void)hipFuncSetAttribute((const void*)k_rollout_w<NTV, P, M, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
     hipLaunchKernelGGL((k_rollout_w<NTV, P, M, SP>), (SP) ? grid_s : grid, (SP) ? blk_s : blk, shm, st, *w, *io, tail_g, \
                        (SP) ? lds_inst_s : lds_inst);                                                        \
@@ -162,6 +175,9 @@ extern "C" int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStrea
       if (io->use_split == 2 && (P) <= 2) {        /* 16-mixed: one fp16 piece per operand (rr_rollout_w.inc, HALF) */ \
         (void)hipFuncSetAttribute((const void*)k_rollout_w<NTV, ((P) <= 2 ? (P) : 0), M, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_i); \
         hipLaunchKernelGGL((k_rollout_w<NTV, ((P) <= 2 ? (P) : 0), M, true, true, true>), dim3(io->Bp), blk_s, shm_i, st, *w, *io, 0, 0); \
+      } else if (filt) {                                                                                     \
+      (void)hipFuncSetAttribute((const void*)k_rollout_w<NTV, P, M, true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_i); \
+      hipLaunchKernelGGL((k_rollout_w<NTV, P, M, true, true, false, true>), dim3(io->Bp), blk_s, shm_i, st, *w, *io, 0, 0); \
       } else {                                                                                               \
       (void)hipFuncSetAttribute((const void*)k_rollout_w<NTV, P, M, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_i); \
       hipLaunchKernelGGL((k_rollout_w<NTV, P, M, true, true>), dim3(io->Bp), blk_s, shm_i, st, *w, *io, 0, 0); \
@@ -201,6 +217,41 @@ extern "C" int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStrea
 #undef RR_LAUNCHW3
 #undef RR_LAUNCHW4
 #undef RR_LAUNCHW
+  return rr_check(hipGetLastError());
+}
+
+// The rollout's in-register top-k / top-p filters (rr_rollout_w.inc: rr_filter_top_k / rr_filter_top_p) on rows of processed logits
+// (masked keys -inf, already / temperature): out = the rows with the removed keys at -inf (decoding.py:37-63, 352-358, top-k first).
+// Same device functions, same lane layout as the rollout's selection stage (a wave = 16 rows, the four lanes that share j hold a
+// row): what tests/test_gpu_filters_fused.py pins against process_logits key by key, ties included.  N <= 112.
+__global__ __launch_bounds__(256) void k_filter_rows(const float* __restrict__ in, float* __restrict__ out, int R, int N, int top_k, float top_p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, gs = lane >> 4;
+  const long long r = ((long long)blockIdx.x * 4 + wave) * 16 + j;
+  f32x4 la[7];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < 7; ++kt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int key = 16 * kt + 4 * gs + q;
+      const float v = (r < R && key < N) ? in[r * N + key] : -INFINITY;
+      la[kt][q] = v; mx = fmaxf(mx, v);
+    }
+  mx = rr_max_g(mx);
+  if (mx == -INFINITY) mx = 0.f;
+  if (top_k > 0 && top_k < N) rr_filter_top_k<7>(la, top_k);
+  if (top_p > 0.f && top_p < 1.f) rr_filter_top_p<7>(la, mx, gs, top_p);
+#pragma unroll
+  for (int kt = 0; kt < 7; ++kt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int key = 16 * kt + 4 * gs + q;
+      if (r < R && key < N) out[r * N + key] = la[kt][q];
+    }
+}
+extern "C" int rr_filter_rows(const float* logits, float* out, int R, int N, int top_k, float top_p, hipStream_t st) {
+  if (logits == nullptr || out == nullptr || R <= 0 || N < 1 || N > 112 || top_k < 0 || top_p < 0.f || top_p > 1.f) return RR_EINVAL;
+  hipLaunchKernelGGL(k_filter_rows, dim3((R + 63) / 64), dim3(256), 0, st, logits, out, R, N, top_k, top_p);
   return rr_check(hipGetLastError());
 }
 

@@ -58,7 +58,7 @@ class RolloutIO(C.Structure):
         [(n, i32) for n in ("Bp", "N", "S", "T", "t0", "nsteps", "mode", "use_placeholder", "set_first",
                             "write_state", "logits_only", "stagger")] + \
         [("tanh_clip", f32), ("temperature", f32), ("seed", u64)] + [(n, vp) for n in ("used_b", "open_route", "dist_limit", "demand_b", "bclass")] + \
-        [(n, vp) for n in ("dump_g0", "dump_g", "dump_meta", "dump_scal")] + [("dumpT", i32), ("use_split", i32), ("Ks", vp), ("Vts", vp), ("Ls", vp), ("status", vp)]
+        [(n, vp) for n in ("dump_g0", "dump_g", "dump_meta", "dump_scal")] + [("dumpT", i32), ("use_split", i32), ("Ks", vp), ("Vts", vp), ("Ls", vp), ("status", vp), ("top_k", i32), ("top_p", f32)]
 
 
 class DecLogitIO(C.Structure):          # csrc/rr_train_dec.hip
@@ -121,6 +121,7 @@ _SIGS = {
     "rr_enc_stats": [vp, vp, vp, i32, i32, vp],
     "rr_enc_layer_split": [C.POINTER(EncBlockW), C.POINTER(EncBlockW), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "rr_nab_dist_family": [C.POINTER(EncBlockW), C.POINTER(EncBlockW), vp, vp, i32, i32, vp],
+    "rr_filter_rows": [vp, vp, i32, i32, i32, f32, vp],
     "rr_edge_angles": [vp, vp, i32, i32, vp],
     "rr_nab_dur": [C.POINTER(NabDurW), C.POINTER(NabDurW), vp, vp, vp, vp, i32, i32, vp],
     "rr_nab_dur_aug": [C.POINTER(NabDurW), C.POINTER(NabDurW), vp, vp, vp, vp, i32, i32, i32, vp],

@@ -10,7 +10,7 @@ from ..ops import calculate_entropy, get_log_likelihood
 from .decoder import RRNetDecoder
 from .decoding import get_decoding_strategy
 from .encoder import RRNetEncoder
-from .rollout import PROB_ID, launch_rollout
+from .rollout import PROB_ID, fused_filters_ok, launch_rollout
 
 
 class RRNetPolicy(nn.Module):
@@ -327,7 +327,12 @@ class RRNetPolicy(nn.Module):
         # the fused rollout keeps one log-probability per step; full rows (store_all_logp / return_entropy) come from the step-wise loop
         if td["action_mask"].shape[-1] > 103:
             fused = False          # N > 103: the reference's own step-by-step loop on the row-parallel kernels (models/bign.py)
-        if (fused and not strategy.store_all_logp and self.env_name in PROB_ID and strategy.mask_logits and strategy.top_k == 0 and not (0.0 < strategy.top_p < 1.0)
+        # top-k / top-p (decoding.py:352-358) run inside the rollout on the two-piece greedy / sampling kernels (csrc/rr_rollout_w.inc, FILT);
+        # with the fp32-MFMA or 16-mixed kernels, in evaluate mode and in a training step they take the per-step loop (rr_select filters there)
+        filters = strategy.top_k > 0 or 0.0 < strategy.top_p < 1.0
+        filters_fused = (not filters) or (fused_filters_ok(getattr(self, "precision", "32"), capture is not None)
+                                          and strategy.mode in ("greedy", "sampling"))
+        if (fused and not strategy.store_all_logp and self.env_name in PROB_ID and strategy.mask_logits and filters_fused
                 and not getattr(strategy, "is_beam_search", False)):
             dump = None
             if capture is not None:      # training: keep what the hand-written backward needs (models/dec_backward.py)
@@ -403,7 +408,7 @@ class RRNetPolicy(nn.Module):
                             nsteps=nsteps, mode=strategy.mode, actions_in=ain, write_state=True,
                             tanh_clip=strategy.tanh_clipping, temperature=strategy.temperature, seed=strategy.seed,
                             steps_out=steps_out, dump=dump, status=getattr(self, "_range_status", None),
-                            precision=getattr(self, "precision", "32"))
+                            precision=getattr(self, "precision", "32"), top_k=strategy.top_k, top_p=strategy.top_p)
         if dump is not None:
             dump.update({"first": st["first"], "tanh_clip": strategy.tanh_clipping, "temperature": strategy.temperature})
         status = getattr(self, "_range_status", None)

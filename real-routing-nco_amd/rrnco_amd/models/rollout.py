@@ -18,9 +18,16 @@ STAGGER = int(os.environ.get("RR_STAGGER", "0"))   # initial delay of the second
 TIMING = None   # bench.py sets this to a list to collect (start, end) HIP events around each full rollout launch
 
 
+def fused_filters_ok(precision="32", training=False):
+    """top-k / top-p inside the fused rollout: the FILT builds of the two-piece greedy / sampling kernels only (csrc/rr_decode.hip)."""
+    from .. import packing
+    return bool(SPLIT_MLP and packing.mlp_split_enabled()) and precision != "16-mixed" and not training
+
+
 def launch_rollout(env_name, packed, cache, td, num_starts, *, actions=None, logp=None, t0=0, nsteps=1,
                    mode="greedy", actions_in=None, logits_out=None, logits_only=False, write_state=False,
-                   tanh_clip=10.0, temperature=1.0, seed=0, steps_out=None, state=None, dump=None, status=None, precision="32"):
+                   tanh_clip=10.0, temperature=1.0, seed=0, steps_out=None, state=None, dump=None, status=None, precision="32",
+                   top_k=0, top_p=0.0):
     """Runs `nsteps` decode steps (nsteps <= 0: until every rollout is done) for all rollouts of `td`.
     `td` is the batchified rollout state (R = S*Bp rows, per-instance keys left at Bp rows)."""
     if env_name not in PROB_ID:
@@ -106,6 +113,7 @@ def launch_rollout(env_name, packed, cache, td, num_starts, *, actions=None, log
         io.Ks, io.Vts, io.Ls = L.ptr(ks), L.ptr(vts), L.ptr(ls)
         io.status = L.ptr(status)
     io.tanh_clip, io.temperature, io.seed = float(tanh_clip), float(temperature), int(seed)
+    io.top_k, io.top_p = (0, 0.0) if logits_only else (int(top_k), float(top_p))
     timed = TIMING is not None and not logits_only
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
