@@ -766,6 +766,31 @@ def main():
             vf["unfiltered_sampling"] = timed_decode({"decode_type": "multistart_sampling", "temperature": 1.0, "seed": 3}, max(min(args.steps, 8), 1))["value"]
             vf["per_step_loop"] = timed_decode({**filt, "fused": False}, 2)["value"]
             line["variants"]["sampling_top_k10_top_p0.9_fused"] = vf
+            # the whole step (augmentation, reset, neighbour sample, encoder, rollout, reward, best-of) captured ONCE into a hipGraph and
+            # replayed: no launcher allocates through the runtime or reads back while capturing (tests/test_gpu_graph.py).  What the
+            # replay saves over the eager loop is the host side of ~60 launches; the captured neighbour sample repeats (a timing variant)
+            try:
+                gph, gs = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+                with torch.cuda.stream(gs):
+                    hot_path_step(pol, env, insts[0])
+                    torch.cuda.synchronize()
+                    with torch.cuda.graph(gph, stream=gs):
+                        best_g, _ = hot_path_step(pol, env, insts[0])
+                torch.cuda.synchronize()
+                gph.replay()
+                torch.cuda.synchronize()
+                nv = max(min(args.steps, 8), 1)
+                t1 = time.perf_counter()
+                for _ in range(nv):
+                    gph.replay()
+                torch.cuda.synchronize()
+                dtg = time.perf_counter() - t1
+                pol.check_range()
+                line["variants"]["hipgraph_replay"] = {"value": local_batch * nv / dtg, "unit": "instances/s", "ms_per_step": dtg / nv * 1e3, "steps": nv,
+                                                       "mean_best_cost": float(-best_g.mean().item())}
+                del gph
+            except Exception as e:      # (a variant: never fails the headline)
+                line["variants"]["hipgraph_replay"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not args.no_other_configs:
             del pol
             torch.cuda.empty_cache()

@@ -36,13 +36,54 @@ def build(problem, checkpoint, problem_size, device, seed):
     return policy.to(device).eval(), env
 
 
-def evaluate_dataset(path, problem, policy, env, batch_size, n_aug, n_start, device, log=print):
+class _GraphedPolicy:
+    """The policy call (encoder, decoder cache, fused rollout, reward) of one batch SHAPE captured into a hipGraph and replayed for
+    every batch of that shape (--hipgraph): the reset state of a batch is copied into the captured call's input buffers, the
+    neighbour sample (drawn per forward, env_embeddings/atsp.py:55-67) is drawn outside and copied in as well, so every batch still
+    gets its own.  No launcher allocates through the runtime or reads back while capturing (tests/test_gpu_graph.py); the range
+    guard runs deferred (the caller checks it once per dataset) and VRP outputs keep their allocated length (policy.lazy_trim)."""
+
+    def __init__(self, policy, env, n_start):
+        self.policy, self.env, self.n_start, self.graphs = policy, env, n_start, {}
+
+    def _call(self, td):
+        return self.policy(td, self.env, phase="val", return_actions=True, num_starts=self.n_start, range_guard="deferred")
+
+    def __call__(self, td):
+        from rrnco_amd import TensorDict
+        from rrnco_amd.models.encoder import ATSPInitEmbedding
+        sidx = ATSPInitEmbedding.sample_indices(td["distance_matrix"], self.policy.encoder.init_embedding.sample_size).contiguous()
+        key = tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(td.items()))
+        if key not in self.graphs:
+            static = TensorDict({k: v.clone() for k, v in td.items()}, batch_size=td.batch_size, meta=dict(td.meta))
+            static.set("sample_idx", sidx.clone())
+            was_lazy, self.policy.lazy_trim = getattr(self.policy, "lazy_trim", False), True
+            g, s = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self._call(static.clone())                      # packs, allocations, the kernels' first-use attributes
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g, stream=s):
+                    out = self._call(static.clone())
+            torch.cuda.current_stream().wait_stream(s)
+            self.policy.lazy_trim = was_lazy
+            self.graphs[key] = (g, static, out)
+        g, static, out = self.graphs[key]
+        for k, v in td.items():
+            static[k].copy_(v)
+        static["sample_idx"].copy_(sidx)
+        g.replay()
+        return out
+
+
+def evaluate_dataset(path, problem, policy, env, batch_size, n_aug, n_start, device, log=print, hipgraph=False):
     from rrnco_amd import data
     from rrnco_amd.models.transforms import StateAugmentation
     from rrnco_amd.ops import unbatchify
     augment = StateAugmentation(augment_fn="dihedral8", no_aug_coords=False)          # test.py:28
     td_all = data.prepare_for_env(data.load_npz_to_tensordict(path), problem)
     costs, times = [], []
+    graphed = _GraphedPolicy(policy, env, n_start) if hipgraph else None
     for batch in data.iter_batches(td_all, batch_size):
         batch = batch.to(device)
         if n_aug > 1:
@@ -50,14 +91,19 @@ def evaluate_dataset(path, problem, policy, env, batch_size, n_aug, n_start, dev
         td = env.reset(batch)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        out = policy(td, env, phase="val", return_actions=True, num_starts=n_start,       # test.py:192-207 (reward inside)
-                     range_guard="sync")      # the timing brackets synchronise anyway: out-of-range calls repeat on the fp32 kernels
+        if graphed is not None:
+            out = graphed(td)
+        else:
+            out = policy(td, env, phase="val", return_actions=True, num_starts=n_start,       # test.py:192-207 (reward inside)
+                         range_guard="sync")      # the timing brackets synchronise anyway: out-of-range calls repeat on the fp32 kernels
         reward = out["reward"]
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
         best = unbatchify(reward, (n_aug if n_aug > 1 else 0, n_start)).max(dim=-1).values
         best = best.max(dim=-1).values if n_aug > 1 else best
         costs.append((float(-best.sum()), best.numel()))
+    if graphed is not None:
+        policy.check_range()                   # the deferred range guard's words of every replayed call: raises if one left the fp16 range
     avg = sum(c for c, _ in costs) / sum(n for _, n in costs)
     log(f"Average cost:\n{avg:.4f}")
     log(f"Per step inference time (s):\n{sum(times) / len(times):.4f}")
@@ -76,6 +122,7 @@ def main(argv=None):
     ap.add_argument("--no_aug", action="store_true")
     ap.add_argument("--problem_size", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--hipgraph", action="store_true", help="capture the policy call of each batch shape into a hipGraph and replay it")
     o = ap.parse_args(argv)
     if not torch.cuda.is_available():
         raise RuntimeError("evaluate.py runs on the HIP path only (no CPU fallback)")
@@ -88,7 +135,7 @@ def main(argv=None):
     results = {}
     for p in sorted(paths):
         print(f"Loading {p}")
-        results[p] = evaluate_dataset(p, o.problem, policy, env, o.batch_size, n_aug, n_start, device)[0]
+        results[p] = evaluate_dataset(p, o.problem, policy, env, o.batch_size, n_aug, n_start, device, hipgraph=o.hipgraph)[0]
     return results
 
 

@@ -49,6 +49,27 @@ def test_evaluate_driver_matches_direct_policy_call(tmp_path, problem):
     assert abs(float(-best.mean()) - avg) / avg < 0.05          # different random neighbour samples: close, not equal
 
 
+@pytest.mark.parametrize("problem", ["atsp", "rcvrp", "rcvrptw"])
+def test_evaluate_driver_hipgraph_replay_gives_the_eager_costs(tmp_path, problem, monkeypatch):
+    """--hipgraph: the policy call of each batch shape captured once and replayed per batch (two full batches + a ragged one = two
+    graphs).  With the neighbour sample pinned the replayed costs are the eager ones."""
+    import evaluate
+    from rrnco_amd.models.encoder import ATSPInitEmbedding
+    n, count = 20, 10
+    path = _write(tmp_path, problem, n, count)
+    dev = torch.device("cuda:0")
+    policy, env = evaluate.build(problem, None, n, dev, seed=5)
+    S = n if problem != "rcvrp" else n + 1
+
+    def fixed(distance, k):                      # (deterministic stand-in for the multinomial draw: the k nearest columns by index order)
+        B, N = distance.shape[0], distance.shape[-1]
+        return (torch.arange(k, device=distance.device)[None, None, :] + torch.arange(N, device=distance.device)[None, :, None] + 1).remainder(N).expand(B, N, k).contiguous()
+    monkeypatch.setattr(ATSPInitEmbedding, "sample_indices", staticmethod(fixed))
+    a = evaluate.evaluate_dataset(path, problem, policy, env, batch_size=4, n_aug=8, n_start=S, device=dev, log=lambda *_: None)[0]
+    b = evaluate.evaluate_dataset(path, problem, policy, env, batch_size=4, n_aug=8, n_start=S, device=dev, log=lambda *_: None, hipgraph=True)[0]
+    assert np.isfinite(a) and abs(a - b) <= 1e-6 * abs(a), (a, b)
+
+
 def test_evaluate_cli_with_checkpoint_and_augmentation(tmp_path):
     import evaluate
     path = _write(tmp_path, "atsp", 20, 3)
