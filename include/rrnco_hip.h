@@ -231,9 +231,12 @@ int rr_rmtvrp_step(const int64_t* action, const float* D, const float* T,
 int rr_init_embed(const InitW* w, int kind, const float* D, const float* locs, const int64_t* sidx,
                   const float* vfeat, float* row_out, float* col_out, int Bp, int N, int SS, hipStream_t stream);
 
-/* RRNetDecoder._precompute_cache (rrnco/models/decoder.py:214-232) + per-node step-context tables. */
+/* RRNetDecoder._precompute_cache (rrnco/models/decoder.py:214-232) + per-node step-context tables.
+ * Ks / Vts / Ls (optional, all three or none; same shapes and byte offsets as K / Vt / L): the split rollout's two-piece fp16 images
+ * (what rr_pack_f16x2 makes of K / Vt / L, bit for bit) written from the accumulators in the same launch; status (optional device
+ * word): bit 0 is set when an image value is non-finite or leaves the fp16 range, as rr_pack_f16x2 does. */
 int rr_dec_cache(const CacheW* w, const float* row_emb, const float* col_emb, float* K, float* Vt, float* L,
-                 float* ctxA, float* ctxB, int Bp, int N, hipStream_t stream);
+                 float* ctxA, float* ctxB, void* Ks, void* Vts, void* Ls, int* status, int Bp, int N, hipStream_t stream);
 
 /* The decode loop of RRNetPolicy.forward (rrnco/models/policy.py:210-228) = RRNetDecoder.forward
  * (decoder.py:151-206) + DecodingStrategy.step (decoding.py:219-270) + env.step, `nsteps` steps in one launch;

@@ -1231,9 +1231,22 @@ struct CacheW {
 template <int NT, bool SPLIT = false>
 __global__ __launch_bounds__(ENC_THREADS, 2) void k_dec_cache(CacheW w, const float* __restrict__ row_emb, const float* __restrict__ col_emb,
                                                               float* __restrict__ K, float* __restrict__ Vt, float* __restrict__ L,
-                                                              float* __restrict__ ctxA, float* __restrict__ ctxB, int N) {
+                                                              float* __restrict__ ctxA, float* __restrict__ ctxB, int N,
+                                                              float4* __restrict__ Ks, float4* __restrict__ Vts, float4* __restrict__ Ls,
+                                                              int* __restrict__ status) {
   __shared__ __attribute__((aligned(16))) float smem[2 * BUF_FLOATS];
   float* R = smem; float* Cc = smem + BUF_FLOATS;
+  // Ks / Vts / Ls (optional, all or none): the rollout's two-piece fp16 images of K / Vt / L (rr_pack_f16x2's arithmetic and range
+  // guard, same byte offsets) written from the accumulators instead of by three more passes over the fp32 tensors
+  bool bad = false;
+  auto image4 = [&](const float (&v)[4]) {
+    const float sc = (float)(1 << RR_KS);
+    const float x[4] = {v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bad = bad || !(fabsf(x[q]) < RR_F16_LIMIT);
+    const rr_f16x8 sp = rr_usplit4s(x);                          // [lo | hi]
+    return __builtin_bit_cast(float4, rr_cat4(rr_hi4(sp), rr_lo4(sp)));
+  };
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, g = lane >> 4, fb = 16 * wave;
@@ -1261,8 +1274,19 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_dec_cache(CacheW w, const fl
       rr_gemm_wx<NT>(a, wp + (size_t)wave * 8 * 64, 0, 8, X, LD, 0, N, lane);
     }
   };
+  auto store_image = [&](float4* img) {      // a lane's four consecutive features of a node are one 16-byte group of the image
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int node = nt * 16 + j;
+      const float v[4] = {a[nt][0], a[nt][1], a[nt][2], a[nt][3]};
+      const float4 im = image4(v);
+      if (node < N) img[(off + (size_t)node * RR_E + fb + 4 * g) >> 2] = im;
+    }
+  };
   run(w.wk, w.wks, Cc); rr_store_tiles<NT>(a, K + off, RR_E, fb, N, lane);
+  if (Ks) store_image(Ks);
   run(w.wl, w.wls, Cc); rr_store_tiles<NT>(a, L + off, RR_E, fb, N, lane);
+  if (Ls) store_image(Ls);
   run(w.wv, w.wvs, Cc);
   {  // Vt[b][feature][key], keys padded to 112 with zeros
     float* vt = Vt + (size_t)b * RR_E * 112;
@@ -1274,23 +1298,33 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_dec_cache(CacheW w, const fl
         float v = 0.f;
         if (nt < NT && node < N) v = a[nt < NT ? nt : 0][r];
         vt[(fb + 4 * g + r) * 112 + node] = v;
+        if (Vts) {      // the image groups four consecutive KEYS of a feature: the four lanes of a quad (DPP quad broadcasts), stored by its first lane
+          const int iv = __float_as_int(v);
+          const float q4[4] = {__int_as_float(__builtin_amdgcn_mov_dpp(iv, 0x00, 0xf, 0xf, true)), __int_as_float(__builtin_amdgcn_mov_dpp(iv, 0x55, 0xf, 0xf, true)),
+                               __int_as_float(__builtin_amdgcn_mov_dpp(iv, 0xaa, 0xf, 0xf, true)), __int_as_float(__builtin_amdgcn_mov_dpp(iv, 0xff, 0xf, 0xf, true))};
+          const float4 im = image4(q4);
+          if ((j & 3) == 0) Vts[((size_t)b * RR_E * 112 + (size_t)(fb + 4 * g + r) * 112 + node) >> 2] = im;
+        }
       }
     }
   }
+  if (status != nullptr && __any(bad) && lane == 0) atomicOr(status, 1);
   if (w.wca) { run(w.wca, w.wcas, R); rr_store_tiles<NT>(a, ctxA + off, RR_E, fb, N, lane); }
   run(w.wcb, w.wcbs, R); rr_store_tiles<NT>(a, ctxB + off, RR_E, fb, N, lane);
 }
 
 extern "C" int rr_dec_cache(const CacheW* w, const float* row_emb, const float* col_emb, float* K, float* Vt, float* L,
-                            float* ctxA, float* ctxB, int Bp, int N, hipStream_t st) {
+                            float* ctxA, float* ctxB, void* Ks_, void* Vts_, void* Ls_, int* status, int Bp, int N, hipStream_t st) {
   if (Bp <= 0 || N < 2 || N > RR_MAXN || w == nullptr) return RR_EINVAL;
+  if ((Ks_ != nullptr) != (Vts_ != nullptr) || (Ks_ != nullptr) != (Ls_ != nullptr)) return RR_EINVAL;      // the three images together or none
+  float4 *Ks = (float4*)Ks_, *Vts = (float4*)Vts_, *Ls = (float4*)Ls_;
   dim3 grid(Bp), blk(ENC_THREADS);
   const char* es = getenv("RR_MLP_SPLIT");
   const bool split = (es == nullptr || atoi(es) != 0) && w->wks && w->wvs && w->wls && w->wcbs && (w->wca == nullptr || w->wcas);
 #define RR_DC(NTV)                                                                                                        \
   do {                                                                                                                    \
-    if (split) hipLaunchKernelGGL((k_dec_cache<NTV, true>), grid, blk, 0, st, *w, row_emb, col_emb, K, Vt, L, ctxA, ctxB, N); \
-    else hipLaunchKernelGGL((k_dec_cache<NTV, false>), grid, blk, 0, st, *w, row_emb, col_emb, K, Vt, L, ctxA, ctxB, N);   \
+    if (split) hipLaunchKernelGGL((k_dec_cache<NTV, true>), grid, blk, 0, st, *w, row_emb, col_emb, K, Vt, L, ctxA, ctxB, N, Ks, Vts, Ls, status); \
+    else hipLaunchKernelGGL((k_dec_cache<NTV, false>), grid, blk, 0, st, *w, row_emb, col_emb, K, Vt, L, ctxA, ctxB, N, Ks, Vts, Ls, status);   \
   } while (0)
   if (N <= 32) RR_DC(2);
   else if (N <= 64) RR_DC(4);

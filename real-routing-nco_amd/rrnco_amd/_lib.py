@@ -129,7 +129,7 @@ _SIGS = {
     "rr_rmtvrp_step": [vp] * 16 + [i32, i32, i32, C.POINTER(MtvrpExtra), vp],
     "rr_reinforce_loss": [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "rr_init_embed": [C.POINTER(InitW), i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
-    "rr_dec_cache": [C.POINTER(CacheW), vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "rr_dec_cache": [C.POINTER(CacheW), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "rr_rollout": [C.POINTER(DecW), C.POINTER(RolloutIO), i32, vp],
     "rr_submatrix_gather": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "rr_matnet_layer": [C.POINTER(MatNetSideW), C.POINTER(MatNetSideW), vp, vp, vp, vp, vp, vp, C.c_size_t] + [i32] * 5 + [vp],

@@ -85,11 +85,12 @@ class RRNetDecoder(nn.Module):
         self.use_graph_context = use_graph_context
         self.alpha = nn.Parameter(torch.tensor([1.0]))
 
-    def pre_decoder_hook(self, td, env, embeddings, num_starts: int = 0, packed=None):
-        return td, env, self._precompute_cache(embeddings, num_starts, packed)
+    def pre_decoder_hook(self, td, env, embeddings, num_starts: int = 0, packed=None, status=None):
+        return td, env, self._precompute_cache(embeddings, num_starts, packed, status=status)
 
-    def _precompute_cache(self, embeddings, num_starts: int = 0, packed=None) -> PrecomputedCache:
-        """decoder.py:214-232 on csrc/rr_encoder.hip:k_dec_cache."""
+    def _precompute_cache(self, embeddings, num_starts: int = 0, packed=None, status=None) -> PrecomputedCache:
+        """decoder.py:214-232 on csrc/rr_encoder.hip:k_dec_cache.  With the two-piece kernels on (the default) the same launch writes
+        the rollout's fp16 images of K / V^T / L; `status` (the policy's range-guard word) collects their range check."""
         assert packed is not None
         row, col = (e.contiguous() for e in embeddings)
         L.require_gpu(row)
@@ -100,9 +101,16 @@ class RRNetDecoder(nn.Module):
         K, Lk, cb = torch.empty_like(row), torch.empty_like(row), torch.empty_like(row)
         ca = torch.empty_like(row) if self.env_name == "atsp" else None
         Vt = torch.empty(Bp, E, 112, device=row.device, dtype=torch.float32)
+        from .. import packing
+        from . import rollout as _R
+        import os as _os
+        images = None
+        if _R.SPLIT_MLP and packing.mlp_split_enabled() and _os.environ.get("RR_CACHE_IMAGES", "1") != "0":     # (0: rr_pack_f16x2 on demand, A/B)
+            images = (torch.empty_like(K), torch.empty_like(Vt), torch.empty_like(Lk))
         L.check(L.lib().rr_dec_cache(packed["cache"], L.ptr(row), L.ptr(col), L.ptr(K), L.ptr(Vt), L.ptr(Lk),
-                                     L.ptr(ca), L.ptr(cb), Bp, N, L.stream()), "rr_dec_cache")
-        return PrecomputedCache(row, 0, K, Vt, Lk, ca, cb)
+                                     L.ptr(ca), L.ptr(cb), *(L.ptr(t) for t in (images or (None, None, None))),
+                                     L.ptr(status) if images is not None else None, Bp, N, L.stream()), "rr_dec_cache")
+        return PrecomputedCache(row, 0, K, Vt, Lk, ca, cb, split=images)
 
     def forward(self, td, cached: PrecomputedCache, num_starts: int = 0, packed=None):
         """decoder.py:151-206: -> (logits [S*B,N] post inductive-bias transform, mask [S*B,N]).

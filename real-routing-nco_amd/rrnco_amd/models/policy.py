@@ -322,7 +322,8 @@ class RRNetPolicy(nn.Module):
             store_all_logp=decoding_kwargs.pop("store_all_logp", return_entropy), **decoding_kwargs)
 
         td, env, num_starts = strategy.pre_decoder_hook(td, env)
-        td, env, cache = self.decoder.pre_decoder_hook(td, env, (row_emb, col_emb), num_starts, packed=packed)
+        td, env, cache = self.decoder.pre_decoder_hook(td, env, (row_emb, col_emb), num_starts, packed=packed,
+                                                       status=getattr(self, "_range_status", None))
 
         # the fused rollout keeps one log-probability per step; full rows (store_all_logp / return_entropy) come from the step-wise loop
         if td["action_mask"].shape[-1] > 103:

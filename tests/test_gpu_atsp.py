@@ -121,6 +121,28 @@ def test_decoder_forward_logits_match_golden_trace_given_reference_embeddings():
         td.set("action", fx["actions"][:, k + 1].cuda()); td = env.step(td)["next"]
 
 
+@pytest.mark.parametrize("name", ["atsp_n20_b4_pomo", "atsp_n50_b3_pomo_trained", "atsp_n100_b2_pomo_trained"])
+def test_decoder_cache_writes_the_rollout_images_itself(name):
+    """rr_dec_cache's optional Ks / Vts / Ls (round 5): the two-piece fp16 images of K / V^T / L from the accumulators, bit for bit what
+    rr_pack_f16x2 makes of the fp32 tensors (all three tile counts, V^T's zero-padded keys included), and the same range guard."""
+    from rrnco_amd import _lib as L
+    fx, w, pol, st, env, td_in = _setup(name)
+    packed = pol.packed(torch.device("cuda"))
+    row, col = fx["row_emb"].cuda(), fx["col_emb"].cuda()
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    cache = pol.decoder._precompute_cache((row, col), packed=packed, status=status)
+    assert cache.split is not None and int(status.item()) == 0
+    for img, src in zip(cache.split, (cache.glimpse_key, cache.glimpse_val_t, cache.logit_key)):
+        ref = torch.empty_like(src)
+        L.check(L.lib().rr_pack_f16x2(L.ptr(src), L.ptr(ref), src.numel(), None, L.stream()), "rr_pack_f16x2")
+        assert torch.equal(img.view(torch.int32), ref.view(torch.int32))
+    # an embedding that leaves the fp16 range after the image's scale raises bit 0, as the pack kernel does
+    big = col.clone(); big[0, 1, 5] = 3.0e6
+    status.zero_()
+    pol.decoder._precompute_cache((row, big), packed=packed, status=status)
+    assert int(status.item()) & 1
+
+
 def _decision_gaps(fx, w, st):
     tr = {}
     with torch.inference_mode():
