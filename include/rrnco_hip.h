@@ -351,8 +351,10 @@ int rr_aft_bwd(const AftBwdIO* io, int Bp, hipStream_t stream);
 int rr_nab_hist_bwd(const float* pwl, const float* xd, const float* xa, const float* gout, float* hist, long M,
                     hipStream_t stream);
 
-/* ---- instances with 104 .. 208 nodes (csrc/rr_bign.hip): the same operators as row-parallel kernels over HBM-resident
- * tensors, the decode loop step by step.  rr_enc_layer / rr_rollout keep one instance's activations on chip (N <= 103). */
+/* ---- instances with 104 .. 1 024 nodes (csrc/rr_bign.hip; the reference's generators, rrnco/envs/rcvrp/generator.py:21-37, go to
+ * 1 000): the same operators as row-parallel kernels over HBM-resident tensors, the decode loop step by step.  rr_enc_layer /
+ * rr_rollout keep one instance's activations on chip (N <= 103).  rr_aft_mix_big / rr_dec_fwd_big hold a row of up to 208 keys in
+ * registers and stream longer rows in two or three sweeps (same order of every sum: bit-identical where both forms apply). */
 /* Normalization "instance" (attn_freenet.py:84, 104-105) of x (+ res) over the node axis. */
 int rr_inorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* out, int Bp, int N, hipStream_t stream);
 /* alpha * DistAngleFusion (attn_freenet.py:242-289) per edge from the folded piecewise-linear table (EncBlockW.nab);
@@ -368,7 +370,7 @@ typedef struct {
 } DecBigIO;
 /* RRNetDecoder.forward (decoder.py:151-206, 281-323) for all S*Bp rollouts: logits [R][N] after the inductive-bias transform. */
 int rr_dec_fwd_big(const DecBigIO* io, hipStream_t stream);
-/* process_logits + greedy / sampling / evaluate (decoding.py:311-361) for rows of up to 256 keys. */
+/* process_logits + greedy / sampling / evaluate (decoding.py:311-361) for rows of up to 1 024 keys. */
 int rr_select_big(const float* logits, const uint8_t* mask, const int64_t* action_in, int64_t* action_out, float* logp_out,
                   float* logp_all, int R, int N, float tanh_clip, float temperature, int mode, unsigned long long seed,
                   unsigned int step, hipStream_t stream);

@@ -1,4 +1,4 @@
-// Instances with more than 103 nodes (up to 208): the reference's generators go to 1000+ nodes
+// Instances with more than 103 nodes (up to 1 024; rows of up to 208 keys in registers, longer ones streamed): the reference's generators go to 1000+ nodes
 // (rrnco/envs/rcvrp/generator.py:22-37), while the register / LDS-resident kernels of rr_encoder.hip and rr_decode.hip hold one
 // instance's [N, 128] activations, its N x N mixing weights and 7 key tiles per wave on chip (N <= 103).  Here the same
 // operators run as row-parallel kernels over HBM / L2-resident tensors — every wave autonomous, no LDS images, key tiles as a
@@ -10,6 +10,7 @@
 //   k_dec_fwd_big    RRNetDecoder.forward (decoder.py:151-206, 281-323): context, masked 8-head attention, pointer MLP, logits
 //   k_select_big     process_logits + greedy / sampling / evaluate (decoding.py:311-361) for rows of up to 256 keys
 #include "rr_common.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------ instance norm forward
 __global__ __launch_bounds__(256) void k_inorm_fwd(const float* __restrict__ x, const float* __restrict__ res,
@@ -189,13 +190,89 @@ __global__ __launch_bounds__(256, 2) void k_aft_mix_big(const float* __restrict_
     if (nvalid) rr_st4(y + roff + 16 * t, make_float4(o[0], o[1], o[2], o[3]));
   }
 }
+// The same mixing for any N (rows of more than 208 keys do not fit a lane's registers): three sweeps over the bias row — maximum,
+// denominator, then per key tile the four weights of the lane rebuilt and the two products of all eight feature tiles accumulated.
+// Every accumulator receives its key tiles in the same order as in k_aft_mix_big: bit-identical results where both apply.
+__global__ __launch_bounds__(256, 2) void k_aft_mix_stream(const float* __restrict__ bias, const float* __restrict__ q,
+                                                           const float* __restrict__ ekT, const float* __restrict__ kvT,
+                                                           float* __restrict__ y, int N, int NP, int tiles_per_inst, int ntask) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int task = blockIdx.x * 4 + wave;
+  if (task >= ntask) return;
+  const int b = task / tiles_per_inst, tile = task - b * tiles_per_inst;
+  const int node = 16 * tile + j;
+  const bool nvalid = node < N;
+  const int nc = nvalid ? node : N - 1;
+  const float* brow = bias + ((size_t)b * N + nc) * N;
+  const int nkt = NP >> 4;
+  float mx = -INFINITY;
+#pragma unroll 1
+  for (int kt = 0; kt < nkt; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int jj = 16 * kt + 4 * g + r;
+      mx = fmaxf(mx, jj < N ? brow[jj] : -INFINITY);
+    }
+  mx = rr_max_g(mx);
+  float sum = 0.f;
+#pragma unroll 1
+  for (int kt = 0; kt < nkt; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int jj = 16 * kt + 4 * g + r;
+      sum += rr_exp((jj < N ? brow[jj] : -INFINITY) - mx);
+    }
+  sum = rr_sum_g(sum);
+  const float is = 1.0f / sum;
+  const float* pe = ekT + (size_t)b * RR_E * NP + 4 * g;
+  const float* pk = kvT + (size_t)b * RR_E * NP + 4 * g;
+  const size_t roff = ((size_t)b * N + nc) * RR_E + 4 * g;
+  f32x4 dn[8], nm[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) { dn[t] = rr_zero4(); nm[t] = rr_zero4(); }
+#pragma unroll 1
+  for (int kt = 0; kt < nkt; ++kt) {
+    float ea[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int jj = 16 * kt + 4 * g + r;
+      ea[r] = jj < N ? rr_exp(rr_exp(brow[jj] - mx) * is) : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const size_t ao = (size_t)(16 * t + j) * NP;
+      const float4 ae = rr_ld4(pe + ao + 16 * kt), az = rr_ld4(pk + ao + 16 * kt);
+      dn[t] = rr_mfma(ae.x, ea[0], dn[t]); nm[t] = rr_mfma(az.x, ea[0], nm[t]);
+      dn[t] = rr_mfma(ae.y, ea[1], dn[t]); nm[t] = rr_mfma(az.y, ea[1], nm[t]);
+      dn[t] = rr_mfma(ae.z, ea[2], dn[t]); nm[t] = rr_mfma(az.z, ea[2], nm[t]);
+      dn[t] = rr_mfma(ae.w, ea[3], dn[t]); nm[t] = rr_mfma(az.w, ea[3], nm[t]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const float4 qq = rr_ld4(q + roff + 16 * t);
+    const float qv[4] = {qq.x, qq.y, qq.z, qq.w};
+    float o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = rr_sigmoid(qv[r]) * nm[t][r] / dn[t][r];
+    if (nvalid) rr_st4(y + roff + 16 * t, make_float4(o[0], o[1], o[2], o[3]));
+  }
+}
+#define RR_BIGN_MAX 1024     // nodes of the row-parallel path (the reference's generators go to 1 000)
+static bool rr_bign_force_stream() {      // tests: the any-N kernels at every N (read per call: a test flips it inside one process)
+  const char* e = getenv("RR_BIGN_STREAM");
+  return e != nullptr && atoi(e) != 0;
+}
 extern "C" int rr_aft_mix_big(const float* bias, const float* q, const float* ekT, const float* kvT, float* y, int Bp, int N,
                               int NP, hipStream_t st) {
-  if (bias == nullptr || q == nullptr || ekT == nullptr || kvT == nullptr || y == nullptr || Bp <= 0 || N < 2 || N > 208 || NP < N || (NP & 15))
+  if (bias == nullptr || q == nullptr || ekT == nullptr || kvT == nullptr || y == nullptr || Bp <= 0 || N < 2 || N > RR_BIGN_MAX || NP < N || (NP & 15))
     return RR_EINVAL;
   const int tpi = (N + 15) / 16, ntask = Bp * tpi;
   const dim3 grid((ntask + 3) / 4);
-  if (N <= 128) hipLaunchKernelGGL((k_aft_mix_big<8>), grid, dim3(256), 0, st, bias, q, ekT, kvT, y, N, NP, tpi, ntask);
+  if (N > 208 || rr_bign_force_stream()) hipLaunchKernelGGL(k_aft_mix_stream, grid, dim3(256), 0, st, bias, q, ekT, kvT, y, N, NP, tpi, ntask);
+  else if (N <= 128) hipLaunchKernelGGL((k_aft_mix_big<8>), grid, dim3(256), 0, st, bias, q, ekT, kvT, y, N, NP, tpi, ntask);
   else hipLaunchKernelGGL((k_aft_mix_big<13>), grid, dim3(256), 0, st, bias, q, ekT, kvT, y, N, NP, tpi, ntask);
   return rr_check(hipGetLastError());
 }
@@ -249,21 +326,68 @@ __global__ __launch_bounds__(256, 1) void k_dec_fwd_big(DecBigIO io, int tiles_p
       G[h] = f32x4{c.x, c.y, c.z, c.w};
     }
   }
-  // ---- masked multi-head attention (decoder.py:308-323): all key tiles of a head in registers
-  f32x4 mneg[NTK];
-#pragma unroll
-  for (int kt = 0; kt < NTK; ++kt)
+  // ---- masked multi-head attention (decoder.py:308-323): all key tiles of a head in registers; NTK == 0 (any N): two sweeps per head,
+  // the scores rebuilt in the second one (same matrix instructions, same order of every sum: bit-identical where both forms apply)
+  constexpr int NA = NTK > 0 ? NTK : 1;
+  const int nkt = NP >> 4;
+  f32x4 mneg[NA];
+  auto mask4 = [&](int kt) {
+    f32x4 m;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int key = 16 * kt + 4 * g + q;
-      mneg[kt][q] = (key < N && mrow[key]) ? 0.f : -INFINITY;
+      m[q] = (key < N && mrow[key]) ? 0.f : -INFINITY;
     }
+    return m;
+  };
+  if constexpr (NTK > 0) {
+#pragma unroll
+    for (int kt = 0; kt < NTK; ++kt) mneg[kt] = mask4(kt);
+  }
   const float* Kb = io.K + (size_t)b * N * RR_E;
   const float* Vb = io.Vt + (size_t)b * RR_E * NP;
 #pragma unroll 1
   for (int h = 0; h < 8; ++h) {
     const float g0 = G[0][0] * 0.25f, g1 = G[0][1] * 0.25f, g2 = G[0][2] * 0.25f, g3 = G[0][3] * 0.25f;
-    f32x4 sc[NTK];
+    if constexpr (NTK == 0) {
+      auto score = [&](int kt) {
+        int key = 16 * kt + j; key = key < N ? key : N - 1;
+        const float4 kf = rr_ld4(Kb + (size_t)key * RR_E + 16 * h + 4 * g);
+        f32x4 a = rr_mfma(kf.x, g0, mask4(kt));
+        a = rr_mfma(kf.y, g1, a); a = rr_mfma(kf.z, g2, a); a = rr_mfma(kf.w, g3, a);
+        return a;
+      };
+      float mx = -INFINITY;
+#pragma unroll 1
+      for (int kt = 0; kt < nkt; ++kt) {
+        const f32x4 a = score(kt);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mx = fmaxf(mx, a[q]);
+      }
+      mx = rr_max_g(mx);
+      if (mx == -INFINITY) mx = 0.f;
+      float sum = 0.f;
+      f32x4 o0 = rr_zero4(), o1 = rr_zero4();
+#pragma unroll 1
+      for (int kt = 0; kt < nkt; ++kt) {
+        f32x4 a = score(kt);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a[q] = rr_exp(a[q] - mx); sum += a[q]; }
+        const float4 vf = rr_ld4(Vb + (size_t)(16 * h + j) * NP + 16 * kt + 4 * g);
+        o0 = rr_mfma(vf.x, a[0], o0); o1 = rr_mfma(vf.y, a[1], o1);
+        o0 = rr_mfma(vf.z, a[2], o0); o1 = rr_mfma(vf.w, a[3], o1);
+      }
+      sum = rr_sum_g(sum);
+      const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+      f32x4 gsel;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gsel[q] = fmaf(o0[q] + o1[q], inv, G[0][q]);
+#pragma unroll
+      for (int q = 0; q < 7; ++q) G[q] = G[q + 1];
+      G[7] = gsel;
+      continue;
+    }
+    f32x4 sc[NA];
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NTK; ++kt) {
@@ -355,7 +479,7 @@ __global__ __launch_bounds__(256, 1) void k_dec_fwd_big(DecBigIO io, int tiles_p
   const float* Trow = io.Dur ? io.Dur + ((size_t)b * N + cur) * N : nullptr;
   float* lout = io.logits + r * N;
 #pragma unroll 1
-  for (int kt = 0; kt < NTK; ++kt) {
+  for (int kt = 0; kt < (NTK > 0 ? NTK : nkt); ++kt) {
     if (16 * kt >= N) break;                         // wave-uniform
     int key = 16 * kt + j; key = key < N ? key : N - 1;
     const float* lp = Lb + (size_t)key * RR_E + 4 * g;
@@ -385,16 +509,19 @@ extern "C" int rr_dec_fwd_big(const DecBigIO* io, hipStream_t st) {
     return RR_EINVAL;
   if ((io->first != nullptr) != (io->ctxA != nullptr)) return RR_EINVAL;
   if (io->nscal < 0 || io->nscal > 4 || (io->nscal > 0 && (io->scal == nullptr || io->wstate == nullptr))) return RR_EINVAL;
-  if (io->Bp <= 0 || io->N < 2 || io->N > 208 || io->S < 1 || io->NP < io->N || (io->NP & 15)) return RR_EINVAL;
+  if (io->Bp <= 0 || io->N < 2 || io->N > RR_BIGN_MAX || io->S < 1 || io->NP < io->N || (io->NP & 15)) return RR_EINVAL;
   const int tpi = (io->S + 15) / 16, ntask = io->Bp * tpi;
   const dim3 grid((ntask + 3) / 4);
-  if (io->N <= 128) hipLaunchKernelGGL((k_dec_fwd_big<8>), grid, dim3(256), 0, st, *io, tpi, ntask);
+  if (io->N > 208 || rr_bign_force_stream()) hipLaunchKernelGGL((k_dec_fwd_big<0>), grid, dim3(256), 0, st, *io, tpi, ntask);
+  else if (io->N <= 128) hipLaunchKernelGGL((k_dec_fwd_big<8>), grid, dim3(256), 0, st, *io, tpi, ntask);
   else hipLaunchKernelGGL((k_dec_fwd_big<13>), grid, dim3(256), 0, st, *io, tpi, ntask);
   return rr_check(hipGetLastError());
 }
 
-// ------------------------------------------------------------------------------------------------ selection, N <= 256
-// One wave per row, keys lane + 64 q.  mode 0 greedy (first index on ties), 1 sampling (inverse CDF, keyed uniform: rr_common.h), 2 evaluate.
+// ------------------------------------------------------------------------------------------------ selection, N <= 64 Q
+// One wave per row, keys lane + 64 q (Q = 4: rows of up to 256 keys, 16: up to 1 024).  mode 0 greedy (first index on ties), 1 sampling
+// (inverse CDF, keyed uniform: rr_common.h), 2 evaluate.
+template <int Q>
 __global__ __launch_bounds__(256) void k_select_big(const float* __restrict__ logits, const uint8_t* __restrict__ mask,
                                                     const int64_t* __restrict__ action_in, int64_t* __restrict__ action_out,
                                                     float* __restrict__ logp_out, float* __restrict__ logp_all, int R, int N,
@@ -403,10 +530,10 @@ __global__ __launch_bounds__(256) void k_select_big(const float* __restrict__ lo
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= R) return;
   const float inv_temp = 1.0f / temperature;
-  float x[4];
+  float x[Q];
   float m = -INFINITY;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < Q; ++q) {
     const int jx = lane + 64 * q;
     float v = -INFINITY;
     if (jx < N) {
@@ -420,18 +547,20 @@ __global__ __launch_bounds__(256) void k_select_big(const float* __restrict__ lo
   m = rr_wave_max(m);
   float s = 0.f;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) s += (lane + 64 * q < N) ? rr_exp(x[q] - m) : 0.f;
+  for (int q = 0; q < Q; ++q) s += (lane + 64 * q < N) ? rr_exp(x[q] - m) : 0.f;
   const float lse = rr_log(rr_wave_sum(s));
   const int want = mode == 2 ? (int)action_in[r] : -1;
   float bv = -INFINITY, blp = 0.f;
   int bi = 0x7fffffff;
   // sampling: inverse CDF over the keys in ascending order (rr_common.h): a key's value is its index where it is eligible — it has mass
   // and its exclusive prefix is <= target — so the maximum below is the last eligible key
-  float en[4] = {0.f, 0.f, 0.f, 0.f}, cpre[4] = {0.f, 0.f, 0.f, 0.f}, target = 0.f;
+  float en[Q], cpre[Q], target = 0.f;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) { en[q] = 0.f; cpre[q] = 0.f; }
   if (mode == 1) {
     float base = 0.f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < Q; ++q) {
       en[q] = (lane + 64 * q < N) ? rr_exp(x[q] - m) : 0.f;
       float tq;
       cpre[q] = base + rr_wave_excl_scan(en[q], tq);
@@ -440,7 +569,7 @@ __global__ __launch_bounds__(256) void k_select_big(const float* __restrict__ lo
     target = rr_cdf_target(rr_uniform(seed, (uint32_t)r, step, RR_CDF_SLOT), base);
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < Q; ++q) {
     const int jx = lane + 64 * q;
     const float lp = x[q] - m - lse;
     if (logp_all != nullptr && jx < N) logp_all[(size_t)r * N + jx] = lp;
@@ -463,9 +592,13 @@ __global__ __launch_bounds__(256) void k_select_big(const float* __restrict__ lo
 extern "C" int rr_select_big(const float* logits, const uint8_t* mask, const int64_t* action_in, int64_t* action_out,
                              float* logp_out, float* logp_all, int R, int N, float tanh_clip, float temperature, int mode,
                              uint64_t seed, uint32_t step, hipStream_t st) {
-  if (R <= 0 || N <= 0 || N > 256 || temperature <= 0.f || mode < 0 || mode > 2) return RR_EINVAL;
+  if (R <= 0 || N <= 0 || N > RR_BIGN_MAX || temperature <= 0.f || mode < 0 || mode > 2) return RR_EINVAL;
   if (logits == nullptr || action_out == nullptr || logp_out == nullptr || (mode == 2 && action_in == nullptr)) return RR_EINVAL;
-  hipLaunchKernelGGL(k_select_big, dim3((R + 3) / 4), dim3(256), 0, st, logits, mask, action_in, action_out, logp_out, logp_all, R, N,
-                     tanh_clip, temperature, mode, seed, step);
+  if (N <= 256 && !rr_bign_force_stream())
+    hipLaunchKernelGGL(k_select_big<4>, dim3((R + 3) / 4), dim3(256), 0, st, logits, mask, action_in, action_out, logp_out, logp_all, R, N,
+                       tanh_clip, temperature, mode, seed, step);
+  else
+    hipLaunchKernelGGL(k_select_big<16>, dim3((R + 3) / 4), dim3(256), 0, st, logits, mask, action_in, action_out, logp_out, logp_all, R, N,
+                       tanh_clip, temperature, mode, seed, step);
   return rr_check(hipGetLastError());
 }

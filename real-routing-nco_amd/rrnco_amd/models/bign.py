@@ -1,4 +1,4 @@
-"""Host side of csrc/rr_bign.hip: encoder, decoder cache, decoder.forward and the selection for instances with 104 .. 208 nodes
+"""Host side of csrc/rr_bign.hip: encoder, decoder cache, decoder.forward and the selection for instances with 104 .. 1 024 nodes
 (ATSP, RCVRP, RCVRPTW / the multi-task variants; gating NAB without or with the duration matrix, instance norm).  The on-chip kernels (rr_enc_layer, rr_rollout) hold one instance's
 activations in registers / LDS and stop at 103 nodes; here the same operators (rrnco/models/nn/attn_freenet.py:417-441,
 rrnco/models/decoder.py:151-329) run as row-parallel kernels over HBM / L2-resident tensors and the decode loop runs step by step,
@@ -11,7 +11,7 @@ from .. import _lib as L
 from .. import packing
 
 E = 128
-MAX_N_ONCHIP, MAX_N_BIG = 103, 208
+MAX_N_ONCHIP, MAX_N_BIG = 103, 1024      # (rows of up to 208 keys stay in registers, longer ones are streamed: csrc/rr_bign.hip)
 
 
 def _np(n: int) -> int:

@@ -86,7 +86,34 @@ def test_atsp_max_nodes_103_and_more_starts_than_a_workgroup_tile_set():
     _run(103, 2, 103, 25, seed=7)
 
 
-@pytest.mark.parametrize("N,S", [(128, 16), (200, 24)])
+def test_streamed_rows_equal_the_register_forms_bit_for_bit(monkeypatch):
+    """csrc/rr_bign.hip: rows of more than 208 keys are streamed (k_aft_mix_stream, k_dec_fwd_big<0>, k_select_big<16>); RR_BIGN_STREAM=1
+    sends every N through those forms.  Same matrix instructions, same order of every sum: embeddings, tours and log-likelihoods of
+    a 150- and a 200-node instance are identical to the register forms' bit for bit."""
+    from rrnco_amd import TensorDict
+    from rrnco_amd.envs import ATSPEnv
+    w = restate.make_weights(restate.atsp_weight_template(128, 2, 512, 25), 3)
+    pol = H.make_policy(w)
+    for N, S in ((150, 20), (200, 9)):
+        inst = restate.atsp_synthetic(2, N, 13)
+        env = ATSPEnv(generator_params=dict(num_loc=N))
+        sidx = restate.sample_neighbor_indices(restate.atsp_reset(inst)["distance_matrix"], 25, generator=torch.Generator().manual_seed(5)).cuda()
+        res = {}
+        for sw in ("0", "1"):
+            monkeypatch.setenv("RR_BIGN_STREAM", sw)
+            td = TensorDict({k: v.cuda() for k, v in inst.items()}, batch_size=[2]); td["sample_idx"] = sidx
+            td = env.reset(td)
+            row, col = pol.encoder(td, packed=pol.packed(torch.device("cuda")))
+            g = pol(td, env, phase="val", decode_type="multistart_greedy", num_starts=S)
+            td2 = TensorDict({k: v.cuda() for k, v in inst.items()}, batch_size=[2]); td2["sample_idx"] = sidx
+            smp = pol(env.reset(td2), env, phase="val", decode_type="multistart_sampling", num_starts=S, seed=4)
+            res[sw] = (row, col, g["actions"], g["log_likelihood"], smp["actions"], smp["log_likelihood"])
+        monkeypatch.delenv("RR_BIGN_STREAM")
+        for a, b in zip(res["0"], res["1"]):
+            assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("N,S", [(128, 16), (200, 24), (300, 12)])
 def test_atsp_more_than_103_nodes_matches_the_live_oracle(N, S):
     """N > 103: the row-parallel kernels of csrc/rr_bign.hip under the same policy API (step-by-step decode loop), against the
     oracle run live: embeddings, greedy POMO tours (every divergence at an oracle decision gap < GAP_TOL), costs, log-likelihoods."""
@@ -145,6 +172,81 @@ def test_rcvrp_more_than_103_nodes_roundtrip_properties():
     assert bool(served[:, 1:].all()) and bool(torch.isfinite(out["reward"]).all())
 
 
+def test_rcvrp_500_nodes_roundtrip_properties():
+    """RCVRP with 500 customers (streamed rows): every customer once, capacity kept (the env's own check), finite costs, and the greedy
+    tours' cost recomputed from the real distance matrix."""
+    from rrnco_amd.envs import RCVRPEnv
+    w = restate.make_weights(restate.rcvrp_weight_template(128, 2, 512, 20), 5)
+    pol = H.make_policy(w, env_name="rcvrp")
+    env = RCVRPEnv(generator_params=dict(num_loc=500), check_solution=True)
+    td_in = env.generator(2, generator=torch.Generator(device="cuda").manual_seed(2))
+    out = pol(env.reset(td_in), env, phase="val", decode_type="multistart_greedy", num_starts=6)
+    a = out["actions"]
+    served = torch.zeros(a.shape[0], 501, dtype=torch.bool, device="cuda").scatter_(1, a, True)
+    assert bool(served[:, 1:].all()) and bool(torch.isfinite(out["reward"]).all())
+    D = td_in["distance_matrix"]
+    R = a.shape[0]
+    b = torch.arange(R, device="cuda") % 2
+    path = torch.cat([torch.zeros(R, 1, dtype=torch.int64, device="cuda"), a, torch.zeros(R, 1, dtype=torch.int64, device="cuda")], 1)
+    cost = D[b[:, None], path[:, :-1], path[:, 1:]].sum(1)
+    assert torch.allclose(-out["reward"], cost, rtol=2e-5, atol=1e-3)
+
+
+def test_atsp_1000_nodes_roundtrip_properties():
+    """The reference's generators go to 1 000 nodes (rcvrp/generator.py:21-37): one ATSP instance of 1 000 nodes end to end (streamed
+    rows, 999 decode steps): every start yields a permutation, the reported cost is the tour's length on the real matrix, greedy and
+    evaluate agree on the log-likelihood."""
+    from rrnco_amd import TensorDict
+    from rrnco_amd.envs import ATSPEnv
+    N, S = 1000, 5
+    w = restate.make_weights(restate.atsp_weight_template(128, 1, 512, 25), 3)
+    pol = H.make_policy(w)
+    inst = restate.atsp_synthetic(1, N, 17)
+    env = ATSPEnv(generator_params=dict(num_loc=N))
+    td = env.reset(TensorDict({k: v.cuda() for k, v in inst.items()}, batch_size=[1]))
+    sidx = restate.sample_neighbor_indices(td["distance_matrix"].cpu(), 25, generator=torch.Generator().manual_seed(5)).cuda()
+    td["sample_idx"] = sidx
+    out = pol(td, env, phase="val", decode_type="multistart_greedy", num_starts=S)
+    acts = out["actions"].cpu()
+    assert acts.shape == (S, N) and restate.atsp_check(acts)
+    D = inst["distance_matrix"][0]
+    cost = D[acts, acts.roll(-1, 1)].sum(1)
+    assert torch.allclose(-out["reward"].cpu(), cost, rtol=2e-5, atol=1e-3)
+    td2 = env.reset(TensorDict({k: v.cuda() for k, v in inst.items()}, batch_size=[1])); td2["sample_idx"] = sidx
+    ev = pol(td2, env, phase="val", actions=out["actions"][:, 1:], num_starts=S)
+    assert torch.allclose(ev["log_likelihood"], out["log_likelihood"], rtol=1e-5, atol=2e-3)
+
+
+def test_rcvrptw_300_nodes_roundtrip_properties():
+    """RCVRPTW with 300 customers on the streamed forms (duration NAB, MTVRP context): routes the env's own checker accepts."""
+    from rrnco_amd.envs import RMTVRPEnv
+    w = restate.make_weights(restate.rcvrptw_weight_template(128, 2, 512, 20), 7)
+    pol = H.make_policy(w, env_name="rcvrptw")
+    env = RMTVRPEnv(generator_params=dict(num_loc=300))
+    td_in = env.generator(2, generator=torch.Generator(device="cuda").manual_seed(4))
+    out = pol(env.reset(td_in), env, phase="val", decode_type="multistart_greedy", num_starts=5)
+    a = out["actions"]
+    served = torch.zeros(a.shape[0], 301, dtype=torch.bool, device="cuda").scatter_(1, a, True)
+    assert bool(served[:, 1:].all()) and bool(torch.isfinite(out["reward"]).all())
+    # time windows and capacity re-walked on the host along every route (the reference has no checker: rmtvrp/env.py:457-461)
+    ac, st = a.cpu(), env.reset(td_in)          # (the reset state: the quantities the mask works on, rmtvrp/env.py:289-340)
+    for r in range(ac.shape[0]):
+        b = r % 2
+        T, tw = st["duration_matrix"][b].cpu(), st["time_windows"][b].cpu()
+        sv, dem, cap = st["service_time"][b].cpu(), st["demand_linehaul"][b].cpu(), float(st["vehicle_capacity"].reshape(-1)[b])
+        t, load, cur = 0.0, 0.0, 0
+        for n in ac[r].tolist():
+            if n == 0:
+                t, load, cur = 0.0, 0.0, 0
+                continue
+            arr = t + float(T[cur, n])
+            assert arr < float(tw[n, 1]) + 1e-5, (r, n)
+            t = max(arr, float(tw[n, 0])) + float(sv[n])
+            load += float(dem[n])
+            assert load <= cap + 1e-5, (r, n)
+            cur = n
+
+
 def test_rcvrptw_more_than_103_nodes_matches_the_live_oracle():
     """RCVRPTW with 120 customers (N = 121) on the row-parallel path (duration NAB by rr_nab_dur, MTVRP context, duration inductive
     bias, step-wise loop on rr_rmtvrp_step / rr_select) against the oracle run live: embeddings, greedy tours (divergences only at
@@ -180,13 +282,13 @@ def test_rcvrptw_more_than_103_nodes_matches_the_live_oracle():
     assert torch.allclose(out["reward"].cpu()[same], ref["reward"][same], atol=2e-4)
 
 
-def test_more_than_208_nodes_is_rejected_loudly():
+def test_more_than_1024_nodes_is_rejected_loudly():
     from rrnco_amd import TensorDict
     from rrnco_amd.envs import ATSPEnv
     w = restate.make_weights(restate.atsp_weight_template(128, 1, 512, 25), 1)
     pol = H.make_policy(w)
-    inst = restate.atsp_synthetic(1, 209, 1)
-    env = ATSPEnv(generator_params=dict(num_loc=209))
+    inst = restate.atsp_synthetic(1, 1025, 1)
+    env = ATSPEnv(generator_params=dict(num_loc=1025))
     td = TensorDict({k: v.cuda() for k, v in inst.items()}, batch_size=[1])
     with pytest.raises(NotImplementedError, match="nodes"):
         pol(env.reset(td), env, phase="val", decode_type="greedy")
