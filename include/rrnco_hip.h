@@ -370,10 +370,11 @@ typedef struct {
 } DecBigIO;
 /* RRNetDecoder.forward (decoder.py:151-206, 281-323) for all S*Bp rollouts: logits [R][N] after the inductive-bias transform. */
 int rr_dec_fwd_big(const DecBigIO* io, hipStream_t stream);
-/* process_logits + greedy / sampling / evaluate (decoding.py:311-361) for rows of up to 1 024 keys. */
+/* process_logits (incl. the top-k / top-p filters, decoding.py:37-63, 352-358; 0 / 0.0 = off) + greedy / sampling / evaluate
+ * (decoding.py:311-361) for rows of up to 1 024 keys. */
 int rr_select_big(const float* logits, const uint8_t* mask, const int64_t* action_in, int64_t* action_out, float* logp_out,
                   float* logp_all, int R, int N, float tanh_clip, float temperature, int mode, unsigned long long seed,
-                  unsigned int step, hipStream_t stream);
+                  unsigned int step, int top_k, float top_p, hipStream_t stream);
 
 /* POMO shared-baseline REINFORCE loss, forward half + d loss / d log-likelihood
  * (rrnco/models/rl.py:112-128; in-tree formula rrnco/baselines/routefinder/model.py:182-202). reward / ll / adv /

@@ -525,7 +525,8 @@ template <int Q>
 __global__ __launch_bounds__(256) void k_select_big(const float* __restrict__ logits, const uint8_t* __restrict__ mask,
                                                     const int64_t* __restrict__ action_in, int64_t* __restrict__ action_out,
                                                     float* __restrict__ logp_out, float* __restrict__ logp_all, int R, int N,
-                                                    float tanh_clip, float temperature, int mode, uint64_t seed, uint32_t step) {
+                                                    float tanh_clip, float temperature, int mode, uint64_t seed, uint32_t step,
+                                                    int top_k, float top_p) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= R) return;
@@ -545,6 +546,60 @@ __global__ __launch_bounds__(256) void k_select_big(const float* __restrict__ lo
     x[q] = v; m = fmaxf(m, v);
   }
   m = rr_wave_max(m);
+  // process_logits' filters (decoding.py:37-63, 352-358), top-k first; the row spans the wave (the same rules as rr_select / the fused
+  // rollout's rr_filter_*: the k-th largest value with multiplicity; the ascending cumulative sum by bisection over the floats' ordered
+  // bit patterns, ties in key order, the last one stays)
+  if (top_k > 0 && top_k < N) {
+    float bound = INFINITY, thr = -INFINITY;
+    int covered = 0;
+    for (int it = 0; it < top_k; ++it) {
+      float cur = -INFINITY;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) cur = fmaxf(cur, x[q] < bound ? x[q] : -INFINITY);
+      cur = rr_wave_max(cur);
+#pragma unroll
+      for (int q = 0; q < Q; ++q) covered += __popcll(__ballot(lane + 64 * q < N && x[q] == cur));
+      thr = cur; bound = cur;
+      if (covered >= top_k || cur == -INFINITY) break;
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) x[q] = x[q] < thr ? -INFINITY : x[q];
+  }
+  if (top_p > 0.f && top_p < 1.f) {
+    const float mm = m == -INFINITY ? 0.f : m;
+    float pe[Q], z = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { pe[q] = (lane + 64 * q < N) ? rr_exp(x[q] - mm) : 0.f; z += pe[q]; }
+    z = rr_wave_sum(z);
+    const float lim = (1.0f - top_p) * z;
+    auto okey = [](float v) { const uint32_t b = __float_as_uint(v); return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u); };
+    auto okey_inv = [](uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); };
+    uint32_t lo = 0x007fffffu, hi = okey(mm);
+    float tlo = 0.f;
+    while (hi - lo > 1u) {                                 // (wave-uniform: one row per wave)
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      const float fm = okey_inv(mid);
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) t += x[q] <= fm ? pe[q] : 0.f;
+      t = rr_wave_sum(t);
+      if (t <= lim) { lo = mid; tlo = t; } else hi = mid;
+    }
+    const float flo = okey_inv(lo), fhi = okey_inv(hi);
+    const float pstar = rr_exp(fhi - mm);
+    int size = 0, before = 0;
+    unsigned long long tb[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { tb[q] = __ballot(lane + 64 * q < N && x[q] == fhi); size += __popcll(tb[q]); }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const bool tied = (tb[q] >> lane) & 1ull;
+      const int rank = before + __popcll(tb[q] & ((2ull << lane) - 1ull));
+      const bool kill = tied && rank < size && fmaf((float)rank, pstar, tlo) <= lim;
+      x[q] = (x[q] <= flo || kill) ? -INFINITY : x[q];
+      before += __popcll(tb[q]);
+    }
+  }
   float s = 0.f;
 #pragma unroll
   for (int q = 0; q < Q; ++q) s += (lane + 64 * q < N) ? rr_exp(x[q] - m) : 0.f;
@@ -591,14 +646,14 @@ __global__ __launch_bounds__(256) void k_select_big(const float* __restrict__ lo
 }
 extern "C" int rr_select_big(const float* logits, const uint8_t* mask, const int64_t* action_in, int64_t* action_out,
                              float* logp_out, float* logp_all, int R, int N, float tanh_clip, float temperature, int mode,
-                             uint64_t seed, uint32_t step, hipStream_t st) {
-  if (R <= 0 || N <= 0 || N > RR_BIGN_MAX || temperature <= 0.f || mode < 0 || mode > 2) return RR_EINVAL;
+                             uint64_t seed, uint32_t step, int top_k, float top_p, hipStream_t st) {
+  if (R <= 0 || N <= 0 || N > RR_BIGN_MAX || temperature <= 0.f || mode < 0 || mode > 2 || top_k < 0 || top_p < 0.f || top_p > 1.f) return RR_EINVAL;
   if (logits == nullptr || action_out == nullptr || logp_out == nullptr || (mode == 2 && action_in == nullptr)) return RR_EINVAL;
   if (N <= 256 && !rr_bign_force_stream())
     hipLaunchKernelGGL(k_select_big<4>, dim3((R + 3) / 4), dim3(256), 0, st, logits, mask, action_in, action_out, logp_out, logp_all, R, N,
-                       tanh_clip, temperature, mode, seed, step);
+                       tanh_clip, temperature, mode, seed, step, top_k, top_p);
   else
     hipLaunchKernelGGL(k_select_big<16>, dim3((R + 3) / 4), dim3(256), 0, st, logits, mask, action_in, action_out, logp_out, logp_all, R, N,
-                       tanh_clip, temperature, mode, seed, step);
+                       tanh_clip, temperature, mode, seed, step, top_k, top_p);
   return rr_check(hipGetLastError());
 }

@@ -153,7 +153,7 @@ _SIGS = {
     "rr_colsoftmax_exp": [vp, vp, vp, vp, i32, i32, i32, vp],
     "rr_aft_mix_big": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "rr_dec_fwd_big": [C.POINTER(DecBigIO), vp],
-    "rr_select_big": [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, u64, u32, vp],
+    "rr_select_big": [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, u64, u32, i32, f32, vp],
     "rr_dec_logit_bwd": [C.POINTER(DecLogitIO), vp],
     "rr_gemm_tn": [vp, vp, vp, i32, i32, i32, i32, i32, i32, C.c_longlong, C.c_longlong, C.c_longlong, i32, i32, vp, vp],
     "rr_mlp_rows": [C.POINTER(MlpRowsW), i32, vp, vp, vp, vp, i32, i32, C.c_longlong, vp],

@@ -96,12 +96,10 @@ class DecodingStrategy:
         lp_all = torch.empty(R, N, dtype=torch.float32, device=logits.device) if self.store_all_logp else None
         mode = {"greedy": 0, "sampling": 1, "evaluate": 2}[self.mode]
         act_in = action.contiguous() if action is not None else None
-        if N > 128 and not getattr(self, "matnet_clamp", False):       # rows of up to 1 024 keys (csrc/rr_bign.hip); no top-k / top-p there
-            if self.top_k > 0 or 0.0 < self.top_p < 1.0:
-                raise NotImplementedError("top-k / top-p filtering is implemented for N <= 128")
+        if N > 128 and not getattr(self, "matnet_clamp", False):       # rows of up to 1 024 keys (csrc/rr_bign.hip)
             L.check(L.lib().rr_select_big(L.ptr(logits), L.ptr(m), L.ptr(act_in), L.ptr(sel), L.ptr(lp), L.ptr(lp_all), R, N,
                                           float(self.tanh_clipping), float(self.temperature), mode, int(self.seed),
-                                          len(self.actions), L.stream()), "rr_select_big")
+                                          len(self.actions), self.top_k, self.top_p, L.stream()), "rr_select_big")
         elif getattr(self, "matnet_clamp", False):       # the MatNet baseline's own process_logits (MatNet/decoding.py:316-372)
             L.check(L.lib().rr_select_matnet(L.ptr(logits), L.ptr(m), L.ptr(act_in), L.ptr(sel), L.ptr(lp), L.ptr(lp_all), R, N,
                                              float(self.tanh_clipping), float(self.temperature), mode, int(self.seed),

@@ -326,14 +326,15 @@ def test_rl_module_metrics_and_reinforce_loss_match_formula():
     assert torch.isfinite(tr["loss"]) and tr["actions"].shape == (S * B, fx["N"])
 
 
+@pytest.mark.parametrize("N", [100, 200, 600])
 @pytest.mark.parametrize("top_k,top_p", [(5, 0.0), (0, 0.9), (12, 0.7), (200, 0.0), (1, 0.0), (0, 1.0)])
-def test_select_kernel_top_k_top_p_filters_match_process_logits(top_k, top_p):
-    """decoding.py:37-63, 352-358 in rr_select: the kept set (finite log-probs) and the renormalised log-probs."""
+def test_select_kernel_top_k_top_p_filters_match_process_logits(top_k, top_p, N):
+    """decoding.py:37-63, 352-358 in rr_select (N <= 128) and rr_select_big (rows of up to 256 / 1 024 keys): the kept set (finite
+    log-probs) and the renormalised log-probs."""
     from rrnco_amd.models.decoding import get_decoding_strategy
     from rrnco_amd import TensorDict
-    fx = H.load_fixture("atsp_n100_b2_pomo")
-    g = torch.Generator().manual_seed(top_k * 7 + int(top_p * 100))
-    R, N = 512, 100
+    g = torch.Generator().manual_seed(top_k * 7 + int(top_p * 100) + N)
+    R = 512
     lg = torch.randn(R, N, generator=g) * 3
     if top_p in (0.0, 1.0):
         lg[:40, :7] = lg[:40, 7:8]       # exact ties across the top-k boundary (kept together: `logits < k-th value`)
@@ -343,6 +344,15 @@ def test_select_kernel_top_k_top_p_filters_match_process_logits(top_k, top_p):
     mk[:, 0] = True
     mk[5] = False; mk[5, 17] = True                                  # a single feasible action
     ref = restate.process_logits(lg, mk, temperature=1.3, tanh_clipping=10.0, top_p=top_p, top_k=top_k)
+    if 0.0 < top_p < 1.0:     # the same rule with the tie order pinned (stable ascending sort): long rows do tie at the saturated top
+        x = torch.tanh(lg) * 10.0
+        x[~mk] = float("-inf")
+        x = x / 1.3
+        if 0 < top_k < N:
+            x = x.masked_fill(x < torch.topk(x, top_k)[0][..., -1, None], float("-inf"))
+        sl, si = torch.sort(x, descending=False, stable=True)
+        rm = sl.softmax(dim=-1).cumsum(dim=-1) <= (1 - top_p)
+        ref = torch.log_softmax(x.masked_fill(rm.scatter(-1, si, rm), float("-inf")), dim=-1)
     strat = get_decoding_strategy("sampling", tanh_clipping=10.0, temperature=1.3, top_k=top_k, top_p=top_p, store_all_logp=True, seed=9)
     td = strat.step(lg.cuda(), mk.cuda(), TensorDict({}, batch_size=[R]))
     lp = strat.logprobs[0].cpu()
