@@ -383,10 +383,14 @@ class RRNetPolicy(nn.Module):
             T, nsteps = N, N - t0
         else:
             T, nsteps = 2 * N + 2, 0                    # data-dependent; trimmed to the longest rollout below
-        acts = torch.zeros(R, T, dtype=torch.int64, device=dev)
-        logp = torch.zeros(R, T, dtype=torch.float32, device=dev)
+        # ATSP: every (rollout, step) of the N - t0 decode steps is written by the kernel — no 490 MB of zero fill at the headline shape;
+        # the VRPs stop at a data-dependent step and leave depot / 0.0 behind each route's end
+        alloc = torch.empty if (self.env_name == "atsp" and dump is None) else torch.zeros
+        acts = alloc(R, T, dtype=torch.int64, device=dev)
+        logp = alloc(R, T, dtype=torch.float32, device=dev)
         if t0:
             acts[:, 0] = strategy.actions[0]
+            logp[:, 0] = 0.0
         steps_out = torch.zeros(1, dtype=torch.int32, device=dev)
         if dump is not None:      # training dump: one row per decoder evaluation (instance, step, start); see rollout.launch_rollout
             Bp = td["distance_matrix"].shape[0]
