@@ -41,8 +41,8 @@ PEAK_F16_MFMA_TFLOPS = 2500.0            # ... dense fp16 / bf16 matrix peak (me
 SPLIT_PRODUCTS = 3
 EXECUTED_F16_FLOP_PER_TILE_STEP = 1104 * 16384
 EXECUTED_F16_FLOP_PER_ROLLOUT_STEP = EXECUTED_F16_FLOP_PER_TILE_STEP // 16      # (a full tile; tools/bench_train.py)
-ROLLOUT_KERNEL = "k_rollout_w<7, 0, 0, true, true, false>"
-ROLLOUT_KERNEL_FP32 = "k_rollout_w<7, 0, 0, false, false, false>"
+ROLLOUT_KERNEL = "k_rollout_w<7, 0, 0, true, true, false, false>"
+ROLLOUT_KERNEL_FP32 = "k_rollout_w<7, 0, 0, false, false, false, false>"
 # HBM-side traffic of ONE rollout launch at the default workload: rocprofv3 PMC, separate FETCH_SIZE / WRITE_SIZE passes,
 # (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B — FETCH_SIZE doubled for gfx950's 16-B/lane reads as MI355X_MICROARCH.md §HBM
 # prescribes; Infinity-Cache hits are included in the counter.  Read at run time from the committed summary
@@ -467,10 +467,10 @@ def other_configs(dev):
 
     env = RCVRPEnv(generator_params=dict(num_loc=N_NODES, device=dev), check_solution=False, device=dev)
     inference("C3 RCVRP n=100 B=512 POMO S=101 greedy (configs[2])", env, vrp_policy("rcvrp"), 512, 101, False, "multistart_greedy",
-              "k_rollout_w<7, 1, 0, true, true, false>")
+              "k_rollout_w<7, 1, 0, true, true, false, false>")
     env = RMTVRPEnv(generator_params=dict(num_loc=N_NODES, device=dev), device=dev)
     c4 = "C4 RCVRPTW n=100 B=256 x8 aug S=100 sampling (configs[3])"
-    c4_step = inference(c4, env, vrp_policy("rcvrptw"), 256, 100, True, "multistart_sampling", "k_rollout_w<7, 2, 1, true, true, false>",
+    c4_step = inference(c4, env, vrp_policy("rcvrptw"), 256, 100, True, "multistart_sampling", "k_rollout_w<7, 2, 1, true, true, false, false>",
                         make_pol=lambda: vrp_policy("rcvrptw"))
     # the step's second kernel: the Neural Adaptive Bias with the duration matrix (k_nab_dur_lds, 6 launches per step), VALU-bound on the
     # SiLU of its gate: per edge and gate unit one v_exp_f32 and one v_rcp_f32 — quarter-rate instructions (16 lanes per SIMD and 4 cycles)
@@ -553,7 +553,7 @@ def other_configs(dev):
             "value": 512 / sec16, "unit": "trained instances/s", "ms_per_step": sec16 * 1e3, "steps": n16,
             "dtype": "bf16 operands (one piece) in the two 128-512-128 MLPs' backward products, f32 accumulate; everything else as the default step"}},
         "value": 512 / sec, "unit": "trained instances/s", "ms_per_step": sec * 1e3, "steps": n,
-        "kernel_ms": sum(ks) / max(len(ks), 1), "kernel": "k_rollout_w<7, 0, 1, true, true, false> (sampling rollout with the training dump)",
+        "kernel_ms": sum(ks) / max(len(ks), 1), "kernel": "k_rollout_w<7, 0, 1, true, true, false, false> (sampling rollout with the training dump)",
         "backward_kernels_ms_per_step": {k: round(v, 3) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
         "loss": float(o["loss"]), "grad_norm": float(o["grad_norm"]), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
         "roofline": roof}
@@ -746,7 +746,7 @@ def main():
             pol.precision = "32"
             a16 = rollout_steps * FLOP_PER_ROLLOUT_STEP / (k16 * 1e-3) / 1e12
             v16["dtype"] = "f16 operands (one piece), f32 accumulate, f32 softmax / logits"
-            v16["roofline"] = {"bound": "mfma", "kernel": "k_rollout_w<7, 0, 0, true, true, true>", "achieved": a16, "peak": PEAK_F16_MFMA_TFLOPS,
+            v16["roofline"] = {"bound": "mfma", "kernel": "k_rollout_w<7, 0, 0, true, true, true, false>", "achieved": a16, "peak": PEAK_F16_MFMA_TFLOPS,
                                "unit": "TFLOP/s", "frac": a16 / PEAK_F16_MFMA_TFLOPS}
             line["variants"]["16_mixed_rollout (precision='16-mixed', the reference's autocast mode)"] = v16
             # sampling with process_logits' top-k / top-p filters (decoding.py:352-358): inside the fused rollout since round 5 (FILT builds of

@@ -77,7 +77,7 @@ if rank == 0:
         steps_ = args.batch * 100 * 98          # rollouts x evaluated decode steps (the forced last move is not evaluated)
         ach = steps_ * bench.FLOP_PER_ROLLOUT_STEP / (k_ms * 1e-3) / 1e12
         peak = bench.PEAK_F16_MFMA_TFLOPS / bench.SPLIT_PRODUCTS
-        line["roofline"] = {"bound": "mfma", "kernel": "k_rollout_w<7, 0, 1, true, true, false> (sampling rollout with the training dump)", "achieved": ach,
+        line["roofline"] = {"bound": "mfma", "kernel": "k_rollout_w<7, 0, 1, true, true, false, false> (sampling rollout with the training dump)", "achieved": ach,
                             "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "kernel_ms": k_ms, "traffic": None}
     print(json.dumps(line))
 if world > 1:

@@ -18,7 +18,7 @@ print('   headline %.0f inst/s  step %.2f ms  rollout %.2f ms  frac %.4f' % (d['
   python3 tools/clock_power_sample.py 2>/dev/null | tail -3
   cd /tmp; rm -rf /tmp/pk
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pk -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-configs --no-variants > /dev/null 2>&1
-  python3 $R/tools/pmc_summary.py /tmp/pk | grep -A1 "k_rollout_w<7, 0, 0, true, true, false" | tail -1
+  python3 $R/tools/pmc_summary.py /tmp/pk | grep -A1 "k_rollout_w<7, 0, 0, true, true, false, false" | tail -1
   cd $R/real-routing-nco_amd/csrc
 done
 cp /tmp/lib_good.so librrnco_hip.so
