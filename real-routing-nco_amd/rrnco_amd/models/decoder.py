@@ -19,17 +19,19 @@ class PrecomputedCache:              # decoder.py:25-44 plus the per-node step-c
     ctx_a: torch.Tensor              # Wctx[:, :E] row_emb (ATSP first-node half) or None
     ctx_b: torch.Tensor              # Wctx[:, E:2E] row_emb (ATSP) / Wctx[:, :E] row_emb (VRP)
     split: tuple = None              # fp16 two-piece images of (glimpse_key, glimpse_val_t, logit_key) for the split rollout
+    split_guarded: bool = False      # the images' range check has reported into a status word (rr_dec_cache / rr_pack_f16x2)
 
     def split_images(self, status=None):
         """K / V^T / L as two-piece fp16 images of 2^4 x (hi + lo, csrc/rr_common.h second form), built once per cache by
         rr_pack_f16x2; `status` (int32 device word): bit 0 is set when a value is non-finite or leaves the fp16 range."""
-        if self.split is None:
+        if self.split is None or (status is not None and not self.split_guarded):      # (images built without a status word: check them now)
             out = []
             for t in (self.glimpse_key, self.glimpse_val_t, self.logit_key):
                 d = torch.empty_like(t)
                 L.check(L.lib().rr_pack_f16x2(L.ptr(t), L.ptr(d), t.numel(), L.ptr(status), L.stream()), "rr_pack_f16x2")
                 out.append(d)
             self.split = tuple(out)
+            self.split_guarded = status is not None
         return self.split
 
     @property
@@ -110,7 +112,7 @@ class RRNetDecoder(nn.Module):
         L.check(L.lib().rr_dec_cache(packed["cache"], L.ptr(row), L.ptr(col), L.ptr(K), L.ptr(Vt), L.ptr(Lk),
                                      L.ptr(ca), L.ptr(cb), *(L.ptr(t) for t in (images or (None, None, None))),
                                      L.ptr(status) if images is not None else None, Bp, N, L.stream()), "rr_dec_cache")
-        return PrecomputedCache(row, 0, K, Vt, Lk, ca, cb, split=images)
+        return PrecomputedCache(row, 0, K, Vt, Lk, ca, cb, split=images, split_guarded=images is not None and status is not None)
 
     def forward(self, td, cached: PrecomputedCache, num_starts: int = 0, packed=None):
         """decoder.py:151-206: -> (logits [S*B,N] post inductive-bias transform, mask [S*B,N]).
