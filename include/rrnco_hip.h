@@ -350,6 +350,13 @@ int rr_aft_bwd(const AftBwdIO* io, int Bp, hipStream_t stream);
  * and d alpha; the prefix sums that turn the moments into d (folded table) are the caller's (tiny). */
 int rr_nab_hist_bwd(const float* pwl, const float* xd, const float* xa, const float* gout, float* hist, long M,
                     hipStream_t stream);
+/* From those moments to the gradients of DistAngleFusion's parameters (attn_freenet.py:201-289: dist_emb / angle_emb .0 / .2, out_lin,
+ * gate.0, the block's alpha), all nb blocks in one launch: float64 prefix sums over the 129 segments, each unit's active range by the
+ * rank of its breakpoint, then the chain rule through the fold (co = W2^T wo, cg = W2^T wg, wo . b2, wg . b2).  tbl [nb][26] int64 on
+ * the device: 13 parameter addresses (per family .0.weight, .0.bias, .2.weight, .2.bias; then out_lin.weight, out_lin.bias,
+ * gate.0.weight, gate.0.bias, alpha) and the 13 offsets, in floats, of their gradient accumulators in gflat (added to);
+ * hist [nb][2 * 129 * 4 + 1] as rr_nab_hist_bwd wrote it. */
+int rr_nab_tab_bwd(const long long* tbl, const float* hist, float* gflat, int nb, hipStream_t stream);
 
 /* ---- instances with 104 .. 1 024 nodes (csrc/rr_bign.hip; the reference's generators, rrnco/envs/rcvrp/generator.py:21-37, go to
  * 1 000): the same operators as row-parallel kernels over HBM-resident tensors, the decode loop step by step.  rr_enc_layer /

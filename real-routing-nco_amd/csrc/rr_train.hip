@@ -215,6 +215,80 @@ extern "C" int rr_nab_hist_bwd(const float* pwl, const float* xd, const float* x
   return rr_check(hipGetLastError());
 }
 
+// ------------------------------------------------------------------------------------------------
+// Chain rule from the per-segment moments of k_nab_hist_bwd to the PARAMETERS of DistAngleFusion (attn_freenet.py:201-289), for
+// every block of the encoder in one launch: what `nab_grad_from_hist` (d loss / d folded table) followed by torch autograd through the
+// fold did until round 5.  The folded table of a family: a_k = W0[k], b_k = b0[k], co_k = (W2^T wo)_k, cg_k = (W2^T wg_f)_k, scalars
+// wo . b2, wg_f . b2, bg, bo, alpha (models/grad_replay._nab_table).  Unit k is active behind its breakpoint t_k = -b_k / a_k when
+// a_k > 0 and up to it when a_k < 0 (rank of t_k among the family's sorted breakpoints = the segment index the histogram kernel
+// counted in): A_k = the four moments summed over the unit's active segments (float64 prefix sums over 129 segments).
+//   d a = co A1 + cg A3,  d b = co A0 + cg A2,  d co = a A1 + b A0,  d cg = a A3 + b A2          (A0..3 = sum w_o, w_o x, w_g, w_g x)
+//   d W2[i][j] = wo_i d co_j + wg_i d cg_j,  d wo_i += (W2 d co)_i + b2_i T0,  d wg_i = (W2 d cg)_i + b2_i T2,
+//   d b2_i = wo_i T0 + wg_i T2,  d bg = T2 (distance family),  d bo = T0_d + T0_a,  d alpha = the moment the histogram kernel summed.
+// tbl [nb][26] int64: 13 parameter addresses (per family .0.weight, .0.bias, .2.weight, .2.bias; out_lin.weight, out_lin.bias,
+// gate.0.weight, gate.0.bias, alpha) and 13 offsets (floats) of their gradients in `gflat`; grid (block, family) x 128 threads.
+// The gradient buffers are the step's zero-filled accumulators; the two families of a block meet in d wo / d bo only (two addends:
+// order-independent).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_nab_tab_bwd(const long long* __restrict__ tbl, const float* __restrict__ hist,
+                                                     float* __restrict__ gflat) {
+  const int blk = blockIdx.x, f = blockIdx.y, k = threadIdx.x;
+  const long long* T = tbl + (size_t)blk * 26;
+  const float* W0 = reinterpret_cast<const float*>(T[4 * f + 0]);
+  const float* b0 = reinterpret_cast<const float*>(T[4 * f + 1]);
+  const float* W2 = reinterpret_cast<const float*>(T[4 * f + 2]);
+  const float* b2 = reinterpret_cast<const float*>(T[4 * f + 3]);
+  const float* wo = reinterpret_cast<const float*>(T[8]);
+  const float* wg = reinterpret_cast<const float*>(T[10]) + RR_E * f;
+  float *gW0 = gflat + T[13 + 4 * f + 0], *gb0 = gflat + T[13 + 4 * f + 1], *gW2 = gflat + T[13 + 4 * f + 2], *gb2 = gflat + T[13 + 4 * f + 3];
+  float *gwo = gflat + T[13 + 8], *gbo = gflat + T[13 + 9], *gwg = gflat + T[13 + 10] + RR_E * f, *gbg = gflat + T[13 + 11], *galpha = gflat + T[13 + 12];
+  __shared__ double ts[RR_E];
+  __shared__ double C[129][4];
+  __shared__ float wos[RR_E], wgs[RR_E], gco[RR_E], gcg[RR_E];
+  const float a = W0[k], b = b0[k];
+  wos[k] = wo[k]; wgs[k] = wg[k];
+  ts[k] = a != 0.f ? -(double)b / (double)a : (double)INFINITY;
+  if (k < 4) {                                       // prefix sums of the family's 129 x 4 moments, float64
+    const float* H = hist + (size_t)blk * (2 * 129 * 4 + 1) + (size_t)f * 129 * 4;
+    double c = 0.0;
+    for (int s = 0; s < 129; ++s) { c += (double)H[s * 4 + k]; C[s][k] = c; }
+  }
+  __syncthreads();
+  float co = 0.f, cg = 0.f;
+  for (int i = 0; i < RR_E; ++i) { const float w = W2[i * RR_E + k]; co = fmaf(w, wos[i], co); cg = fmaf(w, wgs[i], cg); }
+  int rank = 0;
+  const double tk = ts[k];
+  for (int j = 0; j < RR_E; ++j) rank += (ts[j] < tk || (ts[j] == tk && j < k)) ? 1 : 0;      // position in a stable ascending sort
+  double A[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const double tot = C[128][q], cr = C[rank][q];
+    A[q] = a > 0.f ? tot - cr : a < 0.f ? cr : (b > 0.f ? tot : 0.0);
+  }
+  const double da = (double)co * A[1] + (double)cg * A[3], db = (double)co * A[0] + (double)cg * A[2];
+  const double dco = (double)a * A[1] + (double)b * A[0], dcg = (double)a * A[3] + (double)b * A[2];
+  gW0[k] += (float)da; gb0[k] += (float)db;
+  gco[k] = (float)dco; gcg[k] = (float)dcg;
+  __syncthreads();
+  const float gck = gco[k], ggk = gcg[k];
+  for (int i = 0; i < RR_E; ++i) gW2[i * RR_E + k] += fmaf(wos[i], gck, wgs[i] * ggk);
+  float so = 0.f, sg = 0.f;
+  for (int j = 0; j < RR_E; ++j) { const float w = W2[k * RR_E + j]; so = fmaf(w, gco[j], so); sg = fmaf(w, gcg[j], sg); }
+  const float T0 = (float)C[128][0], T2 = (float)C[128][2];
+  atomicAdd(gwo + k, fmaf(b2[k], T0, so));
+  gwg[k] += fmaf(b2[k], T2, sg);
+  gb2[k] += fmaf(wos[k], T0, wgs[k] * T2);
+  if (k == 0) {
+    atomicAdd(gbo, T0);
+    if (f == 0) { *gbg += T2; *galpha += hist[(size_t)blk * (2 * 129 * 4 + 1) + 2 * 129 * 4]; }
+  }
+}
+extern "C" int rr_nab_tab_bwd(const long long* tbl, const float* hist, float* gflat, int nb, hipStream_t st) {
+  if (tbl == nullptr || hist == nullptr || gflat == nullptr || nb <= 0) return RR_EINVAL;
+  hipLaunchKernelGGL(k_nab_tab_bwd, dim3(nb, 2), dim3(128), 0, st, tbl, hist, gflat);
+  return rr_check(hipGetLastError());
+}
+
 extern "C" int rr_nab_train_fwd(const float* tab, const float* xd, const float* xa, float* out, long M, hipStream_t st) {
   if (tab == nullptr || xd == nullptr || xa == nullptr || out == nullptr || M <= 0) return RR_EINVAL;
   const long want = (M + TR_THREADS - 1) / TR_THREADS;

@@ -122,6 +122,7 @@ _SIGS = {
     "rr_enc_layer_split": [C.POINTER(EncBlockW), C.POINTER(EncBlockW), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "rr_nab_dist_family": [C.POINTER(EncBlockW), C.POINTER(EncBlockW), vp, vp, i32, i32, vp],
     "rr_filter_rows": [vp, vp, i32, i32, i32, f32, vp],
+    "rr_nab_tab_bwd": [vp, vp, vp, i32, vp],
     "rr_edge_angles": [vp, vp, i32, i32, vp],
     "rr_nab_dur": [C.POINTER(NabDurW), C.POINTER(NabDurW), vp, vp, vp, vp, i32, i32, vp],
     "rr_nab_dur_aug": [C.POINTER(NabDurW), C.POINTER(NabDurW), vp, vp, vp, vp, i32, i32, i32, vp],

@@ -114,6 +114,28 @@ def nab_grad_from_hist(tabs: torch.Tensor, hist: torch.Tensor) -> torch.Tensor:
     return torch.cat([g.reshape(nb, 8 * E), scal], dim=1).float()
 
 
+NAB_TAB_PARAMS = (".dist_emb.0.weight", ".dist_emb.0.bias", ".dist_emb.2.weight", ".dist_emb.2.bias",
+                  ".angle_emb.0.weight", ".angle_emb.0.bias", ".angle_emb.2.weight", ".angle_emb.2.bias",
+                  ".out_lin.weight", ".out_lin.bias", ".gate.0.weight", ".gate.0.bias")
+
+
+def _nab_tab_table(policy, P, G, order, dev):
+    """Device table of csrc/rr_train.hip:rr_nab_tab_bwd for the blocks in processing order: per block the addresses of the 13
+    DistAngleFusion parameters (+ alpha) and the offsets of their gradient accumulators in G.flat.  Cached on the policy: parameter
+    storage and the layout of the gradient buffer do not change between steps."""
+    names = [[b + ".angle_distance_fusion" + s for s in NAB_TAB_PARAMS] + [b + ".alpha"] for b in order]
+    key = tuple(P[n].data_ptr() for row in names for n in row) + tuple(G.offsets[n] for row in names for n in row)
+    c = getattr(policy, "_nab_tab_tbl", None)
+    if c is None or c[0] != key:
+        for row in names:
+            for n in row:
+                assert P[n].dtype == torch.float32 and P[n].is_contiguous(), n
+        rows = [[P[n].data_ptr() for n in row] + [G.offsets[n] for n in row] for row in names]
+        c = (key, torch.tensor(rows, dtype=torch.int64).to(dev), [n for row in names for n in row])
+        policy._nab_tab_tbl = c
+    return c[1], c[2]
+
+
 class _Grads:
     """Gradient buffers of the parameters the kernels write (zero-filled: float atomics add into them)."""
 
@@ -122,6 +144,10 @@ class _Grads:
         sizes = [(p.numel() + 3) // 4 * 4 for p in P.values()]      # 16-byte aligned views (float4 stores / atomics on rows)
         self.flat = torch.zeros(sum(sizes), dtype=torch.float32, device=next(iter(P.values())).device)   # one memset
         self.chunks = dict(zip(P.keys(), self.flat.split(sizes)))   # one op for all the views
+        self.offsets, o = {}, 0                                     # (floats into `flat`: kernels that take the buffer as a whole, rr_nab_tab_bwd)
+        for n, sz in zip(P.keys(), sizes):
+            self.offsets[n] = o
+            o += sz
 
     def buf(self, name):
         if name not in self.g:
@@ -208,7 +234,10 @@ def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
         order_all = [f"encoder.net.layers.{l}.{side}_encoding_block" for l in reversed(range(packs["num_layers"])) for side in ("row", "col")]
         dWpc_all, dbpc_all, bidx = torch.zeros(len(order_all), E, E, device=dev), torch.zeros(len(order_all), E, device=dev), 0
         tabs_all = None       # the folded NAB tables of all blocks in processing order as ONE expression (RR_NAB_TAB_PERBLOCK=1: one per block)
-        if not vtw and os.environ.get("RR_NAB_TAB_PERBLOCK", "0") != "1":
+        # round 5: the moments -> parameter gradients on ONE kernel launch (csrc/rr_train.hip:rr_nab_tab_bwd); RR_NAB_TAB_TORCH=1 keeps the
+        # torch route (nab_grad_from_hist + autograd through the fold) for A/B and for the tests that compare the two
+        nab_on_kernel = not vtw and os.environ.get("RR_NAB_TAB_TORCH", "0") != "1"
+        if not vtw and not nab_on_kernel and os.environ.get("RR_NAB_TAB_PERBLOCK", "0") != "1":
             order = [f"encoder.net.layers.{l}.{side}_encoding_block" for l in reversed(range(packs["num_layers"])) for side in ("row", "col")]
             with torch.enable_grad():
                 tabs_all = _nab_tabs_batched(P, [b + ".angle_distance_fusion" for b in order], [P[b + ".alpha"] for b in order])
@@ -263,7 +292,7 @@ def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
                     dur_todo.append((b, si, dbias))
                 else:
                     # alpha * NAB (:427-429): the folded-table backward of csrc/rr_train.hip, chained to the module parameters by autograd
-                    if tabs_all is None:
+                    if tabs_all is None and not nab_on_kernel:
                         with torch.enable_grad():
                             tab = _nab_tab(P, b + ".angle_distance_fusion", P[b + ".alpha"])
                     else:
@@ -298,7 +327,12 @@ def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
         for i, b in enumerate(order_all):
             G.buf(b + ".multi_head_combine.weight").add_(dWc[i]); G.buf(b + ".attn_free.project.weight").add_(dWp[i])
             G.buf(b + ".attn_free.project.bias").add_(dbp[i]); G.buf(b + ".multi_head_combine.bias").add_(dbpc_all[i])
-        if nab_tabs:          # the NAB moments of all blocks -> d (folded tables), one batched prefix-sum pass
+        if nab_tabs and nab_on_kernel:
+            tbl, tbl_names = _nab_tab_table(policy, P, G, order_all, dev)
+            L.check(lib.rr_nab_tab_bwd(L.ptr(tbl), L.ptr(nab_hists), L.ptr(G.flat), len(nab_tabs), st), "rr_nab_tab_bwd")
+            for n in tbl_names:
+                G.buf(n)          # (registers the view: flush hands it to the parameter)
+        elif nab_tabs:        # the NAB moments of all blocks -> d (folded tables), one batched prefix-sum pass
             if tabs_all is None:
                 gtabs = nab_grad_from_hist(torch.stack([t.detach() for t in nab_tabs]), nab_hists)
                 small += [(t, gtabs[i]) for i, t in enumerate(nab_tabs)]

@@ -202,6 +202,30 @@ def test_nab_training_kernels_match_the_torch_formula():
         assert float((g.cpu() - ref).abs().max()) < tol, (k, float((g.cpu() - ref).abs().max()), tol)
 
 
+@pytest.mark.parametrize("name", ["atsp_n20_b4_pomo", "atsp_n100_b2_pomo"])
+def test_nab_parameter_gradients_from_one_kernel_equal_the_torch_route(name, monkeypatch):
+    """csrc/rr_train.hip:rr_nab_tab_bwd (round 5): the moments of rr_nab_hist_bwd -> the gradients of DistAngleFusion's parameters of all
+    twelve blocks in one launch, against the route it replaces (RR_NAB_TAB_TORCH=1: nab_grad_from_hist's float64 prefix sums + torch
+    autograd through the fold) on the same sampled tours (same seed): every one of the 12 x 13 tensors."""
+    fx = H.load_fixture(name)
+    grads = {}
+    for route in ("1", "0"):
+        monkeypatch.setenv("RR_NAB_TAB_TORCH", route)
+        w, pol, model, st, td_in = _model(fx)
+        model.training_step(td_in, seed=11)
+        grads[route] = {n: p.grad.detach().clone() for n, p in pol.named_parameters()}
+    monkeypatch.delenv("RR_NAB_TAB_TORCH")
+    seen = 0
+    for n, g in grads["0"].items():
+        ref = grads["1"][n]
+        if ".angle_distance_fusion." in n or n.endswith("_encoding_block.alpha"):
+            seen += 1
+            tol = 2e-4 * float(ref.abs().max()) + 1e-7
+            assert float((g - ref).abs().max()) <= tol, (n, float((g - ref).abs().max()), tol)
+            assert float(ref.abs().max()) > 0.0, n
+    assert seen == 13 * 12
+
+
 def test_rcvrp_training_step_gradients_match_oracle_autograd():
     """The same step for RCVRP (sampled routes of different lengths, S = N+1 starts)."""
     from rrnco_amd import TensorDict
