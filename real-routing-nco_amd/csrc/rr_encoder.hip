@@ -240,18 +240,20 @@ __global__ __launch_bounds__(256) void k_nab_dist_family(const float* __restrict
     nabtab[NAB_TAB2_FLOATS + i] = k < 128 ? src[128 * f + k] : INFINITY;
   }
   __syncthreads();
-  const int e = blockIdx.x * 256 + tid;
-  if (e >= N * N) return;
-  const int i = e / N, j = e - i * N;
-  const float d = D[(size_t)b * N * N + (is_col ? j * N + i : e)];
-  float fo, fg;
-  nab_family_grid(nabtab, nabtab + NAB_TAB2_FLOATS, 0, d, fo, fg);
-  reinterpret_cast<float2*>(out)[((size_t)b * 2 + is_col) * N * N + e] = make_float2(fo, fg);
+  // (a workgroup takes a quarter of the block's edges: the 8 KB table copy per 256 edges was most of the kernel's time)
+  for (int e = blockIdx.x * 256 + tid; e < N * N; e += gridDim.x * 256) {
+    const int i = e / N, j = e - i * N;
+    const float d = D[(size_t)b * N * N + (is_col ? j * N + i : e)];
+    float fo, fg;
+    nab_family_grid(nabtab, nabtab + NAB_TAB2_FLOATS, 0, d, fo, fg);
+    reinterpret_cast<float2*>(out)[((size_t)b * 2 + is_col) * N * N + e] = make_float2(fo, fg);
+  }
 }
 extern "C" int rr_nab_dist_family(const EncBlockW* wrow, const EncBlockW* wcol, const float* D, float* out, int B, int N, hipStream_t st) {
   if (B <= 0 || N < 2 || wrow == nullptr || wcol == nullptr || wrow->nab == nullptr || wcol->nab == nullptr || D == nullptr || out == nullptr)
     return RR_EINVAL;
-  hipLaunchKernelGGL(k_nab_dist_family, dim3((N * N + 255) / 256, B, 2), dim3(256), 0, st, wrow->nab, wcol->nab, D, out, N);
+  const int gx = (N * N + 255) / 256;
+  hipLaunchKernelGGL(k_nab_dist_family, dim3(gx < 4 ? gx : 4, B, 2), dim3(256), 0, st, wrow->nab, wcol->nab, D, out, N);
   return rr_check(hipGetLastError());
 }
 

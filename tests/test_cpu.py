@@ -782,3 +782,27 @@ def test_marker_labels_name_exported_launchers():
     assert set(L.MARKER_LABELS) <= set(L.exported_symbols())
     for k in ("rr_init_embed", "rr_dec_cache", "rr_rollout", "rr_select", "rr_enc_layer_split"):
         assert L.MARKER_LABELS[k].startswith("K")
+
+
+def test_augmentation_note_travels_with_the_matrices_and_only_with_them():
+    """StateAugmentation leaves `num_augment` in td.meta (the 8 copies share their matrices: the encoder looks the distance / duration
+    parts of the NAB up once per base instance).  The note survives clone / to / a reset's rebuild, and is dropped by anything that can
+    break the layout it describes: row indexing and replacing a matrix."""
+    import torch
+    from rrnco_amd import TensorDict
+    from rrnco_amd.models.transforms import StateAugmentation
+    B, N = 3, 6
+    td = TensorDict({"locs": torch.rand(B, N, 2), "distance_matrix": torch.rand(B, N, N)}, batch_size=[B])
+    aug = StateAugmentation(num_augment=8)(td)
+    assert aug.meta.get("num_augment") == 8 and aug["distance_matrix"].shape[0] == 8 * B
+    assert torch.equal(aug["distance_matrix"][B:2 * B], td["distance_matrix"])              # copy a of instance b sits at a * B + b
+    assert aug.clone().meta.get("num_augment") == 8 and aug.to("cpu").meta.get("num_augment") == 8
+    assert "num_augment" not in aug[:4].meta                                                 # a slice is no longer "8 copies of B instances"
+    c = aug.clone(); c.set("distance_matrix", aug["distance_matrix"] * 2.0)
+    assert "num_augment" not in c.meta
+    c = aug.clone(); c["duration_matrix"] = aug["distance_matrix"].clone()
+    assert "num_augment" not in c.meta
+    c = aug.clone(); c.update({"distance_matrix": aug["distance_matrix"].clone()})
+    assert "num_augment" not in c.meta
+    c = aug.clone(); c.set("locs", aug["locs"] + 1.0)
+    assert c.meta.get("num_augment") == 8                                                    # coordinates may differ per copy: that is the augmentation
