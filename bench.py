@@ -668,6 +668,7 @@ def main():
             "unit": "instances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "devices": devices,
+            "configs_summary": None,         # (filled below; placed early so that a reader of the line's head sees the other configs too)
             "arithmetic": "fp32 operands and fp32 accumulation throughout; the products of the rollout (scores, P.V, pointer MLP, logits), "
                           "of the encoder (projections, AFT mixing, FFN) and of the decoder cache multiply two-piece fp16 splits of the fp32 "
                           "operands on the fp16 matrix pipe (3 partial products: hi*hi, hi*lo, lo*hi; error of a dot product 4e-8 .. 8e-8 of "
@@ -806,6 +807,25 @@ def main():
                            "note": "the rollout's achieved rate over what a pure fp16 matrix stream on data sustains under the 1 400 W cap, "
                                    "three partial products per product; roofline.frac above is against the guide's 2 500 / 3"})
             line["roofline"]["power_limited"] = pl
+        # compact digest of the line (instances/s unless named otherwise): at its head (placeholder above) and again at its very end
+        cs = {"headline": round(line["value"], 1), "rollout_ms": round(line["roofline"]["kernel_ms"], 2), "rollout_frac": round(line["roofline"]["frac"], 4),
+              "encoder_layer_ms": round(line["roofline_encoder"]["kernel_ms"], 3), "encoder_frac": round(line["roofline_encoder"]["frac"], 4)}
+        for k, v in (line.get("configs") or {}).items():
+            tag = k.split()[0]
+            cs[tag] = round(v["value"], 1)
+            if "exact_shape" in v:
+                cs[tag + "_exact_shape"] = round(v["exact_shape"]["value"], 1)
+            if "two_streams" in v:
+                cs[tag + "_two_streams"] = round(v["two_streams"]["value"], 1)
+            for vk, vv in (v.get("variants") or {}).items():
+                cs[tag + "_" + vk.split()[0]] = round(vv["value"], 1)
+        for k, v in (line.get("variants") or {}).items():
+            if isinstance(v, dict) and v.get("value"):
+                cs[k.split()[0]] = round(v["value"], 1)
+        if line.get("cpu_baseline"):
+            cs["cpu_baseline"] = round(line["cpu_baseline"]["value"], 3)
+        line["configs_summary"] = cs
+        line["summary_tail"] = cs
         print(json.dumps(line))
     if dist:
         td_.destroy_process_group()
