@@ -180,17 +180,19 @@ def test_fused_filtered_greedy_keeps_the_tours_and_renormalises():
     assert float((out["log_likelihood"].cpu() - ref).abs().max()) < 2e-3
 
 
-@pytest.mark.parametrize("problem", ["rcvrp", "rcvrptw"])
+@pytest.mark.parametrize("problem", ["rcvrp", "rcvrptw", "rcvrp_n20", "rcvrptw_n20", "rcvrp_n50", "rcvrptw_n50"])
 def test_fused_filtered_sampling_vrp_matches_the_step_loop(problem):
     """RCVRP / RCVRPTW: the filtered fused rollout against the per-step loop (rr_select's filters, pinned to process_logits in
     test_gpu_atsp.py) from the same seed: same uniforms, same rule — tours equal except where fp32 noise moves a boundary."""
     from rrnco_amd import _lib as L
-    if problem == "rcvrp":
-        from tests.test_gpu_rcvrp import _setup
-        fx, w, pol, inst, env, td_in = _setup("rcvrp_n100_b2_pomo_trained")
-    else:
+    # n = 100: instance mode (7 key tiles); n = 50 / 20: the 4- and 2-tile builds of the workgroup-shared form
+    names = {"rcvrp": "rcvrp_n100_b2_pomo_trained", "rcvrptw": "rcvrptw_n100_b2_pomo_trained", "rcvrp_n20": "rcvrp_n20_b4_pomo",
+             "rcvrptw_n20": "rcvrptw_n20_b4_pomo", "rcvrp_n50": "rcvrp_n50_b3_pomo_trained", "rcvrptw_n50": "rcvrptw_n50_b3_pomo_trained"}
+    if problem.startswith("rcvrptw"):
         from tests.test_gpu_rcvrptw import _setup
-        fx, w, pol, inst, env, td_in = _setup("rcvrptw_n100_b2_pomo_trained")
+    else:
+        from tests.test_gpu_rcvrp import _setup
+    fx, w, pol, inst, env, td_in = _setup(names[problem])
     S = fx["S"]
     env.check_solution = False
     kw = dict(phase="test", decode_type="multistart_sampling", num_starts=S, top_k=6, top_p=0.85, temperature=1.1, seed=4, return_actions=True)
