@@ -180,14 +180,15 @@ def test_fused_filtered_greedy_keeps_the_tours_and_renormalises():
     assert float((out["log_likelihood"].cpu() - ref).abs().max()) < 2e-3
 
 
-@pytest.mark.parametrize("problem", ["rcvrp", "rcvrptw", "rcvrp_n20", "rcvrptw_n20", "rcvrp_n50", "rcvrptw_n50"])
+@pytest.mark.parametrize("problem", ["rcvrp", "rcvrptw", "rcvrp_n20", "rcvrptw_n20", "rcvrp_n50", "rcvrptw_n50", "rcvrptw_variants"])
 def test_fused_filtered_sampling_vrp_matches_the_step_loop(problem):
     """RCVRP / RCVRPTW: the filtered fused rollout against the per-step loop (rr_select's filters, pinned to process_logits in
     test_gpu_atsp.py) from the same seed: same uniforms, same rule — tours equal except where fp32 noise moves a boundary."""
     from rrnco_amd import _lib as L
     # n = 100: instance mode (7 key tiles); n = 50 / 20: the 4- and 2-tile builds of the workgroup-shared form
     names = {"rcvrp": "rcvrp_n100_b2_pomo_trained", "rcvrptw": "rcvrptw_n100_b2_pomo_trained", "rcvrp_n20": "rcvrp_n20_b4_pomo",
-             "rcvrptw_n20": "rcvrptw_n20_b4_pomo", "rcvrp_n50": "rcvrp_n50_b3_pomo_trained", "rcvrptw_n50": "rcvrptw_n50_b3_pomo_trained"}
+             "rcvrptw_n20": "rcvrptw_n20_b4_pomo", "rcvrp_n50": "rcvrp_n50_b3_pomo_trained", "rcvrptw_n50": "rcvrptw_n50_b3_pomo_trained",
+             "rcvrptw_variants": "rmtvrp_n20_b8_pomo_variants"}       # (backhauls, open routes, distance limits: the general mask's build)
     if problem.startswith("rcvrptw"):
         from tests.test_gpu_rcvrptw import _setup
     else:
