@@ -368,9 +368,20 @@ int rr_inorm_fwd(const float* x, const float* res, const float* gamma, const flo
  * transpose_d: the col block's D^T (:480-486). out [Bp][N][N]. */
 int rr_nab_pwl_fwd(const float* pwl, const float* D, const float* theta, float* out, int Bp, int N, int transpose_d, hipStream_t stream);
 /* ekT = exp(softmax_nodes(K))^T, kvT = (ek * V)^T as [Bp][128][NP] (NP = 16 ceil(N/16), zero padded): attn_freenet.py:319-321. */
-int rr_colsoftmax_exp(const float* K, const float* V, float* ekT, float* kvT, int Bp, int N, int NP, hipStream_t stream);
-/* y = sigmoid(q) * (exp(softmax(bias)) @ kv) / (exp(softmax(bias)) @ ek): AFTFull mixing (attn_freenet.py:318-324). */
-int rr_aft_mix_big(const float* bias, const float* q, const float* ekT, const float* kvT, float* y, int Bp, int N, int NP, hipStream_t stream);
+int rr_colsoftmax_exp(const float* K, const float* V, float* ekT, float* kvT, float* ek_rows, int Bp, int N, int NP, hipStream_t stream);
+/* y = sigmoid(q) * (exp(softmax(bias)) @ kv) / (exp(softmax(bias)) @ ek): AFTFull mixing (attn_freenet.py:318-324).
+ * ek_rows (above) and num_out / den_out / eaT_out (all three or none; eaT [Bp][112][112] zero-filled by the caller, N <= 112) are the
+ * tensors the hand-written block backward reads (csrc/rr_enc_w.inc: EncSave): optional, NULL for inference. */
+int rr_aft_mix_big(const float* bias, const float* q, const float* ekT, const float* kvT, float* y, float* num_out, float* den_out,
+                   float* eaT_out, int Bp, int N, int NP, hipStream_t stream);
+/* Normalization("batch") in TRAIN mode (attn_freenet.py:82-83, 102-103: nn.BatchNorm1d over the flattened M = Bp * N rows, batch
+ * statistics): out = (x (+ res) - mean) rstd gamma + beta with the biased batch variance, eps 1e-5; running_mean / running_var (both or
+ * neither) move by `momentum` (variance unbiased); sum_out (optional) receives x + res; ws: 256 doubles of scratch.  The backward:
+ * dx (+)= gamma rstd (dy - mean(dy) - xh mean(dy xh)) with dy = dy1 (+ dy2), d gamma / d beta added; ws: 512 doubles. */
+int rr_bnorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* out, float* sum_out, double* ws,
+                 float* running_mean, float* running_var, float momentum, long long M, hipStream_t stream);
+int rr_bnorm_bwd(const float* x, const float* dy1, const float* dy2, const float* gamma, float* dx, float* dgamma, float* dbeta,
+                 double* ws, long long M, int accumulate, hipStream_t stream);
 typedef struct {
   const float *K, *Vt, *L, *ctxA, *ctxB, *D, *Dur; const int64_t *cur, *first; const float *scal, *wstate; const uint8_t *mask;
   const void *w1, *w2; const float *b1, *b2; float *logits; int Bp, N, NP, S, nscal; float alpha, beta;

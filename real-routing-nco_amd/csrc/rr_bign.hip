@@ -46,6 +46,55 @@ extern "C" int rr_inorm_fwd(const float* x, const float* res, const float* gamma
   return rr_check(hipGetLastError());
 }
 
+// ------------------------------------------------------------------------------------------------ batch norm forward, TRAINING mode
+// Normalization("batch") with module.train() (attn_freenet.py:82-83, 102-103): nn.BatchNorm1d over the flattened M = Bp * N rows — batch
+// mean and BIASED variance per feature normalise, the running statistics move by `momentum` (the variance UNBIASED, M / (M - 1)), eps 1e-5.
+// Two launches: per-feature sums of v = x (+ res) and v^2 in float64 (atomics into ws[256], zeroed here), then the affine map.
+// sum_out (optional) receives v (the hand-written backward wants ffn.norm1's input r + norm3(o)).
+__global__ __launch_bounds__(256) void k_bn_stats(const float* __restrict__ x, const float* __restrict__ res, double* __restrict__ ws, long long M) {
+  __shared__ double red[2][256];
+  const int tid = threadIdx.x, f = tid & 127, half = tid >> 7;
+  double s = 0.0, q = 0.0;
+  for (long long m = (long long)blockIdx.x * 2 + half; m < M; m += (long long)gridDim.x * 2) {
+    const float v = x[m * RR_E + f] + (res ? res[m * RR_E + f] : 0.f);
+    s += (double)v; q += (double)v * (double)v;
+  }
+  red[0][tid] = s; red[1][tid] = q;
+  __syncthreads();
+  if (half == 0) { atomicAdd(ws + f, red[0][f] + red[0][128 + f]); atomicAdd(ws + 128 + f, red[1][f] + red[1][128 + f]); }
+}
+__global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, float* __restrict__ out, float* __restrict__ sum_out,
+                                                  const double* __restrict__ ws, float* __restrict__ running_mean,
+                                                  float* __restrict__ running_var, float momentum, long long M) {
+  const int tid = threadIdx.x, f = tid & 127, half = tid >> 7;
+  const double mean = ws[f] / (double)M;
+  const double var = fmax(ws[128 + f] / (double)M - mean * mean, 0.0);
+  const float mu = (float)mean, rstd = 1.0f / sqrtf((float)var + 1e-5f);
+  const float gm = gamma[f] * rstd, bt = beta[f];
+  for (long long m = (long long)blockIdx.x * 2 + half; m < M; m += (long long)gridDim.x * 2) {
+    const float v = x[m * RR_E + f] + (res ? res[m * RR_E + f] : 0.f);
+    if (sum_out) sum_out[m * RR_E + f] = v;
+    out[m * RR_E + f] = fmaf(v - mu, gm, bt);
+  }
+  if (blockIdx.x == 0 && half == 0 && running_mean != nullptr && momentum > 0.f) {
+    running_mean[f] = fmaf(momentum, mu - running_mean[f], running_mean[f]);
+    const float unb = (float)(var * ((double)M / (double)(M > 1 ? M - 1 : 1)));
+    running_var[f] = fmaf(momentum, unb - running_var[f], running_var[f]);
+  }
+}
+extern "C" int rr_bnorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* out, float* sum_out,
+                            double* ws, float* running_mean, float* running_var, float momentum, long long M, hipStream_t st) {
+  if (x == nullptr || gamma == nullptr || beta == nullptr || out == nullptr || ws == nullptr || M <= 0) return RR_EINVAL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return RR_EINVAL;
+  if (hipMemsetAsync(ws, 0, 256 * sizeof(double), st) != hipSuccess) return RR_ELAUNCH;
+  const long long want = (M + 1) / 2;
+  const unsigned grid = (unsigned)(want < 2048 ? want : 2048);
+  hipLaunchKernelGGL(k_bn_stats, dim3(grid), dim3(256), 0, st, x, res, ws, M);
+  hipLaunchKernelGGL(k_bn_apply, dim3(grid), dim3(256), 0, st, x, res, gamma, beta, out, sum_out, ws, running_mean, running_var, momentum, M);
+  return rr_check(hipGetLastError());
+}
+
 // ------------------------------------------------------------------------------------------------ NAB forward per edge
 #define BN_TAB (256 + 2 * 129 * 4 + 8)
 __device__ __forceinline__ int bn_segment(const float* t, float x) {
@@ -95,7 +144,8 @@ extern "C" int rr_nab_pwl_fwd(const float* pwl, const float* D, const float* the
 // ------------------------------------------------------------------------------------------------ exp(softmax_nodes(K)), times V
 // ekT / kvT [Bp][128][NP] (NP = 16 * ceil(N / 16), zero beyond N): eK = exp(softmax over the NODE axis of K) (attn_freenet.py:319, 321)
 __global__ __launch_bounds__(256) void k_colsoftmax_exp(const float* __restrict__ K, const float* __restrict__ V,
-                                                        float* __restrict__ ekT, float* __restrict__ kvT, int N, int NP) {
+                                                        float* __restrict__ ekT, float* __restrict__ kvT, int N, int NP,
+                                                        float* __restrict__ ek_rows) {
   __shared__ float red[2][256];
   const int b = blockIdx.x, tid = threadIdx.x, f = tid & 127, half = tid >> 7;
   const size_t base = (size_t)b * N * RR_E + f;
@@ -116,23 +166,25 @@ __global__ __launch_bounds__(256) void k_colsoftmax_exp(const float* __restrict_
     if (n < N) {
       e = rr_exp(rr_exp(K[base + (size_t)n * RR_E] - mx) * inv);
       kv = e * V[base + (size_t)n * RR_E];
+      if (ek_rows) ek_rows[base + (size_t)n * RR_E] = e;     // [Bp][N][128]: what the block backward reads (EncSave.ek)
     }
     pe[n] = e; pk[n] = kv;
   }
 }
-extern "C" int rr_colsoftmax_exp(const float* K, const float* V, float* ekT, float* kvT, int Bp, int N, int NP, hipStream_t st) {
+extern "C" int rr_colsoftmax_exp(const float* K, const float* V, float* ekT, float* kvT, float* ek_rows, int Bp, int N, int NP, hipStream_t st) {
   if (K == nullptr || V == nullptr || ekT == nullptr || kvT == nullptr || Bp <= 0 || N < 1 || NP < N || (NP & 15)) return RR_EINVAL;
-  hipLaunchKernelGGL(k_colsoftmax_exp, dim3(Bp), dim3(256), 0, st, K, V, ekT, kvT, N, NP);
+  hipLaunchKernelGGL(k_colsoftmax_exp, dim3(Bp), dim3(256), 0, st, K, V, ekT, kvT, N, NP, ek_rows);
   return rr_check(hipGetLastError());
 }
 
 // ------------------------------------------------------------------------------------------------ AFT mixing
 // y[i][f] = sigmoid(q[i][f]) * (sum_j ea[i][j] kv[j][f]) / (sum_j ea[i][j] ek[j][f]),  ea = exp(softmax_j(bias[i][:]))
 // One wave = 16 rows i of one instance; ea as the B operand (k = j) in registers; A operands = rows of kvT / ekT from L2.
+struct AftMixSave { float *num, *den, *eaT; };   // optional (all or none): [Bp][N][128] x 2 and exp(softmax(bias))^T [Bp][112][112] (zero-filled by the caller; N <= 112): EncSave's fields
 template <int NTK>
 __global__ __launch_bounds__(256, 2) void k_aft_mix_big(const float* __restrict__ bias, const float* __restrict__ q,
                                                         const float* __restrict__ ekT, const float* __restrict__ kvT,
-                                                        float* __restrict__ y, int N, int NP, int tiles_per_inst, int ntask) {
+                                                        float* __restrict__ y, int N, int NP, int tiles_per_inst, int ntask, AftMixSave sv) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, g = lane >> 4;
@@ -165,6 +217,15 @@ __global__ __launch_bounds__(256, 2) void k_aft_mix_big(const float* __restrict_
   for (int kt = 0; kt < NTK; ++kt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) ea[kt][r] = (16 * kt + 4 * g + r) < N ? rr_exp(ea[kt][r] * is) : 0.f;
+  if (sv.eaT != nullptr && nvalid) {                         // [j][i]: lanes j = consecutive nodes i -> contiguous stores
+#pragma unroll
+    for (int kt = 0; kt < NTK; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int jj = 16 * kt + 4 * g + r;
+        if (jj < N) sv.eaT[((size_t)b * 112 + jj) * 112 + node] = ea[kt][r];
+      }
+  }
   const float* pe = ekT + (size_t)b * RR_E * NP + 4 * g;
   const float* pk = kvT + (size_t)b * RR_E * NP + 4 * g;
   const size_t roff = ((size_t)b * N + nc) * RR_E + 4 * g;
@@ -188,6 +249,10 @@ __global__ __launch_bounds__(256, 2) void k_aft_mix_big(const float* __restrict_
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] = rr_sigmoid(qv[r]) * nm[r] / dn[r];
     if (nvalid) rr_st4(y + roff + 16 * t, make_float4(o[0], o[1], o[2], o[3]));
+    if (sv.num != nullptr && nvalid) {
+      rr_st4(sv.num + roff + 16 * t, make_float4(nm[0], nm[1], nm[2], nm[3]));
+      rr_st4(sv.den + roff + 16 * t, make_float4(dn[0], dn[1], dn[2], dn[3]));
+    }
   }
 }
 // The same mixing for any N (rows of more than 208 keys do not fit a lane's registers): three sweeps over the bias row — maximum,
@@ -265,15 +330,18 @@ static bool rr_bign_force_stream() {      // tests: the any-N kernels at every N
   const char* e = getenv("RR_BIGN_STREAM");
   return e != nullptr && atoi(e) != 0;
 }
-extern "C" int rr_aft_mix_big(const float* bias, const float* q, const float* ekT, const float* kvT, float* y, int Bp, int N,
-                              int NP, hipStream_t st) {
+extern "C" int rr_aft_mix_big(const float* bias, const float* q, const float* ekT, const float* kvT, float* y, float* num_out,
+                              float* den_out, float* eaT_out, int Bp, int N, int NP, hipStream_t st) {
   if (bias == nullptr || q == nullptr || ekT == nullptr || kvT == nullptr || y == nullptr || Bp <= 0 || N < 2 || N > RR_BIGN_MAX || NP < N || (NP & 15))
     return RR_EINVAL;
+  const bool saving = num_out != nullptr;
+  if (saving != (den_out != nullptr) || saving != (eaT_out != nullptr) || (saving && N > 112)) return RR_EINVAL;
+  const AftMixSave sv{num_out, den_out, eaT_out};
   const int tpi = (N + 15) / 16, ntask = Bp * tpi;
   const dim3 grid((ntask + 3) / 4);
-  if (N > 208 || rr_bign_force_stream()) hipLaunchKernelGGL(k_aft_mix_stream, grid, dim3(256), 0, st, bias, q, ekT, kvT, y, N, NP, tpi, ntask);
-  else if (N <= 128) hipLaunchKernelGGL((k_aft_mix_big<8>), grid, dim3(256), 0, st, bias, q, ekT, kvT, y, N, NP, tpi, ntask);
-  else hipLaunchKernelGGL((k_aft_mix_big<13>), grid, dim3(256), 0, st, bias, q, ekT, kvT, y, N, NP, tpi, ntask);
+  if ((N > 208 || rr_bign_force_stream()) && !saving) hipLaunchKernelGGL(k_aft_mix_stream, grid, dim3(256), 0, st, bias, q, ekT, kvT, y, N, NP, tpi, ntask);
+  else if (N <= 128) hipLaunchKernelGGL((k_aft_mix_big<8>), grid, dim3(256), 0, st, bias, q, ekT, kvT, y, N, NP, tpi, ntask, sv);
+  else hipLaunchKernelGGL((k_aft_mix_big<13>), grid, dim3(256), 0, st, bias, q, ekT, kvT, y, N, NP, tpi, ntask, sv);
   return rr_check(hipGetLastError());
 }
 

@@ -81,6 +81,59 @@ extern "C" int rr_inorm_bwd(const float* x, const float* dy1, const float* dy2, 
   return rr_check(hipGetLastError());
 }
 
+// ------------------------------------------------------------------------------------------------ batch norm backward (TRAINING statistics)
+// nn.BatchNorm1d over the M = Bp * N rows in train mode (attn_freenet.py:82-83, 102-103), x = the norm's input, dy = dy1 (+ dy2):
+//   xh = (x - mean) rstd,  d beta = sum dy,  d gamma = sum dy xh,  dx = gamma rstd (dy - d beta / M - xh d gamma / M)   (+ dx when accumulating)
+// Two launches: the four per-feature sums (x, x^2, dy, dy x) in float64 atomics (ws[512], zeroed here), then the map.
+__global__ __launch_bounds__(256) void k_bn_bwd_stats(const float* __restrict__ x, const float* __restrict__ dy1, const float* __restrict__ dy2,
+                                                      double* __restrict__ ws, long long M) {
+  __shared__ double red[4][256];
+  const int tid = threadIdx.x, f = tid & 127, half = tid >> 7;
+  double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
+  for (long long m = (long long)blockIdx.x * 2 + half; m < M; m += (long long)gridDim.x * 2) {
+    const double xv = (double)x[m * RR_E + f];
+    const double g = (double)(dy1[m * RR_E + f] + (dy2 ? dy2[m * RR_E + f] : 0.f));
+    a += xv; b += xv * xv; c += g; d += g * xv;
+  }
+  red[0][tid] = a; red[1][tid] = b; red[2][tid] = c; red[3][tid] = d;
+  __syncthreads();
+  if (half == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) atomicAdd(ws + 128 * q + f, red[q][f] + red[q][128 + f]);
+  }
+}
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ dy1, const float* __restrict__ dy2,
+                                                      const float* __restrict__ gamma, float* __restrict__ dx, float* __restrict__ dgamma,
+                                                      float* __restrict__ dbeta, const double* __restrict__ ws, long long M, int accumulate) {
+  const int tid = threadIdx.x, f = tid & 127, half = tid >> 7;
+  const double inv = 1.0 / (double)M;
+  const double mean = ws[f] * inv;
+  const double var = fmax(ws[128 + f] * inv - mean * mean, 0.0);
+  const float mu = (float)mean, rstd = 1.0f / sqrtf((float)var + 1e-5f);
+  const double sdy = ws[256 + f], sdyx = ws[384 + f];
+  const float dbt = (float)sdy, dgm = (float)((sdyx - mean * sdy) * (double)rstd);
+  const float k1 = (float)(sdy * inv), k2 = (float)((sdyx - mean * sdy) * (double)rstd * inv);
+  const float gr = gamma[f] * rstd;
+  for (long long m = (long long)blockIdx.x * 2 + half; m < M; m += (long long)gridDim.x * 2) {
+    const float g = dy1[m * RR_E + f] + (dy2 ? dy2[m * RR_E + f] : 0.f);
+    const float xh = (x[m * RR_E + f] - mu) * rstd;
+    const float v = gr * (g - k1 - xh * k2);
+    dx[m * RR_E + f] = accumulate ? dx[m * RR_E + f] + v : v;
+  }
+  if (blockIdx.x == 0 && half == 0) { atomicAdd(dgamma + f, dgm); atomicAdd(dbeta + f, dbt); }
+}
+extern "C" int rr_bnorm_bwd(const float* x, const float* dy1, const float* dy2, const float* gamma, float* dx, float* dgamma,
+                            float* dbeta, double* ws, long long M, int accumulate, hipStream_t st) {
+  if (x == nullptr || dy1 == nullptr || gamma == nullptr || dx == nullptr || dgamma == nullptr || dbeta == nullptr || ws == nullptr || M <= 0)
+    return RR_EINVAL;
+  if (hipMemsetAsync(ws, 0, 512 * sizeof(double), st) != hipSuccess) return RR_ELAUNCH;
+  const long long want = (M + 1) / 2;
+  const unsigned grid = (unsigned)(want < 2048 ? want : 2048);
+  hipLaunchKernelGGL(k_bn_bwd_stats, dim3(grid), dim3(256), 0, st, x, dy1, dy2, ws, M);
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid), dim3(256), 0, st, x, dy1, dy2, gamma, dx, dgamma, dbeta, ws, M, accumulate);
+  return rr_check(hipGetLastError());
+}
+
 // ------------------------------------------------------------------------------------------------ Linear on rows (128 -> 128)
 // out[m][n] = sum_k x[m][k] W[n][k] (+ bias[n]) (+ out[m][n]);  W as an fp32 MFMA A operand pack [8][8][64][4] (packing.pack_a).
 // One wave = 64 rows (four 16-row tiles as B operands in registers), the eight output tiles in turn.

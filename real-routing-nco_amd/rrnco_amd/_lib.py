@@ -151,8 +151,10 @@ _SIGS = {
     "rr_small_gemm": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "rr_inorm_fwd": [vp, vp, vp, vp, vp, i32, i32, vp],
     "rr_nab_pwl_fwd": [vp, vp, vp, vp, i32, i32, i32, vp],
-    "rr_colsoftmax_exp": [vp, vp, vp, vp, i32, i32, i32, vp],
-    "rr_aft_mix_big": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "rr_colsoftmax_exp": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "rr_aft_mix_big": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "rr_bnorm_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, C.c_longlong, vp],
+    "rr_bnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, C.c_longlong, i32, vp],
     "rr_dec_fwd_big": [C.POINTER(DecBigIO), vp],
     "rr_select_big": [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, u64, u32, i32, f32, vp],
     "rr_dec_logit_bwd": [C.POINTER(DecLogitIO), vp],

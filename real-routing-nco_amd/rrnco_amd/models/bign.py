@@ -88,8 +88,8 @@ def encode(encoder, td, packed):
                 bias.view(Bp, N * N).copy_(bias2[:, si])
             else:
                 L.check(lib.rr_nab_pwl_fwd(w.nab, L.ptr(D), L.ptr(theta), L.ptr(bias), Bp, N, si, st), "rr_nab_pwl_fwd")
-            L.check(lib.rr_colsoftmax_exp(L.ptr(k), L.ptr(v), L.ptr(ekT), L.ptr(kvT), Bp, N, NP, st), "rr_colsoftmax_exp")
-            L.check(lib.rr_aft_mix_big(L.ptr(bias), L.ptr(q), L.ptr(ekT), L.ptr(kvT), L.ptr(yy), Bp, N, NP, st), "rr_aft_mix_big")
+            L.check(lib.rr_colsoftmax_exp(L.ptr(k), L.ptr(v), L.ptr(ekT), L.ptr(kvT), None, Bp, N, NP, st), "rr_colsoftmax_exp")
+            L.check(lib.rr_aft_mix_big(L.ptr(bias), L.ptr(q), L.ptr(ekT), L.ptr(kvT), L.ptr(yy), None, None, None, Bp, N, NP, st), "rr_aft_mix_big")
             lin(w.wp, w.bp, yy, o)                                     # project o multi_head_combine, folded (packing.py)
             o3 = q                                                     # reuse
             norm(o, None, w.n3g, w.n3b, o3)
@@ -101,6 +101,89 @@ def encode(encoder, td, packed):
             norm(F, None, w.f2g, w.f2b, out)
             outs.append(out)
         row, col = outs
+    return row, col
+
+
+@torch.no_grad()
+def encode_bn_train(encoder, td, packed, P, saves, momentum=0.1):
+    """RRNetEncoder.forward for normalization='batch' with module.train() (attn_freenet.py:82-83, 102-103: BatchNorm1d over the
+    flattened B * N rows, batch statistics, running statistics moved once by `momentum`) on kernels: the block as the row-parallel
+    composition of `encode` above with rr_bnorm_fwd in place of the instance norm, the init embedding on rr_init_embed, N <= 103.
+    `P` = parameters and BatchNorm buffers by name (grad_replay.params_and_buffers: the kernels' packs carry the running statistics
+    folded for eval mode; training needs the raw gamma / beta).  `saves` (a list) receives per layer what the hand-written block
+    backward reads (models/enc_backward.py; csrc/rr_enc_w.inc: EncSave) and finally {"theta"}: the gradients run on kernels too."""
+    lib, st = L.lib(), L.stream()
+    D = td["distance_matrix"].float().contiguous()
+    locs = td["locs"].float().contiguous()
+    Bp, N = D.shape[0], D.shape[-1]
+    M, NP, dev = Bp * N, _np(N), D.device
+    assert N <= MAX_N_ONCHIP, "the block backward kernels hold an instance's N x N weights on chip"
+    sidx = td.get("sample_idx", None)
+    if sidx is None:
+        from .encoder import ATSPInitEmbedding
+        sidx = ATSPInitEmbedding.sample_indices(D, encoder.init_embedding.sample_size)
+    sidx = sidx.contiguous()
+    vtw = encoder.env_name == "rcvrptw"
+    row, col = torch.empty(Bp, N, E, device=dev), torch.empty(Bp, N, E, device=dev)
+    if encoder.env_name == "atsp":
+        L.check(lib.rr_init_embed(packed["init"], 0, L.ptr(D), L.ptr(locs), L.ptr(sidx), None, L.ptr(row), L.ptr(col), Bp, N,
+                                  sidx.shape[-1], st), "rr_init_embed")
+    else:
+        vfeat = encoder.init_embedding.node_features(td).contiguous()
+        L.check(lib.rr_init_embed(packed["init"], 1, L.ptr(D), L.ptr(locs), L.ptr(sidx), L.ptr(vfeat), L.ptr(row), L.ptr(col), Bp, N,
+                                  sidx.shape[-1], st), "rr_init_embed")
+    T = td["duration_matrix"].float().contiguous() if vtw else None
+    bias2 = torch.empty(Bp, 2, N * N, device=dev) if vtw else None
+    theta = torch.empty(Bp, N, N, device=dev)
+    L.check(lib.rr_edge_angles(L.ptr(locs), L.ptr(theta), Bp, N, st), "rr_edge_angles")
+    ffn = _ffn_packs(packed)
+    new = lambda: torch.empty(Bp, N, E, device=dev)                                        # noqa: E731
+    bias = torch.empty(Bp, N, N, device=dev)
+    ekT, kvT = torch.empty(Bp, E, NP, device=dev), torch.empty(Bp, E, NP, device=dev)
+    ws = torch.empty(256, dtype=torch.float64, device=dev)
+
+    def lin(wp, b, x, out):
+        L.check(lib.rr_linear_rows(wp, b, L.ptr(x), L.ptr(out), M, 0, None, st), "rr_linear_rows")
+
+    def norm(x, res, pname, out, sum_out=None):
+        n = pname + ".normalizer."
+        L.check(lib.rr_bnorm_fwd(L.ptr(x), L.ptr(res), L.ptr(P[n + "weight"].detach()), L.ptr(P[n + "bias"].detach()), L.ptr(out), L.ptr(sum_out),
+                                 L.ptr(ws), L.ptr(P[n + "running_mean"]), L.ptr(P[n + "running_var"]), float(momentum), M, st), "rr_bnorm_fwd")
+
+    for l, pair in enumerate(packed["blocks"]):
+        outs, sv = [], {"row_in": row, "col_in": col}
+        for si, (w, side) in enumerate(zip(pair, ("row", "col"))):
+            b = f"encoder.net.layers.{l}.{side}_encoding_block"
+            x, y = (row, col) if si == 0 else (col, row)
+            r, c, q, k, v, ek, yy, o = new(), new(), new(), new(), new(), new(), new(), new()
+            num, den, u1, x1 = new(), new(), new(), new()
+            eaT = torch.zeros(Bp, 112, 112, device=dev)
+            norm(x, None, b + ".norm1", r)
+            norm(y, None, b + ".norm2", c)
+            lin(w.wq, w.bq, r, q); lin(w.wk, w.bk, c, k); lin(w.wv, w.bv, c, v)
+            if vtw:
+                if si == 0:
+                    nr, nc = packed["nabdur"][l]
+                    L.check(lib.rr_nab_dur(nr, nc, L.ptr(D), L.ptr(T), L.ptr(locs), L.ptr(bias2), Bp, N, st), "rr_nab_dur")
+                bias.view(Bp, N * N).copy_(bias2[:, si])
+            else:
+                L.check(lib.rr_nab_pwl_fwd(w.nab, L.ptr(D), L.ptr(theta), L.ptr(bias), Bp, N, si, st), "rr_nab_pwl_fwd")
+            L.check(lib.rr_colsoftmax_exp(L.ptr(k), L.ptr(v), L.ptr(ekT), L.ptr(kvT), L.ptr(ek), Bp, N, NP, st), "rr_colsoftmax_exp")
+            L.check(lib.rr_aft_mix_big(L.ptr(bias), L.ptr(q), L.ptr(ekT), L.ptr(kvT), L.ptr(yy), L.ptr(num), L.ptr(den), L.ptr(eaT),
+                                       Bp, N, NP, st), "rr_aft_mix_big")
+            lin(w.wp, w.bp, yy, o)                                     # project o multi_head_combine, folded (packing.py)
+            o3 = k                                                     # reuse (K is dead: ek / kvT carry it)
+            norm(o, None, b + ".norm3", o3)
+            norm(r, o3, b + ".feed_forward.ops.norm1", x1, sum_out=u1)  # ffn.norm1(r + norm3(.)) (:355, 436); u1 = its input
+            F = new()
+            L.check(lib.rr_mlp_rows(ffn[2 * l + si]["fwd"], 0, L.ptr(x1), None, L.ptr(F), None, 1, M, M, st), "rr_mlp_rows")
+            out = new()
+            norm(F, None, b + ".feed_forward.ops.norm2", out)
+            outs.append(out)
+            sv[side] = {"r": r, "c": c, "q": q, "ek": ek, "v": v, "num": num, "den": den, "y": yy, "o": o, "u1": u1, "x1": x1, "eaT": eaT}
+        saves.append(sv)
+        row, col = outs
+    saves.append({"theta": theta})
     return row, col
 
 

@@ -194,7 +194,15 @@ def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
         """gbuf (+ off floats) [128][ldc] += dy^T x"""
         L.check(lib.rr_gemm_tn(L.ptr(dy), L.ptr(x), gbuf.data_ptr() + 4 * off, 1, M, E, E, E, ldc, 0, 0, 0, MS, 1, L.ptr(ws_tn), st), "rr_gemm_tn")
 
+    bn_train = GR.uses_batch_statistics(policy)      # normalization='batch', module.train(): batch statistics over all Bp * N rows
+    ws_bn = torch.empty(512, dtype=torch.float64, device=dev) if bn_train else None
+
     def inorm(x, dy1, dy2, pname, dx, acc=0):
+        if bn_train:
+            L.check(lib.rr_bnorm_bwd(L.ptr(x), L.ptr(dy1), L.ptr(dy2), L.ptr(P[pname + ".normalizer.weight"].detach()), L.ptr(dx),
+                                     L.ptr(G.buf(pname + ".normalizer.weight")), L.ptr(G.buf(pname + ".normalizer.bias")), L.ptr(ws_bn),
+                                     M, acc, st), "rr_bnorm_bwd")
+            return
         L.check(lib.rr_inorm_bwd(L.ptr(x), L.ptr(dy1), L.ptr(dy2), L.ptr(P[pname + ".normalizer.weight"].detach()), L.ptr(dx),
                                  L.ptr(G.buf(pname + ".normalizer.weight")), L.ptr(G.buf(pname + ".normalizer.bias")), Bp, N, acc, st),
                 "rr_inorm_bwd")

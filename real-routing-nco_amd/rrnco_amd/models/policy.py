@@ -301,7 +301,18 @@ class RRNetPolicy(nn.Module):
             if td.get("sample_idx", None) is None:
                 from .encoder import ATSPInitEmbedding
                 td.set("sample_idx", ATSPInitEmbedding.sample_indices(td["distance_matrix"], self.encoder.init_embedding.sample_size))
-            row_emb, col_emb = GR.encode_for_policy(self, td, td["sample_idx"], bn_momentum=0.1)
+            from . import bign
+            import os as _os
+            if (td["distance_matrix"].shape[-1] <= bign.MAX_N_ONCHIP and bign.supported(self.env_name, packed, "instance")
+                    and _os.environ.get("RR_BN_TORCH", "0") != "1"):
+                # round 5: on kernels too — the block as the row-parallel composition of models/bign.py with rr_bnorm_fwd (batch statistics,
+                # running statistics moved once), saving what the hand-written block backward reads (enc_backward: rr_bnorm_bwd)
+                bn_saves = []
+                row_emb, col_emb = bign.encode_bn_train(self.encoder, td, packed, GR.params_and_buffers(self, 0.1), bn_saves, momentum=0.1)
+                if capture is not None and capture.get("enc_saves", True):
+                    capture["enc"] = bn_saves
+            else:       # (RR_BN_TORCH=1, the ablation NABs: the model restated in torch ops, models/grad_replay.py)
+                row_emb, col_emb = GR.encode_for_policy(self, td, td["sample_idx"], bn_momentum=0.1)
             row_emb, col_emb = row_emb.contiguous(), col_emb.contiguous()
             self._pack_dirty = True
             self._pack_verified = False      # (the running statistics just moved)

@@ -341,29 +341,86 @@ def test_gradient_clipping_as_the_reference_trainer():
     assert float(out["grad_norm"]) > 0.05 and abs(float(total) - 0.05) < 1e-4
 
 
-def test_batch_norm_train_mode_step_runs_and_matches_the_torch_replay():
+def test_batch_norm_kernels_match_torch_batch_norm():
+    """rr_bnorm_fwd / rr_bnorm_bwd (csrc/rr_bign.hip, rr_train_enc.hip): nn.BatchNorm1d in train mode over the flattened rows — output,
+    running statistics (momentum 0.1, unbiased variance), and the backward with two incoming gradients and accumulation, against
+    torch's own batch_norm in float64."""
+    import torch.nn.functional as F
+    from rrnco_amd import _lib as L
+    lib, st = L.lib(), L.stream()
+    g = torch.Generator().manual_seed(3)
+    M, E = 6 * 37, 128
+    x = (torch.randn(M, E, generator=g) * 1.7 + torch.randn(E, generator=g) * 3).cuda()
+    res = torch.randn(M, E, generator=g).cuda()
+    gamma, beta = (torch.rand(E, generator=g) + 0.5).cuda(), torch.randn(E, generator=g).cuda()
+    rm, rv = torch.randn(E, generator=g).cuda(), (torch.rand(E, generator=g) + 0.5).cuda()
+    rm_ref, rv_ref = rm.double().clone(), rv.double().clone()
+    out, usum = torch.empty_like(x), torch.empty_like(x)
+    ws = torch.empty(512, dtype=torch.float64, device="cuda")
+    L.check(lib.rr_bnorm_fwd(L.ptr(x), L.ptr(res), L.ptr(gamma), L.ptr(beta), L.ptr(out), L.ptr(usum), L.ptr(ws), L.ptr(rm), L.ptr(rv), 0.1, M, st), "rr_bnorm_fwd")
+    xd = (x + res).double().requires_grad_()
+    gd, bd = gamma.double().requires_grad_(), beta.double().requires_grad_()
+    ref = F.batch_norm(xd, rm_ref, rv_ref, gd, bd, True, 0.1, 1e-5)
+    assert torch.equal(usum, x + res)
+    assert float((out.double() - ref.detach()).abs().max()) < 2e-5
+    assert float((rm.double() - rm_ref).abs().max()) < 1e-6 and float((rv.double() - rv_ref).abs().max()) < 1e-5
+    dy1, dy2 = torch.randn(M, E, generator=g).cuda(), torch.randn(M, E, generator=g).cuda()
+    ref.backward((dy1 + dy2).double())
+    dx0 = torch.randn(M, E, generator=g).cuda()
+    dx, dgm, dbt = dx0.clone(), torch.zeros(E, device="cuda"), torch.zeros(E, device="cuda")
+    L.check(lib.rr_bnorm_bwd(L.ptr(usum), L.ptr(dy1), L.ptr(dy2), L.ptr(gamma), L.ptr(dx), L.ptr(dgm), L.ptr(dbt), L.ptr(ws), M, 1, st), "rr_bnorm_bwd")
+    assert float(((dx - dx0).double() - xd.grad).abs().max()) < 2e-5 * float(xd.grad.abs().max()) + 1e-6
+    assert float((dgm.double() - gd.grad).abs().max()) < 1e-4 * float(gd.grad.abs().max())
+    assert float((dbt.double() - bd.grad).abs().max()) < 1e-4 * float(bd.grad.abs().max())
+    dx2 = torch.empty_like(x)                       # not accumulating, one incoming gradient
+    L.check(lib.rr_bnorm_bwd(L.ptr(usum), L.ptr(dy1), None, L.ptr(gamma), L.ptr(dx2), L.ptr(dgm), L.ptr(dbt), L.ptr(ws), M, 0, st), "rr_bnorm_bwd")
+    xd2 = (x + res).double().requires_grad_()
+    F.batch_norm(xd2, None, None, gamma.double(), beta.double(), True, 0.0, 1e-5).backward(dy1.double())
+    assert float((dx2.double() - xd2.grad).abs().max()) < 2e-5 * float(xd2.grad.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("problem", ["atsp", "rcvrp", "rcvrptw"])
+def test_batch_norm_train_mode_step_runs_and_matches_the_torch_replay(problem):
     """normalization='batch' with module.train() (attn_freenet.py:82-83, 102-103; the constructor default of RRNetPolicy): batch
-    statistics across the instances of the call.  The encoder then runs through torch ops (models/grad_replay.encode_for_policy);
-    the step's gradients on the kernel decoder backward equal those of the all-torch teacher-forced replay, the running statistics
+    statistics across the instances of the call.  Since round 5 the encoder of such a step runs on kernels as well (models/bign.py:
+    encode_bn_train with rr_bnorm_fwd; backward: models/enc_backward.py with rr_bnorm_bwd); RR_BN_TORCH=1 keeps the torch-op encoder.
+    The step's gradients equal those of the all-torch teacher-forced replay, the running statistics
     move once per step, and the eval-mode forward (kernels, folded running statistics) works afterwards."""
-    from rrnco_amd.envs import ATSPEnv
+    from rrnco_amd.envs import ATSPEnv, RCVRPEnv, RMTVRPEnv
     from rrnco_amd.models import RRNetPolicy
     from rrnco_amd.models.rl import RRNet
     dev = torch.device("cuda")
     torch.manual_seed(5)
-    pol = RRNetPolicy(env_name="atsp", embed_dim=128, num_heads=8, num_encoder_layers=2, normalization="batch",
+    pol = RRNetPolicy(env_name=problem, embed_dim=128, num_heads=8, num_encoder_layers=2, normalization="batch",
                       use_graph_context=False, nab_type="gating", init_embedding_kwargs=dict(sample_size=10)).to(dev).train()
-    env = ATSPEnv(generator_params=dict(num_loc=20, device=dev), check_solution=False, device=dev)
+    gp = dict(num_loc=20, device=dev)
+    env = {"atsp": lambda: ATSPEnv(generator_params=gp, check_solution=False, device=dev),
+           "rcvrp": lambda: RCVRPEnv(generator_params=gp, check_solution=False, device=dev),
+           "rcvrptw": lambda: RMTVRPEnv(generator_params=gp, device=dev)}[problem]()
     model = RRNet(env, policy=pol)
     batch = env.generator(6, generator=torch.Generator(device=dev).manual_seed(2))
-    batch["sample_idx"] = torch.stack([torch.stack([torch.randperm(20, device=dev)[:10] for _ in range(20)]) for _ in range(6)])
+    nn_ = batch["distance_matrix"].shape[-1]
+    batch["sample_idx"] = torch.stack([torch.stack([torch.randperm(nn_, device=dev)[:10] for _ in range(nn_)]) for _ in range(6)])
     rm0 = pol.state_dict()["encoder.net.layers.0.row_encoding_block.norm1.normalizer.running_mean"].clone()
     grads = {}
-    for replay in ("hip", "torch"):
-        pol.zero_grad(set_to_none=True)
-        out = model.training_step(batch, optimizer=None, seed=7, replay=replay)
-        assert torch.isfinite(out["loss"]) and torch.allclose(out["replay_log_likelihood"], out["log_likelihood"], atol=2e-3)
-        grads[replay] = {n: p.grad.clone() for n, p in pol.named_parameters() if p.grad is not None}
+    from rrnco_amd import _lib as L
+    lib, calls = L.lib(), {"rr_bnorm_fwd": 0, "rr_bnorm_bwd": 0}
+    real = {n: getattr(lib, n) for n in calls}
+    for n in calls:
+        setattr(lib, n, (lambda *a, _n=n: (calls.__setitem__(_n, calls[_n] + 1), real[_n](*a))[1]))
+    try:
+        for replay in ("hip", "torch"):
+            pol.zero_grad(set_to_none=True)
+            before = dict(calls)
+            out = model.training_step(batch, optimizer=None, seed=7, replay=replay)
+            assert torch.isfinite(out["loss"]) and torch.allclose(out["replay_log_likelihood"], out["log_likelihood"], atol=2e-3)
+            grads[replay] = {n: p.grad.clone() for n, p in pol.named_parameters() if p.grad is not None}
+            # round 5: the train-mode encoder runs on kernels (2 layers x 2 blocks x 5 norms), and with replay="hip" so does its backward
+            assert calls["rr_bnorm_fwd"] - before["rr_bnorm_fwd"] == 20
+            assert calls["rr_bnorm_bwd"] - before["rr_bnorm_bwd"] == (20 if replay == "hip" else 0)
+    finally:
+        for n in calls:
+            setattr(lib, n, real[n])
     rm1 = pol.state_dict()["encoder.net.layers.0.row_encoding_block.norm1.normalizer.running_mean"]
     assert not torch.equal(rm0, rm1)                                        # the forward updated the running statistics
     num = sum(float((grads["hip"][n] - grads["torch"][n]).pow(2).sum()) for n in grads["torch"])
