@@ -311,7 +311,11 @@ extern "C" int rr_enc_layer_split(const EncBlockW* wrow, const EncBlockW* wcol, 
     hipLaunchKernelGGL((k_enc_mix<7, true>), dim3(Bp, 2), dim3(64 * 7), 0, st, ws, Kb, Vb, Rt, D, theta, bias_pre, dist_family, n_base, Bp, N);
   else
     hipLaunchKernelGGL((k_enc_mix<7, false>), dim3(Bp, 2), dim3(64 * 7), 0, st, ws, Kb, Vb, Rt, D, theta, bias_pre, dist_family, n_base, Bp, N);
-  static const int upw = [] { const char* e = getenv("RR_ENC_TAIL_UPW"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 8; }();     // instances per workgroup
+  // instances per workgroup of the persistent tail: 8 at the headline size (1 024 workgroups); small batches take fewer so that every
+  // CU has a workgroup (512 instances: 4 -> 256 workgroups; with 8 half the chip idled through every layer of BASELINE configs[2])
+  static const int upw_env = [] { const char* e = getenv("RR_ENC_TAIL_UPW"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+  int upw = upw_env;
+  if (upw == 0) { upw = (2 * Bp) / 256; upw = upw < 1 ? 1 : upw > 8 ? 8 : upw; }
   hipLaunchKernelGGL((k_enc_tail<7>), dim3((Bp + upw - 1) / upw, 2), dim3(64 * 8), 0, st, ws, row_in, col_in, Rt, stats_in, row_out, col_out, stats_out, Bp, N, upw);
   return rr_check(hipGetLastError());
 }
