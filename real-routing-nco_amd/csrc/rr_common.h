@@ -272,6 +272,75 @@ __device__ __forceinline__ float rr_relu(float x) {
   const int i = __float_as_int(x);
   return __int_as_float(i > 0 ? i : 0);
 }
+// ---- Hand-scheduled half regions of the pointer MLP (rr_rollout_w.inc, instance mode; round 6).  A half = 12 v_mfma_f32_16x16x32_f16 on
+// the eight weight fragments Xp a wave read EARLIER, and beside them the eight ds_read_b128 of the fragments Xn the NEXT half needs: one
+// read behind each of the first eight matrix instructions, none waited for before the end of the half.  hipcc's own schedule of the same
+// work sinks every read to its use (an `s_waitcnt lgkmcnt` that exposes an LDS round trip in front of most matrix instructions:
+// 1 250 cycles per region in the kernel, 1 136 in tools/clockprobe/mlpprobe.hip); this order measured 880 cycles per region for seven
+// waves in tools/clockprobe/pipeprobe.hip (profiles/r06/NOTES.md §1).  Same products into the same accumulators in the same order as
+// hid() / output4(): results are bit-identical.  Inline asm is invisible to hipcc's hazard recognizer and to its waitcnt pass, so each
+// block (1) starts with s_nop 1 (a VALU write of a source right before it), (2) waits for its own reads (lgkmcnt(0)) before it ends,
+// (3) must not be followed within a few cycles by a VALU read of its accumulators: callers keep a sched_barrier + other work behind it.
+// rr_half_hid: c = seed + sum_sl (Xp[2 sl] Gs[sl][0] + Xp[2 sl] Gs[sl][1] + Xp[2 sl + 1] Gs[sl][0])      (one dependent chain)
+__device__ __forceinline__ void rr_half_hid(f32x4& c, f32x4 seed, const rr_f16x8 (&Xp)[8], rr_f16x8 (&Xn)[8], const rr_f16x8 (&Gs)[4][2], unsigned addr) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %10, %18, %9\n\t"
+      "ds_read_b128 %1, %26 offset:0\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %10, %19, %0\n\t"
+      "ds_read_b128 %2, %26 offset:1024\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %11, %18, %0\n\t"
+      "ds_read_b128 %3, %26 offset:2048\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %12, %20, %0\n\t"
+      "ds_read_b128 %4, %26 offset:3072\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %12, %21, %0\n\t"
+      "ds_read_b128 %5, %26 offset:4096\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %13, %20, %0\n\t"
+      "ds_read_b128 %6, %26 offset:5120\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %14, %22, %0\n\t"
+      "ds_read_b128 %7, %26 offset:6144\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %14, %23, %0\n\t"
+      "ds_read_b128 %8, %26 offset:7168\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %15, %22, %0\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %16, %24, %0\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %16, %25, %0\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %17, %24, %0\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(c), "=&v"(Xn[0]), "=&v"(Xn[1]), "=&v"(Xn[2]), "=&v"(Xn[3]), "=&v"(Xn[4]), "=&v"(Xn[5]), "=&v"(Xn[6]), "=&v"(Xn[7])
+      : "v"(seed), "v"(Xp[0]), "v"(Xp[1]), "v"(Xp[2]), "v"(Xp[3]), "v"(Xp[4]), "v"(Xp[5]), "v"(Xp[6]), "v"(Xp[7]),
+        "v"(Gs[0][0]), "v"(Gs[0][1]), "v"(Gs[1][0]), "v"(Gs[1][1]), "v"(Gs[2][0]), "v"(Gs[2][1]), "v"(Gs[3][0]), "v"(Gs[3][1]), "v"(addr)
+      : "memory");
+}
+// rr_half_out: F[u] += Xp[2 u] Hh + Xp[2 u] Hl + Xp[2 u + 1] Hh, u = 0 .. 3      (four chains, each product pass over the four before the next)
+__device__ __forceinline__ void rr_half_out(f32x4& F0, f32x4& F1, f32x4& F2, f32x4& F3, const rr_f16x8 (&Xp)[8], rr_f16x8 (&Xn)[8],
+                                            rr_f16x8 Hh, rr_f16x8 Hl, unsigned addr) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %12, %20, %0\n\t"
+      "ds_read_b128 %4, %22 offset:0\n\t"
+      "v_mfma_f32_16x16x32_f16 %1, %14, %20, %1\n\t"
+      "ds_read_b128 %5, %22 offset:1024\n\t"
+      "v_mfma_f32_16x16x32_f16 %2, %16, %20, %2\n\t"
+      "ds_read_b128 %6, %22 offset:2048\n\t"
+      "v_mfma_f32_16x16x32_f16 %3, %18, %20, %3\n\t"
+      "ds_read_b128 %7, %22 offset:3072\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %12, %21, %0\n\t"
+      "ds_read_b128 %8, %22 offset:4096\n\t"
+      "v_mfma_f32_16x16x32_f16 %1, %14, %21, %1\n\t"
+      "ds_read_b128 %9, %22 offset:5120\n\t"
+      "v_mfma_f32_16x16x32_f16 %2, %16, %21, %2\n\t"
+      "ds_read_b128 %10, %22 offset:6144\n\t"
+      "v_mfma_f32_16x16x32_f16 %3, %18, %21, %3\n\t"
+      "ds_read_b128 %11, %22 offset:7168\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %13, %20, %0\n\t"
+      "v_mfma_f32_16x16x32_f16 %1, %15, %20, %1\n\t"
+      "v_mfma_f32_16x16x32_f16 %2, %17, %20, %2\n\t"
+      "v_mfma_f32_16x16x32_f16 %3, %19, %20, %3\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "+v"(F0), "+v"(F1), "+v"(F2), "+v"(F3), "=&v"(Xn[0]), "=&v"(Xn[1]), "=&v"(Xn[2]), "=&v"(Xn[3]), "=&v"(Xn[4]), "=&v"(Xn[5]), "=&v"(Xn[6]), "=&v"(Xn[7])
+      : "v"(Xp[0]), "v"(Xp[1]), "v"(Xp[2]), "v"(Xp[3]), "v"(Xp[4]), "v"(Xp[5]), "v"(Xp[6]), "v"(Xp[7]), "v"(Hh), "v"(Hl), "v"(addr)
+      : "memory");
+}
 // One 16 KB weight stage = 16 LDS-DMA requests of 1 KB to consecutive LDS slots.  What a request costs its wave is what its
 // instructions cost: with per-fragment pointer arithmetic (a 64-bit vector add and a dozen scalar instructions, as the builtin form
 // compiles) 68 cycles; with the lane offsets of the fragments precomputed in registers (`vo`), the stage's global base in a scalar
