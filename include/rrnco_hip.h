@@ -77,7 +77,8 @@ typedef struct {                /* arguments of the persistent rollout: see csrc
   const int32_t *bclass;        /* [Bp] backhaul class 1 / 2 */
   /* training dump (NULL / 0 otherwise), row m = (b*dumpT + step)*S + s per decoder evaluation: pointer-MLP input g0 and
    * output g [m][128], meta [m][8] = 4 action-mask words seen, node decided at, node chosen, live flag, 0; VRP state
-   * scalars scal [m][4] (context.py:51-70).  Consumed by rr_dec_* below (the REINFORCE backward of decoder.py:151-329). */
+   * scalars scal [m][4] (context.py:51-70).  Consumed by rr_dec_* below (the REINFORCE backward of decoder.py:151-329).
+   * g0 and g must hold Bp*dumpT*S + 1 rows (the last one is a trash row for lanes without a live rollout). */
   float *dump_g0, *dump_g; uint32_t *dump_meta; float *dump_scal; int dumpT;
   int use_split;                /* 1: greedy / sampling launch on the fp16 matrix pipe with two-piece split fp32 operands (x~ = hi + lo,
                                  * three f16 MFMAs per product, error of a dot product 4e-8 of sum |a b|: csrc/rr_common.h); needs DecW.w1s /

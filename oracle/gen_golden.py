@@ -24,7 +24,8 @@ from oracle import ref_shim, restate  # noqa: E402
 ref_shim.install()
 from tensordict import TensorDict  # noqa: E402  (the shim's stand-in)
 
-GOLD = os.path.join(ROOT, "tests", "golden")
+GOLD_READ = os.path.join(ROOT, "tests", "golden")                 # committed fixtures / weights that generators READ (base fixtures, trained weights)
+GOLD = os.environ.get("RR_GOLDEN_OUT", GOLD_READ)                 # where fixtures are WRITTEN (--check regenerates into a temporary directory)
 POLICY_KW = dict(embed_dim=128, num_heads=8, num_encoder_layers=6, normalization="instance",
                  use_graph_context=False, nab_type="gating")
 
@@ -81,7 +82,7 @@ def gen_atsp(tag, B, N, S, sample_size, seed, layers=6, aug=False, keep_trace=Tr
     if weights_file is None:
         w = restate.make_weights(tmpl, seed)
     else:
-        z = np.load(os.path.join(GOLD, weights_file))
+        z = np.load(os.path.join(GOLD_READ, weights_file))
         w = {k: torch.from_numpy(z[k]).float() for k in z.files}
         assert {k: tuple(v.shape) for k, v in w.items()} == tmpl, "trained state_dict does not match the reference's template"
     pol.load_state_dict(w, strict=True)
@@ -160,7 +161,7 @@ def gen_atsp_autocast(tag, base_tag):
     base fixture.  tests/test_gpu_mixed.py holds the 16-mixed kernels to deviations of this size, not to the fp32 tolerances."""
     from rrnco.envs.atsp.env import ATSPEnv
     from rrnco.models.policy import RRNetPolicy
-    z = np.load(os.path.join(GOLD, base_tag + ".npz"))
+    z = np.load(os.path.join(GOLD_READ, base_tag + ".npz"))
     B, N, S, ss, seed, layers = (int(z[k]) for k in ("B", "N", "S", "sample_size", "seed", "layers"))
     env = ATSPEnv(generator=_Gen(N), check_solution=True)
     pol = RRNetPolicy(env_name="atsp", init_embedding_kwargs=dict(
@@ -210,7 +211,7 @@ def gen_atsp_autocast_grad(tag, base_tag):
     a few kB).  tests/test_gpu_mixed.py holds the 16-mixed kernels' own deviation to this size."""
     from rrnco.envs.atsp.env import ATSPEnv
     from rrnco.models.policy import RRNetPolicy
-    z = np.load(os.path.join(GOLD, base_tag + ".npz"))
+    z = np.load(os.path.join(GOLD_READ, base_tag + ".npz"))
     B, N, S, ss, seed, layers = (int(z[k]) for k in ("B", "N", "S", "sample_size", "seed", "layers"))
     env = ATSPEnv(generator=_Gen(N), check_solution=True)
     pol = RRNetPolicy(env_name="atsp", init_embedding_kwargs=dict(
@@ -256,6 +257,90 @@ def gen_atsp_autocast_grad(tag, base_tag):
     print(f"wrote {path}  ({os.path.getsize(path)/1e3:.0f} kB)")
 
 
+def _reference_policy(kind, N, sample_size, layers):
+    """The real reference policy + env of a fixture kind (atsp / rcvrp / rcvrptw), eval mode, and its state_dict template."""
+    from rrnco.models.policy import RRNetPolicy
+    if kind == "atsp":
+        from rrnco.envs.atsp.env import ATSPEnv
+        env = ATSPEnv(generator=_Gen(N), check_solution=True)
+    elif kind == "rcvrp":
+        from rrnco.envs.rcvrp.env import RCVRPEnv
+        env = RCVRPEnv(generator=_Gen(N), check_solution=True)
+    else:
+        from rrnco.envs.rmtvrp.env import RMTVRPEnv
+        env = RMTVRPEnv(generator=_Gen(N), check_solution=False)
+    pol = RRNetPolicy(env_name=kind, init_embedding_kwargs=dict(
+        use_coords=True, use_polar_feats=True, use_dist=True, use_matnet_init=False,
+        sample_type="prob", sample_size=sample_size), **dict(POLICY_KW, num_encoder_layers=layers)).eval()
+    return pol, env, {k: tuple(v.shape) for k, v in pol.state_dict().items()}
+
+
+def gen_grad(tag, base_tag):
+    """SURVEY §8(c) "the loss/grad of one REINFORCE step", VERDICT r05 next #3(a): the REAL reference policy on the instances / weights /
+    neighbour samples of fixture `base_tag`, the fixture's tours teacher-forced (evaluate mode, decoding.py:386-399), loss =
+    sum_r LL_r * g_r with g = -(advantage) / R of the fixture's rewards (shared baseline: routefinder/model.py:189-195, rl.py:123-128),
+    torch autograd through the reference's own modules.  Stored (oracle/gradfix.py): per parameter tensor its norm and either every
+    element (<= 2 048 elements) or 32 seeded random projections; the weights g, the evaluate-mode log-likelihood.  Refuses to write unless
+    autograd through oracle/restate.py gives the same gradient (<= 1e-5 of each tensor's norm + 1e-7 of the whole gradient's)."""
+    from oracle import gradfix
+    z = np.load(os.path.join(GOLD_READ, base_tag + ".npz"))
+    kind = str(z["kind"])
+    B, N, S, ss, seed, layers = (int(z[k]) for k in ("B", "N", "S", "sample_size", "seed", "layers"))
+    pol, env, tmpl = _reference_policy(kind, N, ss, layers)
+    w = _load_trained(str(z["weights_file"]), tmpl) if "weights_file" in z.files else restate.make_weights(tmpl, seed)
+    pol.load_state_dict(w, strict=True)
+    if kind == "atsp":
+        inst = restate.atsp_synthetic(B, N, seed)
+        st0 = restate.atsp_reset(dict(inst))
+        mine_fn = restate.atsp_policy
+    elif kind == "rcvrp":
+        inst = restate.rcvrp_synthetic(B, N, seed, float(z["capacity"]))
+        st0 = restate.rcvrp_reset(inst)
+        mine_fn = restate.rcvrp_policy
+    else:
+        inst = restate.rcvrptw_synthetic(B, N, seed)
+        st0 = restate.rmtvrp_reset(inst)
+        mine_fn = restate.rcvrptw_policy
+    for k, v in inst.items():
+        if k in z.files:
+            assert np.array_equal(v.numpy(), z[k]), f"instance key {k} of {base_tag} is not what its seed regenerates"
+    td = env.reset(TensorDict({k: v.clone() for k, v in inst.items()}, batch_size=[B]))
+    sidx = torch.from_numpy(z["sample_idx"])
+    acts = torch.from_numpy(z["actions"])
+    r = torch.from_numpy(z["normalized_reward"]).view(S, B)
+    gll = (-(r - r.mean(0, keepdim=True)) / (S * B)).reshape(-1)
+    names = [n for n, _ in pol.named_parameters()]
+    orig = torch.multinomial
+    try:
+        torch.multinomial = lambda *a, **k: sidx.reshape(-1, ss)           # replay the base fixture's neighbour samples
+        pol.zero_grad(set_to_none=True)
+        ev = pol(td.clone(), env, phase="val", actions=acts[:, 1:], num_starts=S, return_actions=True)
+        T = min(ev["actions"].shape[1], acts.shape[1])
+        assert torch.equal(ev["actions"][:, :T], acts[:, :T]), "evaluate mode did not replay the fixture's tours"
+        assert torch.allclose(ev["log_likelihood"], torch.from_numpy(z["log_likelihood"]), rtol=1e-5, atol=2e-4), "evaluate-mode LL differs from the decode loop's"
+        (ev["log_likelihood"] * gll).sum().backward()
+    finally:
+        torch.multinomial = orig
+    ref = {n: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)) for n, p in pol.named_parameters()}
+    tot = sum(float((g.double() ** 2).sum()) for g in ref.values()) ** 0.5
+    # the restatement's autograd on the same tours and weights
+    wg = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in w.items()}
+    mine = mine_fn(wg, st0, sidx, S, decode="evaluate", actions=acts[:, 1:])
+    (mine["log_likelihood"] * gll).sum().backward()
+    worst = 0.0
+    for n in names:
+        g = wg[n].grad if wg[n].grad is not None else torch.zeros_like(wg[n])
+        d = float((g.double() - ref[n].double()).norm())
+        assert d <= 1e-5 * float(ref[n].double().norm()) + 1e-7 * tot, (n, d, float(ref[n].norm()))
+        worst = max(worst, d / tot)
+    fx = dict(kind=kind + "_grad", base=base_tag, grad_weights=gll.numpy(), log_likelihood_eval=ev["log_likelihood"].detach().numpy(),
+              grad_total_norm=tot, **gradfix.compress(names, ref))
+    path = os.path.join(GOLD, f"{tag}.npz")
+    np.savez_compressed(path, **_np(fx))
+    print(f"wrote {path}  ({os.path.getsize(path)/1e3:.0f} kB)  |grad| = {tot:.4e} over {len(names)} tensors; restatement autograd within "
+          f"{worst:.1e} of it (largest tensor distance / |grad|)")
+
+
 def gen_atsp_beam(tag, B, N, W, sample_size, seed, layers=6):
     """decode_type='beam_search' (decoding.py:402-554) through the reference policy; the restatement must reproduce it."""
     from rrnco.envs.atsp.env import ATSPEnv
@@ -288,7 +373,7 @@ def gen_atsp_beam(tag, B, N, W, sample_size, seed, layers=6):
 
 def _load_trained(weights_file, tmpl):
     """An .npz state_dict under tests/golden/ (tools/train_fixture_weights.py: trained on the MI355X engine) for the reference to run."""
-    z = np.load(os.path.join(GOLD, weights_file))
+    z = np.load(os.path.join(GOLD_READ, weights_file))
     w = {k: torch.from_numpy(z[k]).float() for k in z.files}
     assert {k: tuple(v.shape) for k, v in w.items()} == tmpl, "trained state_dict does not match the reference's template"
     return w
@@ -553,7 +638,47 @@ def gen_matnet_policy(tag, B, N, S, seed, layers, embed_dim=256, heads=16):
     print(f"wrote {path}  ({os.path.getsize(path)/1e3:.0f} kB) reward[:3]={out['reward'][:3].tolist()}")
 
 
+def check_against_committed(groups):
+    """`gen_golden.py --check <groups>`: regenerate the fixtures of `groups` from the reference into a temporary directory and compare
+    every key and every array with the committed files under tests/golden/ (nothing used to notice when
+    this script and the fixtures drifted apart).  Returns the list of differences (empty = in sync)."""
+    import glob
+    import subprocess
+    import tempfile
+    problems = []
+    with tempfile.TemporaryDirectory() as tmp:
+        env = dict(os.environ, RR_GOLDEN_OUT=tmp)
+        # fixtures that read other committed files (weights, base fixtures) find them through the committed directory
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)] + list(groups), env=env, capture_output=True, text=True)
+        if r.returncode != 0:
+            return [f"generator failed: {r.stderr[-2000:]}"]
+        made = sorted(glob.glob(os.path.join(tmp, "*.npz")))
+        if not made:
+            return ["the generator wrote nothing"]
+        for path in made:
+            name = os.path.basename(path)
+            ref_path = os.path.join(GOLD_READ, name)
+            if not os.path.exists(ref_path):
+                problems.append(f"{name}: not committed")
+                continue
+            a, b = np.load(path), np.load(ref_path)
+            if sorted(a.files) != sorted(b.files):
+                problems.append(f"{name}: keys differ: only regenerated {sorted(set(a.files) - set(b.files))}, only committed {sorted(set(b.files) - set(a.files))}")
+            for k in sorted(set(a.files) & set(b.files)):
+                x, y = a[k], b[k]
+                same = x.shape == y.shape and x.dtype == y.dtype and (np.array_equal(x, y, equal_nan=True) if x.dtype.kind in "fc" else np.array_equal(x, y))
+                if not same:
+                    problems.append(f"{name}[{k}]: regenerated array differs from the committed one")
+    return problems
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--check":
+        probs = check_against_committed(sys.argv[2:] or ["atsp"])
+        for p in probs:
+            print("DRIFT:", p)
+        print("fixtures in sync with the generator" if not probs else f"{len(probs)} difference(s)")
+        sys.exit(1 if probs else 0)
     os.makedirs(GOLD, exist_ok=True)
     which = sys.argv[1:] or ["atsp"]
     if "atsp" in which:
@@ -572,6 +697,13 @@ if __name__ == "__main__":
     if "autocast_grad" in which:     # ... and of its training gradient: the yardstick of the 16-mixed training step
         gen_atsp_autocast_grad("atsp_n20_b4_pomo_autocast_grad", "atsp_n20_b4_pomo")
         gen_atsp_autocast_grad("atsp_n100_b2_pomo_autocast_grad", "atsp_n100_b2_pomo")
+    if "grad" in which:              # the reference's own REINFORCE gradient, three problems, n = 20 and n = 100
+        gen_grad("atsp_n20_b4_pomo_grad", "atsp_n20_b4_pomo")
+        gen_grad("rcvrp_n20_b4_pomo_grad", "rcvrp_n20_b4_pomo")
+        gen_grad("rcvrptw_n20_b4_pomo_grad", "rcvrptw_n20_b4_pomo")
+        gen_grad("atsp_n100_b2_pomo_grad", "atsp_n100_b2_pomo")
+        gen_grad("rcvrp_n100_b2_pomo_grad", "rcvrp_n100_b2_pomo")
+        gen_grad("rcvrptw_n100_b2_pomo_grad", "rcvrptw_n100_b2_pomo")
     if "rcvrp_trained" in which:     # VERDICT r03 missing #2: RCVRP on a TRAINED policy (tests/golden/rcvrp_trained_weights.npz)
         gen_rcvrp("rcvrp_n100_b2_pomo_trained", B=2, N=100, S=101, sample_size=25, seed=35, capacity=50.0, keep_trace=False,
                   weights_file="rcvrp_trained_weights.npz")

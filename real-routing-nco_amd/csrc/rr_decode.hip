@@ -66,6 +66,7 @@ struct RolloutIO {
   // anyway: the glimpse input of the pointer MLP g0 [m][128], its output g [m][128], and meta [m][8] = the 4 action-mask
   // words the decision saw, the node it was taken at, the chosen node, 1 if the row is live (not a finished / padding
   // rollout), 0; VRP: the step-context state scalars scal [m][4] (available load, current time, open route, remaining distance).
+  // g0 and g hold Bp*dumpT*S + 1 rows: lanes without a live rollout store into the last one (a trash row nobody reads).
   float* dump_g0; float* dump_g; uint32_t* dump_meta; float* dump_scal;
   int dumpT;
   int use_split;                         // 1: this launch runs on the fp16 matrix pipe with two-piece split operands (rr_common.h), if DecW has w1s / w2s and Ks / Vts / Ls are given

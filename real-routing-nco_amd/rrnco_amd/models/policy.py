@@ -412,7 +412,8 @@ class RRNetPolicy(nn.Module):
             alloc = (lambda *sh: torch.full(sh, float("nan"), device=dev)) if getattr(self, "_debug_poison_dump", False) \
                 else (lambda *sh: torch.empty(*sh, device=dev))
             dump.update({"T": dT, "S": Sd, "Bp": Bp, "N": N, "t0": t0,
-                         "g0": alloc(rows, 128), "g": alloc(rows, 128),
+                         # (+ 1: the trash row lanes without a live rollout store into, csrc/rr_rollout_w.inc)
+                         "g0": alloc(rows + 1, 128)[:rows], "g": alloc(rows + 1, 128)[:rows],
                          # zeroed: rows a finished tile of rollouts never reaches must read as "not live"
                          "meta": torch.zeros(rows, 8, dtype=torch.int32, device=dev),
                          "scal": None if self.env_name == "atsp" else alloc(rows, 4)})

@@ -806,3 +806,60 @@ def test_augmentation_note_travels_with_the_matrices_and_only_with_them():
     assert "num_augment" not in c.meta
     c = aug.clone(); c.set("locs", aug["locs"] + 1.0)
     assert c.meta.get("num_augment") == 8                                                    # coordinates may differ per copy: that is the augmentation
+
+
+@pytest.mark.parametrize("base,kind", [("atsp_n20_b4_pomo", "atsp"), ("rcvrp_n20_b4_pomo", "rcvrp"), ("rcvrptw_n20_b4_pomo", "rcvrptw")])
+def test_oracle_autograd_reproduces_the_reference_gradient_fixture(base, kind):
+    """SURVEY section 8(c) "the loss/grad of one REINFORCE step": tests/golden/*_grad.npz hold the gradient torch autograd gives through
+    the REAL reference modules (oracle/gen_golden.py gen_grad: fixture tours teacher-forced, weights g = -(advantage) / R).  The oracle's
+    own autograd on the same tours must reproduce it: every tensor to 1e-5 of its norm (measured: bit-identical on the build machine;
+    the slack is for another CPU's vector paths).  The GPU side of the same fixtures: tests/test_gpu_grad_reference.py."""
+    from oracle import gradfix
+    fx = H.load_fixture(base)
+    gz = np.load(H.fixture_path(base + "_grad"))
+    g = {k: gz[k] for k in gz.files}
+    S = fx["S"]
+    if kind == "atsp":
+        w, st0, fn = H.atsp_weights(fx), restate.atsp_reset(H.fixture_state(fx)), restate.atsp_policy
+    elif kind == "rcvrp":
+        w, st0, fn = H.rcvrp_weights(fx), restate.rcvrp_reset(H.rcvrp_instance(fx)), restate.rcvrp_policy
+    else:
+        w, st0, fn = H.rcvrptw_weights(fx), restate.rmtvrp_reset(H.rcvrptw_instance(fx)), restate.rcvrptw_policy
+    wg = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in w.items()}
+    out = fn(wg, st0, fx["sample_idx"], S, decode="evaluate", actions=fx["actions"][:, 1:])
+    assert torch.allclose(out["log_likelihood"], torch.from_numpy(g["log_likelihood_eval"]), rtol=1e-6, atol=1e-5)
+    (out["log_likelihood"] * torch.from_numpy(g["grad_weights"])).sum().backward()
+    grads = {str(n): (wg[str(n)].grad if wg[str(n)].grad is not None else torch.zeros_like(wg[str(n)])) for n in g["grad_names"].tolist()}
+    rows, (num, den) = gradfix.deviation(g, grads)
+    assert abs(den - float(g["grad_total_norm"])) <= 1e-9 * den
+    assert num <= 1e-6 * den, num / den
+    for n, d, nr, exact in rows:
+        assert d <= 1e-5 * nr + 1e-7 * den, (n, d, nr)
+
+
+def test_gradient_fixture_projections_estimate_distances():
+    """oracle/gradfix.py: the 32 seeded projections of a large tensor estimate |g' - g| (25 % relative standard deviation per tensor), small
+    tensors are compared element by element; an unperturbed gradient has distance 0."""
+    from oracle import gradfix
+    gen = torch.Generator().manual_seed(3)
+    grads = {"big.weight": torch.randn(512, 128, generator=gen), "small.bias": torch.randn(128, generator=gen)}
+    fx = gradfix.compress(list(grads), grads)
+    assert "grad_proj_0" in fx and "grad_full_1" in fx
+    rows, (num, den) = gradfix.deviation(fx, grads)
+    assert num == 0.0 and abs(den - float(sum(float((v.double() ** 2).sum()) for v in grads.values()) ** 0.5)) < 1e-6 * den
+    ests = []
+    for seed in range(8):
+        pert = {k: v + 1e-2 * torch.randn(v.shape, generator=torch.Generator().manual_seed(100 + seed)) for k, v in grads.items()}
+        rows, _ = gradfix.deviation(fx, pert)
+        true_big = float((pert["big.weight"] - grads["big.weight"]).double().norm())
+        ests.append(rows[0][1] / true_big)
+        assert abs(rows[1][1] - float((pert["small.bias"] - grads["small.bias"]).double().norm())) < 1e-6      # exact for small tensors
+    assert 0.5 < min(ests) and max(ests) < 1.6 and abs(sum(ests) / len(ests) - 1.0) < 0.2
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference checkout (build container only)")
+def test_golden_generator_and_committed_fixtures_are_in_sync():
+    """`oracle/gen_golden.py --check`: the n = 20 / n = 100 ATSP fixtures regenerated from the real reference into a temporary directory
+    carry the committed files' keys and arrays (`atsp_n20_b4_pomo.npz` had silently lost two keys the generator writes)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "gen_golden.py"), "--check", "atsp"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
