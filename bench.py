@@ -444,11 +444,14 @@ def other_configs(dev):
         live_steps = int((((acts != 0).long() * pos).max(dim=1).values + 1).clamp(max=T - 1).sum())
         ach = live_steps * FLOP_PER_ROLLOUT_STEP / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         exe = Rr * (T - 1) * FLOP_PER_ROLLOUT_STEP / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-        out[label] = {"value": B / sec, "unit": "instances/s", "ms_per_step": sec * 1e3, "steps": n, "kernel_ms": k_ms,
-                      "call_form": "policy.lazy_trim = True: actions / log-probabilities keep their allocated length (depot / 0.0 behind each "
-                                   "route's end), the step count stays on the device, the range guard runs deferred — no host read in the call",
-                      "exact_shape": {"value": B / sec_exact, "ms_per_step": sec_exact * 1e3, "steps": n_exact,
-                                      "note": "the reference's output shape (actions trimmed to the longest route): one host read per call"},
+        # `value` = the reference's own output contract (actions / log-probabilities trimmed to the longest route, the range guard read in
+        # the call: one host read per call); the padded, read-free call form is a named variant
+        out[label] = {"value": B / sec_exact, "unit": "instances/s", "ms_per_step": sec_exact * 1e3, "steps": n_exact, "kernel_ms": k_ms,
+                      "call_form": "the reference's output shape: actions trimmed to the longest route, per-call range guard (one host read per call)",
+                      "variants": {"lazy_trim": {"value": B / sec, "ms_per_step": sec * 1e3, "steps": n,
+                                                 "note": "policy.lazy_trim = True: actions / log-probabilities keep their allocated length (depot / 0.0 "
+                                                         "behind each route's end), the step count stays on the device, the range guard runs deferred "
+                                                         "— no host read in the call; NOT the reference's output shape"}},
                       "rollouts": Rr, "decode_steps": T, "live_rollout_steps": live_steps, "executed_rollout_steps": Rr * (T - 1),
                       "mean_best_cost": float(-o["reward"].view(S, -1).max(0).values.mean()),
                       "roofline": {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": peak_split, "unit": "TFLOP/s",
@@ -548,16 +551,28 @@ def other_configs(dev):
     train_step()
     sec16, n16 = timed_loop(train_step)
     pol.precision = "32"
+    # the reference's own default training batch (configs/experiment/rrnet.yaml:39, train.py: 64 instances per device): 64 rollout
+    # workgroups for 256 CUs unless the launcher splits the instances (csrc/rr_decode.hip, RolloutIO::wg_split)
+    b64 = [env.generator(64, generator=gen) for _ in range(3)]
+
+    def train_step64():
+        state["out64"] = model.training_step(b64[state["i"] % 3], optimizer=opt, world=1, seed=2 + state["i"], grad_clip=1.0)
+        state["i"] += 1
+    train_step64()
+    sec64, n64 = timed_loop(train_step64)
     out["C5 ATSP n=100 REINFORCE step, 512 instances (one rank's shard of configs[4])"] = {
         "variants": {"16_mixed_training_step (precision='16-mixed')": {
             "value": 512 / sec16, "unit": "trained instances/s", "ms_per_step": sec16 * 1e3, "steps": n16,
-            "dtype": "bf16 operands (one piece) in the two 128-512-128 MLPs' backward products, f32 accumulate; everything else as the default step"}},
+            "dtype": "bf16 operands (one piece) in the two 128-512-128 MLPs' backward products, f32 accumulate; everything else as the default step"},
+            "train_b64 (the reference's default batch per device, rrnet.yaml:39)": {
+                "value": 64 / sec64, "unit": "trained instances/s", "ms_per_step": sec64 * 1e3, "steps": n64,
+                "share_of_b512_rate": (64 / sec64) / (512 / sec)}},
         "value": 512 / sec, "unit": "trained instances/s", "ms_per_step": sec * 1e3, "steps": n,
         "kernel_ms": sum(ks) / max(len(ks), 1), "kernel": "k_rollout_w<7, 0, 1, true, true, false, false> (sampling rollout with the training dump)",
         "backward_kernels_ms_per_step": {k: round(v, 3) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
         "loss": float(o["loss"]), "grad_norm": float(o["grad_norm"]), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
         "roofline": roof}
-    del model, opt, pol, batches, state
+    del model, opt, pol, batches, state, b64
     torch.cuda.empty_cache()
     return out
 
@@ -767,6 +782,21 @@ def main():
             vf["unfiltered_sampling"] = timed_decode({"decode_type": "multistart_sampling", "temperature": 1.0, "seed": 3}, max(min(args.steps, 8), 1))["value"]
             vf["per_step_loop"] = timed_decode({**filt, "fused": False}, 2)["value"]
             line["variants"]["sampling_top_k10_top_p0.9_fused"] = vf
+            # the reference's own default evaluation batch (test.py:90 --batch_size 32, x8 augmentation = 256 instance-augmentations = one
+            # rollout workgroup per CU, a single round of the grid): same step, 32 instances per call
+            small = [{k: v[:32].contiguous() for k, v in b.items()} for b in insts]
+            hot_path_step(pol, env, small[0])
+            torch.cuda.synchronize()
+            nsm = max(min(4 * args.steps, 60), 4)
+            t1 = time.perf_counter()
+            for k in range(nsm):
+                torch.manual_seed(sample_seed(rank, k))
+                hot_path_step(pol, env, small[k % N_INSTANCE_BATCHES])
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - t1
+            line["variants"]["eval_b32_aug8 (the reference's default evaluation batch, test.py:90)"] = {
+                "value": 32 * nsm / dts, "unit": "instances/s", "ms_per_step": dts / nsm * 1e3, "steps": nsm,
+                "share_of_headline_rate": (32 * nsm / dts) / line["value"]}
             # the whole step (augmentation, reset, neighbour sample, encoder, rollout, reward, best-of) captured ONCE into a hipGraph and
             # replayed: no launcher allocates through the runtime or reads back while capturing (tests/test_gpu_graph.py).  What the
             # replay saves over the eager loop is the host side of ~60 launches; the captured neighbour sample repeats (a timing variant)
@@ -813,8 +843,6 @@ def main():
         for k, v in (line.get("configs") or {}).items():
             tag = k.split()[0]
             cs[tag] = round(v["value"], 1)
-            if "exact_shape" in v:
-                cs[tag + "_exact_shape"] = round(v["exact_shape"]["value"], 1)
             if "two_streams" in v:
                 cs[tag + "_two_streams"] = round(v["two_streams"]["value"], 1)
             for vk, vv in (v.get("variants") or {}).items():

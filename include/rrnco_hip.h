@@ -232,6 +232,13 @@ int rr_rmtvrp_step(const int64_t* action, const float* D, const float* T,
 int rr_init_embed(const InitW* w, int kind, const float* D, const float* locs, const int64_t* sidx,
                   const float* vfeat, float* row_out, float* col_out, int Bp, int N, int SS, hipStream_t stream);
 
+/* The non-default branches of ATSPInitEmbedding.forward (rrnco/models/env_embeddings/atsp.py:92 and :94-104; no reference config uses them):
+ * mode 1 (use_coords, not use_dist): row = col = init_embed(locs) — needs InitW.wi / bi;
+ * mode 2 (not use_coords): row = row_embed(D[n, sidx[n, :]]), col = col_embed(D[sidx[n, :], n]), gathers in sample order (unsorted) —
+ * needs InitW.wr / br / wcl / bcl ([SS][E] transposed weights) and sidx [Bp,N,SS]. */
+int rr_init_embed_plain(const InitW* w, int mode, const float* D, const float* locs, const int64_t* sidx,
+                        float* row_out, float* col_out, int Bp, int N, int SS, hipStream_t stream);
+
 /* RRNetDecoder._precompute_cache (rrnco/models/decoder.py:214-232) + per-node step-context tables.
  * Ks / Vts / Ls (optional, all three or none; same shapes and byte offsets as K / Vt / L): the split rollout's two-piece fp16 images
  * (what rr_pack_f16x2 makes of K / Vt / L, bit for bit) written from the accumulators in the same launch; status (optional device

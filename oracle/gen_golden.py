@@ -56,8 +56,25 @@ def _np(d):
     return {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in d.items()}
 
 
+class _CaptureRandint(_CaptureMultinomial):
+    """sample_type="random" draws its shared index rows with torch.randint (atsp.py:38-54)."""
+
+    def __enter__(self):
+        self.calls, self._orig = [], torch.randint
+
+        def wrapped(*a, **k):
+            out = self._orig(*a, **k)
+            self.calls.append(out.clone())
+            return out
+        torch.randint = wrapped
+        return self
+
+    def __exit__(self, *exc):
+        torch.randint = self._orig
+
+
 def gen_atsp(tag, B, N, S, sample_size, seed, layers=6, aug=False, keep_trace=True, nab_type="gating", normalization="instance",
-             weights_file=None):
+             weights_file=None, use_coords=True, use_dist=True, sample_type="prob"):
     """weights_file: an .npz state_dict under tests/golden/ (tools/train_fixture_weights.py: a policy TRAINED on the MI355X engine
     for 1 600 REINFORCE steps) instead of restate.make_weights(seed) — the reference then runs the trained weights."""
     from rrnco.envs.atsp.env import ATSPEnv
@@ -68,10 +85,10 @@ def gen_atsp(tag, B, N, S, sample_size, seed, layers=6, aug=False, keep_trace=Tr
     env = ATSPEnv(generator=_Gen(N), check_solution=True)
     kw = dict(POLICY_KW, num_encoder_layers=layers, nab_type=nab_type, normalization=normalization)
     pol = RRNetPolicy(env_name="atsp", init_embedding_kwargs=dict(
-        use_coords=True, use_polar_feats=True, use_dist=True, use_matnet_init=False,
-        sample_type="prob", sample_size=sample_size), **kw).eval()
+        use_coords=use_coords, use_polar_feats=True, use_dist=use_dist, use_matnet_init=False,
+        sample_type=sample_type, sample_size=sample_size), **kw).eval()
     tmpl = {k: tuple(v.shape) for k, v in pol.state_dict().items()}
-    mine_t = restate.atsp_weight_template(128, layers, 512, sample_size)
+    mine_t = restate.atsp_init_variant_template(restate.atsp_weight_template(128, layers, 512, sample_size), use_coords, use_dist)
     if nab_type != "gating":
         mine_t = restate.ablation_template(mine_t, nab_type, use_duration=False)
     if normalization == "batch":
@@ -95,14 +112,21 @@ def gen_atsp(tag, B, N, S, sample_size, seed, layers=6, aug=False, keep_trace=Tr
     decode = "multistart_greedy" if S > 1 else "greedy"
     enc_out = []
     hook = pol.encoder.register_forward_hook(lambda m, a, o: enc_out.append(o))
-    with torch.inference_mode(), _CaptureMultinomial() as cap:
+    Bp = td["distance_matrix"].shape[0]
+    with torch.inference_mode(), (_CaptureMultinomial() if sample_type == "prob" else _CaptureRandint()) as cap:
         out = pol(td.clone(), env, phase="val", decode_type=decode, num_starts=S if S > 1 else None,
                   return_actions=True)
     hook.remove()
     out["hidden"] = enc_out[0]
-    assert len(cap.calls) == 1
-    Bp = td["distance_matrix"].shape[0]
-    sidx = cap.calls[0].reshape(Bp, N, sample_size)
+    if use_coords and not use_dist:                    # atsp.py:92: no neighbour sample at all; the fixture keeps a dummy index tensor
+        assert len(cap.calls) == 0
+        sidx = torch.zeros(Bp, N, sample_size, dtype=torch.int64)
+    elif sample_type == "prob":
+        assert len(cap.calls) == 1
+        sidx = cap.calls[0].reshape(Bp, N, sample_size)
+    else:                                              # atsp.py:45-54 (phase != train): 8 shared rows, one per block of Bp / 8 instances
+        assert len(cap.calls) == 1 and tuple(cap.calls[0].shape) == (8, 1, sample_size)
+        sidx = cap.calls[0].unsqueeze(1).expand(8, Bp // 8, N, sample_size).reshape(Bp, N, sample_size).contiguous()
 
     # ---- restatement must agree exactly with the reference on this machine
     st = dict(inst)
@@ -120,7 +144,7 @@ def gen_atsp(tag, B, N, S, sample_size, seed, layers=6, aug=False, keep_trace=Tr
     assert torch.equal(trace["row_emb"], out["hidden"][0]) and torch.equal(trace["col_emb"], out["hidden"][1])
 
     # evaluate mode: feeding the decode-loop actions back must reproduce the log-likelihood (reference + restatement)
-    if N <= 20:
+    if N <= 20 and sample_type == "prob" and use_dist:
         a_in = out["actions"][:, 1:] if S > 1 else out["actions"]
         with torch.inference_mode(), _CaptureMultinomial():
             torch.multinomial = lambda *a, **k: sidx.reshape(-1, sample_size)   # replay the same neighbour samples
@@ -132,7 +156,8 @@ def gen_atsp(tag, B, N, S, sample_size, seed, layers=6, aug=False, keep_trace=Tr
 
     fx = dict(
         kind="atsp", B=B, N=N, S=S, sample_size=sample_size, seed=seed, layers=layers, aug=int(aug), nab_type=nab_type,
-        normalization=normalization,
+        normalization=normalization, **({} if (use_coords and use_dist and sample_type == "prob") else
+                                        dict(use_coords=int(use_coords), use_dist=int(use_dist), sample_type=sample_type)),
         locs=inst["locs"], distance_matrix=inst["distance_matrix"], sample_idx=sidx,
         norm_distance=td["distance_matrix"], min_distance=td["min_distance"], max_distance=td["max_distance"],
         row_emb=out["hidden"][0], col_emb=out["hidden"][1],
@@ -734,6 +759,11 @@ if __name__ == "__main__":
     if "norms" in which:         # the other two Normalization kinds (attn_freenet.py:85, 92-93): RMSNorm and the parameter-free "layer"
         gen_atsp("atsp_n20_b4_pomo_rmsnorm", B=4, N=20, S=20, sample_size=15, seed=62, layers=3, keep_trace=False, normalization="rms")
         gen_atsp("atsp_n20_b4_pomo_layernorm", B=4, N=20, S=20, sample_size=15, seed=63, layers=3, keep_trace=False, normalization="layer")
+    if "initvariants" in which:  # the non-default branches of ATSPInitEmbedding (atsp.py:38-54, 92, 94-104)
+        gen_atsp("atsp_n20_b8_pomo_random_idx", B=8, N=20, S=20, sample_size=15, seed=101, layers=3, keep_trace=False, sample_type="random")
+        gen_atsp("atsp_n20_b4_pomo_coords_only", B=4, N=20, S=20, sample_size=15, seed=102, layers=3, keep_trace=False, use_dist=False)
+        gen_atsp("atsp_n20_b4_pomo_dist_only", B=4, N=20, S=20, sample_size=15, seed=103, layers=3, keep_trace=False, use_coords=False)
+        gen_atsp("atsp_n100_b2_pomo_dist_only", B=2, N=100, S=100, sample_size=25, seed=104, layers=3, keep_trace=False, use_coords=False)
     if "variant" in which:       # RMTVRPEnv beyond the vrptw preset: backhauls (classes 1, 2), open routes, distance limits
         gen_rcvrptw("rmtvrp_n20_b8_pomo_variants", B=8, N=20, S=20, sample_size=15, seed=51, variant=True)
         # (at N=50 the reference and its restatement already part ways on 11 % of the rollouts, each at a decision gap

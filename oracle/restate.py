@@ -174,8 +174,14 @@ def contextual_gating(w: W, p: str, coord: Tensor, dist: Tensor) -> Tensor:
 
 
 def atsp_init_embedding(w: W, locs: Tensor, distance: Tensor, sidx: Tensor):
-    """atsp.py:69-91 (use_coords and use_dist)."""
+    """atsp.py:69-104.  The branch follows from the parameters the state_dict holds (atsp.py:29-35): init_embed exists with use_coords,
+    the gates with use_coords and use_dist.  The index tensor is an input whatever law drew it (sample_type "prob" / "random")."""
     p = "encoder.init_embedding"
+    if (p + ".init_embed.weight") not in w:            # use_coords=False (:94-104): unsorted gathers straight into row_embed / col_embed
+        return (lin(w, p + ".row_embed", distance.gather(2, sidx)), lin(w, p + ".col_embed", distance.transpose(1, 2).gather(2, sidx)))
+    if (p + ".gating_network_row.gating_fc.0.weight") not in w:      # use_coords, not use_dist (:92)
+        node = lin(w, p + ".init_embed", locs.to(w[p + ".init_embed.weight"].dtype))
+        return node.clone(), node.clone()
     node = lin(w, p + ".init_embed", locs.to(w[p + ".init_embed.weight"].dtype))      # (.float() in the reference: fp32 weights; a float64 run of the oracle keeps its dtype)
     rowd = distance.gather(2, sidx)
     cold = distance.transpose(1, 2).gather(2, sidx)
@@ -201,6 +207,17 @@ def instance_norm(w: W, p: str, x: Tensor) -> Tensor:
         return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5) * w[p + ".normalizer.weight"]
     return F.instance_norm(x.permute(0, 2, 1), weight=w[p + ".normalizer.weight"],
                            bias=w[p + ".normalizer.bias"], eps=1e-5).permute(0, 2, 1)
+
+
+def atsp_init_variant_template(template: Dict[str, tuple], use_coords: bool, use_dist: bool) -> Dict[str, tuple]:
+    """state_dict template of the ATSP policy built with use_coords / use_dist switched off (atsp.py:29-35)."""
+    p = "encoder.init_embedding"
+    t = dict(template)
+    if not use_coords:
+        t = {k: v for k, v in t.items() if not k.startswith(p + ".init_embed.")}
+    if not (use_coords and use_dist):
+        t = {k: v for k, v in t.items() if not k.startswith(p + ".gating_network_")}
+    return t
 
 
 def norm_template(template: Dict[str, tuple], normalization: str) -> Dict[str, tuple]:

@@ -1222,6 +1222,46 @@ extern "C" int rr_init_embed(const InitW* w, int kind, const float* D, const flo
   return rr_check(hipGetLastError());
 }
 
+// The two non-default branches of ATSPInitEmbedding (rrnco/models/env_embeddings/atsp.py:69-104), neither used by a reference
+// config: no gate, no sort.  One thread = one (node, feature); HBM-bound (2 x N x 128 floats stored per instance).
+//   mode 1 (use_coords, not use_dist, :92):  row = col = init_embed(locs)
+//   mode 2 (not use_coords, :94-104):        row = row_embed(D[n, idx[n, :]]), col = col_embed(D[idx[n, :], n]) — gathers in SAMPLE order
+__global__ __launch_bounds__(256) void k_init_embed_plain(InitW w, int mode, const float* __restrict__ D, const float* __restrict__ locs,
+                                                          const int64_t* __restrict__ sidx, float* __restrict__ row_out,
+                                                          float* __restrict__ col_out, int N, int SS) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= N * RR_E) return;
+  const int n = t / RR_E, f = t - n * RR_E;
+  const size_t o = ((size_t)b * N + n) * RR_E + f;
+  if (mode == 1) {
+    const float x = locs[((size_t)b * N + n) * 2], y = locs[((size_t)b * N + n) * 2 + 1];
+    // nn.Linear: x W^T + b, accumulated in input order (k = 0, 1) as the reference's fp32 GEMM row does
+    const float v = fmaf(y, w.wi[f * 2 + 1], x * w.wi[f * 2]) + w.bi[f];
+    row_out[o] = v; col_out[o] = v;
+    return;
+  }
+  const float* Db = D + (size_t)b * N * N;
+  const int64_t* ix = sidx + ((size_t)b * N + n) * SS;
+  float r = 0.f, c = 0.f;
+  for (int s = 0; s < SS; ++s) {
+    int k = (int)ix[s];
+    k = k < 0 ? 0 : (k >= N ? N - 1 : k);
+    r = fmaf(Db[(size_t)n * N + k], w.wr[s * RR_E + f], r);          // wr / wcl are stored transposed [SS][E]
+    c = fmaf(Db[(size_t)k * N + n], w.wcl[s * RR_E + f], c);
+  }
+  row_out[o] = r + w.br[f]; col_out[o] = c + w.bcl[f];
+}
+
+extern "C" int rr_init_embed_plain(const InitW* w, int mode, const float* D, const float* locs, const int64_t* sidx,
+                                   float* row_out, float* col_out, int Bp, int N, int SS, hipStream_t st) {
+  if (w == nullptr || Bp <= 0 || N < 2 || N > 1024 || (mode != 1 && mode != 2) || row_out == nullptr || col_out == nullptr) return RR_EINVAL;
+  if (mode == 1 && (locs == nullptr || w->wi == nullptr || w->bi == nullptr)) return RR_EINVAL;
+  if (mode == 2 && (D == nullptr || sidx == nullptr || SS < 1 || SS > MAXSS || w->wr == nullptr || w->wcl == nullptr)) return RR_EINVAL;
+  hipLaunchKernelGGL(k_init_embed_plain, dim3((N * RR_E + 255) / 256, Bp), dim3(256), 0, st, *w, mode, D, locs, sidx, row_out, col_out, N, SS);
+  return rr_check(hipGetLastError());
+}
+
 // ------------------------------------------------------------------------------------------------
 // Decoder cache (rrnco/models/decoder.py:214-232) + per-node step-context tables.
 //   K, V, L = chunk3(project_node_embeddings(col_emb));  Vt = V^T zero-padded to 112 keys

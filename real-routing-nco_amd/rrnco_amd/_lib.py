@@ -130,6 +130,7 @@ _SIGS = {
     "rr_rmtvrp_step": [vp] * 16 + [i32, i32, i32, C.POINTER(MtvrpExtra), vp],
     "rr_reinforce_loss": [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "rr_init_embed": [C.POINTER(InitW), i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "rr_init_embed_plain": [C.POINTER(InitW), i32, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "rr_dec_cache": [C.POINTER(CacheW), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "rr_rollout": [C.POINTER(DecW), C.POINTER(RolloutIO), i32, vp],
     "rr_submatrix_gather": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
@@ -201,6 +202,7 @@ MARKER_LABELS = {
     "rr_enc_layer_split": "K1+K2+K3 encoder layer, three launches (attn_freenet.py:292-327, 360-488)",
     "rr_enc_layer_train": "K1+K2+K3 encoder layer, training forward (attn_freenet.py:292-327, 360-488)",
     "rr_init_embed": "K4 init embedding (env_embeddings/atsp.py:69-91, rcvrp.py:88-124)",
+    "rr_init_embed_plain": "K4 init embedding, coordinates-only / distances-only branches (env_embeddings/atsp.py:92-104)",
     "rr_dec_cache": "K5 decoder cache (decoder.py:214-232)",
     "rr_rollout": "K6-K10 decode loop: context, pointer, inductive bias, select, env.step (policy.py:210-228)",
     "rr_select": "K9 select (decoding.py:341-361, 272-298)",

@@ -46,8 +46,8 @@ def encode(encoder, td, packed):
     M, NP, dev = Bp * N, _np(N), D.device
     sidx = td.get("sample_idx", None)
     if sidx is None:
-        from .encoder import ATSPInitEmbedding
-        sidx = ATSPInitEmbedding.sample_indices(D, encoder.init_embedding.sample_size)
+        from .encoder import ATSPInitEmbedding, draw_sample_indices
+        sidx = draw_sample_indices(encoder.init_embedding, D, "val")
     P = packed["sd_ref"]
     vtw = encoder.env_name == "rcvrptw"
     if encoder.env_name == "atsp":
@@ -120,8 +120,8 @@ def encode_bn_train(encoder, td, packed, P, saves, momentum=0.1):
     assert N <= MAX_N_ONCHIP, "the block backward kernels hold an instance's N x N weights on chip"
     sidx = td.get("sample_idx", None)
     if sidx is None:
-        from .encoder import ATSPInitEmbedding
-        sidx = ATSPInitEmbedding.sample_indices(D, encoder.init_embedding.sample_size)
+        from .encoder import ATSPInitEmbedding, draw_sample_indices
+        sidx = draw_sample_indices(encoder.init_embedding, D, "val")
     sidx = sidx.contiguous()
     vtw = encoder.env_name == "rcvrptw"
     row, col = torch.empty(Bp, N, E, device=dev), torch.empty(Bp, N, E, device=dev)

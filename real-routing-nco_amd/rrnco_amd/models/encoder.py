@@ -130,17 +130,37 @@ def rank_noise_seed(seed: int, rank: int) -> int:
     return (int(seed) + 0x9E3779B97F4A7C15 * int(rank)) % (2 ** 62)
 
 
+def shared_random_indices(phase: str, B: int, N: int, sample_size: int, device) -> torch.Tensor:
+    """sample_type="random" (env_embeddings/atsp.py:38-54, rcvrp.py:153-169): ONE index row (drawn with replacement) shared by every
+    node of every instance in training, one per block of B / 8 instances (the 8 augmentation copies) otherwise.  -> [B, N, sample_size]."""
+    if phase == "train":
+        r = torch.randint(0, N, (1, sample_size), device=device)
+        return r.unsqueeze(1).expand(B, N, sample_size).contiguous()
+    r = torch.randint(0, N, (8, 1, sample_size), device=device)
+    return r.unsqueeze(1).expand(8, B // 8, N, sample_size).reshape(8 * B // 8, N, sample_size).contiguous()      # (fails as the reference does unless 8 | B)
+
+
 class ATSPInitEmbedding(nn.Module):   # env_embeddings/atsp.py:5-35
     def __init__(self, embed_dim, linear_bias=True, use_coords=True, use_polar_feats=False, use_dist=True,
                  use_matnet_init=True, sample_type="prob", sample_size=25):
         super().__init__()
-        if not (use_coords and use_dist and sample_type == "prob"):
-            raise NotImplementedError("rrnco_amd implements the RRNet configuration: use_coords, use_dist, sample_type='prob'")
-        self.sample_size = sample_size
-        self.init_embed = nn.Linear(2, embed_dim, linear_bias)
+        if sample_type not in ("prob", "random"):
+            raise ValueError(f"sample_type {sample_type!r}: the reference knows 'prob' and 'random' (atsp.py:38-67)")
+        if not linear_bias:
+            raise NotImplementedError("rrnco_amd: ATSPInitEmbedding without linear_bias (no reference config)")
+        self.use_coords, self.use_dist, self.sample_type, self.sample_size = use_coords, use_dist, sample_type, sample_size
+        # same parameters as the reference builds (atsp.py:29-35): init_embed only with use_coords, the gates only with both
+        self.init_embed = nn.Linear(2, embed_dim, linear_bias) if use_coords else None
         self.row_embed = nn.Linear(sample_size, embed_dim, linear_bias)
         self.col_embed = nn.Linear(sample_size, embed_dim, linear_bias)
-        self.gating_network_row, self.gating_network_col = _Gating(embed_dim), _Gating(embed_dim)
+        if use_coords and use_dist:
+            self.gating_network_row, self.gating_network_col = _Gating(embed_dim), _Gating(embed_dim)
+
+    def indices_for(self, distance, phase):
+        """The neighbour index tensor of one forward (atsp.py:37-67) when the caller supplies none in td["sample_idx"]."""
+        if self.sample_type == "random":
+            return shared_random_indices(phase, distance.shape[0], distance.shape[1], self.sample_size, distance.device)
+        return ATSPInitEmbedding.sample_indices(distance, self.sample_size)
 
     @staticmethod
     def sample_indices(distance, sample_size):
@@ -161,6 +181,15 @@ class ATSPInitEmbedding(nn.Module):   # env_embeddings/atsp.py:5-35
         inv = 1 / (pd + 1e-6)
         prob = (inv / inv.sum(dim=-1, keepdim=True)).reshape(B * N, -1)
         return torch.multinomial(prob, sample_size, replacement=False).reshape(B, N, sample_size)
+
+
+def draw_sample_indices(init_embedding, distance, phase="val"):
+    """The neighbour index tensor a forward draws when td carries no "sample_idx": the init embedding's own law (sample_type "prob":
+    multinomial without replacement per node, atsp.py:55-67; "random": shared index rows, atsp.py:38-54)."""
+    fn = getattr(init_embedding, "indices_for", None)
+    if fn is not None:
+        return fn(distance, phase)
+    return ATSPInitEmbedding.sample_indices(distance, init_embedding.sample_size)
 
 
 class RRNetEncoder(nn.Module):
@@ -216,17 +245,26 @@ class RRNetEncoder(nn.Module):
         lib = L.lib()
         row = torch.empty(Bp, N, 128, device=dev, dtype=torch.float32)
         col = torch.empty_like(row)
+        ie = self.init_embedding
+        draw = lambda d, ph: draw_sample_indices(ie, d, ph)
         if self.env_name == "atsp":
+            mode = packed.get("init_mode", 0)           # 0: coordinates + sorted distances + gate; 1: coordinates only; 2: unsorted distances only
             sidx = td.get("sample_idx", None)
-            if sidx is None:
-                sidx = ATSPInitEmbedding.sample_indices(D, self.init_embedding.sample_size)
-            sidx = sidx.contiguous()
-            L.check(lib.rr_init_embed(packed["init"], 0, L.ptr(D), L.ptr(locs), L.ptr(sidx), None, L.ptr(row), L.ptr(col),
-                                      Bp, N, sidx.shape[-1], L.stream()), "rr_init_embed")
+            if sidx is None and mode != 1:
+                sidx = draw(D, phase)
+            sidx = sidx.contiguous() if sidx is not None else None
+            if mode == 0:
+                L.check(lib.rr_init_embed(packed["init"], 0, L.ptr(D), L.ptr(locs), L.ptr(sidx), None, L.ptr(row), L.ptr(col),
+                                          Bp, N, sidx.shape[-1], L.stream()), "rr_init_embed")
+            else:
+                if train_saves is not None:
+                    raise NotImplementedError("training with use_coords=False / use_dist=False init embeddings (inference branches only)")
+                L.check(lib.rr_init_embed_plain(packed["init"], mode, L.ptr(D), L.ptr(locs), L.ptr(sidx), L.ptr(row), L.ptr(col),
+                                                Bp, N, sidx.shape[-1] if sidx is not None else 0, L.stream()), "rr_init_embed_plain")
         else:
             sidx = td.get("sample_idx", None)
             if sidx is None:
-                sidx = ATSPInitEmbedding.sample_indices(D, self.init_embedding.sample_size)
+                sidx = draw(D, phase)
             sidx = sidx.contiguous()
             vfeat = self.init_embedding.node_features(td).contiguous()
             L.check(lib.rr_init_embed(packed["init"], 1, L.ptr(D), L.ptr(locs), L.ptr(sidx), L.ptr(vfeat), L.ptr(row),

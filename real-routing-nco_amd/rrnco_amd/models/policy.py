@@ -134,9 +134,9 @@ class RRNetPolicy(nn.Module):
                 and any(p.requires_grad for p in self.parameters()))
         if not want:
             return self._forward_impl(td, env, phase, *args, capture=capture, **kwargs)
-        from .encoder import ATSPInitEmbedding
+        from .encoder import ATSPInitEmbedding, draw_sample_indices
         if td.get("sample_idx", None) is None:       # forward and backward must see the same neighbour sample (atsp.py:55-67)
-            td.set("sample_idx", ATSPInitEmbedding.sample_indices(td["distance_matrix"], self.encoder.init_embedding.sample_size))
+            td.set("sample_idx", draw_sample_indices(self.encoder.init_embedding, td["distance_matrix"], phase))
         keys = ("distance_matrix", "locs", "demand", "duration_matrix", "demand_linehaul", "time_windows", "service_time")
         state = {k: td[k] for k in keys if k in td.keys()}
         sidx = td["sample_idx"]
@@ -243,9 +243,23 @@ class RRNetPolicy(nn.Module):
             ev = torch.cuda.Event()
             ev.record()
             pend.append((host, ev))
+        elif status.is_cuda and getattr(self, "_range_graph_word", None) is not None:
+            # inside a hipGraph capture (prepare_graph_capture() was called first): the call's word is created and zeroed INSIDE the captured
+            # call, so every replay starts it from 0 — queueing it would only ever show the LAST replay.  The captured call ORs
+            # it into a persistent word allocated outside the capture instead; that word is what check_range() reads (and clears).
+            acc = self._range_graph_word
+            acc.bitwise_or_(status.reshape(()).to(acc.dtype))
+            if not any(w is acc for w, _ in pend):
+                pend.append((acc, None))
         else:
             pend.append((status, None))
         self._range_pending = pend
+
+    def prepare_graph_capture(self, device) -> None:
+        """Call once BEFORE capturing a policy call into a hipGraph: allocates (outside the capture) the persistent range-guard word the
+        captured call ORs its own status word into on every replay; check_range() reads and clears it."""
+        if getattr(self, "_range_graph_word", None) is None:
+            self._range_graph_word = torch.zeros((), dtype=torch.int32, device=device)
 
     def _range_poll(self, wait: bool) -> None:
         """Reads the pending guard words whose call has finished (wait=False: event query, never blocks) or all of them (wait=True)."""
@@ -270,6 +284,10 @@ class RRNetPolicy(nn.Module):
         if dev_words:
             for f in torch.stack([p.reshape(()) for p in dev_words]).tolist():      # ONE host read for all of them
                 flags |= int(f)
+            acc = getattr(self, "_range_graph_word", None)
+            if acc is not None and any(w is acc for w in dev_words):                # the graph replays' accumulator: read, now cleared; it stays
+                acc.zero_()                                                          # pending (later replays OR into it without a new push)
+                keep.append((acc, None))
         self._range_pending = keep or None
         self.last_range_flags = flags
         if flags != 0:
@@ -299,8 +317,8 @@ class RRNetPolicy(nn.Module):
             # block kernel (one instance per workgroup) does not serve; the encoder runs through torch ops on the device here
             # (forward: running statistics updated once, momentum 0.1; its backward recomputes with the same batch statistics)
             if td.get("sample_idx", None) is None:
-                from .encoder import ATSPInitEmbedding
-                td.set("sample_idx", ATSPInitEmbedding.sample_indices(td["distance_matrix"], self.encoder.init_embedding.sample_size))
+                from .encoder import ATSPInitEmbedding, draw_sample_indices
+                td.set("sample_idx", draw_sample_indices(self.encoder.init_embedding, td["distance_matrix"], phase))
             from . import bign
             import os as _os
             if (td["distance_matrix"].shape[-1] <= bign.MAX_N_ONCHIP and bign.supported(self.env_name, packed, "instance")

@@ -55,10 +55,10 @@ class RRNet:
         `replay_log_likelihood` (must agree with the rollout's) and `grad_norm`."""
         if self.env_name not in ("atsp", "rcvrp", "rcvrptw"):
             raise NotImplementedError(f"training_step for env '{self.env_name}'")
-        from .encoder import ATSPInitEmbedding
+        from .encoder import ATSPInitEmbedding, draw_sample_indices
         td = self.env.reset(batch)
         if td.get("sample_idx", None) is None:            # the rollout and the replay must see the same neighbour sample
-            td.set("sample_idx", ATSPInitEmbedding.sample_indices(td["distance_matrix"], self.policy.encoder.init_embedding.sample_size))
+            td.set("sample_idx", draw_sample_indices(self.policy.encoder.init_embedding, td["distance_matrix"], "train"))
         state = {"distance_matrix": td["distance_matrix"], "locs": td["locs"]}
         if self.env_name == "rcvrp":
             state["demand"] = td["demand"]

@@ -32,15 +32,30 @@ class RVRPInitEmbedding(nn.Module):
     def __init__(self, embed_dim, linear_bias=True, use_coords=True, use_polar_feats=True, use_dist=True,
                  use_matnet_init=True, sample_type="prob", sample_size=25):
         super().__init__()
-        if not (use_coords and use_dist and sample_type == "prob" and linear_bias):
-            raise NotImplementedError("rrnco_amd implements the RRNet configuration: use_coords, use_dist, sample_type='prob'")
+        if sample_type not in ("prob", "random"):
+            raise ValueError(f"sample_type {sample_type!r}: the reference knows 'prob' and 'random' (rcvrp.py:153-182)")
+        if not (use_coords and use_dist and linear_bias):
+            # not a gap of this engine: these branches do not run in the reference either.  use_dist=False: _embed_without_distance
+            # concatenates the N customers' coordinates with the depot-padded demand of N + 1 rows (rcvrp.py:50-57 / :66: a shape error;
+            # rcvrptw.py:51-68 likewise); use_coords=False with use_dist: forward calls self.coord_expert, which __init__ only builds
+            # under use_coords (rcvrp.py:40-46 / :90: AttributeError).
+            raise NotImplementedError("RVRPInitEmbedding: use_coords=False and use_dist=False fail inside the reference itself "
+                                      "(rcvrp.py:40-46, 50-66, 90); rrnco_amd implements the branches that run: use_coords and use_dist, "
+                                      "sample_type 'prob' or 'random'")
         E = embed_dim
-        self.sample_size = sample_size
+        self.sample_size, self.sample_type = sample_size, sample_type
         self.coord_expert = _CoordinateExpert(E)
         self.gating_network_row, self.gating_network_col = _Gating(E), _Gating(E)
         self.demand_init = nn.Linear(self.demand_feats, E)
         self.combine_row_embed, self.combine_col_embed = nn.Linear(2 * E, E), nn.Linear(2 * E, E)
         self.distance_expert = _DistanceExpert(E, sample_size)
+
+    def indices_for(self, distance, phase):
+        """The neighbour index tensor of one forward (DistanceExpert._sample_indices, rcvrp.py:153-182)."""
+        from .encoder import ATSPInitEmbedding, shared_random_indices
+        if self.sample_type == "random":
+            return shared_random_indices(phase, distance.shape[0], distance.shape[1], self.sample_size, distance.device)
+        return ATSPInitEmbedding.sample_indices(distance, self.sample_size)
 
     def node_features(self, td):
         """[B, N+1, F]: demand with a zero for the depot (rcvrp.py:50-57)."""

@@ -637,10 +637,17 @@ def _pack_policy(sd: dict, env_name: str, device) -> dict:
     gate_w = []            # weights with fp16 images beside the pointer MLP's: they join the range guard's bit 1
     if env_name == "atsp":
         iw = L.InitW()
-        iw.wi, iw.bi = ar.put(sd[p + ".init_embed.weight"]), ar.put(sd[p + ".init_embed.bias"])
+        # ATSPInitEmbedding's non-default branches (atsp.py:29-35): without use_coords there is no init_embed, without use_coords AND
+        # use_dist there are no gates; out["init_mode"]: 0 the published configuration, 1 coordinates only, 2 distances only (unsorted)
+        has_coords, has_gate = (p + ".init_embed.weight") in sd, (p + ".gating_network_row.gating_fc.0.weight") in sd
+        out["init_mode"] = 0 if (has_coords and has_gate) else (1 if has_coords else 2)
+        if has_coords:
+            iw.wi, iw.bi = ar.put(sd[p + ".init_embed.weight"]), ar.put(sd[p + ".init_embed.bias"])
+        if (p + ".row_embed.bias") not in sd:
+            raise NotImplementedError("ATSPInitEmbedding without linear_bias")
         iw.wr, iw.br = ar.put(sd[p + ".row_embed.weight"].t().contiguous()), ar.put(sd[p + ".row_embed.bias"])   # [SS,E]: coalesced over features
         iw.wcl, iw.bcl = ar.put(sd[p + ".col_embed.weight"].t().contiguous()), ar.put(sd[p + ".col_embed.bias"])
-        for rc, s in (("row", "r"), ("col", "c")):
+        for rc, s in ((("row", "r"), ("col", "c")) if has_gate else ()):
             q = f"{p}.gating_network_{rc}.gating_fc"
             setattr(iw, "g0" + s, ar.put(pack_a(sd[q + ".0.weight"].detach().float())))
             if split:       # the gate's first layer on the fp16 pipe (csrc/rr_encoder.hip: ie_gemm_split2)

@@ -39,6 +39,8 @@ def atsp_weights(fx_or_ss, layers=6, seed=None):
         t = restate.batchnorm_template(t)
     if isinstance(fx_or_ss, dict) and fx_or_ss.get("normalization", "instance") in ("rms", "layer"):
         t = restate.norm_template(t, fx_or_ss["normalization"])
+    if isinstance(fx_or_ss, dict) and "use_coords" in fx_or_ss:      # non-default ATSPInitEmbedding branches (atsp.py:29-35)
+        t = restate.atsp_init_variant_template(t, bool(fx_or_ss["use_coords"]), bool(fx_or_ss["use_dist"]))
     return restate.make_weights(t, seed)
 
 
@@ -51,9 +53,12 @@ def make_policy(w, env_name="atsp", device="cuda"):
     n1 = "encoder.net.layers.0.row_encoding_block.norm1.normalizer"
     norm = ("batch" if (n1 + ".running_mean") in w else "layer" if (n1 + ".weight") not in w
             else "rms" if (n1 + ".bias") not in w else "instance")
+    ie = "encoder.init_embedding"
+    use_coords = env_name != "atsp" or (ie + ".init_embed.weight") in w
+    use_dist = env_name != "atsp" or not use_coords or (ie + ".gating_network_row.gating_fc.0.weight") in w
     pol = RRNetPolicy(env_name=env_name, embed_dim=128, num_heads=8, num_encoder_layers=layers,
                       normalization=norm, use_graph_context=False, nab_type=nab_type,
-                      init_embedding_kwargs=dict(use_coords=True, use_polar_feats=True, use_dist=True,
+                      init_embedding_kwargs=dict(use_coords=use_coords, use_polar_feats=True, use_dist=use_dist,
                                                  use_matnet_init=False, sample_type="prob", sample_size=ss))
     pol.load_state_dict(w, strict=True)
     return pol.to(device).eval()

@@ -92,3 +92,66 @@ def test_rms_and_layer_normalization_policies_match_reference(name, kind):
     same = first < 0
     assert torch.allclose(out["reward"].cpu()[same], fx["reward"][same], atol=COST_ATOL)
 
+
+
+@pytest.mark.parametrize("name", ["atsp_n20_b8_pomo_random_idx", "atsp_n20_b4_pomo_coords_only", "atsp_n20_b4_pomo_dist_only",
+                                  "atsp_n100_b2_pomo_dist_only"])
+def test_init_embedding_branches_match_reference(name):
+    """The non-default branches of ATSPInitEmbedding (env_embeddings/atsp.py) against golden vectors of the real
+    reference built with the same switches (oracle/gen_golden.py initvariants): sample_type="random" (:38-54: index rows shared by all
+    nodes of an augmentation block — the published kernel given those indices), use_dist=False (:92: row = col = init_embed(locs)) and
+    use_coords=False (:94-104: unsorted gathers into row_embed / col_embed) on rr_init_embed_plain."""
+    fx, w, pol, inst, env, td_in = _run_plain(name)
+    ie = pol.encoder.init_embedding
+    assert (ie.init_embed is None) == ("dist_only" in name) and hasattr(ie, "gating_network_row") == ("random_idx" in name)
+    assert sorted(pol.state_dict().keys()) == sorted(w.keys())                 # the same parameters as the reference builds (atsp.py:29-35)
+    packed = pol.packed(torch.device("cuda"))
+    assert packed["init_mode"] == (2 if "dist_only" in name else 1 if "coords_only" in name else 0)
+    row, col = pol.encoder(env.reset(td_in), packed=packed)
+    dev_emb = max(float((row.cpu() - fx["row_emb"]).abs().max()), float((col.cpu() - fx["col_emb"]).abs().max()))
+    S = fx["S"]
+    out = pol(env.reset(td_in), env, phase="val", decode_type="multistart_greedy", num_starts=S, return_actions=True)
+    frac, first = H.tour_agreement(out["actions"].cpu(), fx["actions"])
+    print(f"\n[{name}] max |embedding - reference| {dev_emb:.2e}; tours identical on {frac * 100:.2f} % of the rollouts")
+    assert dev_emb < 2e-4
+    assert frac >= 0.99
+    same = first < 0
+    assert torch.allclose(out["reward"].cpu()[same], fx["reward"][same], atol=COST_ATOL)
+    assert torch.allclose(out["log_likelihood"].cpu()[same], fx["log_likelihood"][same], rtol=LL_RTOL, atol=LL_ATOL)
+
+
+def test_shared_random_indices_law_and_default_draw():
+    """sample_type="random" without an explicit td["sample_idx"]: one index row for the whole batch in training, one per block of
+    B / 8 instances otherwise (atsp.py:38-54) — same torch.randint calls in the same order as the reference, so the same generator state
+    gives the same indices; the VRP embeddings share the law (rcvrp.py:153-169).  The forward runs on it."""
+    from rrnco_amd import TensorDict
+    from rrnco_amd.envs import ATSPEnv
+    from rrnco_amd.models import RRNetPolicy
+    from rrnco_amd.models.encoder import shared_random_indices
+    dev = torch.device("cuda")
+    torch.manual_seed(5)
+    a = shared_random_indices("train", 6, 20, 15, dev)
+    assert a.shape == (6, 20, 15) and bool((a == a[0, 0]).all()) and int(a.min()) >= 0 and int(a.max()) < 20
+    torch.manual_seed(5)
+    assert torch.equal(a[0, 0], torch.randint(0, 20, (1, 15), device=dev)[0])
+    b = shared_random_indices("val", 16, 20, 15, dev)
+    assert b.shape == (16, 20, 15)
+    blocks = b.view(8, 2, 20, 15)
+    assert bool((blocks == blocks[:, :1, :1]).all()) and len({tuple(blocks[i, 0, 0].tolist()) for i in range(8)}) > 1
+    with pytest.raises(RuntimeError):
+        shared_random_indices("val", 12, 20, 15, dev)            # the reference's reshape fails too unless 8 | B
+    torch.manual_seed(1)
+    pol = RRNetPolicy(env_name="atsp", embed_dim=128, num_heads=8, num_encoder_layers=2, normalization="instance", use_graph_context=False,
+                      init_embedding_kwargs=dict(sample_type="random", sample_size=15)).to(dev).eval()
+    env = ATSPEnv(generator_params=dict(num_loc=20, device=dev), check_solution=True, device=dev)
+    td = env.generator(16, generator=torch.Generator(device=dev).manual_seed(2))
+    out = pol(env.reset(TensorDict(dict(td.items()), batch_size=[16])), env, phase="val", decode_type="multistart_greedy", num_starts=20,
+              return_actions=True)
+    assert bool(torch.isfinite(out["reward"]).all()) and out["actions"].shape == (320, 20)
+    for env_name in ("rcvrp", "rcvrptw"):
+        from rrnco_amd.models.vrp_embeddings import make_vrp_init_embedding
+        e = make_vrp_init_embedding(env_name, 128, sample_type="random", sample_size=10)
+        i = e.indices_for(torch.rand(8, 21, 21, device=dev), "val")
+        assert i.shape == (8, 21, 10) and bool((i == i[:, :1]).all())
+        with pytest.raises(NotImplementedError, match="fail inside the reference"):
+            make_vrp_init_embedding(env_name, 128, use_dist=False)

@@ -41,3 +41,45 @@ def test_hot_path_captures_into_a_hip_graph_and_replays_identically():
         torch.cuda.synchronize()
     assert torch.equal(out["actions"], ref["actions"]) and torch.equal(out["reward"], ref["reward"])
     pol.check_range()          # the word the captured call left pending is clean
+
+
+def test_replayed_graph_keeps_a_range_flag_raised_by_a_middle_batch():
+    """the guard word of a captured call is created and zeroed INSIDE the capture, so every replay resets it and
+    check_range() used to see the LAST replay only — an out-of-range batch in the middle of a dataset showed up as `Average cost: nan`
+    and nothing else.  Now every replay ORs its word into a persistent device word (RRNetPolicy.prepare_graph_capture); evaluate.py's
+    _GraphedPolicy replays clean / poisoned / clean batches: the poisoned one's rewards are NaN-marked inside the graph, the clean
+    ones are untouched, and check_range() raises although the LAST replay was clean."""
+    import evaluate
+    from rrnco_amd import TensorDict
+    from rrnco_amd.envs import ATSPEnv
+    fx = H.load_fixture("atsp_n20_b4_pomo")
+    pol = H.make_policy(H.atsp_weights(fx)).eval()
+    env = ATSPEnv(generator_params=dict(num_loc=fx["N"]), check_solution=False)
+    st = {k: v.cuda() for k, v in H.fixture_state(fx).items()}
+    B = st["locs"].shape[0]
+    graphed = evaluate._GraphedPolicy(pol, env, fx["S"])
+
+    def batch(poison):
+        d = {k: v.clone() for k, v in st.items()}
+        if poison:
+            d["locs"][0, 0, 0] = float("nan")            # the encoder's embeddings of instance 0 become non-finite: the K / V / L images raise bit 0
+        return env.reset(TensorDict(d, batch_size=[B]))
+
+    def run(poison):
+        torch.manual_seed(0)                              # the same neighbour sample for every call (drawn per forward, outside the graph)
+        return graphed(batch(poison))["reward"].clone()
+
+    with torch.no_grad():
+        run(False)                                       # (captures; its own neighbour sample comes second in the seeded stream)
+        clean0 = run(False)
+        pol.check_range()                                # a clean replay: nothing raised, the persistent word stays pending
+        bad = run(True)
+        clean1 = run(False)
+        torch.cuda.synchronize()
+    assert len(graphed.graphs) == 1                       # one capture, three replays
+    assert bool(torch.isfinite(clean0).all()) and torch.equal(clean0, clean1)
+    assert bool(torch.isnan(bad).all())                   # device-side poison of the flagged replay
+    with pytest.raises(FloatingPointError):
+        pol.check_range()
+    assert pol.last_range_flags & 1
+    pol.check_range()                                     # read and cleared
