@@ -95,6 +95,8 @@ typedef struct {                /* arguments of the persistent rollout: see csrc
                                  * 0 / 0.0 (or top_k >= N, top_p >= 1) = off.  Served by the two-piece greedy / sampling kernels
                                  * (use_split = 1, mode 0 / 1); any other launch with a filter set returns RR_EINVAL — the per-step
                                  * loop (rr_select) carries the same filters */
+  int tail_pack;                /* 1: the S % 16 left-over rollouts of 16 / (S % 16) consecutive instances share one tile (off by default) */
+  int no_inst;                  /* 1: never the instance-mode kernel (A/B measurements); the launcher itself reads no environment variable */
 } RolloutIO;
 
 /* Backward of the Neural Adaptive Bias with the duration matrix (rrnco/models/nn/attn_freenet.py:226-237, 265-286) in its folded

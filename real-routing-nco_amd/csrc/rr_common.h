@@ -279,10 +279,14 @@ __device__ __forceinline__ float rr_relu(float x) {
 // 1 250 cycles per region in the kernel, 1 136 in tools/clockprobe/mlpprobe.hip); this order measured 880 cycles per region for seven
 // waves in tools/clockprobe/pipeprobe.hip (profiles/r06/NOTES.md §1).  Same products into the same accumulators in the same order as
 // hid() / output4(): results are bit-identical.  Inline asm is invisible to hipcc's hazard recognizer and to its waitcnt pass, so each
-// block (1) starts with s_nop 1 (a VALU write of a source right before it), (2) waits for its own reads (lgkmcnt(0)) before it ends,
+// block (1) starts with s_nop 1 (a VALU write of a source right before it), (2) its reads are waited for (lgkmcnt(0)) before anything
+// multiplies by them: a region's FIRST half leaves them in flight across the region's vector work (nothing touches Xn there: checked in
+// the listing) and the SECOND half (SECOND = true) opens with the wait and closes with the wait for its own, in front of the region's barrier,
 // (3) must not be followed within a few cycles by a VALU read of its accumulators: callers keep a sched_barrier + other work behind it.
 // rr_half_hid: c = seed + sum_sl (Xp[2 sl] Gs[sl][0] + Xp[2 sl] Gs[sl][1] + Xp[2 sl + 1] Gs[sl][0])      (one dependent chain)
+template <bool SECOND>
 __device__ __forceinline__ void rr_half_hid(f32x4& c, f32x4 seed, const rr_f16x8 (&Xp)[8], rr_f16x8 (&Xn)[8], const rr_f16x8 (&Gs)[4][2], unsigned addr) {
+  if constexpr (SECOND) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the first half's reads (its Xn = this half's Xp) have landed
   asm volatile(
       "s_nop 1\n\t"
       "v_mfma_f32_16x16x32_f16 %0, %10, %18, %9\n\t"
@@ -305,15 +309,21 @@ __device__ __forceinline__ void rr_half_hid(f32x4& c, f32x4 seed, const rr_f16x8
       "v_mfma_f32_16x16x32_f16 %0, %16, %24, %0\n\t"
       "v_mfma_f32_16x16x32_f16 %0, %16, %25, %0\n\t"
       "v_mfma_f32_16x16x32_f16 %0, %17, %24, %0\n\t"
-      "s_waitcnt lgkmcnt(0)"
+      "s_nop 0"
       : "=&v"(c), "=&v"(Xn[0]), "=&v"(Xn[1]), "=&v"(Xn[2]), "=&v"(Xn[3]), "=&v"(Xn[4]), "=&v"(Xn[5]), "=&v"(Xn[6]), "=&v"(Xn[7])
       : "v"(seed), "v"(Xp[0]), "v"(Xp[1]), "v"(Xp[2]), "v"(Xp[3]), "v"(Xp[4]), "v"(Xp[5]), "v"(Xp[6]), "v"(Xp[7]),
         "v"(Gs[0][0]), "v"(Gs[0][1]), "v"(Gs[1][0]), "v"(Gs[1][1]), "v"(Gs[2][0]), "v"(Gs[2][1]), "v"(Gs[3][0]), "v"(Gs[3][1]), "v"(addr)
       : "memory");
+#ifdef RR_HALF_WAIT_END      // diagnostic: the first half waits for its reads at its own end as well (the first form of these blocks)
+  if constexpr (!SECOND) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+  if constexpr (SECOND) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the region's barrier follows: the next region multiplies by Xn)
 }
 // rr_half_out: F[u] += Xp[2 u] Hh + Xp[2 u] Hl + Xp[2 u + 1] Hh, u = 0 .. 3      (four chains, each product pass over the four before the next)
+template <bool SECOND>
 __device__ __forceinline__ void rr_half_out(f32x4& F0, f32x4& F1, f32x4& F2, f32x4& F3, const rr_f16x8 (&Xp)[8], rr_f16x8 (&Xn)[8],
                                             rr_f16x8 Hh, rr_f16x8 Hl, unsigned addr) {
+  if constexpr (SECOND) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   asm volatile(
       "s_nop 1\n\t"
       "v_mfma_f32_16x16x32_f16 %0, %12, %20, %0\n\t"
@@ -336,10 +346,14 @@ __device__ __forceinline__ void rr_half_out(f32x4& F0, f32x4& F1, f32x4& F2, f32
       "v_mfma_f32_16x16x32_f16 %1, %15, %20, %1\n\t"
       "v_mfma_f32_16x16x32_f16 %2, %17, %20, %2\n\t"
       "v_mfma_f32_16x16x32_f16 %3, %19, %20, %3\n\t"
-      "s_waitcnt lgkmcnt(0)"
+      "s_nop 0"
       : "+v"(F0), "+v"(F1), "+v"(F2), "+v"(F3), "=&v"(Xn[0]), "=&v"(Xn[1]), "=&v"(Xn[2]), "=&v"(Xn[3]), "=&v"(Xn[4]), "=&v"(Xn[5]), "=&v"(Xn[6]), "=&v"(Xn[7])
       : "v"(Xp[0]), "v"(Xp[1]), "v"(Xp[2]), "v"(Xp[3]), "v"(Xp[4]), "v"(Xp[5]), "v"(Xp[6]), "v"(Xp[7]), "v"(Hh), "v"(Hl), "v"(addr)
       : "memory");
+#ifdef RR_HALF_WAIT_END
+  if constexpr (!SECOND) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+  if constexpr (SECOND) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 // One 16 KB weight stage = 16 LDS-DMA requests of 1 KB to consecutive LDS slots.  What a request costs its wave is what its
 // instructions cost: with per-fragment pointer arithmetic (a 64-bit vector add and a dozen scalar instructions, as the builtin form

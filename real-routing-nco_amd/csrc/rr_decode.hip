@@ -73,6 +73,8 @@ struct RolloutIO {
   const void *Ks, *Vts, *Ls;             // fp16 two-piece images of K / Vt / L (rr_pack_f16x2), same shapes and byte offsets
   int* status;                           // optional: bit 2 <- a split launch met a non-finite log-probability (an operand left the fp16 range)
   int top_k; float top_p;                // process_logits' filters (decoding.py:352-358) inside the rollout: split greedy / sampling launches only (0 / 0.0: off)
+  int tail_pack;                         // 1: pack the S % 16 left-over rollouts of 16 / (S % 16) instances into one tile (off by default: see rr_rollout)
+  int no_inst;                           // 1: never launch the instance-mode kernel (A/B measurements)
 };
 
 // (The first-generation workgroup-per-instance rollout kernel — activations through LDS, ten barriers per decode step; rounds 1-3 kept
@@ -118,16 +120,16 @@ extern "C" int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStrea
     if (any_var && !io->logits_only && !(io->demand_b && io->bclass)) return RR_EINVAL;
   }
   if (io->mode == 2 && io->actions_in == nullptr) return RR_EINVAL;
-  const char* es = getenv("RR_MLP_SPLIT");
-  // RolloutIO.use_split decides; the environment variable only forces it on for callers that leave the field 0
-  const bool mlp_split = (io->use_split != 0 || (es != nullptr && atoi(es) != 0 && io->use_split < 0)) && w->w1s != nullptr && w->w2s != nullptr && w->b1s != nullptr &&
+  // RolloutIO.use_split decides (the launcher reads no environment variable: the host side passes its switches as fields)
+  const bool mlp_split = io->use_split != 0 && w->w1s != nullptr && w->w2s != nullptr && w->b1s != nullptr &&
                          io->Ks != nullptr && io->Vts != nullptr && io->Ls != nullptr;
   // tail packing (rr_rollout_w.inc): the S % 16 left-over rollouts of 16 / (S % 16) consecutive instances share one tile
   // Off by default since the logit keys of ordinary tiles live in LDS: a packed tile runs its attention and logits once per
   // instance it spans, with every operand from L2, and a workgroup of such tiles takes 3 (a 2-round launch) to ~6 (the 14-round
   // headline launch) ordinary workgroup times for the work of 4 quarter-full tiles.  Measured: headline rollout 73.9 ms packed,
-  // 69.2 ms not (14 full rounds of 256 workgroups); 512-instance training rollout 18.4 / 12.2 ms.  RR_TAIL_PACK=1 turns it on.
-  static const int pack = getenv("RR_TAIL_PACK") ? atoi(getenv("RR_TAIL_PACK")) : 0;
+  // 69.2 ms not (14 full rounds of 256 workgroups); 512-instance training rollout 18.4 / 12.2 ms.  RolloutIO.tail_pack = 1 turns it on
+  // (rrnco_amd.models.rollout reads RR_TAIL_PACK once at import).
+  const int pack = io->tail_pack;
   const int tail_m = S & 15;
   const int tail_g = (pack && S > 16 && tail_m > 0 && tail_m <= 8 && io->Bp > 1) ? 16 / tail_m : 0;
   const int ntask = tail_g ? (io->Bp + tail_g - 1) / tail_g + io->Bp * (S / 16) : io->Bp * ((S + 15) / 16);
@@ -151,7 +153,7 @@ extern "C" int rr_rollout(const DecW* w, const RolloutIO* io, int prob, hipStrea
   if (io->top_k < 0 || io->top_p < 0.f || io->top_p > 1.f) return RR_EINVAL;
   const bool filt = !io->logits_only && ((io->top_k > 0 && io->top_k < N) || (io->top_p > 0.f && io->top_p < 1.f));
   if (filt && !(mlp_split && mode <= 1 && io->use_split != 2)) return RR_EINVAL;
-  static const bool inst_on = getenv("RR_ROLLOUT_INST") == nullptr || atoi(getenv("RR_ROLLOUT_INST")) != 0;
+  const bool inst_on = io->no_inst == 0;
 #define RR_LAUNCHW4(NTV, P, M, SP)                                                                            \
   do {                                                                                                       \
     const int lds_inst_s = wstg + 2 * (size_t)(NTV) * 8192 <= per_wg ? 2 : 0;                               \

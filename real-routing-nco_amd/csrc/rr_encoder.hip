@@ -1016,6 +1016,8 @@ __device__ __forceinline__ void ie_gemm_split2(f32x4 (&h0)[NT], f32x4 (&h1)[NT],
   rr_f16x8 A[2][4];
   A[0][0] = *reinterpret_cast<const rr_f16x8*>(a0); A[0][1] = *reinterpret_cast<const rr_f16x8*>(a0 + 1024);
   A[0][2] = *reinterpret_cast<const rr_f16x8*>(a1); A[0][3] = *reinterpret_cast<const rr_f16x8*>(a1 + 1024);
+  // (the fragments two and three slices ahead instead of one — PF = 3 — measured 1.22 against 1.20 ms: the L2 round trips are not
+  // what this phase waits for; in-kernel stamps of the whole kernel: profiles/r06/NOTES.md section 7)
 #pragma unroll
   for (int sl = 0; sl < 8; ++sl) {
     if (sl + 1 < 8) {
@@ -1061,6 +1063,10 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
   __shared__ float lcs[2 * RR_MAXN];
   for (int i = tid; i < 2 * N; i += ENC_THREADS) lcs[i] = lc[i];
   __syncthreads();
+#ifdef RR_STAMP
+  unsigned long long _acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long _t0 = __builtin_amdgcn_s_memtime();
+#endif
 
   for (int pass = 0; pass < 2; ++pass) {   // 0: row embedding, 1: col embedding
     // gather the SS sampled distances of every node once (unsorted, in the gate-partials scratch area), then rank-sort
@@ -1086,6 +1092,7 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
       }
     }
     __syncthreads();
+    RR_ET(0);
     for (int e = tid; e < N * SS; e += ENC_THREADS) {
       int i = e / SS, s = e - i * SS;
       const float v = raw[i * MAXSS + s];
@@ -1097,6 +1104,7 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
       scr[i * MAXSS + rank] = v;
     }
     __syncthreads();
+    RR_ET(1);
     // comb[:, 0:E] = node embedding, comb[:, E:2E] = Lin(SS,E)(sorted)
     const float* wd = pass == 0 ? w.wr : w.wcl;
     const float* bd = pass == 0 ? w.br : w.bcl;
@@ -1128,6 +1136,7 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
       comb[i * CLD + 128 + f] = acc + bd[f];
     }
     __syncthreads();
+    RR_ET(2);
     // hidden = relu(W0 comb + b0) [2E]; gate logit = w2 . hidden + b2 ; two feature tiles per wave
     const float4* g0 = pass == 0 ? w.g0r : w.g0c;
     const float* g0b = pass == 0 ? w.g0rb : w.g0cb;
@@ -1170,7 +1179,9 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
         if (g == 0) gpart[t * 112 + nt * 16 + j] = p;
       }
     }
+    RR_ET(3);
     __syncthreads();
+    RR_ET(4);
     float* outp = (pass == 0 ? row_out : col_out) + (size_t)b * N * RR_E;
     const float g2b = pass == 0 ? w.g2rb : w.g2cb;
     if (tid < N) {            // the gate is a scalar per node (atsp.py:108-121): once per node, not once per feature
@@ -1202,7 +1213,14 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
       rr_store_tiles<NT>(o, outp, RR_E, 16 * wave, N, lane);
       __syncthreads();
     }
+    RR_ET(5);
   }
+#ifdef RR_STAMP      // (stamped build only: phases of this kernel in rr_enc_stamps — gather, rank sort, embeddings, gate GEMM, its barrier, blend + store)
+  if (lane == 0 && (blockIdx.x & 15) == 0) {
+    for (int i = 0; i < 6; ++i) atomicAdd(&rr_enc_stamps[i], _acc[i]);
+    atomicAdd(&rr_enc_stamps[7], 1ull);
+  }
+#endif
 }
 
 extern "C" int rr_init_embed(const InitW* w, int kind, const float* D, const float* locs, const int64_t* sidx,

@@ -394,6 +394,12 @@ __device__ __forceinline__ void td_glds16(const void* gsrc, void* ldst) {
                                    (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
 }
 
+#ifndef RR_ROWS_ASM
+#define RR_ROWS_ASM 0          // 3: the stage body of k_mlp_rows<1> as hand-scheduled asm (rr_mlp_rows_asm.h) — bit-identical, and NOT faster: the kernel
+                               // runs at the board's power limit (1 340 W, 2.14 GHz; profiles/r06/NOTES.md section 6), cycles saved come back as a lower clock
+#endif
+#include "rr_mlp_rows_asm.h"
+
 struct MlpRowsW {
   const void* wa1;   // W1   [512][128] as A operands, tile-major  [32][4][2][64][8] bf16 (packing.pack_bf16x2)
   const void* wa2;   // MODE 1: W2^T [512][128] likewise
@@ -483,11 +489,23 @@ __global__ __launch_bounds__(512, 1) void k_mlp_rows(MlpRowsW w, const float* __
 #pragma unroll 1
     for (int p = 0; p < RR_FF / 32; ++p) {
       const int buf = p & 1;
+#ifndef RR_ROWS_KO
+#define RR_ROWS_KO 0             // diagnostic knock-outs (results are wrong): 1 no weight DMA, 2 no stage barrier
+#endif
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();                    // stage p landed (every wave's DMA) and stage p-1 is consumed by every wave
-      if (p + 1 < RR_FF / 32) issue(p + 1, buf ^ 1);
+      if (!(RR_ROWS_KO & 2)) __syncthreads();                    // stage p landed (every wave's DMA) and stage p-1 is consumed by every wave
+      if (!(RR_ROWS_KO & 1) && p + 1 < RR_FF / 32) issue(p + 1, buf ^ 1);
       if (p == 0 && blk + gridDim.x < nblk) load_rows(blk + gridDim.x);      // (behind the DMA of stage 1: the wait of stage 1 covers both)
       f32x4 pre[2], dpre[2];
+      constexpr bool ASM_BODY = (RR_ROWS_ASM & 1) && MODE == 1 && !HALF, ASM_BODY2 = (RR_ROWS_ASM & 2) && MODE == 1 && !HALF;     // hand-scheduled stage body (rr_mlp_rows_asm.h); -DRR_ROWS_ASM=0: hipcc's
+      const unsigned la = rr_lds_offset(stage) + (unsigned)buf * (unsigned)(NF * 1024) + lane16;
+      if constexpr (ASM_BODY) {
+        const float4 bv0 = rr_ld4(b1s + 32 * p + 4 * g), bv1 = rr_ld4(b1s + 32 * p + 16 + 4 * g);
+        pre[0] = f32x4{bv0.x, bv0.y, bv0.z, bv0.w}; pre[1] = f32x4{bv1.x, bv1.y, bv1.z, bv1.w};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (the bias reads: the blocks count their own reads only)
+        td_rows_p1<false>(pre[0], dpre[0], Xh, Xl, Yh, Yl, la);
+        td_rows_p1<true>(pre[1], dpre[1], Xh, Xl, Yh, Yl, la + 8u * 1024u);
+      } else
 #pragma unroll
       for (int tl = 0; tl < 2; ++tl) {
         const float4 bv = rr_ld4(b1s + 32 * p + 16 * tl + 4 * g);
@@ -513,12 +531,16 @@ __global__ __launch_bounds__(512, 1) void k_mlp_rows(MlpRowsW w, const float* __
         td_split8(hx, Hh, Hl);
       }
       constexpr int FB = MODE == 1 ? 32 : 16;
+      if constexpr (ASM_BODY2) {
+        td_rows_p2(acc, Hh, Hl, la + (unsigned)FB * 1024u);
+      } else
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const bfrag bh = frag(buf, FB + u * 2), bl = frag(buf, FB + u * 2 + 1);
         acc[u] = td_mfma3<HALF>(bh, bl, Hh, Hl, acc[u]);
       }
     }
+    if constexpr (RR_ROWS_ASM && MODE == 1 && !HALF) asm volatile("s_nop 15" ::: "memory");      // (the asm blocks' accumulators, before the stores read them)
     if (vr) {
 #pragma unroll
       for (int u = 0; u < 8; ++u)

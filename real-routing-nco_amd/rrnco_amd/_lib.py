@@ -58,7 +58,8 @@ class RolloutIO(C.Structure):
         [(n, i32) for n in ("Bp", "N", "S", "T", "t0", "nsteps", "mode", "use_placeholder", "set_first",
                             "write_state", "logits_only", "stagger")] + \
         [("tanh_clip", f32), ("temperature", f32), ("seed", u64)] + [(n, vp) for n in ("used_b", "open_route", "dist_limit", "demand_b", "bclass")] + \
-        [(n, vp) for n in ("dump_g0", "dump_g", "dump_meta", "dump_scal")] + [("dumpT", i32), ("use_split", i32), ("Ks", vp), ("Vts", vp), ("Ls", vp), ("status", vp), ("top_k", i32), ("top_p", f32)]
+        [(n, vp) for n in ("dump_g0", "dump_g", "dump_meta", "dump_scal")] + [("dumpT", i32), ("use_split", i32), ("Ks", vp), ("Vts", vp), ("Ls", vp), ("status", vp), ("top_k", i32), ("top_p", f32),
+                                                                                     ("tail_pack", i32), ("no_inst", i32)]
 
 
 class DecLogitIO(C.Structure):          # csrc/rr_train_dec.hip

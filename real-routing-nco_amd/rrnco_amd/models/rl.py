@@ -1,10 +1,11 @@
 """RRNet RL module — mirror of rrnco.models.rl.RRNet.shared_step (rrnco/models/rl.py:96-166) without Lightning.
 
-val / test phases are complete (augmentation, multistart, best-of metrics).  The train phase runs the sampling rollout and
-the POMO shared-baseline REINFORCE loss on HIP kernels and returns d loss / d log-likelihood; `training_step` turns that into
-parameter gradients by a teacher-forced autograd replay (models/grad_replay.py — torch ops on the device around the HIP
-forward / backward kernels of the Neural Adaptive Bias, csrc/rr_train.hip), combines them across ranks with ONE flat RCCL all-reduce (parallel.allreduce_flat_gradients) and steps the optimizer:
-BASELINE configs[4]."""
+val / test phases are complete (augmentation, multistart, best-of metrics).  The train phase runs the sampling rollout (with the
+training dump) and the POMO shared-baseline REINFORCE loss on HIP kernels and returns d loss / d log-likelihood; `training_step` turns
+that into parameter gradients on the hand-written backward kernels (models/grad_replay.replay_backward_hip: decoder logits / attention /
+pointer MLP in csrc/rr_train_dec.hip, encoder blocks in rr_train_enc.hip, init embeddings, NAB tables), combines them across ranks with
+ONE flat RCCL all-reduce (parallel.allreduce_flat_gradients) and steps the optimizer: BASELINE configs[4].  `replay="torch"` keeps the
+teacher-forced autograd replay of rounds 1-3 (models/grad_replay.replay_backward) for the step-wise decode paths and as an A/B."""
 from __future__ import annotations
 
 import torch

@@ -15,6 +15,9 @@ import os
 # a decision gap < 1e-3 (tests/test_gpu_fullsize.py).  RR_MLP_SPLIT=0 (or SPLIT_MLP = False) runs the fp32 MFMA kernel.
 SPLIT_MLP = True      # False: the fp32 MFMA kernel whatever the pack holds (A/B measurements); packing.mlp_split_enabled() decides otherwise
 STAGGER = int(os.environ.get("RR_STAGGER", "0"))   # initial delay of the second wave of every SIMD (units of ~8k cycles)
+# process-wide A/B switches, read ONCE here and handed to the launcher as RolloutIO fields (csrc/rr_decode.hip reads no environment)
+TAIL_PACK = int(os.environ.get("RR_TAIL_PACK", "0") != "0")          # pack the S % 16 left-over rollouts of several instances into one tile
+NO_INST = int(os.environ.get("RR_ROLLOUT_INST", "1") == "0")         # never the instance-mode kernel
 TIMING = None   # bench.py sets this to a list to collect (start, end) HIP events around each full rollout launch
 
 
@@ -93,6 +96,7 @@ def launch_rollout(env_name, packed, cache, td, num_starts, *, actions=None, log
     io.set_first = int(env_name == "atsp" and td.meta.get("i", 1) == 0)
     io.write_state, io.logits_only = int(write_state), int(logits_only)
     io.stagger = STAGGER
+    io.tail_pack, io.no_inst = TAIL_PACK, NO_INST
     from .. import packing
     split_on = SPLIT_MLP and packing.mlp_split_enabled()
     io.use_split = int(split_on)

@@ -231,7 +231,7 @@ def test_ctypes_struct_sizes_match_header_layout():
     import ctypes as C
     assert C.sizeof(_lib.EncBlockW) == 32 * 8 and C.sizeof(_lib.InitW) == 20 * 8 + 16 + 2 * 8
     assert C.sizeof(_lib.CacheW) == 80 and C.sizeof(_lib.DecW) == 6 * 8 + 8 + 3 * 8
-    assert C.sizeof(_lib.RolloutIO) == 24 * 8 + 12 * 4 + 2 * 4 + 8 + 5 * 8 + 4 * 8 + 8 + 4 * 8 + 8 and C.sizeof(_lib.NabDurW) == 4 * 8 + 9 * 4 + 4 + 8
+    assert C.sizeof(_lib.RolloutIO) == 24 * 8 + 12 * 4 + 2 * 4 + 8 + 5 * 8 + 4 * 8 + 8 + 4 * 8 + 8 + 8 and C.sizeof(_lib.NabDurW) == 4 * 8 + 9 * 4 + 4 + 8
     # the training-side descriptors (include/rrnco_hip.h: DecLogitIO, MlpRowsW, MlpWgradW, DecAttnIO, EncSave, AftBwdIO)
     assert C.sizeof(_lib.DecLogitIO) == 11 * 8 + 4 * 4 + 8 + 4 * 4 + 8 and C.sizeof(_lib.DecAttnIO) == 15 * 8 + 5 * 4 + 4 + 8
     assert C.sizeof(_lib.MlpRowsW) == 40 and C.sizeof(_lib.MlpWgradW) == 24

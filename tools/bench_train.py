@@ -1,4 +1,3 @@
-import os
 """Throughput of BASELINE configs[4]: ATSP n=100 REINFORCE training step, 512 instances per GPU (S=100 sampled starts),
 data-parallel with one flat RCCL gradient all-reduce.  A parity-test config, not the bench line.
   python tools/bench_train.py [--batch 512] [--steps 2]

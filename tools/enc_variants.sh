@@ -4,6 +4,8 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R/real-routing-nco_amd/csrc
 cp librrnco_hip.so /tmp/lib_good.so
+# whatever happens (Ctrl-C, a failed step, a timeout): the product library comes back
+trap 'cp /tmp/lib_good.so "$GRAFT_REPO_ROOT/real-routing-nco_amd/csrc/librrnco_hip.so"' EXIT INT TERM
 i=0
 for fl in "$@"; do
   i=$((i+1))

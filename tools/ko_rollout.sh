@@ -4,6 +4,8 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R/real-routing-nco_amd/csrc
 cp librrnco_hip.so /tmp/lib_good.so
+# whatever happens (Ctrl-C, a failed step, a timeout): the product library comes back
+trap 'cp /tmp/lib_good.so "$GRAFT_REPO_ROOT/real-routing-nco_amd/csrc/librrnco_hip.so"' EXIT INT TERM
 for fl in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -DRR_DEV_HEADLINE_ONLY $fl -c rr_decode.hip -o /tmp/dec_v.o 2>/dev/null || { echo "build failed: $fl"; continue; }
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC rr_env.o rr_sample.o rr_encoder.o /tmp/dec_v.o rr_train.o rr_train_dec.o rr_train_enc.o rr_train_nabdur.o rr_bign.o rr_matnet.o -o librrnco_hip.so

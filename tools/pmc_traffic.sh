@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of the rollout kernel: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (TCC slots), full bench batch.
 # Writes gpurun_out/pmc_{FETCH,WRITE}_SIZE.txt and gpurun_out/bench_pmc_hbm_traffic.json (copy the latter to
-# profiles/r05/: bench.py reads roofline.traffic from it when its source hash matches the rollout's sources).
+# profiles/r06/: bench.py reads roofline.traffic from it when its source hash matches the rollout's sources).
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out

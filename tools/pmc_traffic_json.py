@@ -47,4 +47,7 @@ for path in _paths:
                 rec["gpu_cycles"] = vals["GRBM_GUI_ACTIVE"] / 8.0
 if ctr["kernels"]:
     out["counters"] = ctr
+_oth = os.path.join(ROOT, "gpurun_out", "pmc_others.json")       # tools/pmc_traffic_others.sh (configs[2..4]'s dominant kernels), when it ran
+if os.path.exists(_oth):
+    out["others"] = json.load(open(_oth))
 print(json.dumps(out))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round artefacts in one GPU call: the bench line (headline + BASELINE configs[2..4] + cpu_baseline), rocprofv3 kernel stats of the
 # same command, HBM-side PMC traffic of the rollout, MFMA / VALU / LDS counters, training-step profile.  Run through gpurun; copy
-# gpurun_out/<TAG>_* into profiles/rNN/ (bench.py reads profiles/r05/bench_pmc_hbm_traffic.json).
+# gpurun_out/<TAG>_* into profiles/rNN/ (bench.py reads profiles/r06/bench_pmc_hbm_traffic.json).
 TAG=${1:-v1}
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -16,6 +16,7 @@ cp "$S" $R/gpurun_out/bench_${TAG}_kernel_stats.csv
 head -14 $R/gpurun_out/bench_${TAG}_kernel_stats.csv | cut -c1-160
 bash $R/tools/pmc_mfma.sh > /dev/null
 cp $R/gpurun_out/pmc_mfma.txt $R/gpurun_out/bench_${TAG}_pmc_counters.txt
+bash $R/tools/pmc_traffic_others.sh > /dev/null      # configs[2..4]'s dominant kernels (merged into the JSON by the next script)
 bash $R/tools/pmc_traffic.sh          # (after the counter pass: its JSON also carries mfma_busy from pmc_mfma.txt)
 cp $R/gpurun_out/bench_pmc_hbm_traffic.json $R/gpurun_out/bench_${TAG}_pmc_hbm_traffic.json
 cat $R/gpurun_out/pmc_FETCH_SIZE.txt $R/gpurun_out/pmc_WRITE_SIZE.txt > $R/gpurun_out/bench_${TAG}_pmc_hbm_traffic.txt
