@@ -1090,6 +1090,12 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
         const int e = tid + u * ENC_THREADS, i = e / SS, s = e - i * SS;
         if (e < N * SS) raw[i * MAXSS + s] = dv[u];
       }
+      // the pad behind a node's SS samples reads as +inf: never below and (distances are finite) never equal to a sample, so the rank
+      // count below runs over all MAXSS slots, four per 16-byte LDS read, without a test per slot
+      for (int e = tid; e < N * (MAXSS - SS); e += ENC_THREADS) {
+        const int i = e / (MAXSS - SS), s = SS + (e - i * (MAXSS - SS));
+        raw[i * MAXSS + s] = INFINITY;
+      }
     }
     __syncthreads();
     RR_ET(0);
@@ -1097,11 +1103,23 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
       int i = e / SS, s = e - i * SS;
       const float v = raw[i * MAXSS + s];
       int rank = 0;
-      for (int s2 = 0; s2 < SS; ++s2) {
-        const float v2 = raw[i * MAXSS + s2];
-        rank += (v2 < v) || (v2 == v && s2 < s);
+#pragma unroll
+      for (int s4 = 0; s4 < MAXSS; s4 += 4) {                 // rank = samples below v + equal samples in front of it (a stable ascending sort)
+        const float4 q = rr_ld4(raw + i * MAXSS + s4);
+        rank += (q.x < v) || (q.x == v && s4 < s);
+        rank += (q.y < v) || (q.y == v && s4 + 1 < s);
+        rank += (q.z < v) || (q.z == v && s4 + 2 < s);
+        rank += (q.w < v) || (q.w == v && s4 + 3 < s);
       }
       scr[i * MAXSS + rank] = v;
+    }
+    // the pad behind a node's SS sorted samples reads as zeros (rows 0 .. 3 also held the gates of the previous pass): the dot products
+    // below run over all MAXSS slots without a test per sample — with the runtime `if (s < SS)` per term hipcc kept the weights in the
+    // lanes of one register and put a scalar branch, a v_readlane and a move in front of every fma: 75 k of this kernel's 168 k cycles
+    // per instance (profiles/r06/NOTES.md section 7).  Zero weight x zero sample adds +0: the sums are bit-identical.
+    for (int e = tid; e < N * (MAXSS - SS); e += ENC_THREADS) {
+      const int i = e / (MAXSS - SS), s = SS + (e - i * (MAXSS - SS));
+      scr[i * MAXSS + s] = 0.f;
     }
     __syncthreads();
     RR_ET(1);
@@ -1126,12 +1144,12 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
       }
       float acc = 0.f;
 #pragma unroll
-      for (int s4 = 0; s4 < MAXSS; s4 += 4) {                 // in the order s = 0, 1, 2, ...: the same sum as before
+      for (int s4 = 0; s4 < MAXSS; s4 += 4) {                 // in the order s = 0, 1, 2, ...: the same sum as before (+ exact zeros behind SS)
         const float4 v = rr_ld4(scr + i * MAXSS + s4);
-        if (s4 < SS) acc = fmaf(wreg[s4], v.x, acc);
-        if (s4 + 1 < SS) acc = fmaf(wreg[s4 + 1], v.y, acc);
-        if (s4 + 2 < SS) acc = fmaf(wreg[s4 + 2], v.z, acc);
-        if (s4 + 3 < SS) acc = fmaf(wreg[s4 + 3], v.w, acc);
+        acc = fmaf(wreg[s4], v.x, acc);
+        acc = fmaf(wreg[s4 + 1], v.y, acc);
+        acc = fmaf(wreg[s4 + 2], v.z, acc);
+        acc = fmaf(wreg[s4 + 3], v.w, acc);
       }
       comb[i * CLD + 128 + f] = acc + bd[f];
     }
