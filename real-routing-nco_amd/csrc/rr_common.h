@@ -319,6 +319,42 @@ __device__ __forceinline__ void rr_half_hid(f32x4& c, f32x4 seed, const rr_f16x8
 #endif
   if constexpr (SECOND) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the region's barrier follows: the next region multiplies by Xn)
 }
+// rr_half_hid_inplace: the same with c carrying the seed in (4 registers fewer; k_enc_tail is at the register limit)
+template <bool SECOND>
+__device__ __forceinline__ void rr_half_hid_inplace(f32x4& c, const rr_f16x8 (&Xp)[8], rr_f16x8 (&Xn)[8], const rr_f16x8 (&Gs)[4][2], unsigned addr) {
+  if constexpr (SECOND) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the first half's reads (its Xn = this half's Xp) have landed
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %10, %18, %0\n\t"
+      "ds_read_b128 %1, %26 offset:0\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %10, %19, %0\n\t"
+      "ds_read_b128 %2, %26 offset:1024\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %11, %18, %0\n\t"
+      "ds_read_b128 %3, %26 offset:2048\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %12, %20, %0\n\t"
+      "ds_read_b128 %4, %26 offset:3072\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %12, %21, %0\n\t"
+      "ds_read_b128 %5, %26 offset:4096\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %13, %20, %0\n\t"
+      "ds_read_b128 %6, %26 offset:5120\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %14, %22, %0\n\t"
+      "ds_read_b128 %7, %26 offset:6144\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %14, %23, %0\n\t"
+      "ds_read_b128 %8, %26 offset:7168\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %15, %22, %0\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %16, %24, %0\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %16, %25, %0\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %17, %24, %0\n\t"
+      "s_nop 0"
+      : "+v"(c), "=&v"(Xn[0]), "=&v"(Xn[1]), "=&v"(Xn[2]), "=&v"(Xn[3]), "=&v"(Xn[4]), "=&v"(Xn[5]), "=&v"(Xn[6]), "=&v"(Xn[7])
+      : "v"(c), "v"(Xp[0]), "v"(Xp[1]), "v"(Xp[2]), "v"(Xp[3]), "v"(Xp[4]), "v"(Xp[5]), "v"(Xp[6]), "v"(Xp[7]),
+        "v"(Gs[0][0]), "v"(Gs[0][1]), "v"(Gs[1][0]), "v"(Gs[1][1]), "v"(Gs[2][0]), "v"(Gs[2][1]), "v"(Gs[3][0]), "v"(Gs[3][1]), "v"(addr)
+      : "memory");
+#ifdef RR_HALF_WAIT_END      // diagnostic: the first half waits for its reads at its own end as well (the first form of these blocks)
+  if constexpr (!SECOND) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+  if constexpr (SECOND) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the region's barrier follows: the next region multiplies by Xn)
+}
 // rr_half_out: F[u] += Xp[2 u] Hh + Xp[2 u] Hl + Xp[2 u + 1] Hh, u = 0 .. 3      (four chains, each product pass over the four before the next)
 template <bool SECOND>
 __device__ __forceinline__ void rr_half_out(f32x4& F0, f32x4& F1, f32x4& F2, f32x4& F3, const rr_f16x8 (&Xp)[8], rr_f16x8 (&Xn)[8],
