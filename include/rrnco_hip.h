@@ -176,12 +176,15 @@ int rr_enc_layer(const EncBlockW* wrow, const EncBlockW* wcol, const float* row_
  * previous layer afterwards (NULL: not written).  work: 6 * Bp * N * 128 floats of scratch (K, V, mixing ratio of both blocks).
  * dist_family / n_base (optional): for a batch of Bp / n_base augmentation copies of n_base base instances (instance copy * n_base + b;
  * StateAugmentation, transforms.py:142-154: the matrices are replicated, only the coordinates differ) the distance family of the folded
- * NAB, looked up once per base instance by rr_nab_dist_family -> [n_base][2 blocks][N*N][2]; NULL: every instance looks it up itself. */
+ * NAB, looked up once per base instance by rr_nab_dist_family -> [n_base][2 blocks][N*N][2]; NULL: every instance looks it up itself.
+ * status (optional device word, the policy's range guard): the K projection leaves as exp(K - mean over the nodes) — the reference's
+ * softmax subtracts the MAXIMUM (:319-321) — so a K more than ~88 above its node mean overflows; with a status word the exponent is
+ * clamped at 80 and bit 0 is raised (the caller repeats the call on rr_enc_layer, which subtracts the maximum); NULL: inf / NaN results. */
 int rr_enc_stats(const float* row, const float* col, float* stats, int Bp, int N, hipStream_t stream);
 int rr_enc_layer_split(const EncBlockW* wrow, const EncBlockW* wcol, const float* row_in, const float* col_in,
                        float* row_out, float* col_out, const float* D, const float* theta, const float* bias_pre,
                        const float* stats_in, float* stats_out, float* work, const float* dist_family, int n_base,
-                       int Bp, int N, hipStream_t stream);
+                       int Bp, int N, int* status, hipStream_t stream);
 int rr_nab_dist_family(const EncBlockW* wrow, const EncBlockW* wcol, const float* D, float* out, int B, int N, hipStream_t stream);
 
 /* theta[b][i][j] = atan2(y_i - y_j, x_i - x_j): the angle input of the Neural Adaptive Bias

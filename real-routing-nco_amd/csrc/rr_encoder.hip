@@ -292,7 +292,7 @@ extern "C" int rr_enc_stats(const float* row, const float* col, float* stats, in
 extern "C" int rr_enc_layer_split(const EncBlockW* wrow, const EncBlockW* wcol, const float* row_in, const float* col_in,
                                   float* row_out, float* col_out, const float* D, const float* theta, const float* bias_pre,
                                   const float* stats_in, float* stats_out, float* work, const float* dist_family, int n_base,
-                                  int Bp, int N, hipStream_t st) {
+                                  int Bp, int N, int* status, hipStream_t st) {
   if (Bp <= 0 || N <= 64 || N > RR_MAXN || wrow == nullptr || wcol == nullptr || work == nullptr || stats_in == nullptr) return RR_EINVAL;
   if (theta == nullptr && bias_pre == nullptr) return RR_EINVAL;
   if (!(wrow->w1s && wrow->w2s && wcol->w1s && wcol->w2s && wrow->wqs && wrow->wks && wrow->wvs && wrow->wps && wcol->wqs &&
@@ -306,7 +306,7 @@ extern "C" int rr_enc_layer_split(const EncBlockW* wrow, const EncBlockW* wcol, 
   const size_t R = (size_t)Bp * N * RR_E;
   float *Kb = work, *Vb = work + 2 * R, *Rt = work + 4 * R;
   static const int kv_grid = [] { const char* e = getenv("RR_ENC_KV_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
-  hipLaunchKernelGGL(k_enc_kv, dim3(kv_grid, 2), dim3(64 * EKV_WAVES), 0, st, ws, row_in, col_in, stats_in, Kb, Vb, Bp, N);
+  hipLaunchKernelGGL(k_enc_kv, dim3(kv_grid, 2), dim3(64 * EKV_WAVES), 0, st, ws, row_in, col_in, stats_in, Kb, Vb, Bp, N, status);
   if (dist_family != nullptr)
     hipLaunchKernelGGL((k_enc_mix<7, true>), dim3(Bp, 2), dim3(64 * 7), 0, st, ws, Kb, Vb, Rt, D, theta, bias_pre, dist_family, n_base, Bp, N);
   else

@@ -120,7 +120,7 @@ _SIGS = {
     "rr_select": [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, u64, u32, i32, f32, vp],
     "rr_enc_layer": [C.POINTER(EncBlockW), C.POINTER(EncBlockW), vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp],
     "rr_enc_stats": [vp, vp, vp, i32, i32, vp],
-    "rr_enc_layer_split": [C.POINTER(EncBlockW), C.POINTER(EncBlockW), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "rr_enc_layer_split": [C.POINTER(EncBlockW), C.POINTER(EncBlockW), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp],
     "rr_nab_dist_family": [C.POINTER(EncBlockW), C.POINTER(EncBlockW), vp, vp, i32, i32, vp],
     "rr_filter_rows": [vp, vp, i32, i32, i32, f32, vp],
     "rr_nab_tab_bwd": [vp, vp, vp, i32, vp],

@@ -220,9 +220,10 @@ class RRNetEncoder(nn.Module):
         [Bp,N,N] of every block comes from the kernels, the duration NAB itself is differentiated by grad_replay._NabDurationFolded)."""
         return self.normalization == "instance" and packed.get("nab_kind", "gating") == "gating"
 
-    def forward(self, td, phase: str = "val", mask=None, packed=None, train_saves=None):
+    def forward(self, td, phase: str = "val", mask=None, packed=None, train_saves=None, status=None):
         """-> (row_emb, col_emb) [B,N,E].  `packed` = packing.pack_policy(...) (the policy caches it).  `train_saves` (a list):
-        training forward — every layer's inputs and the per-block tensors of _lib.EncSave are appended to it."""
+        training forward — every layer's inputs and the per-block tensors of _lib.EncSave are appended to it.  `status`: the policy's
+        range-guard word (int32 device scalar) — the re-cut layer raises bit 0 when exp(K - mean K) would overflow (rr_enc_layer_split)."""
         assert packed is not None, "RRNetEncoder.forward needs packed weights (call through RRNetPolicy or pass packed=)"
         bn = self.normalization == "batch"
         norm_mode = {"instance": 0, "batch": 1, "layer": 2, "rms": 3}[self.normalization]        # rr_enc_layer norm_affine_only
@@ -333,7 +334,7 @@ class RRNetEncoder(nn.Module):
                 L.check(lib.rr_enc_layer_split(wr, wc, L.ptr(row), L.ptr(col), L.ptr(row2), L.ptr(col2), L.ptr(D),
                                                L.ptr(theta) if theta is not None else None, L.ptr(bias) if use_dur else None,
                                                L.ptr(stats[l & 1]), L.ptr(stats[1 - (l & 1)]) if l + 1 < nl else None, L.ptr(work),
-                                               L.ptr(dfam), Bp // n_aug if dfam is not None else 0, Bp, N, L.stream()), "rr_enc_layer_split")
+                                               L.ptr(dfam), Bp // n_aug if dfam is not None else 0, Bp, N, L.ptr(status), L.stream()), "rr_enc_layer_split")
                 row, col, row2, col2 = row2, col2, row, col
                 continue
             L.check(lib.rr_enc_layer(wr, wc, L.ptr(row), L.ptr(col), L.ptr(row2), L.ptr(col2), L.ptr(D), L.ptr(locs),

@@ -335,7 +335,7 @@ class RRNetPolicy(nn.Module):
             self._pack_dirty = True
             self._pack_verified = False      # (the running statistics just moved)
         else:
-            row_emb, col_emb = self.encoder(td, phase=phase, packed=packed, train_saves=saves)
+            row_emb, col_emb = self.encoder(td, phase=phase, packed=packed, train_saves=saves, status=getattr(self, "_range_status", None))
         if capture is not None:
             capture["emb"] = (row_emb, col_emb)
 

@@ -203,3 +203,28 @@ def test_stepwise_decode_path_reads_the_guard_word_too():
                   range_guard="sync", fused=False)
     assert pol.last_range_flags & 2 and any("fp16 range" in str(m.message) for m in rec)
     assert (out["actions"].cpu() == fx["actions"]).all()
+
+
+def test_node_softmax_overflow_in_the_recut_encoder_is_flagged_and_repeated_in_fp32():
+    """the re-cut encoder layer emits exp(K - mean over the nodes K) (the reference's softmax subtracts the maximum,
+    attn_freenet.py:319-321): a K more than ~88 above its node mean overflows.  With the policy's range guard rr_enc_layer_split gets the
+    status word: the exponent is clamped (finite results) and bit 0 raised — the call repeats on the fp32 kernels and ends with finite
+    rewards; without a guard (a direct encoder call) the embeddings are not finite, loudly."""
+    from rrnco_amd import TensorDict
+    from rrnco_amd.envs import ATSPEnv
+    fx = H.load_fixture("atsp_n100_b2_pomo")
+    w = dict(H.atsp_weights(fx))
+    k = "encoder.net.layers.0.row_encoding_block.attn_free.to_k.weight"
+    w[k] = w[k] * 400.0                                     # K of the first row block: hundreds above its node mean somewhere
+    pol = H.make_policy(w, device="cuda:0")
+    out, msgs = _run(pol, fx)
+    assert pol.last_range_flags & 1, f"guard did not fire: flags {pol.last_range_flags}"
+    assert any("fp16 range" in m for m in msgs)
+    assert torch.isfinite(out["reward"]).all() and torch.isfinite(out["log_likelihood"]).all()
+    # no guard: nothing hides the overflow
+    env = ATSPEnv(generator_params=dict(num_loc=fx["N"]), check_solution=False)
+    st = {k2: v.cuda() for k2, v in H.fixture_state(fx).items()}
+    td = TensorDict(st, batch_size=[fx["B"]])
+    td["sample_idx"] = fx["sample_idx"].cuda()
+    row, col = pol.encoder(env.reset(td), packed=pol.packed(torch.device("cuda")))
+    assert not bool(torch.isfinite(row).all() and torch.isfinite(col).all())

@@ -33,7 +33,7 @@ stats = torch.zeros(2, 2, Bp, 2, 128, device=dev)
 work = torch.zeros(6, Bp, N, 128, device=dev)
 L.check(lib.rr_enc_stats(L.ptr(row), L.ptr(col), L.ptr(stats[0]), Bp, N, L.stream()), "stats")
 r2, c2 = torch.empty_like(row), torch.empty_like(col)
-L.check(lib.rr_enc_layer_split(wr, wc, L.ptr(row), L.ptr(col), L.ptr(r2), L.ptr(c2), L.ptr(D), L.ptr(theta), None, L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(work), None, 0, Bp, N, L.stream()), "split")
+L.check(lib.rr_enc_layer_split(wr, wc, L.ptr(row), L.ptr(col), L.ptr(r2), L.ptr(c2), L.ptr(D), L.ptr(theta), None, L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(work), None, 0, Bp, N, None, L.stream()), "split")
 torch.cuda.synchronize()
 def cmp(name, a, b):
     d = (a - b).abs().max().item()
