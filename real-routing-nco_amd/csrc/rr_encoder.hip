@@ -1039,6 +1039,12 @@ __device__ __forceinline__ void ie_gemm_split2(f32x4 (&h0)[NT], f32x4 (&h1)[NT],
   }
 }
 
+// lane permutation within a row of 16 by DPP (dpp_ctrl: quad_perm 0x00-0xFF, row_mirror 0x140, row_half_mirror 0x141)
+template <int CTRL>
+__device__ __forceinline__ float ie_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
 template <int NT, int KIND>   // KIND 0 = ATSP, 1 = VRP (depot at node 0, extra node features `vfeat` [Bp][N][F])
 __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const float* __restrict__ D, const float* __restrict__ locs,
                                                                const int64_t* __restrict__ sidx, const float* __restrict__ vfeat,
@@ -1058,81 +1064,193 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
   const float* Db = D + (size_t)b * N * N;
   const float* lc = locs + (size_t)b * N * 2;
   const int64_t* sx = sidx + (size_t)b * N * SS;
-  // the coordinates in LDS: read per node inside the embedding loop below, a global load there was an exposed round trip per
-  // iteration (0.4 of this kernel's 1.33 ms)
-  __shared__ float lcs[2 * RR_MAXN];
-  for (int i = tid; i < 2 * N; i += ENC_THREADS) lcs[i] = lc[i];
-  __syncthreads();
 #ifdef RR_STAMP
   unsigned long long _acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long _t0 = __builtin_amdgcn_s_memtime();
 #endif
-
+  // Sort phase: a half-wave per node, lane hl = sample slot.  A sample is two dependent accesses (neighbour index, then distance), and the
+  // distance access is a 64-address gather: straight from global memory the gathers of both passes were 7 168 cache-line requests per
+  // instance, 11.7 k of the kernel's 90 k cycles at the L1's one line per cycle.  The instance's matrix (N x N floats <= 42 KB) is
+  // staged into LDS by coalesced loads instead — in `comb`, which nothing writes before pass 0's embedding phase — and the gathers
+  // read it there; the indices (the same for both passes) load under the same round trip.  Pass 0's distances stay in registers;
+  // pass 1's (the column of the matrix) wait in a private LDS slot per thread.
+  __shared__ float lcs[2 * RR_MAXN];
+  const int hl = lane & 31, hw = lane >> 5;
+  float* park = gpart + 16 * 112;                // [NT][ENC_THREADS]
+  static_assert(((RR_MAXN * 260 + 3) & ~3) + RR_MAXN * MAXSS + 16 * 112 + 7 * ENC_THREADS <= 3 * BUF_FLOATS, "k_init_embed LDS layout (park)");
+  static_assert(RR_MAXN * RR_MAXN <= RR_MAXN * 260, "k_init_embed: the staged matrix fits comb");
+  float d0[NT];
+  {
+    float* Dl = comb;
+    int kx[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q) kx[q] = (int)sx[min(16 * q + 2 * wave + hw, N - 1) * SS + min(hl, SS - 1)];
+    constexpr int NMAX = NT * 16 < RR_MAXN ? NT * 16 : RR_MAXN;                     // (rr_init_embed picks NT with N <= NT * 16)
+    constexpr int DI = (NMAX * NMAX + ENC_THREADS - 1) / ENC_THREADS;
+    float dreg[DI];
+#pragma unroll
+    for (int u = 0; u < DI; ++u) dreg[u] = Db[min(tid + u * ENC_THREADS, N * N - 1)];
+    // the coordinates in LDS: read per node inside the embedding loop below, a global load there was an exposed round trip per
+    // iteration (0.4 of this kernel's 1.33 ms)
+    for (int i = tid; i < 2 * N; i += ENC_THREADS) lcs[i] = lc[i];
+#pragma unroll
+    for (int u = 0; u < DI; ++u) {
+      const int e = tid + u * ENC_THREADS;
+      if (e < N * N) Dl[e] = dreg[u];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+      const int node = min(16 * q + 2 * wave + hw, N - 1);
+      d0[q] = Dl[node * N + kx[q]];
+      park[q * ENC_THREADS + tid] = Dl[kx[q] * N + node];
+    }
+    // (comb is overwritten in pass 0's embedding phase, behind the barrier that follows the sort: every wave has read Dl by then)
+  }
+  RR_ET(0);
   for (int pass = 0; pass < 2; ++pass) {   // 0: row embedding, 1: col embedding
-    // gather the SS sampled distances of every node once (unsorted, in the gate-partials scratch area), then rank-sort
-    // them (ascending; ties by sample position) from LDS
-    float* raw = gpart;      // [N][MAXSS] floats = 13.2 KB max; gpart is not live yet
+    // The SS sampled distances of every node, sorted ascending (atsp.py:69-80: gather + torch.sort): a HALF-WAVE per node, lane l holds
+    // sample l (+inf behind SS), a 32-wide bitonic network of 15 compare-exchange steps on lane shuffles, NT nodes per half-wave in
+    // lockstep so that a step's shuffles overlap.  Equal values are interchangeable in the sorted VALUES, so no tie rule is needed —
+    // the earlier form ranked every sample against its row (32 compares + a tie term per sample through an LDS copy: 24 k + 12 k of
+    // this kernel's 137 k cycles per instance, profiles/r06/NOTES.md section 7).
     {
-      // two dependent global loads per element (index, then distance): all of a thread's indices first, then all its distances —
-      // two exposed round trips per pass instead of two per element (the loop form cost 0.24 of this kernel's 1.33 ms)
-      constexpr int GI = (RR_MAXN * MAXSS + ENC_THREADS - 1) / ENC_THREADS;
-      int kk[GI];
+      float sv[NT];
 #pragma unroll
-      for (int u = 0; u < GI; ++u) { const int e = tid + u * ENC_THREADS; kk[u] = e < N * SS ? (int)sx[e] : 0; }
-      float dv[GI];
-#pragma unroll
-      for (int u = 0; u < GI; ++u) {
-        const int e = tid + u * ENC_THREADS, i = e / SS;
-        dv[u] = e < N * SS ? (pass == 0 ? Db[i * N + kk[u]] : Db[kk[u] * N + i]) : 0.f;
+      for (int q = 0; q < NT; ++q) {
+        const float d = pass == 0 ? d0[q] : park[q * ENC_THREADS + tid];
+        sv[q] = hl < SS ? d : INFINITY;
       }
+      // Reflected form of the network: a k-block first meets its MIRROR (lane i with i ^ (k - 1)), then i ^ k/4, ..., i ^ 1, the lower
+      // lane of every pair keeping the minimum — 15 steps, all ascending.  Partners within a row of 16 lanes come by DPP (quad_perm,
+      // row_half_mirror, row_mirror and their compositions: no LDS round trip; as `__shfl_xor` every step was a ds_bpermute that hipcc
+      // waited for one at a time: 105 exposed round trips per pass), the one cross-row step (i ^ 16) by ds_swizzle, NT in flight.
+      // The lower lane of a pair takes its partner's value when that is smaller, the upper lane when it is NOT smaller (equal values:
+      // interchangeable): one compare, one mask xor, one select per exchange.
+      const bool m1 = (hl & 1) == 0, m2 = (hl & 2) == 0, m4 = (hl & 4) == 0, m8 = (hl & 8) == 0, m16 = (hl & 16) == 0;
+#define IE_CEX(PARTNER, KEEPMIN)                                                         \
+  _Pragma("unroll") for (int q = 0; q < NT; ++q) {                                        \
+    const float pv = PARTNER(sv[q]);                                                      \
+    sv[q] = ((pv < sv[q]) != !(KEEPMIN)) ? pv : sv[q];                                    \
+  }
+#define IE_X1(v) ie_dpp<0xB1>(v)                       /* quad_perm [1,0,3,2]: i ^ 1 */
+#define IE_X2(v) ie_dpp<0x4E>(v)                       /* quad_perm [2,3,0,1]: i ^ 2 */
+#define IE_M4(v) ie_dpp<0x1B>(v)                       /* quad_perm [3,2,1,0]: mirror within 4 */
+#define IE_M8(v) ie_dpp<0x141>(v)                      /* row_half_mirror: mirror within 8 */
+#define IE_M16(v) ie_dpp<0x140>(v)                     /* row_mirror: mirror within 16 */
+#define IE_X4(v) ie_dpp<0x1B>(ie_dpp<0x141>(v))        /* i ^ 4 = mirror-8 then mirror-4 */
+#define IE_X8(v) ie_dpp<0x141>(ie_dpp<0x140>(v))       /* i ^ 8 = mirror-16 then mirror-8 */
+      IE_CEX(IE_X1, m1)
+      IE_CEX(IE_M4, m2) IE_CEX(IE_X1, m1)
+      IE_CEX(IE_M8, m4) IE_CEX(IE_X2, m2) IE_CEX(IE_X1, m1)
+      IE_CEX(IE_M16, m8) IE_CEX(IE_X4, m4) IE_CEX(IE_X2, m2) IE_CEX(IE_X1, m1)
+      {
+        float sw[NT];
 #pragma unroll
-      for (int u = 0; u < GI; ++u) {
-        const int e = tid + u * ENC_THREADS, i = e / SS, s = e - i * SS;
-        if (e < N * SS) raw[i * MAXSS + s] = dv[u];
+        for (int q = 0; q < NT; ++q) sw[q] = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(sv[q]), 0x401F));      // lane i ^ 16 (bit-mask mode: and 0x1f, xor 0x10)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+          const float pv = IE_M16(sw[q]);                                               // (i ^ 16) mirrored within its row = 31 - i
+          sv[q] = ((pv < sv[q]) != !m16) ? pv : sv[q];
+        }
       }
-      // the pad behind a node's SS samples reads as +inf: never below and (distances are finite) never equal to a sample, so the rank
-      // count below runs over all MAXSS slots, four per 16-byte LDS read, without a test per slot
-      for (int e = tid; e < N * (MAXSS - SS); e += ENC_THREADS) {
-        const int i = e / (MAXSS - SS), s = SS + (e - i * (MAXSS - SS));
-        raw[i * MAXSS + s] = INFINITY;
+      IE_CEX(IE_X8, m8) IE_CEX(IE_X4, m4) IE_CEX(IE_X2, m2) IE_CEX(IE_X1, m1)
+#undef IE_CEX
+#undef IE_X1
+#undef IE_X2
+#undef IE_M4
+#undef IE_M8
+#undef IE_M16
+#undef IE_X4
+#undef IE_X8
+      // the pad behind a node's SS sorted samples is written as zeros (rows 0 .. 3 also held the gates of the previous pass): the dot
+      // products below run over all MAXSS slots without a test per sample (zero weight x zero sample adds +0)
+#pragma unroll
+      for (int q = 0; q < NT; ++q) {
+        const int node = 16 * q + 2 * wave + hw;
+        if (node < N) scr[node * MAXSS + hl] = hl < SS ? sv[q] : 0.f;
       }
     }
-    __syncthreads();
-    RR_ET(0);
-    for (int e = tid; e < N * SS; e += ENC_THREADS) {
-      int i = e / SS, s = e - i * SS;
-      const float v = raw[i * MAXSS + s];
-      int rank = 0;
-#pragma unroll
-      for (int s4 = 0; s4 < MAXSS; s4 += 4) {                 // rank = samples below v + equal samples in front of it (a stable ascending sort)
-        const float4 q = rr_ld4(raw + i * MAXSS + s4);
-        rank += (q.x < v) || (q.x == v && s4 < s);
-        rank += (q.y < v) || (q.y == v && s4 + 1 < s);
-        rank += (q.z < v) || (q.z == v && s4 + 2 < s);
-        rank += (q.w < v) || (q.w == v && s4 + 3 < s);
-      }
-      scr[i * MAXSS + rank] = v;
-    }
-    // the pad behind a node's SS sorted samples reads as zeros (rows 0 .. 3 also held the gates of the previous pass): the dot products
-    // below run over all MAXSS slots without a test per sample — with the runtime `if (s < SS)` per term hipcc kept the weights in the
-    // lanes of one register and put a scalar branch, a v_readlane and a move in front of every fma: 75 k of this kernel's 168 k cycles
-    // per instance (profiles/r06/NOTES.md section 7).  Zero weight x zero sample adds +0: the sums are bit-identical.
-    for (int e = tid; e < N * (MAXSS - SS); e += ENC_THREADS) {
-      const int i = e / (MAXSS - SS), s = SS + (e - i * (MAXSS - SS));
-      scr[i * MAXSS + s] = 0.f;
-    }
-    __syncthreads();
     RR_ET(1);
+    __syncthreads();
+    RR_ET(6);
     // comb[:, 0:E] = node embedding, comb[:, E:2E] = Lin(SS,E)(sorted)
     const float* wd = pass == 0 ? w.wr : w.wcl;
     const float* bd = pass == 0 ? w.br : w.bcl;
+    const void* g0s = pass == 0 ? w.g0rs : w.g0cs;      // (kernel argument: uniform) second-form fp16 images present = the split build
+    if (g0s != nullptr) {
+      // node embedding on the vector pipe (2 - 3 terms per element) ...
+      for (int e = tid; e < N * RR_E; e += ENC_THREADS) {
+        const int i = e >> 7, f = e & 127;
+        if (KIND == 0) {
+          comb[i * CLD + f] = fmaf(w.wi[f * 2 + 1], lcs[i * 2 + 1], w.wi[f * 2] * lcs[i * 2]) + w.bi[f];
+        } else if (i == 0) {   // CoordinateExpert: depot Linear(2,E)
+          comb[f] = fmaf(w.wdep[f * 2 + 1], lcs[1], w.wdep[f * 2] * lcs[0]) + w.bdep[f];
+        } else {               // customers Linear(3,E) on (x, y, atan2(y - y_depot, x - x_depot))
+          float x = lcs[i * 2], y = lcs[i * 2 + 1];
+          float ang = atan2f(y - lcs[1], x - lcs[0]);
+          comb[i * CLD + f] = fmaf(w.wi[f * 3 + 2], ang, fmaf(w.wi[f * 3 + 1], y, w.wi[f * 3] * x)) + w.bi[f];
+        }
+      }
+      // ... and Linear(SS, E) on the matrix pipe: wave = feature tile (A = 2^6 W^T [16 features][32 samples], split here: 8 loads per
+      // lane and pass), the node tiles as B operands from the sorted rows, second-form fp16 pieces, three products per tile into an
+      // accumulator seeded with 2^6 bias.  As 12 800 x 32 fmas per pass this was 38 k of the kernel's 125 k cycles per instance — two
+      // waves per SIMD at the vector pipe's issue rate (profiles/r06/NOTES.md section 7); now 21 matrix instructions per wave and pass.
+      static_assert(ENC_THREADS / 64 == RR_E / 16, "k_init_embed: one wave per feature tile");
+      {
+        float wv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int sq = 8 * g + q;
+          const float* wrow = wd + (sq < SS ? sq : SS - 1) * RR_E;
+          const float v = wrow[16 * wave + j];
+          wv[q] = sq < SS ? 64.f * v : 0.f;
+        }
+        rr_f16x8 Ah, Al;
+        rr_usplit8(wv, Ah, Al);
+        const float4 bq = rr_ld4(bd + 16 * wave + 4 * g);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int node = nt * 16 + j, nc = node < N ? node : N - 1;
+          const float4 xa = rr_ld4(scr + nc * MAXSS + 8 * g), xb = rr_ld4(scr + nc * MAXSS + 8 * g + 4);
+          const float xx[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+          rr_f16x8 xh, xl;
+          rr_usplit8(xx, xh, xl);
+          f32x4 d = {64.f * bq.x, 64.f * bq.y, 64.f * bq.z, 64.f * bq.w};
+          d = rr_mfma_f16(Ah, xl, d);
+          d = rr_mfma_f16(Al, xh, d);
+          d = rr_mfma_f16(Ah, xh, d);
+          if (node < N)
+            rr_st4(comb + node * CLD + 128 + 16 * wave + 4 * g,
+                   make_float4(d[0] * (1.0f / 64.0f), d[1] * (1.0f / 64.0f), d[2] * (1.0f / 64.0f), d[3] * (1.0f / 64.0f)));
+        }
+      }
+    } else {
     // a thread keeps its feature f = tid & 127 for every node it visits (ENC_THREADS is a multiple of 128): the SS weights of that
     // feature are loaded once per pass instead of once per node, and the sorted samples of a node come as 16-byte LDS broadcasts
     float wreg[MAXSS];
 #pragma unroll
-    for (int s = 0; s < MAXSS; ++s) wreg[s] = s < SS ? wd[s * RR_E + (tid & 127)] : 0.f;
+    for (int s = 0; s < MAXSS; ++s) {      // unconditional loads (index clamped) + a select: a load under `if (s < SS)` became a branch per weight
+      const float* wrow = wd + (s < SS ? s : SS - 1) * RR_E;                // with a full vmcnt wait at every join — 32 serialised round trips
+      const float wv = wrow[tid & 127];                                     // (uniform row pointer + one lane offset: no address pair per weight)
+      wreg[s] = s < SS ? wv : 0.f;
+    }
+    // the eight 16-byte reads of a node's sorted samples are requested one node AHEAD of their dot product: hipcc put each read directly
+    // in front of its four fmas with a full wait (nine exposed LDS round trips per node, two waves per SIMD to hide them: 48 k of this
+    // kernel's 137 k cycles per instance — profiles/r06/NOTES.md section 7)
+    float4 vq[MAXSS / 4];
+#pragma unroll
+    for (int q = 0; q < MAXSS / 4; ++q) vq[q] = rr_ld4(scr + (tid >> 7) * MAXSS + 4 * q);      // (rows 0 .. 3 exist whatever N is)
     for (int e = tid; e < N * RR_E; e += ENC_THREADS) {
       int i = e >> 7, f = e & 127;
+      float4 vn[MAXSS / 4];
+      {
+        const int in = e + ENC_THREADS < N * RR_E ? i + ENC_THREADS / RR_E : i;
+#pragma unroll
+        for (int q = 0; q < MAXSS / 4; ++q) vn[q] = rr_ld4(scr + in * MAXSS + 4 * q);
+      }
+      __builtin_amdgcn_sched_barrier(0);
       if (KIND == 0) {
         comb[i * CLD + f] = fmaf(w.wi[f * 2 + 1], lcs[i * 2 + 1], w.wi[f * 2] * lcs[i * 2]) + w.bi[f];
       } else if (i == 0) {   // CoordinateExpert: depot Linear(2,E)
@@ -1145,13 +1263,16 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
       float acc = 0.f;
 #pragma unroll
       for (int s4 = 0; s4 < MAXSS; s4 += 4) {                 // in the order s = 0, 1, 2, ...: the same sum as before (+ exact zeros behind SS)
-        const float4 v = rr_ld4(scr + i * MAXSS + s4);
+        const float4 v = vq[s4 / 4];
         acc = fmaf(wreg[s4], v.x, acc);
         acc = fmaf(wreg[s4 + 1], v.y, acc);
         acc = fmaf(wreg[s4 + 2], v.z, acc);
         acc = fmaf(wreg[s4 + 3], v.w, acc);
       }
       comb[i * CLD + 128 + f] = acc + bd[f];
+#pragma unroll
+      for (int q = 0; q < MAXSS / 4; ++q) vq[q] = vn[q];
+    }
     }
     __syncthreads();
     RR_ET(2);
@@ -1159,7 +1280,6 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
     const float4* g0 = pass == 0 ? w.g0r : w.g0c;
     const float* g0b = pass == 0 ? w.g0rb : w.g0cb;
     const float* g2 = pass == 0 ? w.g2r : w.g2c;
-    const void* g0s = pass == 0 ? w.g0rs : w.g0cs;
     if (g0s != nullptr) {                  // (kernel argument: uniform)
       f32x4 h0[NT], h1[NT];
       const float4 ba = rr_ld4(g0b + 16 * wave + 4 * g), bb = rr_ld4(g0b + 16 * (wave + 8) + 4 * g);
@@ -1235,7 +1355,7 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
   }
 #ifdef RR_STAMP      // (stamped build only: phases of this kernel in rr_enc_stamps — gather, rank sort, embeddings, gate GEMM, its barrier, blend + store)
   if (lane == 0 && (blockIdx.x & 15) == 0) {
-    for (int i = 0; i < 6; ++i) atomicAdd(&rr_enc_stamps[i], _acc[i]);
+    for (int i = 0; i < 7; ++i) atomicAdd(&rr_enc_stamps[i], _acc[i]);
     atomicAdd(&rr_enc_stamps[7], 1ull);
   }
 #endif

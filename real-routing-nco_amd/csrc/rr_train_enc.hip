@@ -27,16 +27,20 @@ __global__ __launch_bounds__(1024) void k_inorm_bwd(const float* __restrict__ x,
   // instance — at 256 the launch had 8 waves per CU in flight and ran at 1.6 TB/s (48 us per call; 512 threads: 36, 1 024: 30)
   const size_t base = (size_t)b * N * RR_E + f;
   constexpr int MAXR = 14;               // nodes per thread (N <= 112)
-  float xv[MAXR], dv[MAXR];
+  float xv[MAXR], dv[MAXR], old[MAXR];
   float s0 = 0.f;
+  // every load unconditional on a clamped node, the test applied to the VALUE: with the loads under `if (n < N)` hipcc gave each node its
+  // own branch with a full vmcnt wait at the join — 14 serialised round trips per thread (profiles/r06/NOTES.md section 7)
+  const float* d2 = dy2 ? dy2 : dy1;
 #pragma unroll
   for (int i = 0; i < MAXR; ++i) {
     const int n = 8 * i + half;
-    if (n < N) {
-      xv[i] = x[base + (size_t)n * RR_E];
-      dv[i] = dy1[base + (size_t)n * RR_E] + (dy2 ? dy2[base + (size_t)n * RR_E] : 0.f);
-      s0 += xv[i];
-    } else { xv[i] = 0.f; dv[i] = 0.f; }
+    const size_t at = base + (size_t)(n < N ? n : N - 1) * RR_E;
+    const float xa = x[at], da = dy1[at], db = d2[at];
+    old[i] = accumulate ? dx_out[at] : 0.f;          // (read before the first barrier; the stores come after the last)
+    xv[i] = n < N ? xa : 0.f;
+    dv[i] = n < N ? da + (dy2 ? db : 0.f) : 0.f;
+    s0 += xv[i];
   }
   red[0][tid] = s0;
   __syncthreads();
@@ -65,9 +69,8 @@ __global__ __launch_bounds__(1024) void k_inorm_bwd(const float* __restrict__ x,
     if (n < N) {
       const float xh = xv[i] * rstd;
       float v = gm * rstd * (dv[i] - m1 - xh * m2);
-      float* dst = dx_out + base + (size_t)n * RR_E;
-      if (accumulate) v += *dst;
-      *dst = v;
+      if (accumulate) v += old[i];
+      dx_out[base + (size_t)n * RR_E] = v;
     }
   }
   if (half == 0) { atomicAdd(dgamma + f, t2); atomicAdd(dbeta + f, t1); }

@@ -25,7 +25,7 @@ def mlp_train_pack(policy):
     """bf16 split operand packs of the pointer MLP, rebuilt when its four tensors change (same rule as policy.packed)."""
     names = ["decoder.pointer.ffn.lins.0.weight", "decoder.pointer.ffn.lins.0.bias",
              "decoder.pointer.ffn.lins.1.weight", "decoder.pointer.ffn.lins.1.bias"]
-    P = dict(policy.named_parameters())
+    P = policy.param_index()["P"]
     ts = [P[n] for n in names]
     # keyed like enc_backward.train_packs: the policy's own pack key (versions, pointers and — while training — the norm
     # fingerprint policy.packed() has already read this step) instead of a second blocking norm read in front of the backward

@@ -22,13 +22,13 @@ _NORMS = (("n1", "norm1"), ("n2", "norm2"), ("n3", "norm3"), ("f1", "feed_forwar
 def train_packs(policy) -> dict:
     """Operand packs of the backward (transposed weights as fp32 MFMA A operands, bf16 split packs of the FFNs), rebuilt when
     the policy's weights change (keyed like policy.packed)."""
-    dev = next(policy.parameters()).device
+    dev = policy.param_index()["params"][0].device
     policy.packed(dev)
     key = policy._pack_cache[0]
     cached = getattr(policy, "_enc_train_pack", None)
     if cached is not None and cached[0] == key:
         return cached[1]
-    sd = dict(policy.named_parameters())          # (used under no_grad below: no ~470 detached views per step)
+    sd = policy.param_index()["P"]                # (used under no_grad below: no ~470 detached views per step)
     nl = 1 + max(int(n.split(".")[3]) for n in sd if n.startswith("encoder.net.layers."))
     keep, blocks = [], []
     with torch.no_grad():
@@ -168,7 +168,7 @@ def encoder_backward(policy, capture, dec, D, locs, sample_idx, td):
     result.  Accumulates the gradients of every encoder-side parameter (and project_node_embeddings / project_context)."""
     from . import grad_replay as GR
     lib, st = L.lib(), L.stream()
-    P = dict(policy.named_parameters())
+    P = policy.param_index()["P"]
     packs = train_packs(policy)
     saves = capture["enc"]
     theta, layers = saves[-1]["theta"], saves[:-1]

@@ -568,9 +568,10 @@ def decode_log_likelihood_rcvrptw(P, row_emb, col_emb, D, Dur, demand_l, tw, ser
 
 def params_and_buffers(policy, bn_momentum=0.0):
     """named_parameters, plus — for normalization='batch' in train mode — the BatchNorm buffers and the momentum `_inorm` applies."""
-    P = dict(policy.named_parameters())
+    pidx = policy.param_index()
+    P = dict(pidx["P"])
     if _has_running_stats(policy):
-        P.update({k: v for k, v in policy.named_buffers() if ".normalizer." in k})
+        P.update({k: v for k, v in pidx["named_buffers"] if ".normalizer." in k})
         P["__bn_momentum__"] = bn_momentum if policy.training else 0.0
         P["__bn_train__"] = bool(policy.training)      # eval mode: gradients of the running-statistics network the kernels ran
     return P

@@ -33,7 +33,7 @@ def _names(env_name: str) -> dict:
 
 
 def supported(policy, sidx) -> bool:
-    P = dict(policy.named_parameters())
+    P = policy.param_index()["P"]
     nm = _names(policy.env_name) if policy.env_name in ("atsp", "rcvrp", "rcvrptw") else None
     if nm is None or sidx.shape[-1] > 32 or f"{_P}.gating_network_row.gating_fc.0.weight" not in P:
         return False

@@ -69,16 +69,29 @@ class RRNetPolicy(nn.Module):
         self.invalidate_pack()               # new weights: every derived pack is stale; the fp32 exile of the range guard ends
         return out
 
+    def param_index(self) -> dict:
+        """{"named": [(name, parameter)], "params": [...], "P": {name: parameter}, "named_buffers": [...], "buffers": [...]} of this module.
+        Inside pack_scope (one training step: nobody registers or replaces a parameter there) the module tree is walked ONCE per step
+        instead of once per consumer — pack key, pack, decoder / encoder / init backward, gradient list: ten walks over ~565 parameters
+        were ~3 ms of a small-batch step's host time (profiles/r06/NOTES.md section 9).  Outside a scope every call walks, as before."""
+        idx = getattr(self, "_pidx", None)
+        if idx is not None and getattr(self, "_pack_scope", False):
+            return idx
+        named, bufs = list(self.named_parameters()), list(self.named_buffers())
+        idx = {"named": named, "params": [q for _, q in named], "P": dict(named), "named_buffers": bufs, "buffers": [q for _, q in bufs]}
+        self._pidx = idx if getattr(self, "_pack_scope", False) else None
+        return idx
+
     def pack_scope(self):
         """Context: the weights do not change inside (one training step up to its optimizer step) — packed() verifies once."""
         pol = self
 
         class _Scope:
             def __enter__(self_):
-                pol._pack_scope, pol._pack_verified = True, False
+                pol._pack_scope, pol._pack_verified, pol._pidx = True, False, None
 
             def __exit__(self_, *exc):
-                pol._pack_scope, pol._pack_verified = False, False
+                pol._pack_scope, pol._pack_verified, pol._pidx = False, False, None
                 return False
         return _Scope()
 
@@ -96,7 +109,8 @@ class RRNetPolicy(nn.Module):
                 and self._pack_cache[0][1] == packing.mlp_split_enabled():
             return self._pack_cache[1]
         # buffers too: BatchNorm running statistics are folded into the pack (packing.py), and a buffer-only load must repack
-        ts = list(self.parameters()) + list(self.buffers())
+        pidx = self.param_index()
+        ts = pidx["params"] + pidx["buffers"]
         key = (str(device), packing.mlp_split_enabled(), tuple(p._version for p in ts), tuple(p.data_ptr() for p in ts))
         # The norm fingerprint (one multi-tensor launch + ONE HOST READ) catches in-place updates that do not bump the version
         # counters (fused optimizers).  Those only happen around training-mode calls: an eval-mode module that has not been in
@@ -109,16 +123,16 @@ class RRNetPolicy(nn.Module):
             key = key + (("in-scope", getattr(self, "_pack_gen", 0)),)
             self._pack_dirty = True
         elif dirty:
-            key = key + (packing.weights_fingerprint(self),)
+            key = key + (packing.weights_fingerprint(self, ts),)
             self._pack_dirty = self.training
         elif self._pack_cache is not None:
             key = key + (self._pack_cache[0][-1],)
         if self._pack_cache is None or self._pack_cache[0] != key:
             if not dirty:
-                key = key[:4] + (packing.weights_fingerprint(self),)
+                key = key[:4] + (packing.weights_fingerprint(self, ts),)
             # (names -> tensors like state_dict(), without its ~470 detached views: this runs once per training step)
-            sd = dict(self.named_parameters())
-            sd.update(self.named_buffers())
+            sd = dict(pidx["P"])
+            sd.update(pidx["named_buffers"])
             self._pack_cache = (key, packing.pack_policy(sd, self.env_name, device))
         self._pack_verified = True
         return self._pack_cache[1]

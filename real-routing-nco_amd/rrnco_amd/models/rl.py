@@ -78,7 +78,7 @@ class RRNet:
         r = out["normalized_reward"] if self.env.normalize else out["reward"]
         out.update(reinforce_loss(r, out["log_likelihood"], n_start))
         out["max_reward"] = unbatchify(out["reward"], (0, n_start)).max(dim=-1).values
-        params = [p for p in self.policy.parameters()]
+        params = self.policy.param_index()["params"] if hasattr(self.policy, "param_index") else list(self.policy.parameters())
         for p in params:
             p.grad = None
         if cap is not None and "dump" in cap:     # decoder backward on the hand-written kernels (csrc/rr_train_dec.hip)

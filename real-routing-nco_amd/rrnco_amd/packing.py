@@ -15,11 +15,13 @@ E = 128
 
 
 @torch.no_grad()
-def weights_fingerprint(module) -> tuple:
+def weights_fingerprint(module, tensors=None) -> tuple:
     """Per-parameter L2 norms (one multi-tensor launch, one host read) for the pack caches.  Version counters alone are not
     enough: fused optimizers (torch.optim.Adam(fused=True)) update the parameters in place WITHOUT bumping `_version`, and a
     stale pack would silently roll out with the previous weights."""
-    ps = [q for q in list(module.parameters()) + list(module.buffers()) if q.is_floating_point() and q.numel() > 0]
+    if tensors is None:        # (`tensors`: the caller's list of the module's parameters + buffers, when it has walked the tree already)
+        tensors = list(module.parameters()) + list(module.buffers())
+    ps = [q for q in tensors if q.is_floating_point() and q.numel() > 0]
     if not ps:
         return ()
     norms = torch._foreach_norm(ps)
