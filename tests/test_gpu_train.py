@@ -151,9 +151,9 @@ def test_pack_scope_verifies_once_per_step_and_expires():
     calls = {"n": 0}
     real = packing.weights_fingerprint
 
-    def counting(module):
+    def counting(module, tensors=None):
         calls["n"] += 1
-        return real(module)
+        return real(module, tensors)
     packing.weights_fingerprint = counting
     try:
         pol.packed(dev)                                    # (a cached pack: the step below has something to verify)
