@@ -40,7 +40,9 @@ typedef struct {                /* ATSPInitEmbedding (rrnco/models/env_embedding
   const float *cmrb, *cmcb;
   float g2rb, g2cb;
   int nfeat;
-  const void *g0rs, *g0cs;      /* gating_fc.0 as two-piece fp16 images of 2^6 W [16][8][2][64][8] (fp16 matrix pipe) or NULL (fp32 MFMA) */
+  /* gating_fc.0 folded through the two embeddings it reads (packing.fold_init_gate), all six or none (none: the fp32 kernels):
+     gf = (W0[:, E:2E] W_dist)^T zero-padded [32][2E]; gn = (W0[:, 0:E] W_node | constants) [2E][4]; gd = gn for the VRP depot (NULL for ATSP) */
+  const float *gfr, *gfc, *gnr, *gnc, *gdr, *gdc;
 } InitW;
 
 typedef struct {                /* folded DistAngleFusion(use_duration_matrix=True): attn_freenet.py:226-237, 265-286 */

@@ -952,7 +952,11 @@ struct InitW {
   const float *cmrb, *cmcb;
   float g2rb, g2cb;                // gating_fc.2 bias
   int nfeat;                       // F: 1 (demand) or 4 (demand, tw0, tw1, service)
-  const void *g0rs, *g0cs;         // gating_fc.0 as second-form fp16 images of 2^6 W [16 t][8 s][2 pieces][64][8] (packing.pack_a_f16u) or NULL
+  // The gate's first layer FOLDED through the two embeddings it reads (packing.fold_init_gate; all six or none — none = the fp32 build):
+  //   hidden = relu(W0 [node_emb | dist_emb] + b0) = relu(gf^T sorted + gn[:, 0:3] . (x, y, angle) + gn[:, 3])
+  // gf = (W0[:, E:2E] W_dist)^T zero-padded to [32][2E]; gn[u] = (W0[:, 0:E] W_node, the constants of both embeddings + b0) [2E][4];
+  // gd = the same for the VRP depot's Linear(2,E) (NULL for ATSP).  K = 32 instead of 2E = 256 for the matrix pipe.
+  const float *gfr, *gfc, *gnr, *gnc, *gdr, *gdc;
 };
 
 #define MAXSS 32
@@ -996,56 +1000,15 @@ __device__ __forceinline__ void ie_gemm_wx16(f32x4 (&acc)[NT], const float4* __r
   }
 }
 
-// The gate's first layer (Linear(2E,2E) on [node | distance embedding]) is 0.83 of k_init_embed's 1.71 ms on the fp32 MFMA (7 168
-// instructions of 32 cycles per pass and instance).  Second-form fp16 operands (rr_common.h): hidden tiles t0 and t1 of this wave
-// for all node tiles at once, the rows of X split once per (node tile, 32-feature slice) and used for both; accumulators seeded
-// with 2^6 bias, results x 2^6.
-template <int NT>
-__device__ __forceinline__ void ie_gemm_split2(f32x4 (&h0)[NT], f32x4 (&h1)[NT], const void* ws, int t0, int t1, const float* X, int ldx,
-                                               int n_valid, int lane) {
-  const int j = lane & 15, g = lane >> 4;
-  int rowoff[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    int node = nt * 16 + j;
-    node = node < n_valid ? node : n_valid - 1;
-    rowoff[nt] = node * ldx + 4 * g;
-  }
-  const char* a0 = (const char*)ws + (size_t)t0 * (16 * 1024) + lane * 16;      // fragment ((t * 8 + s) * 2 + piece)
-  const char* a1 = (const char*)ws + (size_t)t1 * (16 * 1024) + lane * 16;
-  rr_f16x8 A[2][4];
-  A[0][0] = *reinterpret_cast<const rr_f16x8*>(a0); A[0][1] = *reinterpret_cast<const rr_f16x8*>(a0 + 1024);
-  A[0][2] = *reinterpret_cast<const rr_f16x8*>(a1); A[0][3] = *reinterpret_cast<const rr_f16x8*>(a1 + 1024);
-  // (the fragments two and three slices ahead instead of one — PF = 3 — measured 1.22 against 1.20 ms: the L2 round trips are not
-  // what this phase waits for; in-kernel stamps of the whole kernel: profiles/r06/NOTES.md section 7)
-#pragma unroll
-  for (int sl = 0; sl < 8; ++sl) {
-    if (sl + 1 < 8) {
-      A[(sl + 1) & 1][0] = *reinterpret_cast<const rr_f16x8*>(a0 + (sl + 1) * 2048);
-      A[(sl + 1) & 1][1] = *reinterpret_cast<const rr_f16x8*>(a0 + (sl + 1) * 2048 + 1024);
-      A[(sl + 1) & 1][2] = *reinterpret_cast<const rr_f16x8*>(a1 + (sl + 1) * 2048);
-      A[(sl + 1) & 1][3] = *reinterpret_cast<const rr_f16x8*>(a1 + (sl + 1) * 2048 + 1024);
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const float4 xa = rr_ld4(X + rowoff[nt] + 32 * sl), xb = rr_ld4(X + rowoff[nt] + 32 * sl + 16);
-      const float xx[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-      rr_f16x8 xh, xl;
-      rr_usplit8(xx, xh, xl);
-      h0[nt] = rr_mfma_f16(A[sl & 1][0], xl, h0[nt]); h1[nt] = rr_mfma_f16(A[sl & 1][2], xl, h1[nt]);
-      h0[nt] = rr_mfma_f16(A[sl & 1][1], xh, h0[nt]); h1[nt] = rr_mfma_f16(A[sl & 1][3], xh, h1[nt]);
-      h0[nt] = rr_mfma_f16(A[sl & 1][0], xh, h0[nt]); h1[nt] = rr_mfma_f16(A[sl & 1][2], xh, h1[nt]);
-    }
-  }
-}
-
 // lane permutation within a row of 16 by DPP (dpp_ctrl: quad_perm 0x00-0xFF, row_mirror 0x140, row_half_mirror 0x141)
 template <int CTRL>
 __device__ __forceinline__ float ie_dpp(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 
-template <int NT, int KIND>   // KIND 0 = ATSP, 1 = VRP (depot at node 0, extra node features `vfeat` [Bp][N][F])
+// FOLD: the split build — Linear(SS,E) and the folded gate layer on the fp16 matrix pipe (second-form pieces); !FOLD: everything in fp32
+// (fma loop for Linear(SS,E), fp32 MFMA for the gate's Linear(2E,2E)), the arithmetic of rounds 1-5 and of the range guard's retry.
+template <int NT, int KIND, bool FOLD>   // KIND 0 = ATSP, 1 = VRP (depot at node 0, extra node features `vfeat` [Bp][N][F])
 __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const float* __restrict__ D, const float* __restrict__ locs,
                                                                const int64_t* __restrict__ sidx, const float* __restrict__ vfeat,
                                                                float* __restrict__ row_out, float* __restrict__ col_out, int N, int SS) {
@@ -1075,6 +1038,7 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
   // read it there; the indices (the same for both passes) load under the same round trip.  Pass 0's distances stay in registers;
   // pass 1's (the column of the matrix) wait in a private LDS slot per thread.
   __shared__ float lcs[2 * RR_MAXN];
+  __shared__ float angs[KIND == 1 ? RR_MAXN : 1];      // VRP: atan2(y - y_depot, x - x_depot) per customer, once (it was evaluated per (node, feature))
   const int hl = lane & 31, hw = lane >> 5;
   float* park = gpart + 16 * 112;                // [NT][ENC_THREADS]
   static_assert(((RR_MAXN * 260 + 3) & ~3) + RR_MAXN * MAXSS + 16 * 112 + 7 * ENC_THREADS <= 3 * BUF_FLOATS, "k_init_embed LDS layout (park)");
@@ -1099,6 +1063,9 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
       if (e < N * N) Dl[e] = dreg[u];
     }
     __syncthreads();
+    if (KIND == 1) {
+      for (int i = tid; i < N; i += ENC_THREADS) angs[i] = i == 0 ? 0.f : atan2f(lcs[i * 2 + 1] - lcs[1], lcs[i * 2] - lcs[0]);      // (read behind pass 0's sort barrier)
+    }
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
       const int node = min(16 * q + 2 * wave + hw, N - 1);
@@ -1175,11 +1142,13 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
     RR_ET(1);
     __syncthreads();
     RR_ET(6);
-    // comb[:, 0:E] = node embedding, comb[:, E:2E] = Lin(SS,E)(sorted)
+    // comb[:, 0:E] = node embedding, comb[:, E:2E] = Lin(SS,E)(sorted); gate hidden layer -> per-wave partial logits in gpart
     const float* wd = pass == 0 ? w.wr : w.wcl;
     const float* bd = pass == 0 ? w.br : w.bcl;
-    const void* g0s = pass == 0 ? w.g0rs : w.g0cs;      // (kernel argument: uniform) second-form fp16 images present = the split build
-    if (g0s != nullptr) {
+    const float4* g0 = pass == 0 ? w.g0r : w.g0c;
+    const float* g0b = pass == 0 ? w.g0rb : w.g0cb;
+    const float* g2 = pass == 0 ? w.g2r : w.g2c;
+    if constexpr (FOLD) {
       // node embedding on the vector pipe (2 - 3 terms per element) ...
       for (int e = tid; e < N * RR_E; e += ENC_THREADS) {
         const int i = e >> 7, f = e & 127;
@@ -1189,43 +1158,100 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
           comb[f] = fmaf(w.wdep[f * 2 + 1], lcs[1], w.wdep[f * 2] * lcs[0]) + w.bdep[f];
         } else {               // customers Linear(3,E) on (x, y, atan2(y - y_depot, x - x_depot))
           float x = lcs[i * 2], y = lcs[i * 2 + 1];
-          float ang = atan2f(y - lcs[1], x - lcs[0]);
+          float ang = angs[i];
           comb[i * CLD + f] = fmaf(w.wi[f * 3 + 2], ang, fmaf(w.wi[f * 3 + 1], y, w.wi[f * 3] * x)) + w.bi[f];
         }
       }
-      // ... and Linear(SS, E) on the matrix pipe: wave = feature tile (A = 2^6 W^T [16 features][32 samples], split here: 8 loads per
-      // lane and pass), the node tiles as B operands from the sorted rows, second-form fp16 pieces, three products per tile into an
-      // accumulator seeded with 2^6 bias.  As 12 800 x 32 fmas per pass this was 38 k of the kernel's 125 k cycles per instance — two
-      // waves per SIMD at the vector pipe's issue rate (profiles/r06/NOTES.md section 7); now 21 matrix instructions per wave and pass.
+      // ... Linear(SS, E) and the gate's hidden layer on the matrix pipe, both from the SAME B operands (the sorted rows, second-form
+      // fp16 pieces, split once per node tile):
+      //   * distance embedding: wave = feature tile, A = 2^6 W_dist^T [16 features][32 samples] split here (8 loads per lane and pass),
+      //     three products per node tile into an accumulator seeded with 2^6 bias.  As 12 800 x 32 fmas per pass this was 38 k of the
+      //     kernel's 125 k cycles per instance (two waves per SIMD at the vector pipe's issue rate);
+      //   * gate hidden layer, FOLDED (InitW::gf / gn): relu(W0 [node_emb | dist_emb] + b0) with both embeddings linear in their inputs
+      //     is relu(gf^T sorted + gn . (x, y, angle, 1)) — K = 32 on the matrix pipe (hidden tiles wave and wave + 8: 6 instructions
+      //     per node tile) and three fmas per hidden unit for the coordinate part, instead of K = 2E = 256 over the assembled `comb`
+      //     rows: 336 matrix instructions per wave and pass and a split of every comb row in every wave, 41 k cycles
+      //   (profiles/r06/NOTES.md section 7).
       static_assert(ENC_THREADS / 64 == RR_E / 16, "k_init_embed: one wave per feature tile");
       {
-        float wv[8];
+        const float* gf = pass == 0 ? w.gfr : w.gfc;
+        const float4* gn = reinterpret_cast<const float4*>(pass == 0 ? w.gnr : w.gnc);
+        const float4* gd = reinterpret_cast<const float4*>(pass == 0 ? w.gdr : w.gdc);
+        float wv[8], gv0[8], gv1[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const int sq = 8 * g + q;
           const float* wrow = wd + (sq < SS ? sq : SS - 1) * RR_E;
           const float v = wrow[16 * wave + j];
           wv[q] = sq < SS ? 64.f * v : 0.f;
+          gv0[q] = 64.f * gf[sq * (2 * RR_E) + 16 * wave + j];              // (rows >= SS of the padded table are zero)
+          gv1[q] = 64.f * gf[sq * (2 * RR_E) + 16 * (wave + 8) + j];
         }
-        rr_f16x8 Ah, Al;
+        rr_f16x8 Ah, Al, G0h, G0l, G1h, G1l;
         rr_usplit8(wv, Ah, Al);
+        rr_usplit8(gv0, G0h, G0l);
+        rr_usplit8(gv1, G1h, G1l);
         const float4 bq = rr_ld4(bd + 16 * wave + 4 * g);
+        float4 n0[4], n1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { n0[r] = gn[16 * wave + 4 * g + r]; n1[r] = gn[16 * (wave + 8) + 4 * g + r]; }
+        const float4 wa = rr_ld4(g2 + 16 * wave + 4 * g), wb = rr_ld4(g2 + 16 * (wave + 8) + 4 * g);
+        // Scheduling fences around the matrix instructions of a node tile: gfx950 does not interlock a vector WRITE to a register that
+        // a just-issued matrix instruction still has to read as SrcA / SrcB (rr_common.h, above rr_glds16), and hipcc, free to move
+        // code, built the gate's A pieces in the registers of the previous tile's B pieces right behind its matrix instructions —
+        // identical instances came out with different gates (tests/test_gpu_atsp.py, sampling law over 2 048 copies).  Between the
+        // fences of a tile there is nothing but its nine matrix instructions; its B pieces stay allocated until its results have
+        // been read (the empty asm at the end of the tile), i.e. until the matrix instructions have retired.
+        // (the next tile's LDS reads are requested in front of this tile's matrix instructions: a load's destination is never a register
+        // a matrix instruction in flight reads)
+        float4 xa_n, xb_n;
+        float cx_n, cy_n, ca_n;
+        auto fetch = [&](int nt) {
+          const int node = nt * 16 + j, nc = node < N ? node : N - 1;
+          xa_n = rr_ld4(scr + nc * MAXSS + 8 * g); xb_n = rr_ld4(scr + nc * MAXSS + 8 * g + 4);
+          cx_n = lcs[2 * nc]; cy_n = lcs[2 * nc + 1]; ca_n = KIND == 1 ? angs[nc] : 0.f;
+        };
+        fetch(0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          const int node = nt * 16 + j, nc = node < N ? node : N - 1;
-          const float4 xa = rr_ld4(scr + nc * MAXSS + 8 * g), xb = rr_ld4(scr + nc * MAXSS + 8 * g + 4);
+          const int node = nt * 16 + j;
+          const float4 xa = xa_n, xb = xb_n;
+          const float cx = cx_n, cy = cy_n, ca = ca_n;
           const float xx[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
           rr_f16x8 xh, xl;
           rr_usplit8(xx, xh, xl);
+          if (nt + 1 < NT) fetch(nt + 1);
           f32x4 d = {64.f * bq.x, 64.f * bq.y, 64.f * bq.z, 64.f * bq.w};
-          d = rr_mfma_f16(Ah, xl, d);
-          d = rr_mfma_f16(Al, xh, d);
-          d = rr_mfma_f16(Ah, xh, d);
+          f32x4 h0, h1;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float4 a0 = n0[r], a1 = n1[r];
+            if (KIND == 1 && nt == 0 && j == 0) { a0 = gd[16 * wave + 4 * g + r]; a1 = gd[16 * (wave + 8) + 4 * g + r]; }      // the depot's Linear(2,E)
+            h0[r] = 64.f * fmaf(a0.z, ca, fmaf(a0.y, cy, fmaf(a0.x, cx, a0.w)));
+            h1[r] = 64.f * fmaf(a1.z, ca, fmaf(a1.y, cy, fmaf(a1.x, cx, a1.w)));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          d = rr_mfma_f16(Ah, xl, d);   h0 = rr_mfma_f16(G0h, xl, h0); h1 = rr_mfma_f16(G1h, xl, h1);
+          d = rr_mfma_f16(Al, xh, d);   h0 = rr_mfma_f16(G0l, xh, h0); h1 = rr_mfma_f16(G1l, xh, h1);
+          d = rr_mfma_f16(Ah, xh, d);   h0 = rr_mfma_f16(G0h, xh, h0); h1 = rr_mfma_f16(G1h, xh, h1);
+          __builtin_amdgcn_sched_barrier(0);
           if (node < N)
             rr_st4(comb + node * CLD + 128 + 16 * wave + 4 * g,
                    make_float4(d[0] * (1.0f / 64.0f), d[1] * (1.0f / 64.0f), d[2] * (1.0f / 64.0f), d[3] * (1.0f / 64.0f)));
+          // NaN-preserving relu (x < 0 ? 0 : x): fmaxf(NaN, 0) = 0 would hide an fp16 overflow of the split operands from the range
+          // guard — a NaN here reaches the embeddings and raises bit 0 in rr_pack_f16x2
+          auto rl = [](float x) { return x < 0.f ? 0.f : x; };
+          float p0 = rl(h0[0]) * wa.x + rl(h0[1]) * wa.y + rl(h0[2]) * wa.z + rl(h0[3]) * wa.w;
+          float p1 = rl(h1[0]) * wb.x + rl(h1[1]) * wb.y + rl(h1[2]) * wb.z + rl(h1[3]) * wb.w;
+          p0 = rr_sum_g(p0) * (1.0f / 64.0f); p1 = rr_sum_g(p1) * (1.0f / 64.0f);
+          if (g == 0) { gpart[wave * 112 + nt * 16 + j] = p0; gpart[(wave + 8) * 112 + nt * 16 + j] = p1; }
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("" ::"v"(xh), "v"(xl), "v"(Ah), "v"(Al), "v"(G0h), "v"(G0l), "v"(G1h), "v"(G1l));
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
+      RR_ET(2);
     } else {
     // a thread keeps its feature f = tid & 127 for every node it visits (ENC_THREADS is a multiple of 128): the SS weights of that
     // feature are loaded once per pass instead of once per node, and the sorted samples of a node come as 16-byte LDS broadcasts
@@ -1257,7 +1283,7 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
         comb[f] = fmaf(w.wdep[f * 2 + 1], lcs[1], w.wdep[f * 2] * lcs[0]) + w.bdep[f];
       } else {               // customers Linear(3,E) on (x, y, atan2(y - y_depot, x - x_depot))
         float x = lcs[i * 2], y = lcs[i * 2 + 1];
-        float ang = atan2f(y - lcs[1], x - lcs[0]);
+        float ang = angs[i];
         comb[i * CLD + f] = fmaf(w.wi[f * 3 + 2], ang, fmaf(w.wi[f * 3 + 1], y, w.wi[f * 3] * x)) + w.bi[f];
       }
       float acc = 0.f;
@@ -1273,34 +1299,9 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
 #pragma unroll
       for (int q = 0; q < MAXSS / 4; ++q) vq[q] = vn[q];
     }
-    }
     __syncthreads();
     RR_ET(2);
-    // hidden = relu(W0 comb + b0) [2E]; gate logit = w2 . hidden + b2 ; two feature tiles per wave
-    const float4* g0 = pass == 0 ? w.g0r : w.g0c;
-    const float* g0b = pass == 0 ? w.g0rb : w.g0cb;
-    const float* g2 = pass == 0 ? w.g2r : w.g2c;
-    if (g0s != nullptr) {                  // (kernel argument: uniform)
-      f32x4 h0[NT], h1[NT];
-      const float4 ba = rr_ld4(g0b + 16 * wave + 4 * g), bb = rr_ld4(g0b + 16 * (wave + 8) + 4 * g);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        h0[nt] = f32x4{64.f * ba.x, 64.f * ba.y, 64.f * ba.z, 64.f * ba.w};
-        h1[nt] = f32x4{64.f * bb.x, 64.f * bb.y, 64.f * bb.z, 64.f * bb.w};
-      }
-      ie_gemm_split2<NT>(h0, h1, g0s, wave, wave + 8, comb, CLD, N, lane);
-      const float4 wa = rr_ld4(g2 + 16 * wave + 4 * g), wb = rr_ld4(g2 + 16 * (wave + 8) + 4 * g);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        // NaN-preserving relu (x < 0 ? 0 : x): fmaxf(NaN, 0) = 0 would hide an fp16 overflow of the gate's split operands from the
-        // range guard — a NaN here reaches the embeddings and raises bit 0 in rr_pack_f16x2
-        auto rl = [](float x) { return x < 0.f ? 0.f : x; };
-        float p0 = rl(h0[nt][0]) * wa.x + rl(h0[nt][1]) * wa.y + rl(h0[nt][2]) * wa.z + rl(h0[nt][3]) * wa.w;
-        float p1 = rl(h1[nt][0]) * wb.x + rl(h1[nt][1]) * wb.y + rl(h1[nt][2]) * wb.z + rl(h1[nt][3]) * wb.w;
-        p0 = rr_sum_g(p0) * (1.0f / 64.0f); p1 = rr_sum_g(p1) * (1.0f / 64.0f);
-        if (g == 0) { gpart[wave * 112 + nt * 16 + j] = p0; gpart[(wave + 8) * 112 + nt * 16 + j] = p1; }
-      }
-    } else
+    // hidden = relu(W0 comb + b0) [2E]; gate logit = w2 . hidden + b2 ; two feature tiles per wave (fp32 MFMA)
     for (int tt = 0; tt < 2; ++tt) {
       int t = wave + 8 * tt;
       f32x4 h[NT];
@@ -1316,6 +1317,7 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
         p = rr_sum_g(p);
         if (g == 0) gpart[t * 112 + nt * 16 + j] = p;
       }
+    }
     }
     RR_ET(3);
     __syncthreads();
@@ -1366,14 +1368,20 @@ extern "C" int rr_init_embed(const InitW* w, int kind, const float* D, const flo
   if (Bp <= 0 || N < 2 || N > RR_MAXN || SS < 1 || SS > MAXSS || w == nullptr || kind < 0 || kind > 1) return RR_EINVAL;
   if (kind == 1 && (vfeat == nullptr || w->nfeat < 1 || w->nfeat > 8)) return RR_EINVAL;
   dim3 grid(Bp), blk(ENC_THREADS);
-#define RR_INIT(NTV)                                                                                               \
-  do {                                                                                                             \
-    if (kind == 0) hipLaunchKernelGGL((k_init_embed<NTV, 0>), grid, blk, 0, st, *w, D, locs, sidx, vfeat, row_out, col_out, N, SS); \
-    else hipLaunchKernelGGL((k_init_embed<NTV, 1>), grid, blk, 0, st, *w, D, locs, sidx, vfeat, row_out, col_out, N, SS);          \
+  // the folded tables come all together or not at all (packing builds them with the split build; the range guard's fp32 retry packs none)
+  const bool any_fold = w->gfr || w->gfc || w->gnr || w->gnc || w->gdr || w->gdc;
+  const bool fold = w->gfr && w->gfc && w->gnr && w->gnc && (kind == 0 || (w->gdr && w->gdc));
+  if (any_fold && !fold) return RR_EINVAL;
+#define RR_INIT2(NTV, KV, FV) hipLaunchKernelGGL((k_init_embed<NTV, KV, FV>), grid, blk, 0, st, *w, D, locs, sidx, vfeat, row_out, col_out, N, SS)
+#define RR_INIT(NTV)                                  \
+  do {                                                \
+    if (kind == 0) { if (fold) RR_INIT2(NTV, 0, true); else RR_INIT2(NTV, 0, false); } \
+    else { if (fold) RR_INIT2(NTV, 1, true); else RR_INIT2(NTV, 1, false); }           \
   } while (0)
   if (N <= 32) RR_INIT(2);
   else if (N <= 64) RR_INIT(4);
   else RR_INIT(7);
+#undef RR_INIT2
 #undef RR_INIT
   return rr_check(hipGetLastError());
 }

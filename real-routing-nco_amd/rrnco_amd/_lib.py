@@ -25,7 +25,7 @@ class EncBlockW(C.Structure):
 class InitW(C.Structure):
     _fields_ = [(n, vp) for n in ("wi", "bi", "wr", "br", "wcl", "bcl", "g0r", "g0c", "g0rb", "g0cb", "g2r", "g2c",
                                   "wdep", "bdep", "wdm", "bdm", "cmr", "cmc", "cmrb", "cmcb")] + \
-               [("g2rb", f32), ("g2cb", f32), ("nfeat", i32), ("g0rs", vp), ("g0cs", vp)]
+               [("g2rb", f32), ("g2cb", f32), ("nfeat", i32)] + [(n, vp) for n in ("gfr", "gfc", "gnr", "gnc", "gdr", "gdc")]
 
 
 class CacheW(C.Structure):

@@ -515,6 +515,32 @@ def fold_nab_dur_pwl(Ms, cg, cos, kos, a_, b_) -> torch.Tensor:
                                             np.ascontiguousarray(sliced).reshape(-1).astype(np.float32)]))
 
 
+def fold_init_gate(W0, b0, Wd, bd, Wn, bn, Wdep=None, bdep=None):
+    """The gate's first layer (gating_fc.0, Linear(2E,2E): atsp.py:108-121 / rcvrp.py:88-103) folded through the two embeddings it
+    reads — both are linear in their inputs, so
+        W0 [node_emb | dist_emb] + b0 = (W0[:, :E] Wn) feat + (W0[:, E:] Wd) sorted + (W0[:, :E] bn + W0[:, E:] bd + b0).
+    -> gf [32, 2E] = (W0[:, E:] Wd)^T zero-padded behind the SS samples; gn [2E, 4] = (the <= 3 coefficients of the node features,
+    the constant); gd = gn for the VRP depot's own Linear(2,E) (None for ATSP).  Products in float64 (small_gemm), results fp32:
+    csrc/rr_encoder.hip:k_init_embed<., ., true> runs the layer as K = 32 on the fp16 matrix pipe + 3 fmas per hidden unit."""
+    E2 = W0.shape[0]
+    W0 = W0.detach().double()
+    W0a, W0b = W0[:, :E].contiguous(), W0[:, E:].contiguous()
+    SS = Wd.shape[1]
+    assert SS <= 32 and W0.shape == (E2, 2 * E)
+    F = small_gemm(W0b, Wd.detach().double().contiguous())                        # [2E, SS]
+    gf = torch.zeros(32, E2, dtype=torch.float64, device=W0.device)
+    gf[:SS] = F.t()
+    c = small_gemm(W0b, bd.detach().double().reshape(-1, 1).contiguous())[:, 0] + b0.detach().double()
+
+    def node(Wx, bx):
+        A = small_gemm(W0a, Wx.detach().double().contiguous())                    # [2E, 2 | 3]
+        g = torch.zeros(E2, 4, dtype=torch.float64, device=W0.device)
+        g[:, :A.shape[1]] = A
+        g[:, 3] = c + small_gemm(W0a, bx.detach().double().reshape(-1, 1).contiguous())[:, 0]
+        return g.float()
+    return gf.float(), node(Wn, bn), (node(Wdep, bdep) if Wdep is not None else None)
+
+
 class _Arena:
     """Keeps every packed tensor alive and hands out raw device pointers."""
 
@@ -652,9 +678,11 @@ def _pack_policy(sd: dict, env_name: str, device) -> dict:
         for rc, s in ((("row", "r"), ("col", "c")) if has_gate else ()):
             q = f"{p}.gating_network_{rc}.gating_fc"
             setattr(iw, "g0" + s, ar.put(pack_a(sd[q + ".0.weight"].detach().float())))
-            if split:       # the gate's first layer on the fp16 pipe (csrc/rr_encoder.hip: ie_gemm_split2)
-                setattr(iw, "g0" + s + "s", ar.put_raw(pack_a_f16u(sd[q + ".0.weight"].to(device))))
-                gate_w.append(sd[q + ".0.weight"].to(device))
+            if split and has_coords:       # the gate's first layer folded through both embeddings, on the fp16 pipe (fold_init_gate)
+                gf, gn, _ = fold_init_gate(dv(sd[q + ".0.weight"]), dv(sd[q + ".0.bias"]), dv(sd[f"{p}.{rc}_embed.weight"]),
+                                           dv(sd[f"{p}.{rc}_embed.bias"]), dv(sd[p + ".init_embed.weight"]), dv(sd[p + ".init_embed.bias"]))
+                setattr(iw, "gf" + s, ar.put(gf)); setattr(iw, "gn" + s, ar.put(gn))
+                gate_w += [gf, dv(sd[f"{p}.{rc}_embed.weight"])]      # (2^6 x these are split into fp16 pieces inside the kernel)
             setattr(iw, "g0" + s + "b", ar.put(sd[q + ".0.bias"]))
             setattr(iw, "g2" + s, ar.put(sd[q + ".2.weight"].reshape(-1)))
             setattr(iw, "g2" + s + "b", float(sd[q + ".2.bias"].reshape(-1)[0]))
@@ -673,9 +701,13 @@ def _pack_policy(sd: dict, env_name: str, device) -> dict:
         for rc, s in (("row", "r"), ("col", "c")):
             q = f"{p}.gating_network_{rc}.gating_fc"
             setattr(iw, "g0" + s, ar.put(pack_a(sd[q + ".0.weight"].detach().float())))
-            if split:       # the gate's first layer on the fp16 pipe (csrc/rr_encoder.hip: ie_gemm_split2)
-                setattr(iw, "g0" + s + "s", ar.put_raw(pack_a_f16u(sd[q + ".0.weight"].to(device))))
-                gate_w.append(sd[q + ".0.weight"].to(device))
+            if split:       # the gate's first layer folded through both embeddings, on the fp16 pipe (fold_init_gate)
+                ce = p + ".coord_expert"
+                gf, gn, gd = fold_init_gate(dv(sd[q + ".0.weight"]), dv(sd[q + ".0.bias"]), dv(sd[f"{p}.distance_expert.{rc}_embed.weight"]),
+                                            dv(sd[f"{p}.distance_expert.{rc}_embed.bias"]), dv(sd[ce + ".init_embed.weight"]),
+                                            dv(sd[ce + ".init_embed.bias"]), dv(sd[ce + ".init_embed_depot.weight"]), dv(sd[ce + ".init_embed_depot.bias"]))
+                setattr(iw, "gf" + s, ar.put(gf)); setattr(iw, "gn" + s, ar.put(gn)); setattr(iw, "gd" + s, ar.put(gd))
+                gate_w += [gf, dv(sd[f"{p}.distance_expert.{rc}_embed.weight"])]
             setattr(iw, "g0" + s + "b", ar.put(sd[q + ".0.bias"]))
             setattr(iw, "g2" + s, ar.put(sd[q + ".2.weight"].reshape(-1)))
             setattr(iw, "g2" + s + "b", float(sd[q + ".2.bias"].reshape(-1)[0]))

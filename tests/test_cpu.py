@@ -229,7 +229,7 @@ def test_c_abi_library_exports_every_declared_symbol():
 def test_ctypes_struct_sizes_match_header_layout():
     from rrnco_amd import _lib
     import ctypes as C
-    assert C.sizeof(_lib.EncBlockW) == 32 * 8 and C.sizeof(_lib.InitW) == 20 * 8 + 16 + 2 * 8
+    assert C.sizeof(_lib.EncBlockW) == 32 * 8 and C.sizeof(_lib.InitW) == 20 * 8 + 16 + 6 * 8
     assert C.sizeof(_lib.CacheW) == 80 and C.sizeof(_lib.DecW) == 6 * 8 + 8 + 3 * 8
     assert C.sizeof(_lib.RolloutIO) == 24 * 8 + 12 * 4 + 2 * 4 + 8 + 5 * 8 + 4 * 8 + 8 + 4 * 8 + 8 + 8 and C.sizeof(_lib.NabDurW) == 4 * 8 + 9 * 4 + 4 + 8
     # the training-side descriptors (include/rrnco_hip.h: DecLogitIO, MlpRowsW, MlpWgradW, DecAttnIO, EncSave, AftBwdIO)
