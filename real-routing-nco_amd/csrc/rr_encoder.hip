@@ -1000,6 +1000,11 @@ __device__ __forceinline__ void ie_gemm_wx16(f32x4 (&acc)[NT], const float4* __r
   }
 }
 
+#ifdef RR_KO_IE_FENCE      // diagnostic: k_init_embed's matrix instructions without their scheduling fences (tests/test_gpu_determinism.py then fails)
+#define IE_FENCE()
+#else
+#define IE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 // lane permutation within a row of 16 by DPP (dpp_ctrl: quad_perm 0x00-0xFF, row_mirror 0x140, row_half_mirror 0x141)
 template <int CTRL>
 __device__ __forceinline__ float ie_dpp(float v) {
@@ -1212,7 +1217,7 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
           cx_n = lcs[2 * nc]; cy_n = lcs[2 * nc + 1]; ca_n = KIND == 1 ? angs[nc] : 0.f;
         };
         fetch(0);
-        __builtin_amdgcn_sched_barrier(0);
+        IE_FENCE();
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const int node = nt * 16 + j;
@@ -1231,11 +1236,11 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
             h0[r] = 64.f * fmaf(a0.z, ca, fmaf(a0.y, cy, fmaf(a0.x, cx, a0.w)));
             h1[r] = 64.f * fmaf(a1.z, ca, fmaf(a1.y, cy, fmaf(a1.x, cx, a1.w)));
           }
-          __builtin_amdgcn_sched_barrier(0);
+          IE_FENCE();
           d = rr_mfma_f16(Ah, xl, d);   h0 = rr_mfma_f16(G0h, xl, h0); h1 = rr_mfma_f16(G1h, xl, h1);
           d = rr_mfma_f16(Al, xh, d);   h0 = rr_mfma_f16(G0l, xh, h0); h1 = rr_mfma_f16(G1l, xh, h1);
           d = rr_mfma_f16(Ah, xh, d);   h0 = rr_mfma_f16(G0h, xh, h0); h1 = rr_mfma_f16(G1h, xh, h1);
-          __builtin_amdgcn_sched_barrier(0);
+          IE_FENCE();
           if (node < N)
             rr_st4(comb + node * CLD + 128 + 16 * wave + 4 * g,
                    make_float4(d[0] * (1.0f / 64.0f), d[1] * (1.0f / 64.0f), d[2] * (1.0f / 64.0f), d[3] * (1.0f / 64.0f)));
@@ -1246,9 +1251,11 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
           float p1 = rl(h1[0]) * wb.x + rl(h1[1]) * wb.y + rl(h1[2]) * wb.z + rl(h1[3]) * wb.w;
           p0 = rr_sum_g(p0) * (1.0f / 64.0f); p1 = rr_sum_g(p1) * (1.0f / 64.0f);
           if (g == 0) { gpart[wave * 112 + nt * 16 + j] = p0; gpart[(wave + 8) * 112 + nt * 16 + j] = p1; }
+#ifndef RR_KO_IE_FENCE
           __builtin_amdgcn_sched_barrier(0);
           asm volatile("" ::"v"(xh), "v"(xl), "v"(Ah), "v"(Al), "v"(G0h), "v"(G0l), "v"(G1h), "v"(G1l));
           __builtin_amdgcn_sched_barrier(0);
+#endif
         }
       }
       RR_ET(2);

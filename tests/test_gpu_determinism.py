@@ -142,3 +142,32 @@ def test_training_step_repeats(name):
         assert torch.equal(cur[0], ref[0]) and torch.equal(cur[1], ref[1]), f"sampled tours / log-likelihoods differ in repeat {i}"
         rel = float((cur[2] - ref[2]).norm() / ref[2].norm())
         assert rel < 1e-5, f"gradients differ by {rel:.3e} of their norm in repeat {i}"
+
+
+@pytest.mark.parametrize("name", ["atsp_n20_b4_pomo", "atsp_n100_b2_pomo", "rcvrp_n100_b2_pomo"])
+def test_encoder_is_identical_across_copies_of_an_instance(name):
+    """2 048 copies of ONE instance through the init embedding and the six encoder layers: every copy (one workgroup each in
+    k_init_embed, scheduled among different neighbours) must come out bit-identical.  Found with the sampling-law test: hipcc had built
+    the folded gate's A pieces in the registers of the previous node tile's B pieces right behind its matrix instructions, and copies
+    of an instance came out with different gates (csrc/rr_encoder.hip: the scheduling fences in k_init_embed; profiles/r06/NOTES.md §7)."""
+    from tests import helpers as H
+    from rrnco_amd import TensorDict
+    B = 2048
+    if name.startswith("atsp"):
+        from rrnco_amd.envs import ATSPEnv
+        fx = H.load_fixture(name)
+        pol = H.make_policy(H.atsp_weights(fx), "atsp")
+        env = ATSPEnv(check_solution=False, device=torch.device("cuda"))
+        st = H.fixture_state(fx)
+    else:
+        from tests import test_gpu_rcvrp as T
+        fx, w, pol, st, env, _ = T._setup(name)
+    one = {k: v[:1].expand(B, *v.shape[1:]).contiguous().cuda() for k, v in st.items()}
+    td = TensorDict(one, batch_size=[B])
+    td["sample_idx"] = fx["sample_idx"][:1].expand(B, -1, -1).contiguous().cuda()
+    packed = pol.packed(torch.device("cuda"))
+    for rep in range(3):
+        row, col = pol.encoder(env.reset(td), packed=packed)
+        for t, side in ((row, "row"), (col, "col")):
+            same = (t == t[:1]).flatten(1).all(1)
+            assert bool(same.all()), f"{name}: {int((~same).sum())} of {B} copies differ in the {side} embeddings (repeat {rep})"
