@@ -462,14 +462,27 @@ __device__ __forceinline__ void rr_load_tiles(f32x4 (&acc)[NT], const float* X, 
   }
 }
 
-// reductions over the 16 lanes that share g (= over the nodes of one tile column set)
+// Lane permutations inside a row of 16 lanes by DPP (dpp_ctrl: quad_perm 0x00-0xFF, row_mirror 0x140, row_half_mirror 0x141): one vector
+// instruction, no LDS round trip.  hipcc turns EVERY __shfl_xor into a ds_bpermute_b32 and waits for each (~100 cycles, serialised in
+// a reduction): profiles/r06/NOTES.md section 7.
+template <int CTRL>
+__device__ __forceinline__ float rr_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float rr_row_xor1(float v) { return rr_dpp<0xB1>(v); }                    // quad_perm [1,0,3,2]
+__device__ __forceinline__ float rr_row_xor2(float v) { return rr_dpp<0x4E>(v); }                    // quad_perm [2,3,0,1]
+__device__ __forceinline__ float rr_row_xor4(float v) { return rr_dpp<0x1B>(rr_dpp<0x141>(v)); }     // mirror within 8, then within 4
+__device__ __forceinline__ float rr_row_xor8(float v) { return rr_dpp<0x141>(rr_dpp<0x140>(v)); }    // mirror within 16, then within 8
+// reductions over the 16 lanes that share g (= over the nodes of one tile column set), the result in every lane.  The xor butterfly's
+// tree (1, 2, 4, 8): after the first two steps the four lanes of a quad hold the same value, so the partner at distance 4 (8) may be
+// any lane of the other quad (half row) — the mirrors, one instruction each; sums and maxima are bit-identical to the __shfl_xor form.
 __device__ __forceinline__ float rr_sum16(float v) {
-  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+  v += rr_dpp<0xB1>(v); v += rr_dpp<0x4E>(v); v += rr_dpp<0x141>(v); v += rr_dpp<0x140>(v);
   return v;
 }
 __device__ __forceinline__ float rr_max16(float v) {
-  v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2));
-  v = fmaxf(v, __shfl_xor(v, 4)); v = fmaxf(v, __shfl_xor(v, 8));
+  v = fmaxf(v, rr_dpp<0xB1>(v)); v = fmaxf(v, rr_dpp<0x4E>(v));
+  v = fmaxf(v, rr_dpp<0x141>(v)); v = fmaxf(v, rr_dpp<0x140>(v));
   return v;
 }
 // lane l <-> l^16 and l <-> l^32 exchanges on the gfx950 VALU (v_permlane16_swap / v_permlane32_swap) instead of
@@ -495,19 +508,27 @@ __device__ __forceinline__ float rr_max_g(float v) {
   rr_pair16(v, a, b); v = __builtin_amdgcn_fmed3f(a, b, INFINITY);
   rr_pair32(v, a, b); return __builtin_amdgcn_fmed3f(a, b, INFINITY);
 }
+// wave reductions in the xor butterfly's order 32, 16, 8, 4, 2, 1 (the same tree as before, bit for bit): the two cross-row steps on
+// v_permlane32_swap / v_permlane16_swap, the rest on DPP (true lane ^ 8 and lane ^ 4: two instructions each)
 __device__ __forceinline__ float rr_wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  float a, b;
+  rr_pair32(v, a, b); v = a + b;
+  rr_pair16(v, a, b); v = a + b;
+  v += rr_row_xor8(v); v += rr_row_xor4(v); v += rr_row_xor2(v); v += rr_row_xor1(v);
   return v;
 }
 __device__ __forceinline__ float rr_wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  float a, b;
+  rr_pair32(v, a, b); v = fmaxf(a, b);
+  rr_pair16(v, a, b); v = fmaxf(a, b);
+  v = fmaxf(v, rr_row_xor8(v)); v = fmaxf(v, rr_row_xor4(v)); v = fmaxf(v, rr_row_xor2(v)); v = fmaxf(v, rr_row_xor1(v));
   return v;
 }
 __device__ __forceinline__ float rr_wave_min(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+  float a, b;
+  rr_pair32(v, a, b); v = fminf(a, b);
+  rr_pair16(v, a, b); v = fminf(a, b);
+  v = fminf(v, rr_row_xor8(v)); v = fminf(v, rr_row_xor4(v)); v = fminf(v, rr_row_xor2(v)); v = fminf(v, rr_row_xor1(v));
   return v;
 }
 

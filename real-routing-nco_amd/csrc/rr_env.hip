@@ -572,9 +572,7 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ logits
 // (quad_perm xor 1 / xor 2, row_half_mirror, row_mirror: every lane ends with the row's result) instead of 6 ds_bpermute
 // round trips per reduction; elementwise formulas are those of rr_select_row.
 #define SEL16_PASSES 4
-template <int CTRL> __device__ __forceinline__ float rr_dpp(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
+// (rr_dpp<CTRL>: rr_common.h)
 template <int CTRL> __device__ __forceinline__ int rr_dppi(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
 __device__ __forceinline__ float rr_row16_max(float v) {
   v = fmaxf(v, rr_dpp<0xB1>(v)); v = fmaxf(v, rr_dpp<0x4E>(v)); v = fmaxf(v, rr_dpp<0x141>(v)); return fmaxf(v, rr_dpp<0x140>(v));

@@ -798,7 +798,7 @@ __global__ __launch_bounds__(512, 1) void k_mlp_wgrad(MlpWgradW w, const float* 
     }
   {
     float v = ab1;
-    v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+    v = rr_sum_g(v);      // (lane ^ 16, then lane ^ 32: v_permlane swaps)
     if (g == 0) atomicAdd(db1 + 16 * T0 + j, v);
   }
   if (slab == 0 && db2 != nullptr) {
@@ -1274,7 +1274,7 @@ __global__ __launch_bounds__(256, BF ? 2 : 1) void k_dec_attn_bwd(DecAttnIO io) 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = live ? dq[r] : 0.f;
-          v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+          v = rr_sum16(v);
           if (j == 0) atomicAdd(&accA[fst * TD_AS + 4 * g + r], v);
         }
       }
@@ -1520,7 +1520,7 @@ __global__ __launch_bounds__(256, BF ? 2 : 1) void k_dec_attn_bwd(DecAttnIO io) 
 #pragma unroll
       for (int r = 0; r < 4; ++r) if (k < io.nscal) {
         float v = dws[k][r];
-        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+        v = rr_sum16(v);
         if (j == 0) atomicAdd(io.dwstate + k * RR_E + 16 * h + 4 * g + r, v);
       }
   }

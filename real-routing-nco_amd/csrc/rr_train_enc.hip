@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void k_linear_rows(const float4* __restrict
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float v = cs[kk][r];
-        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+        v = rr_sum16(v);
         if (j == 0) atomicAdd(&cs_s[16 * kk + 4 * g + r], v);
       }
     __syncthreads();                          // one global atomic per workgroup and column (800 waves on 128 addresses serialise)
@@ -249,8 +249,7 @@ struct AftBwdIO {
 
 // sum over the 16 lanes of a row (same g) in every lane
 __device__ __forceinline__ float te_rowsum(float v) {
-  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-  return v;
+  return rr_sum16(v);      // (DPP: rr_common.h)
 }
 
 // One workgroup = one instance, wave w = node tile w (rows i of the first half, columns j of the second).
@@ -455,8 +454,10 @@ struct GateBwdIO {
   float* mix;          // optional: the forward value g node + (1 - g) dist (the VRPs' combine layer reads it: rcvrp.py:96-101)
 };
 __device__ __forceinline__ float gb_sum32(float v) {
-  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
-  return v;
+  v = rr_sum16(v);
+  float a, b;
+  rr_pair16(v, a, b);
+  return a + b;
 }
 __global__ __launch_bounds__(256) void k_gate_bwd(GateBwdIO io) {
   __shared__ float part[8][264];

@@ -44,7 +44,7 @@ __device__ __forceinline__ void nd_rowsum4(f32x4& v) {
   v[0] = a; v[1] = b; v[2] = c; v[3] = d;
 }
 __device__ __forceinline__ float nd_rowsum1(float v) {
-  v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+  v += rr_row_xor8(v); v += rr_row_xor4(v); v += rr_row_xor2(v); v += rr_row_xor1(v);      // (DPP: rr_common.h)
   return v;
 }
 
