@@ -501,6 +501,14 @@ __device__ __forceinline__ float rr_sum_g(float v) {
   rr_pair16(v, a, b); v = a + b;
   rr_pair32(v, a, b); return a + b;
 }
+// bitwise OR over the 4 lane groups that share j (lane ^ 16, lane ^ 32) on the permlane swaps: as __shfl_xor these were two ds_bpermute
+// round trips per word in every decode step of the VRP rollouts' mask update
+__device__ __forceinline__ uint32_t rr_or_g(uint32_t v) {
+  auto p = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  v = p[0] | p[1];
+  auto q = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return q[0] | q[1];
+}
 __device__ __forceinline__ float rr_max_g(float v) {
   // v_med3_f32(a, b, +inf) = max(a, b) (NaN-free inputs: scores and clipped logits; fmaxf on the two halves of a permlane swap costs
   // three v_max_f32: hipcc canonicalises both inputs first)
