@@ -1451,8 +1451,13 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_dec_cache(CacheW w, const fl
                                                               float* __restrict__ ctxA, float* __restrict__ ctxB, int N,
                                                               float4* __restrict__ Ks, float4* __restrict__ Vts, float4* __restrict__ Ls,
                                                               int* __restrict__ status) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * BUF_FLOATS];
-  float* R = smem; float* Cc = smem + BUF_FLOATS;
+  // Rows of the two embeddings 132 floats apart, not 128: the products read one 16-byte group per lane with the NODE on the lane axis,
+  // and a stride of 128 floats put the 16 nodes of a tile on the same four LDS banks — SQ_LDS_BANK_CONFLICT was 36 % of this kernel's
+  // wave cycles (profiles/r06/bench_r06v6_pmc_counters.txt), every operand read eight times its conflict-free length; 132 = 4 mod 64
+  // spreads a tile over all 64 banks (as `comb` in k_init_embed)
+  constexpr int DLD = 132;
+  __shared__ __attribute__((aligned(16))) float smem[2 * RR_MAXN * DLD];
+  float* R = smem; float* Cc = smem + RR_MAXN * DLD;
   // Ks / Vts / Ls (optional, all or none): the rollout's two-piece fp16 images of K / Vt / L (rr_pack_f16x2's arithmetic and range
   // guard, same byte offsets) written from the accumulators instead of by three more passes over the fp32 tensors
   bool bad = false;
@@ -1470,8 +1475,9 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_dec_cache(CacheW w, const fl
   const size_t off = (size_t)b * N * RR_E;
   for (int i = tid; i < N * (RR_E / 4); i += ENC_THREADS) {      // SPLIT: the LDS images in the [lo' | hi] form of rr_gemm_f16.h
     const float4 rv = rr_ld4(row_emb + off + i * 4), cv = rr_ld4(col_emb + off + i * 4);
-    rr_st4(R + i * 4, SPLIT ? rr_to_lohi(rv) : rv);
-    rr_st4(Cc + i * 4, SPLIT ? rr_to_lohi(cv) : cv);
+    const int at = (i >> 5) * DLD + 4 * (i & 31);          // (RR_E / 4 = 32 groups per node)
+    rr_st4(R + at, SPLIT ? rr_to_lohi(rv) : rv);
+    rr_st4(Cc + at, SPLIT ? rr_to_lohi(cv) : cv);
   }
   __syncthreads();
   f32x4 a[NT];
@@ -1482,13 +1488,13 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_dec_cache(CacheW w, const fl
       f32x4 as[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) as[nt] = rr_zero4();
-      rr_gemm_wx_h<NT>(a, as, wps + (size_t)wave * 8 * 64, 0, 8, X, LD, 0, N, lane);
+      rr_gemm_wx_h<NT>(a, as, wps + (size_t)wave * 8 * 64, 0, 8, X, DLD, 0, N, lane);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) a[nt][r] = fmaf(as[nt][r], RR_LO_INV, a[nt][r]);
     } else {
-      rr_gemm_wx<NT>(a, wp + (size_t)wave * 8 * 64, 0, 8, X, LD, 0, N, lane);
+      rr_gemm_wx<NT>(a, wp + (size_t)wave * 8 * 64, 0, 8, X, DLD, 0, N, lane);
     }
   };
   auto store_image = [&](float4* img) {      // a lane's four consecutive features of a node are one 16-byte group of the image

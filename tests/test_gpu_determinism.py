@@ -171,3 +171,11 @@ def test_encoder_is_identical_across_copies_of_an_instance(name):
         for t, side in ((row, "row"), (col, "col")):
             same = (t == t[:1]).flatten(1).all(1)
             assert bool(same.all()), f"{name}: {int((~same).sum())} of {B} copies differ in the {side} embeddings (repeat {rep})"
+        # ... and through the decoder cache (k_dec_cache: five products per workgroup, fp32 tensors and the rollout's fp16 images)
+        cache = pol.decoder._precompute_cache((row, col), packed=packed)
+        parts = [("K", cache.glimpse_key), ("Vt", cache.glimpse_val_t), ("L", cache.logit_key), ("ctxB", cache.ctx_b)]
+        parts += [("ctxA", cache.ctx_a)] if cache.ctx_a is not None else []
+        parts += [(f"image{i}", t) for i, t in enumerate(cache.split or ())]
+        for what, t in parts:
+            same = (t.view(torch.int32) == t[:1].view(torch.int32)).flatten(1).all(1)      # (images: bit patterns, some are NaN as floats)
+            assert bool(same.all()), f"{name}: {int((~same).sum())} of {B} copies differ in the cache's {what} (repeat {rep})"
