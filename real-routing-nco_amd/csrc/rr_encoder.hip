@@ -1000,11 +1000,15 @@ __device__ __forceinline__ void ie_gemm_wx16(f32x4 (&acc)[NT], const float4* __r
   }
 }
 
-#ifdef RR_KO_IE_FENCE      // diagnostic: k_init_embed's matrix instructions without their scheduling fences (tests/test_gpu_determinism.py then fails)
-#define IE_FENCE()
-#else
-#define IE_FENCE() __builtin_amdgcn_sched_barrier(0)
+// Diagnostic: -DRR_IE_FENCES=<bits> keeps a subset of k_init_embed's scheduling fences (1: in front of the tile loop, 2: in front of a tile's
+// matrix instructions, 4: behind them, 8: the operand keep-alive at the end of a tile); -DRR_KO_IE_FENCE = 0.  Default: all (15).
+#ifdef RR_KO_IE_FENCE
+#define RR_IE_FENCES 0
 #endif
+#ifndef RR_IE_FENCES
+#define RR_IE_FENCES 15
+#endif
+#define IE_FENCE(BIT) do { if constexpr ((RR_IE_FENCES & (BIT)) != 0) __builtin_amdgcn_sched_barrier(0); } while (0)
 // lane permutation within a row of 16 by DPP (dpp_ctrl: quad_perm 0x00-0xFF, row_mirror 0x140, row_half_mirror 0x141)
 template <int CTRL>
 __device__ __forceinline__ float ie_dpp(float v) {
@@ -1201,14 +1205,13 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
 #pragma unroll
         for (int r = 0; r < 4; ++r) { n0[r] = gn[16 * wave + 4 * g + r]; n1[r] = gn[16 * (wave + 8) + 4 * g + r]; }
         const float4 wa = rr_ld4(g2 + 16 * wave + 4 * g), wb = rr_ld4(g2 + 16 * (wave + 8) + 4 * g);
-        // Scheduling fences around the matrix instructions of a node tile: gfx950 does not interlock a vector WRITE to a register that
-        // a just-issued matrix instruction still has to read as SrcA / SrcB (rr_common.h, above rr_glds16), and hipcc, free to move
-        // code, built the gate's A pieces in the registers of the previous tile's B pieces right behind its matrix instructions —
-        // identical instances came out with different gates (tests/test_gpu_atsp.py, sampling law over 2 048 copies).  Between the
-        // fences of a tile there is nothing but its nine matrix instructions; its B pieces stay allocated until its results have
-        // been read (the empty asm at the end of the tile), i.e. until the matrix instructions have retired.
-        // (the next tile's LDS reads are requested in front of this tile's matrix instructions: a load's destination is never a register
-        // a matrix instruction in flight reads)
+        // Scheduling fences around the matrix instructions of a node tile.  Left free, hipcc overlaps the next tile's prologue (the split's
+        // inline asm, the seeds, LDS prefetches into this tile's dead accumulators) with the tile's matrix instructions, and the VRP kernel
+        // (256 registers) then gives copies of one instance different gates — up to 957 of 2 048 (tests/test_gpu_determinism.py; bisected
+        // with -DRR_IE_FENCES, profiles/r06/NOTES.md section 7).  Write-after-read on the operands is NOT the cause (interlocked:
+        // tools/clockprobe/warprobe.hip, srccprobe.hip); the mechanism is open.  Either the fence in front of the matrix instructions or the
+        // operand keep-alive at the tile's end is enough; both stay.
+        // (the next tile's LDS reads are requested in front of this tile's matrix instructions)
         float4 xa_n, xb_n;
         float cx_n, cy_n, ca_n;
         auto fetch = [&](int nt) {
@@ -1217,7 +1220,7 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
           cx_n = lcs[2 * nc]; cy_n = lcs[2 * nc + 1]; ca_n = KIND == 1 ? angs[nc] : 0.f;
         };
         fetch(0);
-        IE_FENCE();
+        IE_FENCE(1);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const int node = nt * 16 + j;
@@ -1236,11 +1239,11 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
             h0[r] = 64.f * fmaf(a0.z, ca, fmaf(a0.y, cy, fmaf(a0.x, cx, a0.w)));
             h1[r] = 64.f * fmaf(a1.z, ca, fmaf(a1.y, cy, fmaf(a1.x, cx, a1.w)));
           }
-          IE_FENCE();
+          IE_FENCE(2);
           d = rr_mfma_f16(Ah, xl, d);   h0 = rr_mfma_f16(G0h, xl, h0); h1 = rr_mfma_f16(G1h, xl, h1);
           d = rr_mfma_f16(Al, xh, d);   h0 = rr_mfma_f16(G0l, xh, h0); h1 = rr_mfma_f16(G1l, xh, h1);
           d = rr_mfma_f16(Ah, xh, d);   h0 = rr_mfma_f16(G0h, xh, h0); h1 = rr_mfma_f16(G1h, xh, h1);
-          IE_FENCE();
+          IE_FENCE(4);
           if (node < N)
             rr_st4(comb + node * CLD + 128 + 16 * wave + 4 * g,
                    make_float4(d[0] * (1.0f / 64.0f), d[1] * (1.0f / 64.0f), d[2] * (1.0f / 64.0f), d[3] * (1.0f / 64.0f)));
@@ -1251,11 +1254,11 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_init_embed(InitW w, const fl
           float p1 = rl(h1[0]) * wb.x + rl(h1[1]) * wb.y + rl(h1[2]) * wb.z + rl(h1[3]) * wb.w;
           p0 = rr_sum_g(p0) * (1.0f / 64.0f); p1 = rr_sum_g(p1) * (1.0f / 64.0f);
           if (g == 0) { gpart[wave * 112 + nt * 16 + j] = p0; gpart[(wave + 8) * 112 + nt * 16 + j] = p1; }
-#ifndef RR_KO_IE_FENCE
-          __builtin_amdgcn_sched_barrier(0);
-          asm volatile("" ::"v"(xh), "v"(xl), "v"(Ah), "v"(Al), "v"(G0h), "v"(G0l), "v"(G1h), "v"(G1l));
-          __builtin_amdgcn_sched_barrier(0);
-#endif
+          if constexpr ((RR_IE_FENCES & 8) != 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::"v"(xh), "v"(xl), "v"(Ah), "v"(Al), "v"(G0h), "v"(G0l), "v"(G1h), "v"(G1l));
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
       }
       RR_ET(2);

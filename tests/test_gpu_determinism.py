@@ -147,9 +147,11 @@ def test_training_step_repeats(name):
 @pytest.mark.parametrize("name", ["atsp_n20_b4_pomo", "atsp_n100_b2_pomo", "rcvrp_n100_b2_pomo"])
 def test_encoder_is_identical_across_copies_of_an_instance(name):
     """2 048 copies of ONE instance through the init embedding and the six encoder layers: every copy (one workgroup each in
-    k_init_embed, scheduled among different neighbours) must come out bit-identical.  Found with the sampling-law test: hipcc had built
-    the folded gate's A pieces in the registers of the previous node tile's B pieces right behind its matrix instructions, and copies
-    of an instance came out with different gates (csrc/rr_encoder.hip: the scheduling fences in k_init_embed; profiles/r06/NOTES.md §7)."""
+    k_init_embed, scheduled among different neighbours) must come out bit-identical, call after call.  Two finds (profiles/r06/NOTES.md
+    §7, §10): an unfenced schedule of k_init_embed's matrix instructions gave copies different gates (most of 2 048 differ on the
+    -DRR_KO_IE_FENCE build), and round 5's k_enc_tail normalised the FIRST instance of a workgroup with per-feature parameters it read
+    from LDS in front of the barrier that publishes them — a handful of copies wrong about once per hundred calls, which is why the
+    n = 100 cases repeat 40 times."""
     from tests import helpers as H
     from rrnco_amd import TensorDict
     B = 2048
@@ -166,7 +168,7 @@ def test_encoder_is_identical_across_copies_of_an_instance(name):
     td = TensorDict(one, batch_size=[B])
     td["sample_idx"] = fx["sample_idx"][:1].expand(B, -1, -1).contiguous().cuda()
     packed = pol.packed(torch.device("cuda"))
-    for rep in range(3):
+    for rep in range(40 if fx["N"] > 64 else 3):
         row, col = pol.encoder(env.reset(td), packed=packed)
         for t, side in ((row, "row"), (col, "col")):
             same = (t == t[:1]).flatten(1).all(1)
