@@ -2,6 +2,7 @@
 //   chain of K dependent v_mfma_f32_16x16x32_f16 (each link writes a NEW register: c1 = A B + c0, c2 = A B + c1, ...), D filler
 //   instructions, then ds_read_b128 INTO the register that the LAST link reads as SrcC; the last link's result must be 32 K.
 // Half of the waves of every SIMD run a dense matrix stream (contention).  srccprobe [iters]
+// Measured on MI355X (profiles/r06/NOTES.md section 7): 0 wrong values of 1.3e8 in all 8 configurations — the load IS interlocked.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
