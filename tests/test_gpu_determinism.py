@@ -181,3 +181,39 @@ def test_encoder_is_identical_across_copies_of_an_instance(name):
         for what, t in parts:
             same = (t.view(torch.int32) == t[:1].view(torch.int32)).flatten(1).all(1)      # (images: bit patterns, some are NaN as floats)
             assert bool(same.all()), f"{name}: {int((~same).sum())} of {B} copies differ in the cache's {what} (repeat {rep})"
+
+
+@pytest.mark.parametrize("name", ["atsp_n100_b2_pomo", "rcvrp_n100_b2_pomo", "rcvrptw_n100_b2_pomo"])
+def test_greedy_rollout_is_identical_across_copies_of_an_instance(name):
+    """512 copies of ONE instance through the whole policy (encoder, cache, fused greedy rollout: one workgroup per copy), 10 calls:
+    every copy's tours, log-likelihoods and rewards must equal copy 0's, bit for bit — the cross-copy form of the run-to-run tests
+    above, the one that exposes a workgroup whose result depends on its start-up timing (profiles/r06/NOTES.md §10)."""
+    from tests import helpers as H
+    from rrnco_amd import TensorDict
+    B = 512
+    if name.startswith("atsp"):
+        from rrnco_amd.envs import ATSPEnv
+        fx = H.load_fixture(name)
+        pol = H.make_policy(H.atsp_weights(fx), "atsp")
+        env = ATSPEnv(check_solution=False, device=torch.device("cuda"))
+        st = H.fixture_state(fx)
+    elif name.startswith("rcvrptw"):
+        from tests import test_gpu_rcvrptw as T
+        fx, w, pol, st, env, _ = T._setup(name)
+    else:
+        from tests import test_gpu_rcvrp as T
+        fx, w, pol, st, env, _ = T._setup(name)
+    one = {k: v[:1].expand(B, *v.shape[1:]).contiguous().cuda() for k, v in st.items()}
+    td = TensorDict(one, batch_size=[B])
+    td["sample_idx"] = fx["sample_idx"][:1].expand(B, -1, -1).contiguous().cuda()
+    S = fx["S"]
+    for rep in range(10):
+        # (per-step log-probabilities: the VRP paths sum them with a torch reduction whose order depends on the row's position — copies
+        # differ in the last bit of the SUM there, 1.5e-5 on -200, with identical terms)
+        out = pol(env.reset(td), env, phase="val", decode_type="multistart_greedy", num_starts=S, return_actions=True, fused=True,
+                  return_sum_log_likelihood=False)
+        for what in ("actions", "log_likelihood", "reward"):
+            t = out[what].reshape(S, B, -1).transpose(0, 1).contiguous()                # rollout r = s * B + b  ->  [copy][start][...]
+            t = t.view(torch.int32) if t.dtype == torch.float32 else t
+            same = (t == t[:1]).flatten(1).all(1)
+            assert bool(same.all()), f"{name}: {int((~same).sum())} of {B} copies differ in {what} (call {rep})"
