@@ -208,8 +208,18 @@ __device__ __forceinline__ rr_f16x8 rr_split4s(const float (&x)[4]) {
 // (it pads its own v_cvt_pk_f16_f32 -> v_mfma with s_nop 1); without them the MFMA reads the register's OLD contents — seen as
 // garbage attention outputs and run-to-run differences.  The block ends with that s_nop 1; the lo / hi writes of one
 // destination sit four (two) instructions apart.
+// (diagnostics for profiles/r06/NOTES.md section 7: -DRR_ULO_VOLATILE pins the block where the source has it, -DRR_ULO_TAIL="s_nop 7" lengthens
+// the wait behind its last write)
+#ifdef RR_ULO_VOLATILE
+#define RR_ULO_ASM asm volatile
+#else
+#define RR_ULO_ASM asm
+#endif
+#ifndef RR_ULO_TAIL
+#define RR_ULO_TAIL "s_nop 1"
+#endif
 __device__ __forceinline__ void rr_ulo8(const rr_f16x2 (&h)[4], const float (&x)[8], rr_f16x2 (&l)[4]) {
-  asm("s_nop 0\n\t"                     // (the hi halves come from a v_cvt_pk right before: hipcc pads its own VALU pairs where gfx950 needs it, not ours)
+  RR_ULO_ASM("s_nop 0\n\t"                     // (the hi halves come from a v_cvt_pk right before: hipcc pads its own VALU pairs where gfx950 needs it, not ours)
       "v_fma_mixlo_f16 %0, %4, -1.0, %8 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
       "v_fma_mixlo_f16 %1, %5, -1.0, %10 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
       "v_fma_mixlo_f16 %2, %6, -1.0, %12 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
@@ -218,7 +228,7 @@ __device__ __forceinline__ void rr_ulo8(const rr_f16x2 (&h)[4], const float (&x)
       "v_fma_mixhi_f16 %1, %5, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
       "v_fma_mixhi_f16 %2, %6, -1.0, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
       "v_fma_mixhi_f16 %3, %7, -1.0, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-      "s_nop 1"
+      RR_ULO_TAIL
       : "=&v"(l[0]), "=&v"(l[1]), "=&v"(l[2]), "=&v"(l[3])
       : "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
 }
