@@ -863,3 +863,33 @@ def test_golden_generator_and_committed_fixtures_are_in_sync():
     carry the committed files' keys and arrays (`atsp_n20_b4_pomo.npz` had silently lost two keys the generator writes)."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "gen_golden.py"), "--check", "atsp"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("vrp", [False, True])
+def test_folded_init_gate_equals_the_layer_on_the_assembled_embeddings(vrp):
+    """packing.fold_init_gate: relu(W0 [node_emb | dist_emb] + b0) with both embeddings linear in their inputs equals
+    relu(gf^T sorted + gn[:, :3] . (x, y, angle) + gn[:, 3]) (csrc/rr_encoder.hip: k_init_embed<., ., true>; atsp.py:108-121, rcvrp.py:88-103)."""
+    from rrnco_amd import packing
+    g = torch.Generator().manual_seed(7 + int(vrp))
+    E, SS, nf = 128, 25, 3 if vrp else 2
+    W0, b0 = torch.randn(2 * E, 2 * E, generator=g) * 0.06, torch.randn(2 * E, generator=g) * 0.06
+    Wd, bd = torch.randn(E, SS, generator=g) * 0.2, torch.randn(E, generator=g) * 0.2
+    Wn, bn = torch.randn(E, nf, generator=g) * 0.5, torch.randn(E, generator=g) * 0.5
+    Wdep, bdep = (torch.randn(E, 2, generator=g) * 0.5, torch.randn(E, generator=g) * 0.5) if vrp else (None, None)
+    gf, gn, gd = packing.fold_init_gate(W0, b0, Wd, bd, Wn, bn, Wdep, bdep)
+    assert gf.shape == (32, 2 * E) and gn.shape == (2 * E, 4) and (gd is None) == (not vrp)
+    assert float(gf[SS:].abs().max()) == 0.0                                   # the pad behind the SS samples multiplies zero samples
+    n = 64
+    srt = torch.rand(n, SS, generator=g).sort(1).values.double()
+    feat = torch.rand(n, nf, generator=g).double()
+    node = feat @ Wn.double().t() + bn.double()
+    dist = srt @ Wd.double().t() + bd.double()
+    ref = torch.cat([node, dist], 1) @ W0.double().t() + b0.double()
+    f3 = torch.cat([feat, torch.zeros(n, 3 - nf, dtype=torch.float64)], 1)
+    got = srt @ gf[:SS].double() + f3 @ gn[:, :3].double().t() + gn[:, 3].double()
+    assert float((got - ref).abs().max()) < 2e-6 * float(ref.abs().max())     # fp32 tables of float64 products
+    if vrp:                                                                     # the depot's own Linear(2,E)
+        xy = torch.rand(n, 2, generator=g).double()
+        ref_d = torch.cat([xy @ Wdep.double().t() + bdep.double(), dist], 1) @ W0.double().t() + b0.double()
+        got_d = srt @ gf[:SS].double() + xy @ gd[:, :2].double().t() + gd[:, 3].double()
+        assert float(gd[:, 2].abs().max()) == 0.0 and float((got_d - ref_d).abs().max()) < 2e-6 * float(ref_d.abs().max())
