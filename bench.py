@@ -404,21 +404,33 @@ def timed_loop(step, min_seconds=1.0, min_steps=2, max_steps=200):
     return (time.perf_counter() - t0) / n, n
 
 
-def graph_replay_exact_shape(step, res, pol, B):
-    """-> the `hipgraph_replay_exact_shape` variant entry of a VRP config (never raises: a variant must not fail the line)."""
+def graph_replay_exact_shape(step, res, pol, B, make_td=None, call=None):
+    """-> the `hipgraph_replay_exact_shape` variant entry of a VRP config (never raises: a variant must not fail the line).
+    Default: the whole step() captured.  make_td / call: augmentation + env.reset stay eager (make_td() per batch, copied into the
+    captured call's input buffers) and only call(static_td) — the policy — is captured: for environments whose reset reads back."""
     try:
+        from rrnco_amd import TensorDict
+        static = None
+        if make_td is not None:
+            td0 = make_td()
+            static = TensorDict({k: v.clone() for k, v in td0.items()}, batch_size=td0.batch_size, meta=dict(td0.meta))
+        body = step if static is None else (lambda: res.__setitem__("out", call(static.clone())))
         gph, gs = torch.cuda.CUDAGraph(), torch.cuda.Stream()
         gs.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(gs):
-            step()
+            body()
             torch.cuda.synchronize()
             with torch.cuda.graph(gph, stream=gs):
-                step()
+                body()
             g_out = res["out"]
         torch.cuda.current_stream().wait_stream(gs)
         torch.cuda.synchronize()
 
         def gstep():
+            if static is not None:
+                td = make_td()
+                for k, v in td.items():
+                    static[k].copy_(v)
             gph.replay()
             Tg = int(g_out["steps"].item()) + 1
             res["trimmed"] = (g_out["actions"][:, :Tg], g_out["reward"])
@@ -462,7 +474,7 @@ def other_configs(dev):
         n = max(3, int(seconds / est / 2))
         return run_on_streams(steps, n) / (2 * n), 2 * n
 
-    def inference(label, env, pol, B, S, aug, decode, kernel, make_pol=None, graph_variant=False):
+    def inference(label, env, pol, B, S, aug, decode, kernel, make_pol=None, graph_variant=None):
         inst = env.generator(B, generator=torch.Generator(device=dev).manual_seed(5))
         sidx = ATSPInitEmbedding.sample_indices(env.reset(inst)["distance_matrix"], 25)
         if aug:
@@ -520,10 +532,19 @@ def other_configs(dev):
         # capturing — and replayed, followed by the ONE host read per call that the reference's output shape needs, the step count, and
         # the trim as a view: what evaluate.py --hipgraph does per batch.  The eager `value` above pays ~70 launch gaps between that read
         # and the next call's first large kernel (the chip idles ~10 % of a C3 step); a replay is one launch.  The captured neighbour
-        # sample repeats: a timing variant, like the headline's hipgraph_replay.  C3 only: RMTVRPEnv.reset (configs[3]) reads a flag back
-        # and cannot be captured — its two_streams entry below covers the same idle time another way.
-        if graph_variant:
+        # sample repeats: a timing variant, like the headline's hipgraph_replay.  configs[3]: RMTVRPEnv.reset reads a flag back and cannot
+        # be captured — augmentation + reset stay eager there and only the policy call is replayed.
+        if graph_variant == "step":
             out[label]["variants"]["hipgraph_replay_exact_shape"] = graph_replay_exact_shape(step, res, pol, B)
+        elif graph_variant == "policy":      # (RMTVRPEnv.reset reads a flag back: augmentation + reset eager, the policy call captured)
+            def make_td():
+                td = TensorDict(dict(inst.items()), batch_size=[B])
+                if aug:
+                    td = StateAugmentation(augment_fn="dihedral8", no_aug_coords=False)(td)
+                td["sample_idx"] = sidx
+                return env.reset(td)
+            out[label]["variants"]["hipgraph_replay_exact_shape"] = graph_replay_exact_shape(
+                step, res, pol, B, make_td, lambda t: pol(t, env, phase="val", decode_type=decode, num_starts=S, seed=1))
         if make_pol is not None:
             sec2, n2 = two_streams(env, pol, make_pol, step_of, B)
             out[label]["two_streams"] = {"value": B / sec2, "unit": "instances/s", "ms_per_batch": sec2 * 1e3, "batches": n2,
@@ -535,11 +556,11 @@ def other_configs(dev):
 
     env = RCVRPEnv(generator_params=dict(num_loc=N_NODES, device=dev), check_solution=False, device=dev)
     inference("C3 RCVRP n=100 B=512 POMO S=101 greedy (configs[2])", env, vrp_policy("rcvrp"), 512, 101, False, "multistart_greedy",
-              "k_rollout_w<7, 1, 0, true, true, false, false>", graph_variant=True)
+              "k_rollout_w<7, 1, 0, true, true, false, false>", graph_variant="step")
     env = RMTVRPEnv(generator_params=dict(num_loc=N_NODES, device=dev), device=dev)
     c4 = "C4 RCVRPTW n=100 B=256 x8 aug S=100 sampling (configs[3])"
     c4_step = inference(c4, env, vrp_policy("rcvrptw"), 256, 100, True, "multistart_sampling", "k_rollout_w<7, 2, 1, true, true, false, false>",
-                        make_pol=lambda: vrp_policy("rcvrptw"))
+                        make_pol=lambda: vrp_policy("rcvrptw"), graph_variant="policy")
     # the step's second kernel: the Neural Adaptive Bias with the duration matrix (k_nab_dur_lds, 6 launches per step), VALU-bound on the
     # SiLU of its gate: per edge and gate unit one v_exp_f32 and one v_rcp_f32 — quarter-rate instructions (16 lanes per SIMD and 4 cycles)
     with kernel_timers("rr_nab_dur", "rr_nab_dur_aug") as kt:
