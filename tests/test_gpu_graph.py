@@ -83,3 +83,42 @@ def test_replayed_graph_keeps_a_range_flag_raised_by_a_middle_batch():
         pol.check_range()
     assert pol.last_range_flags & 1
     pol.check_range()                                     # read and cleared
+
+
+@pytest.mark.parametrize("problem", ["rcvrp", "rcvrptw"])
+def test_vrp_policy_call_replays_from_a_hip_graph_with_the_reference_output_shape(problem):
+    """bench.py's `hipgraph_replay_exact_shape` variant (evaluate.py --hipgraph per batch): the VRP policy call in its padded form
+    (policy.lazy_trim: no host read inside) captured once, replayed, then ONE host read of the step count and the trim as a view — tours,
+    rewards and the trimmed length equal the eager call's (the reference's output shape)."""
+    if problem == "rcvrp":
+        from tests import test_gpu_rcvrp as T
+        fx, w, pol, inst, env, td_in = T._setup("rcvrp_n20_b4_pomo")
+    else:
+        from tests import test_gpu_rcvrptw as T
+        fx, w, pol, inst, env, td_in = T._setup("rcvrptw_n20_b4_pomo")
+    S = fx["S"]
+    kw = dict(phase="val", decode_type="multistart_greedy", num_starts=S, return_actions=True)
+    with torch.no_grad():
+        ref = pol(env.reset(td_in), env, **kw)                      # eager: actions trimmed to the longest route
+        static = env.reset(td_in)                                   # (RMTVRPEnv.reset reads a flag back: outside the capture)
+        pol.lazy_trim = True
+        checked, env.check_solution = env.check_solution, False     # (the validity check of get_reward reads back: the eager call above ran it)
+        try:
+            g, s = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                pol(static.clone(), env, **kw)
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g, stream=s):
+                    out = pol(static.clone(), env, **kw)
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            out["actions"].zero_(); out["reward"].zero_()
+            g.replay()
+            T_used = int(out["steps"].item()) + 1
+        finally:
+            pol.lazy_trim, env.check_solution = False, checked
+    acts = out["actions"][:, :T_used]
+    assert acts.shape == ref["actions"].shape, (acts.shape, ref["actions"].shape)
+    assert torch.equal(acts, ref["actions"]) and torch.equal(out["reward"], ref["reward"])
+    pol.check_range()
