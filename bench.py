@@ -532,8 +532,8 @@ def other_configs(dev):
         # capturing — and replayed, followed by the ONE host read per call that the reference's output shape needs, the step count, and
         # the trim as a view: what evaluate.py --hipgraph does per batch.  The eager `value` above pays ~70 launch gaps between that read
         # and the next call's first large kernel (the chip idles ~10 % of a C3 step); a replay is one launch.  The captured neighbour
-        # sample repeats: a timing variant, like the headline's hipgraph_replay.  configs[3]: RMTVRPEnv.reset reads a flag back and cannot
-        # be captured — augmentation + reset stay eager there and only the policy call is replayed.
+        # sample repeats: a timing variant, like the headline's hipgraph_replay.  (graph_variant="policy": augmentation + reset eager, only
+        # the policy call replayed — for environments whose reset reads back; RMTVRPEnv.reset no longer does for the vrptw preset.)
         if graph_variant == "step":
             out[label]["variants"]["hipgraph_replay_exact_shape"] = graph_replay_exact_shape(step, res, pol, B)
         elif graph_variant == "policy":      # (RMTVRPEnv.reset reads a flag back: augmentation + reset eager, the policy call captured)
@@ -560,7 +560,7 @@ def other_configs(dev):
     env = RMTVRPEnv(generator_params=dict(num_loc=N_NODES, device=dev), device=dev)
     c4 = "C4 RCVRPTW n=100 B=256 x8 aug S=100 sampling (configs[3])"
     c4_step = inference(c4, env, vrp_policy("rcvrptw"), 256, 100, True, "multistart_sampling", "k_rollout_w<7, 2, 1, true, true, false, false>",
-                        make_pol=lambda: vrp_policy("rcvrptw"), graph_variant="policy")
+                        make_pol=lambda: vrp_policy("rcvrptw"), graph_variant="step")
     # the step's second kernel: the Neural Adaptive Bias with the duration matrix (k_nab_dur_lds, 6 launches per step), VALU-bound on the
     # SiLU of its gate: per edge and gate unit one v_exp_f32 and one v_rcp_f32 — quarter-rate instructions (16 lanes per SIMD and 4 cycles)
     with kernel_timers("rr_nab_dur", "rr_nab_dur_aug") as kt:

@@ -147,15 +147,23 @@ class RMTVRPEnv(EnvBase):
         ones = torch.ones_like(dl[..., :1])
         # env.py:225-257: optional multi-task features with their defaults
         db = td.get("demand_backhaul", None)
+        given = [db is not None]
         db = torch.zeros_like(dl) if db is None else torch.cat([torch.zeros_like(dl[..., :1]), db.float()], dim=1)
         bclass = td.get("backhaul_class", None)
+        given.append(bclass is not None)
         bclass = torch.full((*batch_size, 1), 1, dtype=torch.int32, device=dev) if bclass is None else bclass.to(torch.int32).reshape(-1, 1)
         limit = td.get("distance_limit", None)
+        given.append(limit is not None)
         limit = torch.full_like(ones, float("inf")) if limit is None else limit.float().reshape(-1, 1)
         open_route = td.get("open_route", None)
+        given.append(open_route is not None)
         open_route = torch.zeros_like(ones, dtype=torch.bool) if open_route is None else open_route.bool().reshape(-1, 1)
-        # (one host read instead of four: the rollout's instantiation is chosen from the instance data)
-        variant = bool(torch.stack([(db != 0).any(), open_route.any(), torch.isfinite(limit).any(), (bclass != 1).any()]).any())
+        # The rollout's instantiation is chosen from the instance data: ONE host read over the multi-task features that were GIVEN — none
+        # when the batch carries none of them (the vrptw preset of BASELINE configs[3]: the defaults above are known here).  That read was
+        # a synchronisation in every reset: it kept the host from running ahead of the device in the padded call form and made the
+        # reset impossible to capture into a hipGraph.
+        tests = [t for g_, t in zip(given, ((db != 0).any, lambda: (bclass != 1).any(), lambda: torch.isfinite(limit).any(), open_route.any)) if g_]
+        variant = bool(torch.stack([t() for t in tests]).any()) if tests else False
         tw = td.get("time_windows", None)
         if tw is None:
             tw = torch.zeros_like(td["locs"]); tw[..., 1] = float("inf")
