@@ -222,3 +222,30 @@ def test_greedy_rollout_is_identical_across_copies_of_an_instance(name):
             t = t.view(torch.int32) if t.dtype == torch.float32 else t
             same = (t == t[:1]).flatten(1).all(1)
             assert bool(same.all()), f"{name}: {int((~same).sum())} of {B} copies differ in {what} (call {rep})"
+
+
+def test_big_n_path_is_identical_across_copies_of_an_instance():
+    """N = 128 (> 103: the row-parallel kernels of csrc/rr_bign.hip and the step-by-step decode loop): 96 copies of ONE instance, 5 calls —
+    embeddings, tours, per-step log-probabilities and rewards of every copy equal copy 0's."""
+    from oracle import restate
+    from tests import helpers as H
+    from rrnco_amd import TensorDict
+    from rrnco_amd.envs import ATSPEnv
+    N, S, ss, B = 128, 16, 25, 96
+    pol = H.make_policy(restate.make_weights(restate.atsp_weight_template(128, 2, 512, ss), 3))
+    inst = restate.atsp_synthetic(1, N, 11)
+    sidx = restate.sample_neighbor_indices(restate.atsp_reset(inst)["distance_matrix"], ss, generator=torch.Generator().manual_seed(5))
+    env = ATSPEnv(generator_params=dict(num_loc=N), check_solution=False)
+    td = TensorDict({k: v[:1].expand(B, *v.shape[1:]).contiguous().cuda() for k, v in inst.items()}, batch_size=[B])
+    td["sample_idx"] = sidx[:1].expand(B, -1, -1).contiguous().cuda()
+    packed = pol.packed(torch.device("cuda"))
+    for rep in range(5):
+        t = env.reset(td)
+        row, col = pol.encoder(t, packed=packed)
+        out = pol(t, env, phase="val", decode_type="multistart_greedy", num_starts=S, return_actions=True, return_sum_log_likelihood=False)
+        parts = {"row": row, "col": col}
+        parts.update({k: out[k].reshape(S, B, -1).transpose(0, 1).contiguous() for k in ("actions", "log_likelihood", "reward")})
+        for what, v in parts.items():
+            v = v.view(torch.int32) if v.dtype == torch.float32 else v
+            same = (v == v[:1]).flatten(1).all(1)
+            assert bool(same.all()), f"N = {N}: {int((~same).sum())} of {B} copies differ in {what} (call {rep})"
